@@ -1,0 +1,207 @@
+/*
+ * rcx.h -- C ABI of the MI355X-native block-codec engine ("rcx" = rust-compress on CDNA).
+ *
+ * This is the drop-in boundary for the hot path of the Rust crate `compress`
+ * (rusty-shell/rust-compress): every entry point below replaces one per-block
+ * kernel that the crate's `Decoder<R: Read>` / `Encoder<W: Write>` types call
+ * once per block; here it is called once per BATCH of independent blocks.
+ * The reference interface each entry point replaces is cited as
+ * `reference: <file>:<lines>` (paths relative to the crate root).
+ *
+ * Conventions (all entry points):
+ *   - plain C99 types only; no C++/torch/HIP types cross the boundary
+ *     (a HIP stream is passed as `void*`).
+ *   - struct-of-arrays batch descriptors: block i reads
+ *     in_base[in_off[i] .. in_off[i]+in_len[i]) and writes at most out_cap[i]
+ *     bytes at out_base[out_off[i]..]; the callee allocates nothing the caller
+ *     keeps, and retains no pointer after return.
+ *   - `mem` says where the DATA buffers (in_base/out_base) live:
+ *       RCX_MEM_DEVICE: HBM pointers (hipMalloc / torch.cuda tensors);
+ *       RCX_MEM_HOST:   host pointers; the library stages them through HBM.
+ *     The small descriptor arrays (offsets, lengths, status, ...) are ALWAYS
+ *     host arrays; the library copies them to/from the device.
+ *   - return value = batch-level status (bad arguments, HIP failure);
+ *     per-block results go to status[i] (enum rcx_status). A failing block
+ *     never affects another block. Nothing aborts or throws across the ABI.
+ *   - calls are synchronous from the caller's view (results are complete on
+ *     return) unless the ctx was put in async mode with rcx_ctx_set_async(),
+ *     in which case DEVICE-memory calls only enqueue work on the ctx stream.
+ *   - there is NO CPU fallback: without a usable HIP device every call fails
+ *     with RCX_E_NO_DEVICE.
+ */
+#ifndef RCX_H
+#define RCX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- per-block status: mirrors the reference's io::Error strings 1:1 ------ */
+enum rcx_status {
+    RCX_OK = 0,
+    /* lib.rs:53-62,115-118 "unexpected end of file" / byteorder UnexpectedEof */
+    RCX_E_EOF = 1,
+    /* new: caller's out_cap[i] too small (the reference grows a Vec instead) */
+    RCX_E_OUTPUT_TOO_SMALL = 2,
+    /* input on which the reference panics (index OOB / assert!) or reads
+     * uninitialised memory: lz4.rs:93,135,407; bwt/mod.rs:114,230; dc.rs:213;
+     * flate.rs:297,432; ari/mod.rs:282 */
+    RCX_E_MALFORMED = 3,
+    /* flate.rs:56-65 */
+    RCX_E_HUFFMAN_TREE_TOO_LARGE = 10,     /* "huffman tree too large" */
+    RCX_E_INVALID_BLOCK_CODE = 11,         /* "invalid block code" */
+    RCX_E_INVALID_HUFFMAN_HEADER_SYMBOL = 12, /* "invalid huffman header symbol" */
+    RCX_E_INVALID_HUFFMAN_TREE = 13,       /* "invalid huffman tree" */
+    RCX_E_INVALID_HUFFMAN_TREE_HEADER = 14,/* "invalid huffman tree header" */
+    RCX_E_INVALID_HUFFMAN_CODE = 15,       /* "invalid huffman code" */
+    RCX_E_INVALID_STATIC_SIZE = 16,        /* "invalid static size" */
+    RCX_E_NOT_ENOUGH_BITS = 17,            /* "not enough bits" */
+    /* zlib.rs:59-84,111-114 */
+    RCX_E_ZLIB_FORMAT = 20,     /* "unsupported zlib stream format" */
+    RCX_E_ZLIB_WINDOW = 21,     /* "unsupported zlib window size" */
+    RCX_E_ZLIB_DICT = 22,       /* "unsupported initial dictionary in the output stream" */
+    RCX_E_ZLIB_HEADER_CHECKSUM = 23, /* "invalid zlib header checksum" */
+    RCX_E_ZLIB_CHECKSUM = 24,   /* "invalid checksum on zlib stream" */
+    /* rle.rs:153 */
+    RCX_E_RLE_LONG_RUN = 30,    /* "Overly long run" */
+    /* lz4.rs:366,376: InvalidInput with empty message */
+    RCX_E_LZ4_MAGIC = 40,
+    RCX_E_LZ4_VERSION = 41,
+    /* lz4.rs:229-230: compression_bound() == None -> encode returns 0 */
+    RCX_E_LZ4_INPUT_TOO_LARGE = 42
+};
+
+/* ---- batch-level return codes --------------------------------------------- */
+enum rcx_rc {
+    RCX_RC_OK = 0,
+    RCX_RC_BAD_ARG = -1,
+    RCX_RC_NO_DEVICE = -2,   /* no HIP device / runtime: there is no CPU path */
+    RCX_RC_HIP_ERROR = -3,
+    RCX_RC_NO_MEMORY = -4
+};
+
+enum rcx_mem { RCX_MEM_HOST = 0, RCX_MEM_DEVICE = 1 };
+
+/* inflate per-stream flag bits (out: flags[i]) */
+#define RCX_W_EMPTY_BLOCK_MIDSTREAM 1u /* flate.rs:474-476 quirk: the reference's
+                                          read() returns Ok(0) here; we decode on */
+
+typedef struct rcx_ctx rcx_ctx;
+
+/* ---- context ---------------------------------------------------------------- */
+/* One ctx per caller thread and device (thread-compatible, not thread-safe).
+ * device_id < 0 selects the current HIP device. */
+int  rcx_ctx_create(int device_id, rcx_ctx** out);
+void rcx_ctx_destroy(rcx_ctx* ctx);
+/* Launch on the caller's HIP stream (hipStream_t passed as void*; NULL = the
+ * ctx's own stream). */
+int  rcx_ctx_set_stream(rcx_ctx* ctx, void* hip_stream);
+/* async != 0: DEVICE-memory batch calls return after enqueueing; status/out_len
+ * arrays must then be DEVICE arrays too (see *_dev entry points). */
+const char* rcx_last_error(const rcx_ctx* ctx);
+const char* rcx_status_string(int status);   /* the reference's error text */
+int  rcx_version(void);
+
+/* A batch descriptor shared by every codec (struct-of-arrays, host arrays). */
+typedef struct rcx_batch {
+    const uint8_t*  in_base;   /* mem */
+    const uint64_t* in_off;    /* host [n] */
+    const uint64_t* in_len;    /* host [n] */
+    uint8_t*        out_base;  /* mem */
+    const uint64_t* out_off;   /* host [n] */
+    const uint64_t* out_cap;   /* host [n] */
+    uint64_t*       out_len;   /* host [n], written */
+    uint64_t*       in_used;   /* host [n] or NULL, written: bytes consumed */
+    int32_t*        status;    /* host [n], written: enum rcx_status */
+    uint32_t        nblocks;
+    int             mem;       /* enum rcx_mem for in_base/out_base */
+} rcx_batch;
+
+/* ---- LZ4 -------------------------------------------------------------------- */
+/* reference: src/lz4.rs:602-611 decode_block() -> BlockDecoder::decode :67-110 */
+int rcx_lz4_decode_batch(rcx_ctx*, const rcx_batch*);
+/* reference: src/lz4.rs:616-627 encode_block() -> BlockEncoder::encode :226-310
+ * (bit-exact: hash/skip/backtrack heuristics reproduced) */
+int rcx_lz4_encode_batch(rcx_ctx*, const rcx_batch*);
+/* reference: src/lz4.rs:175-181 compression_bound(); 0 == None */
+uint64_t rcx_lz4_compression_bound(uint64_t in_len);
+
+/* ---- DEFLATE / zlib / Adler-32 ---------------------------------------------- */
+/* reference: src/flate.rs:195-206,237-246,262-341,343-450 (one RFC-1951 stream
+ * per block, decoded to BFINAL). flags may be NULL. */
+int rcx_inflate_batch(rcx_ctx*, const rcx_batch*, uint32_t* flags);
+/* reference: src/zlib.rs:55-126 (header checks, inflate, Adler-32 BE trailer) */
+int rcx_zlib_decode_batch(rcx_ctx*, const rcx_batch*, uint32_t* flags);
+/* reference: src/checksum/adler.rs:22-51; out_len/out_base unused,
+ * adler[i] = State32::result() of block i */
+int rcx_adler32_batch(rcx_ctx*, const rcx_batch*, uint32_t* adler);
+
+/* ---- BWT / MTF / DC --------------------------------------------------------- */
+/* reference: src/bwt/mod.rs:136-219 compute_suffixes + TransformIterator.
+ * out block i receives L (n bytes); origin[i] = get_origin(). */
+int rcx_bwt_forward_batch(rcx_ctx*, const rcx_batch*, uint32_t* origin);
+/* reference: src/bwt/mod.rs:223-294 compute_inversion_table + InverseIterator */
+int rcx_bwt_inverse_batch(rcx_ctx*, const rcx_batch*, const uint32_t* origin);
+/* reference: src/bwt/mtf.rs:63-90 with the stream codecs' identity start :103,141 */
+int rcx_mtf_encode_batch(rcx_ctx*, const rcx_batch*);
+int rcx_mtf_decode_batch(rcx_ctx*, const rcx_batch*);
+/* reference: src/bwt/dc.rs:110-159 encode_simple::<u32> order: out block i =
+ * little-endian u32 words: 256 x init, then k distances (out_len = 4*(256+k)) */
+int rcx_dc_encode_batch(rcx_ctx*, const rcx_batch*);
+/* reference: src/bwt/dc.rs:162-252 decode_simple; in = the words above,
+ * n_out[i] = decoded length n (dc carries no length itself) */
+int rcx_dc_decode_batch(rcx_ctx*, const rcx_batch*, const uint64_t* n_out);
+
+/* ---- adaptive byte range coder ---------------------------------------------- */
+/* reference: src/entropy/ari/table.rs:185-224 ByteEncoder::write + finish
+ * (RangeEncoder::process mod.rs:117-150, table::Model :69-117) */
+int rcx_ari_byte_encode_batch(rcx_ctx*, const rcx_batch*);
+/* reference: src/entropy/ari/table.rs:229-273 ByteDecoder::read (+ finish);
+ * in_used[i] = bytes consumed so the next stream stays addressable */
+int rcx_ari_byte_decode_batch(rcx_ctx*, const rcx_batch*);
+uint64_t rcx_ari_byte_encode_bound(uint64_t in_len);
+
+/* ---- RLE -------------------------------------------------------------------- */
+/* reference: src/rle.rs:82-122 (one-shot write + finish) */
+int rcx_rle_encode_batch(rcx_ctx*, const rcx_batch*);
+/* reference: src/rle.rs:194-259 */
+int rcx_rle_decode_batch(rcx_ctx*, const rcx_batch*);
+uint64_t rcx_rle_encode_bound(uint64_t in_len);
+
+/* ---- device-resident descriptors (benchmark / pipeline use) ------------------ */
+/* Same kernels, but every array (offsets, lengths, status, ...) already lives
+ * in HBM, nothing is copied and nothing is synchronised: the call enqueues on
+ * the ctx stream and returns. This is what bench.py times. */
+typedef struct rcx_dev_batch {
+    const uint8_t*  in_base;
+    const uint64_t* in_off;
+    const uint64_t* in_len;
+    uint8_t*        out_base;
+    const uint64_t* out_off;
+    const uint64_t* out_cap;
+    uint64_t*       out_len;
+    uint64_t*       in_used;   /* may be NULL */
+    int32_t*        status;
+    uint32_t*       aux;       /* codec extra (origin / adler / flags), may be NULL */
+    uint32_t        nblocks;
+} rcx_dev_batch;
+
+enum rcx_codec {
+    RCX_LZ4_DECODE = 0, RCX_LZ4_ENCODE, RCX_INFLATE, RCX_ZLIB_DECODE, RCX_ADLER32,
+    RCX_BWT_FORWARD, RCX_BWT_INVERSE, RCX_MTF_ENCODE, RCX_MTF_DECODE,
+    RCX_DC_ENCODE, RCX_DC_DECODE, RCX_ARI_BYTE_ENCODE, RCX_ARI_BYTE_DECODE,
+    RCX_RLE_ENCODE, RCX_RLE_DECODE, RCX_CODEC_COUNT
+};
+/* scratch bytes (HBM) the codec needs for nblocks blocks of <= max_block bytes */
+uint64_t rcx_scratch_bytes(int codec, uint32_t nblocks, uint64_t max_block);
+int rcx_launch_dev(rcx_ctx*, int codec, const rcx_dev_batch*, void* scratch, uint64_t scratch_bytes);
+/* kernel variant knob for A/B measurements (0 = default/best). */
+int rcx_ctx_set_variant(rcx_ctx*, int codec, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCX_H */
