@@ -1,0 +1,76 @@
+"""ctypes binding of csrc/librcx.so (the C-ABI declared in include/rcx.h).
+
+The library is the product: if it is missing this module raises -- there is no CPU fallback and no
+import of anything under oracle/.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librcx.so")
+
+# enum rcx_codec
+(LZ4_DECODE, LZ4_ENCODE, INFLATE, ZLIB_DECODE, ADLER32, BWT_FORWARD, BWT_INVERSE, MTF_ENCODE, MTF_DECODE,
+ DC_ENCODE, DC_DECODE, ARI_BYTE_ENCODE, ARI_BYTE_DECODE, RLE_ENCODE, RLE_DECODE, CODEC_COUNT) = range(16)
+MEM_HOST, MEM_DEVICE = 0, 1
+RC_OK, RC_BAD_ARG, RC_NO_DEVICE, RC_HIP_ERROR, RC_NO_MEMORY = 0, -1, -2, -3, -4
+
+EXPORTS = [
+    "rcx_version", "rcx_ctx_create", "rcx_ctx_destroy", "rcx_ctx_set_stream", "rcx_ctx_set_variant", "rcx_last_error",
+    "rcx_status_string", "rcx_lz4_decode_batch", "rcx_lz4_encode_batch", "rcx_lz4_compression_bound",
+    "rcx_inflate_batch", "rcx_zlib_decode_batch", "rcx_adler32_batch", "rcx_bwt_forward_batch",
+    "rcx_bwt_inverse_batch", "rcx_mtf_encode_batch", "rcx_mtf_decode_batch", "rcx_dc_encode_batch",
+    "rcx_dc_decode_batch", "rcx_ari_byte_encode_batch", "rcx_ari_byte_decode_batch", "rcx_ari_byte_encode_bound",
+    "rcx_rle_encode_batch", "rcx_rle_decode_batch", "rcx_rle_encode_bound", "rcx_scratch_bytes", "rcx_launch_dev",
+]
+
+
+class Batch(C.Structure):          # struct rcx_batch
+    _fields_ = [("in_base", C.c_void_p), ("in_off", C.c_void_p), ("in_len", C.c_void_p),
+                ("out_base", C.c_void_p), ("out_off", C.c_void_p), ("out_cap", C.c_void_p),
+                ("out_len", C.c_void_p), ("in_used", C.c_void_p), ("status", C.c_void_p),
+                ("nblocks", C.c_uint32), ("mem", C.c_int)]
+
+
+class DevBatch(C.Structure):       # struct rcx_dev_batch
+    _fields_ = [("in_base", C.c_void_p), ("in_off", C.c_void_p), ("in_len", C.c_void_p),
+                ("out_base", C.c_void_p), ("out_off", C.c_void_p), ("out_cap", C.c_void_p),
+                ("out_len", C.c_void_p), ("in_used", C.c_void_p), ("status", C.c_void_p),
+                ("aux", C.c_void_p), ("nblocks", C.c_uint32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("rust_compress_amd: %s is missing -- build it with `python __graft_entry__.py build` "
+                               "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.rcx_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.rcx_ctx_destroy.argtypes = [C.c_void_p]
+        L.rcx_ctx_destroy.restype = None
+        L.rcx_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.rcx_ctx_set_variant.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.rcx_last_error.argtypes = [C.c_void_p]
+        L.rcx_last_error.restype = C.c_char_p
+        L.rcx_status_string.argtypes = [C.c_int]
+        L.rcx_status_string.restype = C.c_char_p
+        for name in ("rcx_lz4_compression_bound", "rcx_ari_byte_encode_bound", "rcx_rle_encode_bound"):
+            f = getattr(L, name)
+            f.argtypes = [C.c_uint64]
+            f.restype = C.c_uint64
+        L.rcx_scratch_bytes.argtypes = [C.c_int, C.c_uint32, C.c_uint64]
+        L.rcx_scratch_bytes.restype = C.c_uint64
+        L.rcx_launch_dev.argtypes = [C.c_void_p, C.c_int, C.POINTER(DevBatch), C.c_void_p, C.c_uint64]
+        for name in ("rcx_lz4_decode_batch", "rcx_lz4_encode_batch", "rcx_mtf_encode_batch", "rcx_mtf_decode_batch",
+                     "rcx_dc_encode_batch", "rcx_ari_byte_encode_batch", "rcx_ari_byte_decode_batch",
+                     "rcx_rle_encode_batch", "rcx_rle_decode_batch"):
+            getattr(L, name).argtypes = [C.c_void_p, C.POINTER(Batch)]
+        for name in ("rcx_inflate_batch", "rcx_zlib_decode_batch", "rcx_adler32_batch", "rcx_bwt_forward_batch",
+                     "rcx_bwt_inverse_batch", "rcx_dc_decode_batch"):
+            getattr(L, name).argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p]
+        _lib = L
+    return _lib

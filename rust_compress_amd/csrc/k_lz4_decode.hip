@@ -1,0 +1,449 @@
+// k_lz4_decode.hip -- batched LZ4 block decode for gfx950 (wave64), one wave per LZ4 block.
+//
+// Replaces the reference's BlockDecoder::decode (src/lz4.rs:67-110: token -> length() :112-122 ->
+// literal memcpy :78-82 -> u16 LE offset :91 -> cp() byte loop :131-140) for a whole batch of
+// independent blocks.  Output bytes are identical to the reference for every input it accepts; inputs
+// on which it panics / reads uninitialised bytes return RCX_E_MALFORMED (see oracle/o_lz4.c).
+//
+// Two kernels:
+//   v1  one sequence at a time, all 64 lanes copy its literals and its match straight in HBM/L2.
+//       Simple, used as the A/B baseline and as the fallback for exotic geometry.
+//   v2  the production design.  The token chain is walked on the scalar unit out of a register
+//       window (v_readlane), up to 64 sequences are collected one per lane, then the batch is emitted
+//       lane-per-sequence into an LDS output ring (wave prefix-sum for the output positions, multi-round
+//       resolution for matches that read this batch's own output) and the ring is drained to HBM with
+//       coalesced 16-byte stores.  Compressed bytes are staged through LDS in 2 KiB pieces.
+#include "rcx_dev.h"
+
+// ------------------------------------------------------------------------------------------------
+// v1: sequence-serial, wave-cooperative copies in global memory
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_lz4_decode_v1(rcx_kargs a)
+{
+    const uint32_t b = blockIdx.x;
+    if (b >= a.nblocks) return;
+    const unsigned lane = rcx_lane();
+    const uint8_t* in = a.in_base + a.in_off[b];
+    const uint32_t n = (uint32_t)a.in_len[b];
+    uint8_t* out = a.out_base + a.out_off[b];
+    const uint64_t cap64 = a.out_cap[b];
+    const uint32_t cap = cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)cap64;
+    uint32_t cur = 0, end = 0;
+    int st = RCX_OK;
+    while (cur < n) {
+        uint32_t code = __builtin_amdgcn_readfirstlane((uint32_t)in[cur]);
+        cur++;
+        uint32_t len = code >> 4;
+        if (len == 15) {
+            for (;;) {
+                if (cur >= n) { st = RCX_E_MALFORMED; break; }
+                uint32_t t = __builtin_amdgcn_readfirstlane((uint32_t)in[cur]);
+                cur++;
+                len += t;
+                if (t != 255) break;
+            }
+            if (st) break;
+        }
+        if (len > 0) {
+            if (len > n - cur) { st = RCX_E_MALFORMED; break; }
+            if (len > cap - end) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
+            for (uint32_t i = lane; i < len; i += 64) out[end + i] = in[cur + i];
+            end += len;
+            cur += len;
+        }
+        if (cur == n) break;
+        if (n - cur < 2) { st = RCX_E_MALFORMED; break; }
+        uint32_t back = __builtin_amdgcn_readfirstlane((uint32_t)in[cur] | ((uint32_t)in[cur + 1] << 8));
+        cur += 2;
+        if (back > end || back == 0) { st = RCX_E_MALFORMED; break; }
+        uint32_t mlen = code & 15;
+        if (mlen == 15) {
+            for (;;) {
+                if (cur >= n) { st = RCX_E_MALFORMED; break; }
+                uint32_t t = __builtin_amdgcn_readfirstlane((uint32_t)in[cur]);
+                cur++;
+                mlen += t;
+                if (t != 255) break;
+            }
+            if (st) break;
+        }
+        mlen += 4;
+        if (mlen > cap - end) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
+        rcx_wave_sync();                     // literals of this sequence are visible to the match reads
+        const uint32_t src0 = end - back;
+        if (back >= mlen) {
+            for (uint32_t i = lane; i < mlen; i += 64) out[end + i] = out[src0 + i];
+        } else {
+            // overlapping match == periodic extension of the `back` bytes before `end`
+            uint32_t r = lane % back;
+            const uint32_t step = 64 % back;
+            for (uint32_t i = lane; i < mlen; i += 64) {
+                out[end + i] = out[src0 + r];
+                r += step;
+                if (r >= back) r -= back;
+            }
+        }
+        rcx_wave_sync();
+        end += mlen;
+    }
+    if (lane == 0) {
+        a.status[b] = st;
+        a.out_len[b] = st ? 0 : end;
+        if (a.in_used) a.in_used[b] = n;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// v2: scalar token walk out of a register window + lane-per-sequence batched emission
+// ------------------------------------------------------------------------------------------------
+
+template <int OB, int CB, int LCAP, int MCAP>
+struct Lz4V2 {
+    static constexpr int TFAST = 64 * 32;        // 64 fast sequences, each <= 14 literals + 18 match bytes
+    static constexpr int TSLOW = OB - TFAST - MCAP - 64 > 1024 ? 1024 : OB - TFAST - MCAP - 64;
+    static constexpr int RH = MCAP > 128 ? MCAP : 128;   // ring history re-read after a wide copy
+    static constexpr int MARGIN = LCAP + 16;
+    static constexpr uint32_t FLAG = 0x80000000u;
+    static_assert(TSLOW >= 256, "ring too small");
+    static_assert((OB & (OB - 1)) == 0 && (CB % 1024) == 0, "geometry");
+
+    const uint8_t* in; uint8_t* out; uint32_t n, cap;
+    uint8_t* cbuf; uint8_t* ring;
+    int32_t cbase; uint32_t cend;        // cbuf[i] holds comp byte cbase+i for comp positions < cend
+    uint32_t abs0;                        // low bits of the output address: ring index of position p = (abs0+p)&(OB-1)
+    uint32_t oend, gflush, rlo;
+    unsigned lane;
+
+    __device__ __forceinline__ uint32_t ridx(uint32_t p) const { return (abs0 + p) & (uint32_t)(OB - 1); }
+
+    // stage CB compressed bytes around `cur` into LDS (16-byte global loads on 16-byte aligned addresses)
+    __device__ void stage(uint32_t cur)
+    {
+        const uint32_t inmis = (uint32_t)((uintptr_t)in & 15u);
+        cbase = (int32_t)((cur + inmis) & ~15u) - (int32_t)inmis;
+#pragma unroll
+        for (int r = 0; r < CB / 1024; r++) {
+            const int j = r * 64 + (int)lane;
+            const int32_t pos = cbase + 16 * j;
+            if (pos >= 0 && (uint32_t)pos + 16 <= n) {
+                *(rcx_u32x4*)(cbuf + 16 * j) = *(const rcx_u32x4*)(in + pos);
+            } else {
+                for (int t = 0; t < 16; t++) {
+                    const int32_t q = pos + t;
+                    cbuf[16 * j + t] = (q >= 0 && (uint32_t)q < n) ? in[q] : (uint8_t)0;
+                }
+            }
+        }
+        const uint32_t lim = (uint32_t)(cbase + CB);
+        cend = n < lim ? n : lim;
+        rcx_wave_sync();
+    }
+
+    __device__ __forceinline__ uint32_t peek(uint32_t q) const   // uniform q < n
+    {
+        const int32_t idx = (int32_t)q - cbase;
+        uint32_t v = (idx >= 0 && q < cend) ? (uint32_t)cbuf[idx] : (uint32_t)in[q];
+        return __builtin_amdgcn_readfirstlane(v);
+    }
+
+    // drain ring -> HBM for output positions [gflush, to); keeps a <16-byte tail in LDS unless `final`
+    __device__ void flush(uint32_t to, bool final)
+    {
+        uint32_t from = gflush;
+        if (to <= from) return;
+        const uint32_t mis = (uint32_t)((uintptr_t)(out + from) & 15u);
+        uint32_t head = mis ? 16u - mis : 0u;
+        if (head > to - from) head = final ? to - from : 0u;
+        if (mis && head == 0 && !final) return;            // not enough to reach an aligned boundary yet
+        if (head) {
+            if (lane < head) out[from + lane] = ring[ridx(from + lane)];
+            from += head;
+        }
+        const uint32_t nch = (to - from) >> 4;
+        for (uint32_t c = lane; c < nch; c += 64) {
+            const uint32_t p = from + 16 * c;
+            *(rcx_u32x4*)(out + p) = *(const rcx_u32x4*)(ring + ridx(p));
+        }
+        from += nch * 16;
+        if (final) {
+            const uint32_t tail = to - from;
+            if (lane < tail) out[from + lane] = ring[ridx(from + lane)];
+            from = to;
+        }
+        gflush = from;
+    }
+
+    // after a wide copy wrote HBM directly: re-read the last RH output bytes into the ring
+    __device__ void repair_ring()
+    {
+        rlo = oend > (uint32_t)RH ? oend - RH : 0u;
+        rcx_wave_sync();
+        for (uint32_t p = rlo + lane; p < oend; p += 64) ring[ridx(p)] = out[p];
+        rcx_wave_sync();
+    }
+
+    // out[oend..oend+len) = in[src..src+len), HBM -> HBM, 16 bytes per lane, stores 16-byte aligned
+    __device__ void wide_literals(uint32_t src, uint32_t len)
+    {
+        uint8_t* d = out + oend;
+        const uint8_t* s = in + src;
+        const uint32_t mis = (uint32_t)((uintptr_t)d & 15u);
+        uint32_t head = mis ? 16u - mis : 0u;
+        if (head > len) head = len;
+        if (lane < head) d[lane] = s[lane];
+        const uint32_t nb = (len - head) >> 4;
+        for (uint32_t c = lane; c < nb; c += 64)
+            *(rcx_u32x4*)(d + head + 16 * c) = *(const rcx_u32x4_u*)(s + head + 16 * c);
+        const uint32_t done = head + nb * 16;
+        if (lane < len - done) d[done + lane] = s[done + lane];
+    }
+
+    // out[oend..oend+len) = out[oend-off..], overlapping allowed: copy in pieces no longer than the
+    // (doubling) effective offset so that every piece reads finished bytes only
+    __device__ void wide_match(uint32_t off, uint32_t len)
+    {
+        uint32_t e = off, d = oend, rem = len;
+        while (rem) {
+            uint32_t C = rem < e ? rem : e;
+            if (C > 1024) C = 1024;
+            const uint32_t i0 = 16 * lane;
+            if (i0 + 16 <= C) {
+                *(rcx_u32x4_u*)(out + d + i0) = *(const rcx_u32x4_u*)(out + d - e + i0);
+            } else if (i0 < C) {
+                for (uint32_t t = i0; t < C; t++) out[d + t] = out[d - e + t];
+            }
+            rcx_wave_sync();
+            d += C; rem -= C;
+            if (C == e && e < 1024) e *= 2;
+        }
+    }
+
+    // Emit `ns` collected sequences (one per lane).  Returns 0 or an rcx_status.
+    __device__ int emit(int ns, uint32_t e_pos, uint32_t s_L, uint32_t s_M, uint32_t s_off, uint32_t s_src)
+    {
+        const bool act = (int)lane < ns;
+        uint32_t L = 0, M = 0, off = 0, src = 0;
+        if (act) {
+            if (e_pos & FLAG) { L = s_L; M = s_M; off = s_off; src = s_src; }
+            else {
+                const uint32_t t = cbuf[(int32_t)e_pos - cbase];
+                L = t >> 4; M = (t & 15u) + 4u; src = e_pos + 1;
+                const int32_t oi = (int32_t)(src + L) - cbase;
+                off = (uint32_t)cbuf[oi] | ((uint32_t)cbuf[oi + 1] << 8);
+            }
+        }
+        const uint32_t len = L + M;
+        const uint32_t incl = rcx_wave_incl_scan(len);
+        const uint32_t T = __builtin_amdgcn_readlane(incl, 63);
+        const uint32_t ostart = oend + incl - len;
+        const uint32_t mdst = ostart + L;
+        // validity in stream order (oracle/o_lz4.c): literal overflow, bad offset, match overflow
+        int err = 0;
+        if (act) {
+            if (L > cap - ostart || ostart > cap) err = RCX_E_OUTPUT_TOO_SMALL;
+            else if (M && (off == 0 || off > mdst)) err = RCX_E_MALFORMED;
+            else if (M && M > cap - mdst) err = RCX_E_OUTPUT_TOO_SMALL;
+        }
+        const unsigned long long bad = __ballot(err != 0);
+        if (bad) return __builtin_amdgcn_readlane(err, __ffsll(bad) - 1);
+
+        const uint32_t bend = oend + T;
+        uint32_t rlo_eff = rlo;
+        if (bend > (uint32_t)OB && bend - OB > rlo_eff) rlo_eff = bend - OB;
+
+        // literals: compressed LDS window -> ring (no cross-lane dependence)
+        const uint32_t maxL = rcx_wave_max(L);
+        const int32_t sbase = (int32_t)src - cbase;
+        for (uint32_t i = 0; i < maxL; i++)
+            if (i < L) ring[ridx(ostart + i)] = cbuf[sbase + (int32_t)i];
+
+        // matches whose source is entirely older than the ring: HBM -> ring (already flushed, no overlap)
+        const uint32_t slo = mdst - off;
+        const bool isnear = M && slo >= rlo_eff;
+        const bool isfar = M && !isnear;
+        const uint32_t maxF = rcx_wave_max(isfar ? M : 0u);
+        for (uint32_t i0 = 0; i0 < maxF; i0 += 8) {
+            uint8_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = (isfar && i0 + u < M) ? out[slo + i0 + u] : (uint8_t)0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (isfar && i0 + u < M) ring[ridx(mdst + i0 + u)] = v[u];
+        }
+        rcx_wave_sync();
+
+        // matches that read the ring: multi-round resolution.  A lane may copy once its source (clipped to
+        // below its own destination) lies below the destination of the first still-pending match.
+        bool pending = isnear;
+        const uint32_t shi = (slo + M < mdst) ? slo + M : mdst;
+        for (;;) {
+            const unsigned long long pm = __ballot(pending);
+            if (!pm) break;
+            const int first = __ffsll(pm) - 1;
+            const uint32_t F = __builtin_amdgcn_readlane(mdst, first);
+            const bool ready = pending && ((int)lane == first || shi <= F);
+            const uint32_t maxM = rcx_wave_max(ready ? M : 0u);
+            for (uint32_t i = 0; i < maxM; i++) {
+                uint8_t v = 0;
+                if (ready && i < M) v = ring[ridx(slo + i)];
+                rcx_wave_sync();
+                if (ready && i < M) ring[ridx(mdst + i)] = v;
+                rcx_wave_sync();
+            }
+            pending = pending && !ready;
+        }
+        oend = bend;
+        flush(oend, false);
+        return 0;
+    }
+
+    __device__ void run(int32_t* st_out, uint32_t* len_out)
+    {
+        lane = rcx_lane();
+        abs0 = (uint32_t)((uintptr_t)out & (uintptr_t)(OB - 1));
+        oend = 0; gflush = 0; rlo = 0;
+        int st = RCX_OK;
+        uint32_t cur = 0;
+        if (n) stage(0); else { cbase = 0; cend = 0; }
+
+        uint32_t e_pos = 0, s_L = 0, s_M = 0, s_off = 0, s_src = 0;   // per-lane batch entries
+        int ns = 0;
+        uint32_t tslow = 0;
+        uint32_t wb = 0, rel = 64, dvec = 0;
+        bool have_win = false;
+
+        while (cur < n) {
+            if (cend < n && cur + (uint32_t)MARGIN > cend) {           // compressed window exhausted
+                if (ns) { st = emit(ns, e_pos, s_L, s_M, s_off, s_src); ns = 0; tslow = 0; if (st) break; }
+                stage(cur);
+                have_win = false;
+            }
+            if (!have_win || rel >= 64) {
+                // register window: lane p describes the candidate token at comp position cur+p:
+                // hop distance 3+L for a plain token (no length extensions, not near the end), else 0
+                wb = cur; rel = 0; have_win = true;
+                const uint32_t q = cur + lane;
+                const uint32_t fast_lim = cend >= 20 ? cend - 20 : 0;
+                uint32_t d = 0;
+                if (q < fast_lim) {
+                    const uint32_t t = cbuf[(int32_t)q - cbase];
+                    const uint32_t L = t >> 4, M = t & 15u;
+                    d = (L == 15u || M == 15u) ? 0u : 3u + L;
+                }
+                dvec = d;
+            }
+            // fast walk on the scalar unit
+            uint32_t d = 0;
+            for (;;) {
+                d = __builtin_amdgcn_readlane(dvec, rel);
+                if (d == 0) break;
+                e_pos = ((int)lane == ns) ? (uint32_t)(cur) : e_pos;
+                ns++; cur += d; rel += d;
+                if (rel >= 64 || ns == 64) break;
+            }
+            if (ns == 64) { st = emit(ns, e_pos, s_L, s_M, s_off, s_src); ns = 0; tslow = 0; if (st) break; continue; }
+            if (d != 0) continue;                                       // window ran out: recompute
+
+            // ---- general path for the token at `cur` (length extensions, block end, long sequences)
+            const uint32_t t = peek(cur);
+            uint32_t p = cur + 1;
+            uint32_t L = t >> 4;
+            if (L == 15) {
+                for (;;) {
+                    if (p >= n) { st = RCX_E_MALFORMED; break; }
+                    const uint32_t x = peek(p); p++;
+                    L += x;
+                    if (x != 255) break;
+                }
+                if (st) break;
+            }
+            const uint32_t lit_src = p;
+            if (L > n - p) { st = RCX_E_MALFORMED; break; }
+            p += L;
+            uint32_t M = 0, off = 0;
+            if (p != n) {
+                if (n - p < 2) {
+                    // the reference copies the literals, then panics on the offset read: literal overflow first
+                    if (ns) { st = emit(ns, e_pos, s_L, s_M, s_off, s_src); ns = 0; tslow = 0; if (st) break; }
+                    st = (L > cap - oend) ? RCX_E_OUTPUT_TOO_SMALL : RCX_E_MALFORMED; break;
+                }
+                off = peek(p) | (peek(p + 1) << 8);
+                p += 2;
+                M = t & 15u;
+                if (M == 15) {
+                    for (;;) {
+                        if (p >= n) { st = RCX_E_MALFORMED; break; }
+                        const uint32_t x = peek(p); p++;
+                        M += x;
+                        if (x != 255) break;
+                    }
+                    if (st) {
+                        // stream order: literal overflow / bad offset come before the truncated extension
+                        if (ns) { int e2 = emit(ns, e_pos, s_L, s_M, s_off, s_src); ns = 0; tslow = 0; if (e2) { st = e2; break; } }
+                        if (L > cap - oend) st = RCX_E_OUTPUT_TOO_SMALL;
+                        break;
+                    }
+                }
+                M += 4;
+            }
+            const bool eligible = L <= (uint32_t)LCAP && M <= (uint32_t)MCAP && lit_src + L <= cend &&
+                                  (int32_t)lit_src >= cbase;
+            if (eligible) {
+                if (tslow + L + M > (uint32_t)TSLOW) { st = emit(ns, e_pos, s_L, s_M, s_off, s_src); ns = 0; tslow = 0; if (st) break; }
+                e_pos = ((int)lane == ns) ? (uint32_t)(FLAG) : e_pos;
+                s_L = ((int)lane == ns) ? (uint32_t)(L) : s_L;
+                s_M = ((int)lane == ns) ? (uint32_t)(M) : s_M;
+                s_off = ((int)lane == ns) ? (uint32_t)(off) : s_off;
+                s_src = ((int)lane == ns) ? (uint32_t)(lit_src) : s_src;
+                ns++; tslow += L + M;
+                if (ns == 64) { st = emit(ns, e_pos, s_L, s_M, s_off, s_src); ns = 0; tslow = 0; if (st) break; }
+            } else {
+                // wide sequence: finish what is collected, then copy HBM -> HBM with the whole wave
+                if (ns) { st = emit(ns, e_pos, s_L, s_M, s_off, s_src); ns = 0; tslow = 0; if (st) break; }
+                flush(oend, true);
+                if (L > cap - oend) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
+                if (L) { wide_literals(lit_src, L); oend += L; }
+                if (M) {
+                    if (off == 0 || off > oend) { st = RCX_E_MALFORMED; break; }
+                    if (M > cap - oend) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
+                    rcx_wave_sync();
+                    wide_match(off, M);
+                    oend += M;
+                }
+                gflush = oend;
+                repair_ring();
+            }
+            cur = p;
+            rel = cur - wb;
+        }
+        if (!st && ns) st = emit(ns, e_pos, s_L, s_M, s_off, s_src);
+        else if (st && ns) { int e2 = emit(ns, e_pos, s_L, s_M, s_off, s_src); if (e2) st = e2; }
+        if (!st) flush(oend, true);
+        *st_out = st;
+        *len_out = st ? 0u : oend;
+    }
+};
+
+template <int OB, int CB, int LCAP, int MCAP, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_lz4_decode_v2(rcx_kargs a)
+{
+    __shared__ __align__(16) uint8_t s_cbuf[WAVES][CB + 64];
+    __shared__ __align__(16) uint8_t s_ring[WAVES][OB];
+    const unsigned w = threadIdx.x >> 6;
+    const uint32_t b = blockIdx.x * WAVES + w;
+    if (b >= a.nblocks) return;
+    Lz4V2<OB, CB, LCAP, MCAP> s;
+    s.in = a.in_base + a.in_off[b];
+    s.n = (uint32_t)a.in_len[b];
+    s.out = a.out_base + a.out_off[b];
+    const uint64_t cap64 = a.out_cap[b];
+    s.cap = cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)cap64;
+    s.cbuf = s_cbuf[w];
+    s.ring = s_ring[w];
+    int32_t st; uint32_t olen;
+    s.run(&st, &olen);
+    if ((threadIdx.x & 63u) == 0) {
+        a.status[b] = st;
+        a.out_len[b] = olen;
+        if (a.in_used) a.in_used[b] = s.n;
+    }
+}

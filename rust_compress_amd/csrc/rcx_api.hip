@@ -1,0 +1,293 @@
+// rcx_api.hip -- the C-ABI of include/rcx.h over the gfx950 kernels.  Host side: descriptor staging,
+// HBM staging for host-memory batches, kernel dispatch on the ctx stream.  There is no CPU code path:
+// every entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "rcx_dev.h"
+#include "k_lz4_decode.hip"
+#include "k_lz4_encode.hip"
+#include "k_inflate.hip"
+#include "k_bwt.hip"
+#include "k_serial.hip"
+
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = n + n / 8 + 4096;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct rcx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    std::string err;
+    int variant[RCX_CODEC_COUNT] = {0};
+    DevBuf d_in, d_out, d_desc, d_scratch;
+    std::vector<uint8_t> h_desc;
+};
+
+#define HIPCHK(ctx, call)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            return e_ == hipErrorOutOfMemory ? RCX_RC_NO_MEMORY : RCX_RC_HIP_ERROR;           \
+        }                                                                                     \
+    } while (0)
+
+extern "C" int rcx_version(void) { return 1; }
+
+extern "C" int rcx_ctx_create(int device_id, rcx_ctx** out)
+{
+    if (!out) return RCX_RC_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RCX_RC_NO_DEVICE;
+    rcx_ctx* c = new rcx_ctx();
+    if (device_id < 0) { if (hipGetDevice(&c->device) != hipSuccess) { delete c; return RCX_RC_NO_DEVICE; } }
+    else { if (device_id >= ndev || hipSetDevice(device_id) != hipSuccess) { delete c; return RCX_RC_NO_DEVICE; } c->device = device_id; }
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RCX_RC_HIP_ERROR; }
+    c->stream = c->own_stream;
+    *out = c;
+    return RCX_RC_OK;
+}
+
+extern "C" void rcx_ctx_destroy(rcx_ctx* c)
+{
+    if (!c) return;
+    (void)hipStreamSynchronize(c->stream);
+    c->d_in.release(); c->d_out.release(); c->d_desc.release(); c->d_scratch.release();
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" int rcx_ctx_set_stream(rcx_ctx* c, void* s)
+{
+    if (!c) return RCX_RC_BAD_ARG;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return RCX_RC_OK;
+}
+
+extern "C" int rcx_ctx_set_variant(rcx_ctx* c, int codec, int variant)
+{
+    if (!c || codec < 0 || codec >= RCX_CODEC_COUNT) return RCX_RC_BAD_ARG;
+    c->variant[codec] = variant;
+    return RCX_RC_OK;
+}
+
+extern "C" const char* rcx_last_error(const rcx_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+extern "C" const char* rcx_status_string(int s)
+{
+    switch (s) {
+    case RCX_OK: return "ok";
+    case RCX_E_EOF: return "unexpected end of file";
+    case RCX_E_OUTPUT_TOO_SMALL: return "output buffer too small";
+    case RCX_E_MALFORMED: return "malformed input (the reference panics here)";
+    case RCX_E_HUFFMAN_TREE_TOO_LARGE: return "huffman tree too large";
+    case RCX_E_INVALID_BLOCK_CODE: return "invalid block code";
+    case RCX_E_INVALID_HUFFMAN_HEADER_SYMBOL: return "invalid huffman header symbol";
+    case RCX_E_INVALID_HUFFMAN_TREE: return "invalid huffman tree";
+    case RCX_E_INVALID_HUFFMAN_TREE_HEADER: return "invalid huffman tree header";
+    case RCX_E_INVALID_HUFFMAN_CODE: return "invalid huffman code";
+    case RCX_E_INVALID_STATIC_SIZE: return "invalid static size";
+    case RCX_E_NOT_ENOUGH_BITS: return "not enough bits";
+    case RCX_E_ZLIB_FORMAT: return "unsupported zlib stream format";
+    case RCX_E_ZLIB_WINDOW: return "unsupported zlib window size";
+    case RCX_E_ZLIB_DICT: return "unsupported initial dictionary in the output stream";
+    case RCX_E_ZLIB_HEADER_CHECKSUM: return "invalid zlib header checksum";
+    case RCX_E_ZLIB_CHECKSUM: return "invalid checksum on zlib stream";
+    case RCX_E_RLE_LONG_RUN: return "Overly long run";
+    case RCX_E_LZ4_MAGIC: return "";
+    case RCX_E_LZ4_VERSION: return "";
+    case RCX_E_LZ4_INPUT_TOO_LARGE: return "input too large";
+    default: return "unknown status";
+    }
+}
+
+extern "C" uint64_t rcx_lz4_compression_bound(uint64_t n) { return n > 0x7e000000ull ? 0 : n + n / 255 + 16 + 4; }
+extern "C" uint64_t rcx_ari_byte_encode_bound(uint64_t n) { return 2 * n + 16; }
+extern "C" uint64_t rcx_rle_encode_bound(uint64_t n) { return n + n / 2 + 16; }
+
+// ---- scratch requirements ---------------------------------------------------------------------
+static const uint32_t LZ4E_CHUNK = 2048;        // LZ4 blocks encoded per launch (512 KiB table each)
+
+extern "C" uint64_t rcx_scratch_bytes(int codec, uint32_t nblocks, uint64_t max_block)
+{
+    switch (codec) {
+    case RCX_LZ4_ENCODE: return (uint64_t)(nblocks < LZ4E_CHUNK ? nblocks : LZ4E_CHUNK) * LZ4E_TABLE * 4ull;
+    case RCX_BWT_FORWARD: return bwt_forward_scratch_bytes(nblocks, max_block);
+    case RCX_BWT_INVERSE: return bwt_inverse_scratch_bytes(nblocks, max_block);
+    default: return 0;
+    }
+}
+
+// ---- kernel dispatch ----------------------------------------------------------------------------
+static int launch_codec(rcx_ctx* c, int codec, rcx_kargs& k)
+{
+    hipStream_t s = c->stream;
+    const uint32_t n = k.nblocks;
+    if (n == 0) return RCX_RC_OK;
+    const int v = c->variant[codec];
+    switch (codec) {
+    case RCX_LZ4_DECODE:
+        if (v == 1) hipLaunchKernelGGL(k_lz4_decode_v1, dim3(n), dim3(64), 0, s, k);
+        else if (v == 2) hipLaunchKernelGGL((k_lz4_decode_v2<4096, 2048, 64, 64, 4>), dim3((n + 3) / 4), dim3(256), 0, s, k);
+        else if (v == 3) hipLaunchKernelGGL((k_lz4_decode_v2<4096, 2048, 32, 32, 1>), dim3(n), dim3(64), 0, s, k);
+        else if (v == 4) hipLaunchKernelGGL((k_lz4_decode_v2<8192, 2048, 128, 128, 1>), dim3(n), dim3(64), 0, s, k);
+        else hipLaunchKernelGGL((k_lz4_decode_v2<4096, 2048, 64, 64, 1>), dim3(n), dim3(64), 0, s, k);
+        break;
+    case RCX_LZ4_ENCODE: {
+        if (k.scratch_bytes < rcx_scratch_bytes(codec, n, 0)) { c->err = "lz4 encode: scratch too small"; return RCX_RC_BAD_ARG; }
+        for (uint32_t b0 = 0; b0 < n; b0 += LZ4E_CHUNK) {
+            const uint32_t cnt = n - b0 < LZ4E_CHUNK ? n - b0 : LZ4E_CHUNK;
+            HIPCHK(c, hipMemsetAsync(k.scratch, 0, (size_t)cnt * LZ4E_TABLE * 4ull, s));
+            hipLaunchKernelGGL(k_lz4_encode, dim3(cnt), dim3(64), 0, s, k, b0);
+        }
+        break; }
+    case RCX_INFLATE:
+    case RCX_ZLIB_DECODE:
+        launch_inflate(s, k, codec == RCX_ZLIB_DECODE, v);
+        break;
+    case RCX_ADLER32:
+        launch_adler32(s, k);
+        break;
+    case RCX_BWT_FORWARD: {
+        int rc = launch_bwt_forward(s, k, v, c->err);
+        if (rc) return rc;
+        break; }
+    case RCX_BWT_INVERSE: {
+        int rc = launch_bwt_inverse(s, k, v, c->err);
+        if (rc) return rc;
+        break; }
+    case RCX_MTF_ENCODE: case RCX_MTF_DECODE: case RCX_DC_ENCODE: case RCX_DC_DECODE:
+    case RCX_ARI_BYTE_ENCODE: case RCX_ARI_BYTE_DECODE: case RCX_RLE_ENCODE: case RCX_RLE_DECODE:
+        launch_serial(s, codec, k, v);
+        break;
+    default:
+        c->err = "unknown codec";
+        return RCX_RC_BAD_ARG;
+    }
+    HIPCHK(c, hipGetLastError());
+    return RCX_RC_OK;
+}
+
+extern "C" int rcx_launch_dev(rcx_ctx* c, int codec, const rcx_dev_batch* b, void* scratch, uint64_t scratch_bytes)
+{
+    if (!c || !b || codec < 0 || codec >= RCX_CODEC_COUNT) return RCX_RC_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    rcx_kargs k;
+    k.in_base = b->in_base; k.in_off = b->in_off; k.in_len = b->in_len;
+    k.out_base = b->out_base; k.out_off = b->out_off; k.out_cap = b->out_cap;
+    k.out_len = b->out_len; k.in_used = b->in_used; k.status = b->status; k.aux = b->aux;
+    k.n_out = nullptr; k.scratch = scratch; k.scratch_bytes = scratch_bytes; k.nblocks = b->nblocks;
+    if (codec == RCX_DC_DECODE) { c->err = "dc decode needs n_out: use rcx_dc_decode_batch"; return RCX_RC_BAD_ARG; }
+    return launch_codec(c, codec, k);
+}
+
+// ---- host-descriptor batch path -------------------------------------------------------------------
+// Descriptor block layout in HBM (all 8-byte aligned):
+//   in_off[n] in_len[n] out_off[n] out_cap[n] n_out[n] | out_len[n] in_used[n] | status[n] aux[n]
+static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* aux_in, uint32_t* aux_out,
+                     const uint64_t* n_out, bool needs_out)
+{
+    if (!c) return RCX_RC_BAD_ARG;
+    if (!b || (b->nblocks && (!b->in_off || !b->in_len || !b->status))) { c->err = "null descriptor array"; return RCX_RC_BAD_ARG; }
+    if (needs_out && b->nblocks && (!b->out_off || !b->out_cap || !b->out_len)) { c->err = "null output descriptor"; return RCX_RC_BAD_ARG; }
+    const uint32_t n = b->nblocks;
+    if (n == 0) return RCX_RC_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    uint64_t in_span = 0, out_span = 0, max_block = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint64_t e = b->in_off[i] + b->in_len[i];
+        if (e > in_span) in_span = e;
+        if (b->in_len[i] > max_block) max_block = b->in_len[i];
+        if (needs_out) {
+            const uint64_t o = b->out_off[i] + b->out_cap[i];
+            if (o > out_span) out_span = o;
+            if (b->out_cap[i] > max_block) max_block = b->out_cap[i];
+        }
+    }
+    if ((in_span && !b->in_base) || (out_span && !b->out_base)) { c->err = "null data pointer"; return RCX_RC_BAD_ARG; }
+    const uint8_t* d_in = b->in_base;
+    uint8_t* d_out = b->out_base;
+    if (b->mem == RCX_MEM_HOST) {
+        HIPCHK(c, c->d_in.reserve(in_span + 64));
+        HIPCHK(c, c->d_out.reserve(out_span + 64));
+        if (in_span) HIPCHK(c, hipMemcpyAsync(c->d_in.p, b->in_base, in_span, hipMemcpyHostToDevice, s));
+        d_in = (const uint8_t*)c->d_in.p;
+        d_out = (uint8_t*)c->d_out.p;
+    } else if (b->mem != RCX_MEM_DEVICE) { c->err = "bad mem kind"; return RCX_RC_BAD_ARG; }
+
+    const size_t N = n;
+    const size_t in_words = 5 * N;                 // u64
+    const size_t res_words = 2 * N;                // u64
+    const size_t desc_bytes = (in_words + res_words) * 8 + 2 * N * 4 + 64;
+    HIPCHK(c, c->d_desc.reserve(desc_bytes));
+    c->h_desc.resize(desc_bytes);
+    uint64_t* h64 = (uint64_t*)c->h_desc.data();
+    memcpy(h64 + 0 * N, b->in_off, N * 8);
+    memcpy(h64 + 1 * N, b->in_len, N * 8);
+    if (needs_out) { memcpy(h64 + 2 * N, b->out_off, N * 8); memcpy(h64 + 3 * N, b->out_cap, N * 8); }
+    else memset(h64 + 2 * N, 0, 2 * N * 8);
+    if (n_out) memcpy(h64 + 4 * N, n_out, N * 8); else memset(h64 + 4 * N, 0, N * 8);
+    int32_t* h_status = (int32_t*)(h64 + 7 * N);
+    uint32_t* h_aux = (uint32_t*)(h_status + N);
+    for (size_t i = 0; i < N; i++) h_status[i] = RCX_E_MALFORMED;
+    if (aux_in) memcpy(h_aux, aux_in, N * 4); else memset(h_aux, 0, N * 4);
+    memset(h64 + 5 * N, 0, 2 * N * 8);
+    HIPCHK(c, hipMemcpyAsync(c->d_desc.p, c->h_desc.data(), (7 * N) * 8 + 2 * N * 4, hipMemcpyHostToDevice, s));
+    uint64_t* d64 = (uint64_t*)c->d_desc.p;
+
+    rcx_kargs k;
+    k.in_base = d_in; k.in_off = d64; k.in_len = d64 + N;
+    k.out_base = d_out; k.out_off = d64 + 2 * N; k.out_cap = d64 + 3 * N;
+    k.n_out = d64 + 4 * N;
+    k.out_len = d64 + 5 * N; k.in_used = d64 + 6 * N;
+    k.status = (int32_t*)(d64 + 7 * N); k.aux = (uint32_t*)(k.status + N);
+    k.nblocks = n;
+    const uint64_t sb = rcx_scratch_bytes(codec, n, max_block);
+    HIPCHK(c, c->d_scratch.reserve(sb + 64));
+    k.scratch = c->d_scratch.p; k.scratch_bytes = c->d_scratch.cap;
+    int rc = launch_codec(c, codec, k);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(h64 + 5 * N, d64 + 5 * N, 2 * N * 8 + 2 * N * 4, hipMemcpyDeviceToHost, s));
+    if (b->mem == RCX_MEM_HOST && out_span)
+        HIPCHK(c, hipMemcpyAsync(b->out_base, c->d_out.p, out_span, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (b->out_len) memcpy(b->out_len, h64 + 5 * N, N * 8);
+    if (b->in_used) memcpy(b->in_used, h64 + 6 * N, N * 8);
+    memcpy(b->status, h_status, N * 4);
+    if (aux_out) memcpy(aux_out, h_aux, N * 4);
+    return RCX_RC_OK;
+}
+
+extern "C" int rcx_lz4_decode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_LZ4_DECODE, b, nullptr, nullptr, nullptr, true); }
+extern "C" int rcx_lz4_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_LZ4_ENCODE, b, nullptr, nullptr, nullptr, true); }
+extern "C" int rcx_inflate_batch(rcx_ctx* c, const rcx_batch* b, uint32_t* flags) { return run_batch(c, RCX_INFLATE, b, nullptr, flags, nullptr, true); }
+extern "C" int rcx_zlib_decode_batch(rcx_ctx* c, const rcx_batch* b, uint32_t* flags) { return run_batch(c, RCX_ZLIB_DECODE, b, nullptr, flags, nullptr, true); }
+extern "C" int rcx_adler32_batch(rcx_ctx* c, const rcx_batch* b, uint32_t* adler) { return run_batch(c, RCX_ADLER32, b, nullptr, adler, nullptr, false); }
+extern "C" int rcx_bwt_forward_batch(rcx_ctx* c, const rcx_batch* b, uint32_t* origin) { return run_batch(c, RCX_BWT_FORWARD, b, nullptr, origin, nullptr, true); }
+extern "C" int rcx_bwt_inverse_batch(rcx_ctx* c, const rcx_batch* b, const uint32_t* origin) { return run_batch(c, RCX_BWT_INVERSE, b, origin, nullptr, nullptr, true); }
+extern "C" int rcx_mtf_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_MTF_ENCODE, b, nullptr, nullptr, nullptr, true); }
+extern "C" int rcx_mtf_decode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_MTF_DECODE, b, nullptr, nullptr, nullptr, true); }
+extern "C" int rcx_dc_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_DC_ENCODE, b, nullptr, nullptr, nullptr, true); }
+extern "C" int rcx_dc_decode_batch(rcx_ctx* c, const rcx_batch* b, const uint64_t* n_out) { return run_batch(c, RCX_DC_DECODE, b, nullptr, nullptr, n_out, true); }
+extern "C" int rcx_ari_byte_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_ARI_BYTE_ENCODE, b, nullptr, nullptr, nullptr, true); }
+extern "C" int rcx_ari_byte_decode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_ARI_BYTE_DECODE, b, nullptr, nullptr, nullptr, true); }
+extern "C" int rcx_rle_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_RLE_ENCODE, b, nullptr, nullptr, nullptr, true); }
+extern "C" int rcx_rle_decode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_RLE_DECODE, b, nullptr, nullptr, nullptr, true); }

@@ -1,0 +1,117 @@
+"""GPU parity: LZ4 block decode/encode through the C-ABI vs the oracle (bit-exact) -- fixtures, synthetic
+distributions, ragged / empty / misaligned blocks, malformed inputs, and BASELINE's full size
+(4096 x 64 KiB) through round-trip properties."""
+import numpy as np
+import pytest
+
+from rust_compress_amd import _native as N
+from rust_compress_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _raws(golden):
+    rng = np.random.default_rng(1)
+    raws = [b"", b"a", b"a" * 54, b"abcd" * 9, golden("test.txt")]
+    for kind in ("text", "runs", "rand", "dna4"):
+        for sz in (65536, 5000, 70001, 262144):
+            raws.append(synth.gen(kind, sz, 7).tobytes())
+    raws += [b"\0" * 65536, b"ab" * 30000, bytes(range(256)) * 100,
+             b"x" * 100 + bytes(rng.integers(0, 256, 3000, dtype=np.uint8)) + b"x" * 5000,
+             (b"abcdefghijklmnopqrstuvwxyz0123456789" * 3 + b"Q") * 500]
+    return raws
+
+
+def test_encode_bit_exact_vs_oracle(ctx, oracle, golden):
+    raws = _raws(golden)
+    res = ctx.lz4_encode_blocks(raws).check()
+    for r, e in zip(raws, res.outputs):
+        assert e == oracle.lz4_encode_block(r)
+    assert list(res.in_used) == [len(r) for r in raws]
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+def test_decode_bit_exact_vs_oracle(ctx, oracle, golden, variant):
+    ctx.set_variant(N.LZ4_DECODE, variant)
+    raws = _raws(golden)
+    blobs = [oracle.lz4_encode_block(r) for r in raws]
+    blobs.append(golden("test.lz4.1")[11:11 + 2722])      # the reference's own compressed blocks (lz4.rs:647-659)
+    blobs.append(golden("test.lz4.9")[11:11 + 2664])
+    raws += [golden("test.txt")] * 2
+    res = ctx.lz4_decode_blocks(blobs, [len(r) for r in raws]).check()
+    assert res.outputs == raws
+    assert list(res.in_used) == [len(b) for b in blobs]
+    for b, r in zip(blobs, raws):
+        assert oracle.lz4_decode_block(b, cap=len(r)) == r
+    ctx.set_variant(N.LZ4_DECODE, 0)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_decode_malformed_statuses(ctx, oracle, variant):
+    ctx.set_variant(N.LZ4_DECODE, variant)
+    rng = np.random.default_rng(5)
+    base = [oracle.lz4_encode_block(synth.gen(k, 3000 + 500 * i, i).tobytes())
+            for i, k in enumerate(("text", "runs", "rand", "text", "runs", "dna4"))]
+    blobs, caps = [], []
+    for it in range(600):
+        b = bytearray(base[it % len(base)])
+        mode = it % 5
+        if mode == 0:
+            for _ in range(rng.integers(1, 4)):
+                b[rng.integers(0, len(b))] = rng.integers(0, 256)
+        elif mode == 1:
+            b = b[: rng.integers(0, len(b))]
+        elif mode == 2:
+            b = b + bytes(rng.integers(0, 256, rng.integers(1, 40), dtype=np.uint8))
+        elif mode == 3:
+            b = bytearray(rng.integers(0, 256, rng.integers(0, 300), dtype=np.uint8).tobytes())
+        blobs.append(bytes(b))
+        caps.append(int(rng.choice([100, 3000, 5000, 200000])))
+    res = ctx.lz4_decode_blocks(blobs, caps)
+    for i, (b, c) in enumerate(zip(blobs, caps)):
+        eo, es = oracle.lz4_decode_block(b, cap=c, raise_on_error=False)
+        assert es == res.status[i], (i, es, res.status[i])
+        if es == 0:
+            assert eo == res.outputs[i]
+    ctx.set_variant(N.LZ4_DECODE, 0)
+
+
+@pytest.mark.parametrize("kind", ["text", "mix"])
+def test_full_size_roundtrip_device_resident(ctx, oracle, kind):
+    """BASELINE configs[1]: 4096 x 64 KiB, device-resident: decode(encode(x)) == x for every block, and a
+    sample of blocks is compared with the oracle's encoder/decoder bytes."""
+    import torch
+    import rust_compress_amd as R
+    nb, BLOCK = 4096, 65536
+    dev = torch.device("cuda", 0)
+    raw_np = synth.gen_blocks(kind, nb, BLOCK, 0x4C5A3401)
+    raw = torch.from_numpy(raw_np).to(dev)
+    slot = (int(N.lib().rcx_lz4_compression_bound(BLOCK)) + 63) // 64 * 64
+    i64 = lambda a: torch.tensor(a, dtype=torch.int64, device=dev)
+    ar = np.arange(nb, dtype=np.int64)
+    enc = R.DeviceBatch(raw, i64(ar * BLOCK), i64(np.full(nb, BLOCK)),
+                        torch.zeros(nb * slot + 64, dtype=torch.uint8, device=dev), i64(ar * slot), i64(np.full(nb, slot)))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    scratch = torch.empty(ctx.scratch_bytes(N.LZ4_ENCODE, nb, BLOCK) + 64, dtype=torch.uint8, device=dev)
+    ctx.launch_dev(N.LZ4_ENCODE, enc, scratch)
+    torch.cuda.synchronize()
+    assert int(enc.status.abs().max()) == 0
+    clen = enc.out_len[:nb].clone()
+    for variant in (0, 1):
+        ctx.set_variant(N.LZ4_DECODE, variant)
+        dec = R.DeviceBatch(enc.out_base, enc.out_off, clen, torch.zeros(nb * BLOCK + 64, dtype=torch.uint8, device=dev),
+                            i64(ar * BLOCK), i64(np.full(nb, BLOCK)))
+        ctx.launch_dev(N.LZ4_DECODE, dec)
+        torch.cuda.synchronize()
+        assert int(dec.status.abs().max()) == 0
+        assert bool((dec.out_len[:nb] == BLOCK).all())
+        assert torch.equal(dec.out_base[: nb * BLOCK], raw)
+    ctx.set_variant(N.LZ4_DECODE, 0)
+    comp = enc.out_base.cpu().numpy()
+    cl = clen.cpu().numpy()
+    for i in range(0, nb, 257):
+        blob = comp[i * slot: i * slot + int(cl[i])].tobytes()
+        src = raw_np[i * BLOCK:(i + 1) * BLOCK].tobytes()
+        assert blob == oracle.lz4_encode_block(src)
+        assert oracle.lz4_decode_block(blob, cap=BLOCK) == src
+    ctx.set_stream(0)

@@ -1,0 +1,65 @@
+"""CPU suite: the UNMODIFIED LZ4 .hip kernels, run on the wave64 simulator (tests/wavesim), must agree
+with the oracle byte for byte and status for status.  Kernel-logic debugging aid only; the real parity
+tests are the -m gpu ones."""
+import numpy as np
+import pytest
+
+from rust_compress_amd import synth
+
+LZ4_DECODE, LZ4_ENCODE = 0, 1
+
+
+def _raws():
+    rng = np.random.default_rng(1)
+    raws = [b"", b"a", b"a" * 54, b"abcd" * 9]
+    for kind in ("text", "runs", "rand", "dna4"):
+        for sz in (65536, 5000):
+            raws.append(synth.gen(kind, sz, 7).tobytes())
+    raws += [b"\0" * 65536, b"ab" * 30000, bytes(range(256)) * 100,
+             b"x" * 100 + bytes(rng.integers(0, 256, 3000, dtype=np.uint8)) + b"x" * 5000,
+             (b"abcdefghijklmnopqrstuvwxyz0123456789" * 3 + b"Q") * 500]
+    return raws
+
+
+@pytest.mark.parametrize("variant", [1, 0, 2])
+@pytest.mark.parametrize("mis", [(0, 0), (3, 5)])
+def test_decode_matches_oracle(oracle, golden, variant, mis):
+    import simrun
+    raws = _raws() + [golden("test.txt")]
+    blobs = [oracle.lz4_encode_block(r) for r in raws]
+    blobs.append(golden("test.lz4.1")[11:11 + 2722])          # the reference's own compressed block
+    raws.append(golden("test.txt"))
+    outs, out_len, in_used, st, _ = simrun.run(LZ4_DECODE, variant, blobs, [len(r) for r in raws],
+                                              in_misalign=mis[0], out_misalign=mis[1])
+    assert not st.any()
+    assert outs == raws
+    assert list(in_used) == [len(b) for b in blobs]
+
+
+@pytest.mark.parametrize("variant", [1, 0])
+def test_decode_malformed_statuses_match_oracle(oracle, variant):
+    import simrun
+    rng = np.random.default_rng(5)
+    base = [oracle.lz4_encode_block(synth.gen(k, 3000 + 500 * i, i).tobytes())
+            for i, k in enumerate(("text", "runs", "rand", "text", "runs", "dna4"))]
+    blobs, caps = [], []
+    for it in range(200):
+        b = bytearray(base[it % len(base)])
+        mode = it % 5
+        if mode == 0:
+            for _ in range(rng.integers(1, 4)):
+                b[rng.integers(0, len(b))] = rng.integers(0, 256)
+        elif mode == 1:
+            b = b[: rng.integers(0, len(b))]
+        elif mode == 2:
+            b = b + bytes(rng.integers(0, 256, rng.integers(1, 40), dtype=np.uint8))
+        elif mode == 3:
+            b = bytearray(rng.integers(0, 256, rng.integers(0, 300), dtype=np.uint8).tobytes())
+        blobs.append(bytes(b))
+        caps.append(int(rng.choice([100, 3000, 5000, 200000])))
+    exp = [oracle.lz4_decode_block(b, cap=c, raise_on_error=False) for b, c in zip(blobs, caps)]
+    outs, out_len, _, st, _ = simrun.run(LZ4_DECODE, variant, blobs, caps)
+    for i, ((eo, es), s, out) in enumerate(zip(exp, st, outs)):
+        assert es == s, (i, es, s)
+        if es == 0:
+            assert eo == out

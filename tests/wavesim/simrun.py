@@ -1,0 +1,59 @@
+"""Python driver for the wave64 simulator build of the kernels (TEST INFRASTRUCTURE)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+sys.path.insert(0, HERE)
+from rust_compress_amd import batch as B  # noqa: E402
+import build as _build  # noqa: E402
+
+
+class KArgs(C.Structure):
+    _fields_ = [("in_base", C.c_void_p), ("in_off", C.c_void_p), ("in_len", C.c_void_p),
+                ("out_base", C.c_void_p), ("out_off", C.c_void_p), ("out_cap", C.c_void_p),
+                ("out_len", C.c_void_p), ("in_used", C.c_void_p), ("status", C.c_void_p),
+                ("aux", C.c_void_p), ("n_out", C.c_void_p), ("scratch", C.c_void_p),
+                ("scratch_bytes", C.c_uint64), ("nblocks", C.c_uint32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(_build.build())
+        _lib.sim_launch.argtypes = [C.c_int, C.c_int, C.POINTER(KArgs)]
+    return _lib
+
+
+def run(codec, variant, blobs, caps, aux=None, n_out=None, in_misalign=0, out_misalign=0, scratch_bytes=0):
+    """-> (outputs list[bytes], out_len, in_used, status, aux)"""
+    n = len(blobs)
+    base, off, lens = B.pack(blobs)
+    if in_misalign:
+        base = np.concatenate([np.zeros(in_misalign, np.uint8), base])
+        off = off + np.uint64(in_misalign)
+    total, ooff, ocap = B.layout(caps)
+    ooff = ooff + np.uint64(out_misalign)
+    out = np.full(total + out_misalign + 64, 0xEE, dtype=np.uint8)
+    out_len = np.zeros(n, np.uint64); in_used = np.zeros(n, np.uint64); status = np.full(n, -99, np.int32)
+    if aux is None:
+        aux = np.zeros(max(n, 1), np.uint32)
+    scratch = np.zeros(max(scratch_bytes, 8), np.uint8)
+    p = lambda a: a.ctypes.data
+    k = KArgs(p(base), p(off), p(lens), p(out), p(ooff), p(ocap), p(out_len), p(in_used), p(status), p(aux),
+              p(n_out) if n_out is not None else None, p(scratch), scratch.size, n)
+    rc = lib().sim_launch(codec, variant, C.byref(k))
+    assert rc == 0
+    outs = [bytes(out[int(o):int(o) + int(l)]) for o, l in zip(ooff, out_len)]
+    # guard: nothing outside [off, off+cap) may be touched
+    mask = np.ones(out.size, bool)
+    for o, c in zip(ooff, ocap):
+        mask[int(o):int(o) + int(c)] = False
+    assert (out[mask] == 0xEE).all(), "kernel wrote outside its output slots"
+    return outs, out_len, in_used, status, aux
