@@ -23,9 +23,8 @@
  *   - return value = batch-level status (bad arguments, HIP failure);
  *     per-block results go to status[i] (enum rcx_status). A failing block
  *     never affects another block. Nothing aborts or throws across the ABI.
- *   - calls are synchronous from the caller's view (results are complete on
- *     return) unless the ctx was put in async mode with rcx_ctx_set_async(),
- *     in which case DEVICE-memory calls only enqueue work on the ctx stream.
+ *   - the rcx_*_batch calls are synchronous from the caller's view (results are
+ *     complete on return); rcx_launch_dev() only enqueues on the ctx stream.
  *   - there is NO CPU fallback: without a usable HIP device every call fails
  *     with RCX_E_NO_DEVICE.
  */
@@ -96,11 +95,9 @@ typedef struct rcx_ctx rcx_ctx;
  * device_id < 0 selects the current HIP device. */
 int  rcx_ctx_create(int device_id, rcx_ctx** out);
 void rcx_ctx_destroy(rcx_ctx* ctx);
-/* Launch on the caller's HIP stream (hipStream_t passed as void*; NULL = the
- * ctx's own stream). */
+/* Launch on the caller's HIP stream (hipStream_t passed as void*; NULL = the HIP
+ * null stream).  A new ctx launches on its own non-blocking stream. */
 int  rcx_ctx_set_stream(rcx_ctx* ctx, void* hip_stream);
-/* async != 0: DEVICE-memory batch calls return after enqueueing; status/out_len
- * arrays must then be DEVICE arrays too (see *_dev entry points). */
 const char* rcx_last_error(const rcx_ctx* ctx);
 const char* rcx_status_string(int status);   /* the reference's error text */
 int  rcx_version(void);

@@ -39,7 +39,7 @@ def lib():
         _LIB.o_adler32.restype = C.c_uint32
         _LIB.o_adler32.argtypes = [C.c_void_p, C.c_size_t]
         _LIB.o_batch_run.restype = C.c_double
-        _LIB.o_batch_run.argtypes = [C.c_int] + [C.c_void_p] * 12 + [C.c_uint32, C.c_int]
+        _LIB.o_batch_run.argtypes = [C.c_int] + [C.c_void_p] * 11 + [C.c_uint32, C.c_int]
     return _LIB
 
 

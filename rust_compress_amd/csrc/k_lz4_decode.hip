@@ -97,6 +97,9 @@ __global__ __launch_bounds__(64) void k_lz4_decode_v1(rcx_kargs a)
 // v2: scalar token walk out of a register window + lane-per-sequence batched emission
 // ------------------------------------------------------------------------------------------------
 
+// value is wave-uniform by construction: tell the compiler so it lives in an SGPR and branches are scalar
+#define RCX_U(x) ((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x)))
+
 template <int OB, int CB, int LCAP, int MCAP>
 struct Lz4V2 {
     static constexpr int TFAST = 64 * 32;        // 64 fast sequences, each <= 14 literals + 18 match bytes
@@ -135,7 +138,8 @@ struct Lz4V2 {
             }
         }
         const uint32_t lim = (uint32_t)(cbase + CB);
-        cend = n < lim ? n : lim;
+        cend = RCX_U(n < lim ? n : lim);
+        cbase = (int32_t)RCX_U(cbase);
         rcx_wave_sync();
     }
 
@@ -170,7 +174,7 @@ struct Lz4V2 {
             if (lane < tail) out[from + lane] = ring[ridx(from + lane)];
             from = to;
         }
-        gflush = from;
+        gflush = RCX_U(from);
     }
 
     // after a wide copy wrote HBM directly: re-read the last RH output bytes into the ring
@@ -234,7 +238,7 @@ struct Lz4V2 {
         }
         const uint32_t len = L + M;
         const uint32_t incl = rcx_wave_incl_scan(len);
-        const uint32_t T = __builtin_amdgcn_readlane(incl, 63);
+        const uint32_t T = RCX_U(__builtin_amdgcn_readlane(incl, 63));
         const uint32_t ostart = oend + incl - len;
         const uint32_t mdst = ostart + L;
         // validity in stream order (oracle/o_lz4.c): literal overflow, bad offset, match overflow
@@ -252,7 +256,7 @@ struct Lz4V2 {
         if (bend > (uint32_t)OB && bend - OB > rlo_eff) rlo_eff = bend - OB;
 
         // literals: compressed LDS window -> ring (no cross-lane dependence)
-        const uint32_t maxL = rcx_wave_max(L);
+        const uint32_t maxL = RCX_U(rcx_wave_max(L));
         const int32_t sbase = (int32_t)src - cbase;
         for (uint32_t i = 0; i < maxL; i++)
             if (i < L) ring[ridx(ostart + i)] = cbuf[sbase + (int32_t)i];
@@ -261,7 +265,7 @@ struct Lz4V2 {
         const uint32_t slo = mdst - off;
         const bool isnear = M && slo >= rlo_eff;
         const bool isfar = M && !isnear;
-        const uint32_t maxF = rcx_wave_max(isfar ? M : 0u);
+        const uint32_t maxF = RCX_U(rcx_wave_max(isfar ? M : 0u));
         for (uint32_t i0 = 0; i0 < maxF; i0 += 8) {
             uint8_t v[8];
 #pragma unroll
@@ -281,7 +285,7 @@ struct Lz4V2 {
             const int first = __ffsll(pm) - 1;
             const uint32_t F = __builtin_amdgcn_readlane(mdst, first);
             const bool ready = pending && ((int)lane == first || shi <= F);
-            const uint32_t maxM = rcx_wave_max(ready ? M : 0u);
+            const uint32_t maxM = RCX_U(rcx_wave_max(ready ? M : 0u));
             for (uint32_t i = 0; i < maxM; i++) {
                 uint8_t v = 0;
                 if (ready && i < M) v = ring[ridx(slo + i)];
@@ -291,7 +295,7 @@ struct Lz4V2 {
             }
             pending = pending && !ready;
         }
-        oend = bend;
+        oend = RCX_U(bend);
         flush(oend, false);
         return 0;
     }
@@ -312,6 +316,7 @@ struct Lz4V2 {
         bool have_win = false;
 
         while (cur < n) {
+            cur = RCX_U(cur); ns = (int)RCX_U(ns); rel = RCX_U(rel); wb = RCX_U(wb); tslow = RCX_U(tslow);
             if (cend < n && cur + (uint32_t)MARGIN > cend) {           // compressed window exhausted
                 if (ns) { st = emit(ns, e_pos, s_L, s_M, s_off, s_src); ns = 0; tslow = 0; if (st) break; }
                 stage(cur);
@@ -334,7 +339,7 @@ struct Lz4V2 {
             // fast walk on the scalar unit
             uint32_t d = 0;
             for (;;) {
-                d = __builtin_amdgcn_readlane(dvec, rel);
+                d = RCX_U(__builtin_amdgcn_readlane(dvec, rel));
                 if (d == 0) break;
                 e_pos = ((int)lane == ns) ? (uint32_t)(cur) : e_pos;
                 ns++; cur += d; rel += d;
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_lz4_decode_v2(rcx_kargs a)
     __shared__ __align__(16) uint8_t s_cbuf[WAVES][CB + 64];
     __shared__ __align__(16) uint8_t s_ring[WAVES][OB];
     const unsigned w = threadIdx.x >> 6;
-    const uint32_t b = blockIdx.x * WAVES + w;
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + w));   // wave-uniform: keeps descriptors in SGPRs
     if (b >= a.nblocks) return;
     Lz4V2<OB, CB, LCAP, MCAP> s;
     s.in = a.in_base + a.in_off[b];
@@ -447,3 +452,456 @@ __global__ __launch_bounds__(64 * WAVES) void k_lz4_decode_v2(rcx_kargs a)
         if (a.in_used) a.in_used[b] = s.n;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// v3: same parse as v2; emission reworked after profiling v2 on MI355X (rocprof: ~60 instructions and
+// ~355 wait cycles per sequence, ~8 resolution rounds per batch):
+//   * linear LDS output window (H history bytes + the batch) slid by multiples of 16 instead of a ring:
+//     byte accesses become base + immediate offset, the HBM drain stays 16-byte aligned;
+//   * every copy is "read a chunk into registers, then write it": one LDS round trip per chunk instead
+//     of two per byte; overlapping matches read their period (always finished bytes);
+//   * exact producer masks (binary search of each match's source range over the lanes' output starts)
+//     so a batch resolves in its true dependency depth (2-3 rounds) instead of ~8;
+//   * old matches (source already drained) come from HBM with 16-byte loads; predicated stores go to a
+//     trash slot instead of toggling EXEC; the prefix sum is DPP, loop bounds are ballots.
+// ------------------------------------------------------------------------------------------------
+template <int H, int CB, int LCAP, int MCAP>
+struct Lz4V3 {
+    static constexpr int TFAST = 64 * 32;
+    static constexpr int TSLOW = 1024;
+    static constexpr int TCAP = TFAST + TSLOW;
+    static constexpr int LIN = H + 16 + TCAP + 64;        // history | <16 align slack | batch | read slack
+    static constexpr int TRASH = LIN;                      // 64 bytes: where masked-off lanes store
+    static constexpr int LIN_ALLOC = LIN + 64;
+    static constexpr int RH = MCAP > 128 ? MCAP : 128;
+    static constexpr int MARGIN = LCAP + 16;
+    static constexpr uint32_t FLAG = 0x80000000u;
+    static_assert(H >= 2 * MCAP + 64 && H % 16 == 0 && RH <= H && (CB % 1024) == 0, "geometry");
+
+    const uint8_t* in; uint8_t* out; uint32_t n, cap;
+    uint8_t* cbuf; uint8_t* lin;
+    int32_t cbase; uint32_t cend;
+    int32_t lbase;                        // lin[i] holds output position lbase+i; (out+lbase) is 16-byte aligned
+    uint32_t oend, gflush, rlo;           // produced / drained / lowest position valid in lin
+    uint32_t omis;
+    unsigned lane;
+
+    __device__ __forceinline__ int32_t lbase_for(uint32_t pos) const
+    {
+        return (((int32_t)pos - H + (int32_t)omis) & ~15) - (int32_t)omis;
+    }
+
+    __device__ void stage(uint32_t cur)
+    {
+        const uint32_t inmis = (uint32_t)((uintptr_t)in & 15u);
+        cbase = (int32_t)RCX_U((int32_t)((cur + inmis) & ~15u) - (int32_t)inmis);
+#pragma unroll
+        for (int r = 0; r < CB / 1024; r++) {
+            const int j = r * 64 + (int)lane;
+            const int32_t pos = cbase + 16 * j;
+            if (pos >= 0 && (uint32_t)pos + 16 <= n) {
+                *(rcx_u32x4*)(cbuf + 16 * j) = *(const rcx_u32x4*)(in + pos);
+            } else {
+                for (int t = 0; t < 16; t++) {
+                    const int32_t q = pos + t;
+                    cbuf[16 * j + t] = (q >= 0 && (uint32_t)q < n) ? in[q] : (uint8_t)0;
+                }
+            }
+        }
+        const uint32_t lim = (uint32_t)(cbase + CB);
+        cend = RCX_U(n < lim ? n : lim);
+        rcx_wave_sync();
+    }
+
+    __device__ __forceinline__ uint32_t peek(uint32_t q) const
+    {
+        const int32_t idx = (int32_t)q - cbase;
+        uint32_t v = (idx >= 0 && q < cend) ? (uint32_t)cbuf[idx] : (uint32_t)in[q];
+        return RCX_U(v);
+    }
+
+    // slide the window so that it ends H bytes before `oend` (moves by a multiple of 16)
+    __device__ void slide()
+    {
+        const int32_t nb = (int32_t)RCX_U(lbase_for(oend));
+        const int32_t delta = nb - lbase;
+        if (delta <= 0) return;
+        const int32_t keep = ((int32_t)oend - nb + 15) & ~15;            // bytes that stay: [nb, oend)
+        if (delta < LIN) {
+            for (int32_t j0 = 0; j0 < keep; j0 += 1024) {
+                const int32_t j = j0 + 16 * (int32_t)lane;
+                rcx_u32x4 v = {0, 0, 0, 0};
+                const bool on = j < keep && j + delta + 16 <= LIN_ALLOC;
+                if (on) v = *(const rcx_u32x4*)(lin + j + delta);
+                rcx_wave_sync();
+                if (on) *(rcx_u32x4*)(lin + j) = v;
+                rcx_wave_sync();
+            }
+        }
+        lbase = nb;
+    }
+
+    __device__ void flush(uint32_t to, bool final)
+    {
+        uint32_t from = gflush;
+        if (to <= from) return;
+        const uint32_t mis = (uint32_t)((uintptr_t)(out + from) & 15u);
+        uint32_t head = mis ? 16u - mis : 0u;
+        if (head > to - from) head = final ? to - from : 0u;
+        if (mis && head == 0 && !final) return;
+        if (head) {
+            if (lane < head) out[from + lane] = lin[(int32_t)(from + lane) - lbase];
+            from += head;
+        }
+        const uint32_t nch = (to - from) >> 4;
+        for (uint32_t c = lane; c < nch; c += 64) {
+            const uint32_t p = from + 16 * c;
+            *(rcx_u32x4*)(out + p) = *(const rcx_u32x4*)(lin + ((int32_t)p - lbase));
+        }
+        from += nch * 16;
+        if (final) {
+            const uint32_t tail = to - from;
+            if (lane < tail) out[from + lane] = lin[(int32_t)(from + lane) - lbase];
+            from = to;
+        }
+        gflush = RCX_U(from);
+    }
+
+    __device__ void repair()
+    {
+        lbase = (int32_t)RCX_U(lbase_for(oend));
+        rlo = oend > (uint32_t)RH ? oend - RH : 0u;
+        rcx_wave_sync();
+        for (uint32_t p = rlo + lane; p < oend; p += 64) lin[(int32_t)p - lbase] = out[p];
+        rcx_wave_sync();
+    }
+
+    __device__ void wide_literals(uint32_t src, uint32_t len)
+    {
+        uint8_t* d = out + oend;
+        const uint8_t* s = in + src;
+        const uint32_t mis = (uint32_t)((uintptr_t)d & 15u);
+        uint32_t head = mis ? 16u - mis : 0u;
+        if (head > len) head = len;
+        if (lane < head) d[lane] = s[lane];
+        const uint32_t nb = (len - head) >> 4;
+        for (uint32_t c = lane; c < nb; c += 64)
+            *(rcx_u32x4*)(d + head + 16 * c) = *(const rcx_u32x4_u*)(s + head + 16 * c);
+        const uint32_t done = head + nb * 16;
+        if (lane < len - done) d[done + lane] = s[done + lane];
+    }
+
+    __device__ void wide_match(uint32_t off, uint32_t len)
+    {
+        uint32_t e = off, d = oend, rem = len;
+        while (rem) {
+            uint32_t C = rem < e ? rem : e;
+            if (C > 1024) C = 1024;
+            const uint32_t i0 = 16 * lane;
+            if (i0 + 16 <= C) {
+                *(rcx_u32x4_u*)(out + d + i0) = *(const rcx_u32x4_u*)(out + d - e + i0);
+            } else if (i0 < C) {
+                for (uint32_t t = i0; t < C; t++) out[d + t] = out[d - e + t];
+            }
+            rcx_wave_sync();
+            d += C; rem -= C;
+            if (C == e && e < 1024) e *= 2;
+        }
+    }
+
+    // largest lane k with ostart[k] <= x (ostart is non-decreasing over lanes; ostart[0] <= x is given)
+    __device__ __forceinline__ uint32_t lane_of(uint32_t ostart, uint32_t x) const
+    {
+        uint32_t lo = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const uint32_t c = lo + step;
+            const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)ostart);
+            if (c < 64 && v <= x) lo = c;
+        }
+        return lo;
+    }
+
+    __device__ int emit(int ns, uint32_t e_pos, uint32_t s_L, uint32_t s_M, uint32_t s_off, uint32_t s_src)
+    {
+        slide();
+        const bool act = (int)lane < ns;
+        uint32_t L = 0, M = 0, off = 0, src = (uint32_t)cbase;
+        if (act) {
+            if (e_pos & FLAG) { L = s_L; M = s_M; off = s_off; src = s_src; }
+            else {
+                const uint32_t t = cbuf[(int32_t)e_pos - cbase];
+                L = t >> 4; M = (t & 15u) + 4u; src = e_pos + 1;
+                const int32_t oi = (int32_t)(src + L) - cbase;
+                off = (uint32_t)cbuf[oi] | ((uint32_t)cbuf[oi + 1] << 8);
+            }
+        }
+        const uint32_t len = L + M;
+        const uint32_t incl = rcx_wave_incl_scan(len);
+        const uint32_t T = RCX_U(__builtin_amdgcn_readlane(incl, 63));
+        const uint32_t oend0 = oend;
+        const uint32_t ostart = oend0 + incl - len;
+        const uint32_t mdst = ostart + L;
+        int err = 0;
+        if (act) {
+            if (L > cap - ostart || ostart > cap) err = RCX_E_OUTPUT_TOO_SMALL;
+            else if (M && (off == 0 || off > mdst)) err = RCX_E_MALFORMED;
+            else if (M && M > cap - mdst) err = RCX_E_OUTPUT_TOO_SMALL;
+        }
+        const unsigned long long bad = __ballot(err != 0);
+        if (bad) return __builtin_amdgcn_readlane(err, __ffsll(bad) - 1);
+
+        const uint32_t bend = oend0 + T;
+        const uint32_t lb0 = lbase > 0 ? (uint32_t)lbase : 0u;
+        const uint32_t rlo_eff = rlo > lb0 ? rlo : lb0;
+        const int32_t li_o = (int32_t)ostart - lbase;
+        const int32_t li_m = li_o + (int32_t)L;
+        const int32_t trash = TRASH + (int32_t)lane;
+
+        // ---- literals: compressed window -> output window, 8 bytes per step, reads before writes
+        {
+            const int32_t sb = (int32_t)src - cbase;
+            for (uint32_t i0 = 0; __ballot(i0 < L); i0 += 8) {
+                const int32_t rb = i0 < L ? sb + (int32_t)i0 : 0;
+                uint8_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = cbuf[rb + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) lin[(i0 + u < L) ? li_o + (int32_t)i0 + u : trash] = v[u];
+            }
+        }
+
+        const uint32_t slo = mdst - off;
+        const uint32_t shi = (slo + M < mdst) ? slo + M : mdst;      // source clipped below the own destination
+        const bool isnear = M && slo >= rlo_eff;
+        const bool isfar = M && !isnear;
+
+        // ---- matches older than the window: HBM -> window (source drained long ago, never overlapping)
+        if (__ballot(isfar)) {
+            const bool far16 = isfar && (uint64_t)slo + ((M + 15u) & ~15u) <= (uint64_t)cap;
+            for (uint32_t i0 = 0; __ballot(far16 && i0 < M); i0 += 16) {
+                rcx_u32x4 w = {0, 0, 0, 0};
+                if (far16 && i0 < M) w = *(const rcx_u32x4_u*)(out + slo + i0);
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const uint8_t x = (uint8_t)(w[u >> 2] >> (8 * (u & 3)));
+                    lin[(far16 && i0 + u < M) ? li_m + (int32_t)i0 + u : trash] = x;
+                }
+            }
+            const bool farb = isfar && !far16;                      // within 16 bytes of the slot end: byte loads
+            for (uint32_t i0 = 0; __ballot(farb && i0 < M); i0 += 8) {
+                uint8_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = (farb && i0 + u < M) ? out[slo + i0 + u] : (uint8_t)0;
+#pragma unroll
+                for (int u = 0; u < 8; u++) lin[(farb && i0 + u < M) ? li_m + (int32_t)i0 + u : trash] = v[u];
+            }
+        }
+        rcx_wave_sync();
+
+        // ---- matches inside the window.  Producer lanes of the source range [slo, shi) that belong to this
+        // batch: lanes ka..kb (binary search over the sorted output starts); a lane may copy once none of them
+        // is still pending.
+        if (__ballot(isnear)) {
+            unsigned long long dep = 0;
+            const bool inb = isnear && shi > oend0;
+            if (__ballot(inb)) {
+                const uint32_t ka = lane_of(ostart, slo > oend0 ? slo : oend0);
+                const uint32_t kb = lane_of(ostart, shi > oend0 ? shi - 1 : oend0);
+                if (inb) {
+                    const unsigned long long upto = (kb >= 63) ? ~0ull : ((2ull << kb) - 1ull);
+                    dep = upto & ~((1ull << ka) - 1ull) & ((1ull << lane) - 1ull);
+                }
+            }
+            const int32_t li_s = (int32_t)slo - lbase;
+            const bool ovl = isnear && off < M;
+            bool pending = isnear;
+            for (;;) {
+                const unsigned long long pm = __ballot(pending);
+                if (!pm) break;
+                const bool ready = pending && (pm & dep) == 0;
+                const bool rn = ready && !ovl;
+                for (uint32_t i0 = 0; __ballot(rn && i0 < M); i0 += 8) {
+                    const int32_t rb = (rn && i0 < M) ? li_s + (int32_t)i0 : 0;
+                    uint8_t v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) v[u] = lin[rb + u];
+                    rcx_wave_sync();
+#pragma unroll
+                    for (int u = 0; u < 8; u++) lin[(rn && i0 + u < M) ? li_m + (int32_t)i0 + u : trash] = v[u];
+                    rcx_wave_sync();
+                }
+                const bool ro = ready && ovl;                          // self-overlapping: periodic source
+                if (__ballot(ro)) {
+                    uint32_t r = 0;
+                    for (uint32_t i0 = 0; __ballot(ro && i0 < M); i0 += 8) {
+                        uint8_t v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            v[u] = lin[ro ? li_s + (int32_t)r : 0];
+                            r = (r + 1 == off) ? 0u : r + 1;
+                        }
+                        rcx_wave_sync();
+#pragma unroll
+                        for (int u = 0; u < 8; u++) lin[(ro && i0 + u < M) ? li_m + (int32_t)i0 + u : trash] = v[u];
+                        rcx_wave_sync();
+                    }
+                }
+                pending = pending && !ready;
+            }
+        }
+        oend = RCX_U(bend);
+        rcx_wave_sync();
+        flush(oend, false);
+        return 0;
+    }
+
+    __device__ void run(int32_t* st_out, uint32_t* len_out)
+    {
+        lane = rcx_lane();
+        omis = (uint32_t)((uintptr_t)out & 15u);
+        oend = 0; gflush = 0; rlo = 0;
+        lbase = (int32_t)RCX_U(lbase_for(0));
+        int st = RCX_OK;
+        uint32_t cur = 0;
+        if (n) stage(0); else { cbase = 0; cend = 0; }
+
+        uint32_t e_pos = 0, s_L = 0, s_M = 0, s_off = 0, s_src = 0;
+        int ns = 0;
+        uint32_t tslow = 0;
+        uint32_t wb = 0, rel = 64, dvec = 0;
+        bool have_win = false;
+
+        while (cur < n) {
+            cur = RCX_U(cur); ns = (int)RCX_U(ns); rel = RCX_U(rel); wb = RCX_U(wb); tslow = RCX_U(tslow);
+            if (cend < n && cur + (uint32_t)MARGIN > cend) {
+                if (ns) { st = emit(ns, e_pos, s_L, s_M, s_off, s_src); ns = 0; tslow = 0; if (st) break; }
+                stage(cur);
+                have_win = false;
+            }
+            if (!have_win || rel >= 64) {
+                wb = cur; rel = 0; have_win = true;
+                const uint32_t q = cur + lane;
+                const uint32_t fast_lim = cend >= 20 ? cend - 20 : 0;
+                uint32_t d = 0;
+                if (q < fast_lim) {
+                    const uint32_t t = cbuf[(int32_t)q - cbase];
+                    const uint32_t L = t >> 4, M = t & 15u;
+                    d = (L == 15u || M == 15u) ? 0u : 3u + L;
+                }
+                dvec = d;
+            }
+            uint32_t d = 0;
+            for (;;) {
+                d = RCX_U(__builtin_amdgcn_readlane(dvec, rel));
+                if (d == 0) break;
+                e_pos = ((int)lane == ns) ? cur : e_pos;
+                ns++; cur += d; rel += d;
+                if (rel >= 64 || ns == 64) break;
+            }
+            if (ns == 64) { st = emit(ns, e_pos, s_L, s_M, s_off, s_src); ns = 0; tslow = 0; if (st) break; continue; }
+            if (d != 0) continue;
+
+            const uint32_t t = peek(cur);
+            uint32_t p = cur + 1;
+            uint32_t L = t >> 4;
+            if (L == 15) {
+                for (;;) {
+                    if (p >= n) { st = RCX_E_MALFORMED; break; }
+                    const uint32_t x = peek(p); p++;
+                    L += x;
+                    if (x != 255) break;
+                }
+                if (st) break;
+            }
+            const uint32_t lit_src = p;
+            if (L > n - p) { st = RCX_E_MALFORMED; break; }
+            p += L;
+            uint32_t M = 0, off = 0;
+            if (p != n) {
+                if (n - p < 2) {
+                    if (ns) { st = emit(ns, e_pos, s_L, s_M, s_off, s_src); ns = 0; tslow = 0; if (st) break; }
+                    st = (L > cap - oend) ? RCX_E_OUTPUT_TOO_SMALL : RCX_E_MALFORMED; break;
+                }
+                off = peek(p) | (peek(p + 1) << 8);
+                p += 2;
+                M = t & 15u;
+                if (M == 15) {
+                    for (;;) {
+                        if (p >= n) { st = RCX_E_MALFORMED; break; }
+                        const uint32_t x = peek(p); p++;
+                        M += x;
+                        if (x != 255) break;
+                    }
+                    if (st) {
+                        if (ns) { int e2 = emit(ns, e_pos, s_L, s_M, s_off, s_src); ns = 0; tslow = 0; if (e2) { st = e2; break; } }
+                        if (L > cap - oend) st = RCX_E_OUTPUT_TOO_SMALL;
+                        break;
+                    }
+                }
+                M += 4;
+            }
+            const bool eligible = L <= (uint32_t)LCAP && M <= (uint32_t)MCAP && lit_src + L <= cend &&
+                                  (int32_t)lit_src >= cbase;
+            if (eligible) {
+                if (tslow + L + M > (uint32_t)TSLOW) { st = emit(ns, e_pos, s_L, s_M, s_off, s_src); ns = 0; tslow = 0; if (st) break; }
+                e_pos = ((int)lane == ns) ? FLAG : e_pos;
+                s_L = ((int)lane == ns) ? L : s_L;
+                s_M = ((int)lane == ns) ? M : s_M;
+                s_off = ((int)lane == ns) ? off : s_off;
+                s_src = ((int)lane == ns) ? lit_src : s_src;
+                ns++; tslow += L + M;
+                if (ns == 64) { st = emit(ns, e_pos, s_L, s_M, s_off, s_src); ns = 0; tslow = 0; if (st) break; }
+            } else {
+                if (ns) { st = emit(ns, e_pos, s_L, s_M, s_off, s_src); ns = 0; tslow = 0; if (st) break; }
+                flush(oend, true);
+                if (L > cap - oend) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
+                if (L) { wide_literals(lit_src, L); oend += L; }
+                if (M) {
+                    if (off == 0 || off > oend) { st = RCX_E_MALFORMED; break; }
+                    if (M > cap - oend) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
+                    rcx_wave_sync();
+                    wide_match(off, M);
+                    oend += M;
+                }
+                oend = RCX_U(oend);
+                gflush = oend;
+                repair();
+            }
+            cur = p;
+            rel = cur - wb;
+        }
+        if (!st && ns) st = emit(ns, e_pos, s_L, s_M, s_off, s_src);
+        else if (st && ns) { int e2 = emit(ns, e_pos, s_L, s_M, s_off, s_src); if (e2) st = e2; }
+        if (!st) flush(oend, true);
+        *st_out = st;
+        *len_out = st ? 0u : oend;
+    }
+};
+
+template <int H, int CB, int LCAP, int MCAP, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_lz4_decode_v3(rcx_kargs a)
+{
+    typedef Lz4V3<H, CB, LCAP, MCAP> S;
+    __shared__ __align__(16) uint8_t s_cbuf[WAVES][CB + 64];
+    __shared__ __align__(16) uint8_t s_lin[WAVES][S::LIN_ALLOC];
+    const unsigned w = threadIdx.x >> 6;
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + w));
+    if (b >= a.nblocks) return;
+    S s;
+    s.in = a.in_base + a.in_off[b];
+    s.n = (uint32_t)a.in_len[b];
+    s.out = a.out_base + a.out_off[b];
+    const uint64_t cap64 = a.out_cap[b];
+    s.cap = cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)cap64;
+    s.cbuf = s_cbuf[w];
+    s.lin = s_lin[w];
+    int32_t st; uint32_t olen;
+    s.run(&st, &olen);
+    if ((threadIdx.x & 63u) == 0) {
+        a.status[b] = st;
+        a.out_len[b] = olen;
+        if (a.in_used) a.in_used[b] = s.n;
+    }
+}
+

@@ -1,2 +1,539 @@
+// k_serial.hip -- the stream codecs whose inner loop is a serial chain per stream: MTF, DC, RLE and the
+// adaptive byte range coder.  Parallelism comes from (a) many independent streams per launch and
+// (b) whatever is wide inside one step: run detection/fill (64 bytes per step + ballot), the 256-entry
+// MTF list search (4 entries per lane + ballot) and shift, RLE run emission (ballot + wave prefix sum).
+//   MTF / DC / RLE : one wave per stream (state in LDS), runs of equal symbols skipped 64 bytes at a time
+//   Ari            : one LANE per stream (64 streams per wave): the coder is a chain of u32 divides with a
+//                    257-entry adaptive table per stream (LDS, lane-interleaved, 16-entry block sums)
 #include "rcx_dev.h"
-static void launch_serial(hipStream_t s, int codec, rcx_kargs& k, int v) { hipLaunchKernelGGL(k_not_built, dim3((k.nblocks + 63) / 64), dim3(64), 0, s, k); }
+
+// =================================================================================================
+// MTF -- src/bwt/mtf.rs:63-90 with the stream codecs' identity start (:103-104, :141-142)
+// =================================================================================================
+// list[] (256 bytes, LDS).  find: lane l compares entries 4l..4l+3.
+__device__ __forceinline__ uint32_t mtf_find(const uint8_t* lst, uint32_t sym, unsigned lane)
+{
+    const uint32_t w = *(const uint32_t*)(lst + 4 * lane);
+    uint32_t hit = 4;
+    if (((w >> 24) & 0xff) == sym) hit = 3;
+    if (((w >> 16) & 0xff) == sym) hit = 2;
+    if (((w >> 8) & 0xff) == sym) hit = 1;
+    if ((w & 0xff) == sym) hit = 0;
+    const unsigned long long m = __ballot(hit < 4);
+    const int first = __ffsll(m) - 1;                       // symbols are unique in a well-formed list
+    return 4u * (uint32_t)first + (uint32_t)__builtin_amdgcn_readlane(hit, first);
+}
+// lst[1..rank] = lst[0..rank-1]; lst[0] = sym     (rotate right by one, mtf.rs:68-78 / :85-89)
+__device__ __forceinline__ void mtf_front(uint8_t* lst, uint32_t rank, uint32_t sym, unsigned lane)
+{
+    uint8_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint32_t i = lane + 64u * k; v[k] = (i >= 1 && i <= rank) ? lst[i - 1] : (uint8_t)0; }
+    rcx_wave_sync();
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint32_t i = lane + 64u * k; if (i >= 1 && i <= rank) lst[i] = v[k]; }
+    if (lane == 0) lst[0] = (uint8_t)sym;
+    rcx_wave_sync();
+}
+// length of the run of bytes equal to `sym` starting at in[i] (i < n), found 64 bytes per step
+__device__ __forceinline__ uint32_t run_length(const uint8_t* in, uint32_t i, uint32_t n, uint32_t sym, unsigned lane)
+{
+    uint32_t j = i;
+    for (;;) {
+        const uint32_t p = j + lane;
+        const bool differ = (p >= n) || (in[p] != sym);
+        const unsigned long long m = __ballot(differ);
+        if (m) return j + (uint32_t)(__ffsll(m) - 1) - i;
+        j += 64;
+    }
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_mtf(rcx_kargs a, int decode)
+{
+    __shared__ __align__(16) uint8_t s_lst[WAVES][256];
+    const unsigned w = threadIdx.x >> 6, lane = rcx_lane();
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + w));   // wave-uniform: keeps descriptors in SGPRs
+    if (b >= a.nblocks) return;
+    uint8_t* lst = s_lst[w];
+    const uint8_t* in = a.in_base + a.in_off[b];
+    const uint32_t n = (uint32_t)a.in_len[b];
+    uint8_t* out = a.out_base + a.out_off[b];
+    if (a.out_cap[b] < n) {
+        if (lane == 0) { a.status[b] = RCX_E_OUTPUT_TOO_SMALL; a.out_len[b] = 0; if (a.in_used) a.in_used[b] = 0; }
+        return;
+    }
+    for (int k = 0; k < 4; k++) lst[lane + 64 * k] = (uint8_t)(lane + 64 * k);
+    rcx_wave_sync();
+    uint32_t i = 0;
+    while (i < n) {
+        const uint32_t x = __builtin_amdgcn_readfirstlane((uint32_t)in[i]);
+        if (!decode) {
+            const uint32_t head = __builtin_amdgcn_readfirstlane((uint32_t)lst[0]);
+            if (x == head) {                                  // rank 0: the whole run encodes to zeros
+                const uint32_t rl = run_length(in, i, n, x, lane);
+                for (uint32_t t = lane; t < rl; t += 64) out[i + t] = 0;
+                i += rl;
+            } else {
+                const uint32_t rank = mtf_find(lst, x, lane);
+                if (lane == 0) out[i] = (uint8_t)rank;
+                mtf_front(lst, rank, x, lane);
+                i += 1;
+            }
+        } else {
+            if (x == 0) {                                     // rank 0 repeats the front symbol
+                const uint32_t rl = run_length(in, i, n, 0, lane);
+                const uint8_t head = lst[0];
+                for (uint32_t t = lane; t < rl; t += 64) out[i + t] = head;
+                i += rl;
+            } else {
+                const uint32_t sym = __builtin_amdgcn_readfirstlane((uint32_t)lst[x]);
+                if (lane == 0) out[i] = (uint8_t)sym;
+                mtf_front(lst, x, sym, lane);
+                i += 1;
+            }
+        }
+    }
+    if (lane == 0) { a.status[b] = RCX_OK; a.out_len[b] = n; if (a.in_used) a.in_used[b] = n; }
+}
+
+// =================================================================================================
+// DC -- src/bwt/dc.rs.  encode :110-149 (+ EncodeIterator order :88-104, encode_simple :153-159),
+// decode :162-233 driven as decode_simple :236-252.  Words are little-endian u32.
+// =================================================================================================
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a)
+{
+    __shared__ __align__(16) uint8_t s_lst[WAVES][256];
+    __shared__ uint32_t s_last[WAVES][256];
+    const unsigned w = threadIdx.x >> 6, lane = rcx_lane();
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + w));   // wave-uniform: keeps descriptors in SGPRs
+    if (b >= a.nblocks) return;
+    uint8_t* lst = s_lst[w];
+    uint32_t* last = s_last[w];
+    const uint8_t* in = a.in_base + a.in_off[b];
+    const uint32_t n = (uint32_t)a.in_len[b];
+    uint32_t* words = (uint32_t*)(a.out_base + a.out_off[b]);
+    // the out slot doubles as the dist[] work array (dc.rs:112 `distances`), so it must hold 256+n words
+    if (a.out_cap[b] < 4ull * (256ull + n) || ((uintptr_t)words & 3u)) {
+        if (lane == 0) { a.status[b] = RCX_E_OUTPUT_TOO_SMALL; a.out_len[b] = 0; if (a.in_used) a.in_used[b] = 0; }
+        return;
+    }
+    uint32_t* dist = words + 256;
+    for (int k = 0; k < 4; k++) { lst[lane + 64 * k] = 0; last[lane + 64 * k] = n; words[lane + 64 * k] = n; }   // :114-115, MTF::new()
+    rcx_wave_sync();
+    uint32_t num_unique = 0, i = 0;
+    while (i < n) {                                           // :117-138
+        const uint32_t sym = __builtin_amdgcn_readfirstlane((uint32_t)in[i]);
+        const uint32_t base = __builtin_amdgcn_readfirstlane(last[sym]);
+        if (base == n) {                                      // first occurrence, :121-128
+            if (lane == 0) { lst[num_unique] = (uint8_t)sym; words[sym] = i; last[sym] = i; dist[i] = n; }
+            rcx_wave_sync();
+            const uint32_t rank = mtf_find(lst, sym, lane);   // mtf.encode(sym)
+            if (rank) mtf_front(lst, rank, sym, lane);
+            num_unique++;
+            i += 1;
+        } else if (base == i - 1) {                           // inside a run: rank 0, nothing is emitted
+            const uint32_t rl = run_length(in, i, n, sym, lane);
+            for (uint32_t t = lane; t < rl; t += 64) dist[i + t] = n;
+            if (lane == 0) last[sym] = i + rl - 1;
+            rcx_wave_sync();
+            i += rl;
+        } else {                                              // :129-136
+            const uint32_t rank = mtf_find(lst, sym, lane);
+            if (lane == 0) { dist[i] = n; last[sym] = i; if (rank) dist[base] = i - base - rank - 1; }
+            if (rank) mtf_front(lst, rank, sym, lane); else rcx_wave_sync();
+            i += 1;
+        }
+    }
+    rcx_wave_sync();
+    for (uint32_t rank = lane; rank < num_unique; rank += 64) {      // sweep, :139-144
+        const uint32_t sym = lst[rank];
+        const uint32_t base = last[sym];
+        dist[base] = n - base - rank - 1;
+    }
+    rcx_wave_sync();
+    // compact the non-filler distances in position order (EncodeIterator :88-104): ballot + prefix popcount
+    uint32_t k = 0;
+    for (uint32_t j = 0; j < n; j += 64) {
+        const uint32_t p = j + lane;
+        const uint32_t d = p < n ? dist[p] : n;
+        const bool keep = d != n;
+        const unsigned long long m = __ballot(keep);
+        rcx_wave_sync();                                     // all reads of this 64-slot window precede the writes
+        if (keep) dist[k + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = d;
+        k += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) { a.status[b] = RCX_OK; a.out_len[b] = 4ull * (256ull + k); if (a.in_used) a.in_used[b] = n; }
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_dc_decode(rcx_kargs a)
+{
+    __shared__ __align__(16) uint8_t s_lst[WAVES][256];
+    __shared__ uint32_t s_next[WAVES][256];
+    const unsigned w = threadIdx.x >> 6, lane = rcx_lane();
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + w));   // wave-uniform: keeps descriptors in SGPRs
+    if (b >= a.nblocks) return;
+    uint8_t* lst = s_lst[w];
+    uint32_t* next = s_next[w];
+    const uint32_t* words = (const uint32_t*)(a.in_base + a.in_off[b]);
+    const uint32_t nwords = (uint32_t)(a.in_len[b] / 4);
+    const uint32_t n = (uint32_t)a.n_out[b];
+    uint8_t* out = a.out_base + a.out_off[b];
+    int st = RCX_OK;
+    uint32_t di = 256, i = 0, A = 0;
+    if (nwords < 256 || ((uintptr_t)words & 3u)) st = RCX_E_MALFORMED;          // :239-241
+    else if (a.out_cap[b] < n) st = RCX_E_OUTPUT_TOO_SMALL;
+    if (!st) {
+        for (int k = 0; k < 4; k++) { next[lane + 64 * k] = words[lane + 64 * k]; lst[lane + 64 * k] = 0; }
+        rcx_wave_sync();
+        // :168-179 order the present symbols by first position: rank(sym) = #present symbols with a smaller
+        // init (stable on ties by symbol value, as the insertion sort is)
+        for (int k = 0; k < 4; k++) {
+            const uint32_t sym = lane + 64 * k;
+            const uint32_t d = next[sym];
+            if (d < n) {
+                uint32_t r = 0;
+                for (uint32_t s2 = 0; s2 < 256; s2++) {
+                    const uint32_t d2 = next[s2];
+                    if (d2 < n && (d2 < d || (d2 == d && s2 < sym))) r++;
+                }
+                lst[r] = (uint8_t)sym;
+            }
+        }
+        uint32_t cnt = 0;
+        for (int k = 0; k < 4; k++) cnt += (next[lane + 64 * k] < n) ? 1u : 0u;
+        A = rcx_wave_sum(cnt);
+        rcx_wave_sync();
+        if (A <= 1) {                                          // :180-187 redundant alphabet: no distance is read
+            const uint8_t sym = lst[0];
+            for (uint32_t t = lane; t < n; t += 64) out[t] = sym;
+            i = n;
+        }
+        while (i < n) {                                        // :199-229
+            const uint32_t sym = __builtin_amdgcn_readfirstlane((uint32_t)lst[0]);
+            const uint32_t stop = __builtin_amdgcn_readfirstlane(next[lst[1]]);
+            if (stop > n) { st = RCX_E_MALFORMED; break; }     // output[i] index panic
+            for (uint32_t t = i + lane; t < stop; t += 64) out[t] = (uint8_t)sym;
+            if (stop > i) i = stop;
+            di++;                                              // decode_simple closure :243-249
+            if (di > nwords) { st = RCX_E_EOF; break; }
+            const uint32_t d = __builtin_amdgcn_readfirstlane(words[di - 1]);
+            const uint64_t future64 = (uint64_t)stop + d;
+            if (future64 > n) { st = RCX_E_MALFORMED; break; } /* :213 assert */
+            const uint32_t future = (uint32_t)future64;
+            // :214-218 first rank r >= 1 with !(future + r > next[lst[r]]), else A
+            uint32_t rank = A;
+            for (uint32_t r0 = 1; r0 < A; r0 += 64) {
+                const uint32_t r = r0 + lane;
+                const bool stopper = r < A && !(future + r > next[lst[r]]);
+                const unsigned long long m = __ballot(stopper);
+                if (m) { rank = r0 + (uint32_t)(__ffsll(m) - 1); break; }
+            }
+            // lst[0..rank-2] = lst[1..rank-1]; lst[rank-1] = sym
+            uint8_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const uint32_t q = lane + 64u * k; v[k] = (q + 1 < rank) ? lst[q + 1] : (uint8_t)0; }
+            rcx_wave_sync();
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const uint32_t q = lane + 64u * k; if (q + 1 < rank) lst[q] = v[k]; }
+            if (lane == 0) { lst[rank - 1] = (uint8_t)sym; next[sym] = future + rank - 1; }   // :225-227
+            rcx_wave_sync();
+        }
+        if (!st && A > 1) {                                    // :230 assert over all 256 entries
+            bool bad = false;
+            for (int k = 0; k < 4; k++) { const uint32_t x = next[lane + 64 * k]; bad = bad || x < n || x >= n + A; }
+            if (__ballot(bad)) st = RCX_E_MALFORMED;
+        }
+    }
+    if (lane == 0) {
+        a.status[b] = st; a.out_len[b] = st ? 0 : n;
+        if (a.in_used) a.in_used[b] = st ? 0 : 4ull * di;
+    }
+}
+
+// =================================================================================================
+// RLE -- src/rle.rs.  encode :82-122 (one-shot write+finish), decode :194-259
+// =================================================================================================
+__device__ __forceinline__ uint32_t rle_size(uint32_t reps)            // bytes flush() writes, :96-122
+{
+    if (reps == 1) return 1;
+    uint32_t v = reps - 2, k = 1;
+    while (v >>= 7) k++;
+    return 2 + k;
+}
+__device__ __forceinline__ void rle_put(uint8_t* out, uint32_t o, uint8_t byte, uint32_t reps)
+{
+    out[o] = byte;
+    if (reps == 1) return;
+    out[o + 1] = byte;
+    uint32_t v = reps - 2, idx = o + 2;
+    for (;;) {
+        uint8_t x = (uint8_t)(v & 0x7f);
+        v >>= 7;
+        if (v == 0) { out[idx] = x | 0x80; break; }
+        out[idx++] = x;
+    }
+}
+
+// One wave per stream, 64 input bytes per step: run starts by neighbour compare, run lengths from the
+// ballot of starts, output offsets from a wave prefix sum of the emitted sizes.  The last (open) run of a
+// step is carried into the next step.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_rle_encode(rcx_kargs a)
+{
+    const unsigned w = threadIdx.x >> 6, lane = rcx_lane();
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + w));   // wave-uniform: keeps descriptors in SGPRs
+    if (b >= a.nblocks) return;
+    const uint8_t* in = a.in_base + a.in_off[b];
+    const uint32_t n = (uint32_t)a.in_len[b];
+    uint8_t* out = a.out_base + a.out_off[b];
+    const uint64_t cap = a.out_cap[b];
+    uint32_t o = 0;
+    int st = RCX_OK;
+    bool have = false; uint32_t cbyte = 0, clen = 0;         // carried open run
+    for (uint32_t j = 0; j < n && !st; j += 64) {
+        const uint32_t p = j + lane;
+        const bool valid = p < n;
+        const uint32_t x = valid ? in[p] : 0u;
+        const uint32_t prev = __shfl_up(x, 1);
+        const bool start = valid && (lane == 0 ? (!have || x != cbyte) : (x != prev));
+        const unsigned long long S = __ballot(start);
+        const uint32_t nvalid = n - j < 64 ? n - j : 64;
+        if (!S) { clen += nvalid; continue; }                // the carried run covers the whole step
+        const int first = __ffsll(S) - 1;
+        // run starting at this lane ends at the next start (closed) or at the end of the step (open)
+        const unsigned long long above = (lane == 63) ? 0ull : (S >> (lane + 1));
+        const bool closed = start && above != 0;
+        const uint32_t rl = closed ? (uint32_t)__ffsll(above) : 0u;
+        uint32_t sz = closed ? rle_size(rl) : 0u;
+        const uint32_t csz = have ? rle_size(clen + (uint32_t)first) : 0u;   // the carried run closes at `first`
+        const uint32_t incl = rcx_wave_incl_scan(sz);
+        const uint32_t total = csz + (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+        if ((uint64_t)o + total > cap) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
+        if (have && lane == 0) rle_put(out, o, (uint8_t)cbyte, clen + (uint32_t)first);
+        if (closed) rle_put(out, o + csz + incl - sz, (uint8_t)x, rl);
+        o += total;
+        const int lastl = 63 - __clzll(S);
+        cbyte = __builtin_amdgcn_readlane(x, lastl);
+        clen = nvalid - (uint32_t)lastl;
+        have = true;
+    }
+    if (!st && have) {                                        // finish(): flush the open run, :62-66
+        const uint32_t csz = rle_size(clen);
+        if ((uint64_t)o + csz > cap) st = RCX_E_OUTPUT_TOO_SMALL;
+        else { if (lane == 0) rle_put(out, o, (uint8_t)cbyte, clen); o += csz; }
+    }
+    if (lane == 0) { a.status[b] = st; a.out_len[b] = st ? 0 : o; if (a.in_used) a.in_used[b] = n; }
+}
+
+// decode: the Clean/Single/Run state machine (:194-259) is a serial parse (a length byte is arbitrary data),
+// walked wave-uniformly; run bodies are filled 64 bytes per step.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_rle_decode(rcx_kargs a)
+{
+    const unsigned w = threadIdx.x >> 6, lane = rcx_lane();
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + w));   // wave-uniform: keeps descriptors in SGPRs
+    if (b >= a.nblocks) return;
+    const uint8_t* in = a.in_base + a.in_off[b];
+    const uint32_t n = (uint32_t)a.in_len[b];
+    uint8_t* out = a.out_base + a.out_off[b];
+    const uint64_t cap = a.out_cap[b];
+    uint64_t o = 0;
+    int st = RCX_OK;
+    uint32_t i = 0;
+    while (i < n) {
+        const uint32_t cur = __builtin_amdgcn_readfirstlane((uint32_t)in[i]);           // Clean -> Single(cur)
+        if (i + 1 >= n) { if (o + 1 > cap) { st = RCX_E_OUTPUT_TOO_SMALL; break; } if (lane == 0) out[o] = (uint8_t)cur; o += 1; i += 1; break; }
+        const uint32_t nx = __builtin_amdgcn_readfirstlane((uint32_t)in[i + 1]);
+        if (nx != cur) {                                       // Single(cur) followed by a different byte
+            // a stretch of singles: emit bytes while in[k] != in[k+1], 64 per step
+            uint32_t k = i;
+            for (;;) {
+                const uint32_t p = k + lane;
+                const bool stopper = (p + 1 >= n) || (in[p] == in[p + 1]);
+                const unsigned long long m = __ballot(stopper);
+                const uint32_t cnt = m ? (uint32_t)(__ffsll(m) - 1) : 64u;
+                if (o + cnt > cap) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
+                if (lane < cnt) out[o + lane] = in[p];
+                o += cnt; k += cnt;
+                if (m) break;
+            }
+            if (st) break;
+            i = k;                                             // in[i] starts a pair or is the last byte
+            continue;
+        }
+        // Run(RunBuilder): length bytes until one has bit 7, at most 9 (:151-158, :214-222)
+        uint32_t q = i + 2, cntb = 0;
+        uint64_t reps = 0;
+        bool fin = false;
+        while (q < n) {
+            if (cntb >= 9) { st = RCX_E_RLE_LONG_RUN; break; }
+            const uint32_t x = __builtin_amdgcn_readfirstlane((uint32_t)in[q]);
+            q++;
+            reps |= (uint64_t)(x & 0x7f) << (7 * cntb);
+            cntb++;
+            if (x & 0x80) { fin = true; break; }
+        }
+        if (st) break;
+        (void)fin;                                             // EOF inside the header decodes what was read (:247-256)
+        reps += 2;
+        if (reps > cap - o) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
+        for (uint64_t t = lane; t < reps; t += 64) out[o + t] = (uint8_t)cur;
+        o += reps;
+        i = q;
+    }
+    if (lane == 0) { a.status[b] = st; a.out_len[b] = st ? 0 : o; if (a.in_used) a.in_used[b] = n; }
+}
+
+// =================================================================================================
+// Adaptive byte range coder -- src/entropy/ari/mod.rs:117-159 (RangeEncoder::process/query),
+// table.rs:69-117 (Model::update/downscale/get_range/find_value), table.rs:185-273 (ByteEncoder/Decoder).
+// One lane per stream.  Table in LDS, lane-interleaved: entry e of lane t at tab[e*64+t] (u16), plus
+// 17 block sums of 16 entries (u16) so a cumulative frequency costs <= 16+15 reads, not 256.  The sums are
+// exact integers, so every (lo, hi, total) equals the reference's linear scan.
+// =================================================================================================
+#define ARI_N 257
+#define ARI_NB 17
+struct AriTab {
+    uint16_t* tab; uint16_t* bs; unsigned t; uint32_t total;
+    __device__ __forceinline__ uint16_t& f(uint32_t e) { return tab[e * 64 + t]; }
+    __device__ __forceinline__ uint16_t& s(uint32_t blk) { return bs[blk * 64 + t]; }
+    __device__ void init()
+    {
+        for (uint32_t e = 0; e < ARI_N; e++) f(e) = 1;
+        for (uint32_t k = 0; k < 16; k++) s(k) = 16;
+        s(16) = 1;
+        total = ARI_N;
+    }
+    __device__ void update(uint32_t v)                        // update(value, 10, 1), table.rs:69-79
+    {
+        const uint32_t add = (total >> 10) + 1;
+        f(v) = (uint16_t)(f(v) + add);
+        s(v >> 4) = (uint16_t)(s(v >> 4) + add);
+        total += add;
+        if (total >= 4096) {                                  // downscale, table.rs:82-91 (cut_shift = 1)
+            total = 0;
+            for (uint32_t k = 0; k < ARI_NB; k++) {
+                uint32_t bsum = 0;
+                const uint32_t e1 = k == 16 ? ARI_N : 16 * k + 16;
+                for (uint32_t e = 16 * k; e < e1; e++) { const uint16_t x = (uint16_t)((f(e) + 1) >> 1); f(e) = x; bsum += x; }
+                s(k) = (uint16_t)bsum;
+                total += bsum;
+            }
+        }
+    }
+    __device__ void range_of(uint32_t v, uint32_t& lo, uint32_t& hi)      // get_range, table.rs:100-103
+    {
+        uint32_t l = 0;
+        for (uint32_t k = 0; k < (v >> 4); k++) l += s(k);
+        for (uint32_t e = v & ~15u; e < v; e++) l += f(e);
+        lo = l; hi = l + f(v);
+    }
+    __device__ uint32_t find(uint32_t offset, uint32_t& lo, uint32_t& hi)  // find_value, table.rs:105-117
+    {
+        uint32_t l = 0, k = 0;
+        for (; k < 16; k++) { const uint32_t x = s(k); if (l + x > offset) break; l += x; }
+        uint32_t e = 16 * k, h;
+        for (;;) { h = l + f(e); if (h > offset) break; l = h; e++; }
+        lo = l; hi = h;
+        return e;
+    }
+};
+struct AriRange {                                              // RangeEncoder, mod.rs:67-91
+    uint32_t low, hai;
+    __device__ __forceinline__ unsigned process(uint32_t total, uint32_t from, uint32_t to, uint8_t* o4)   // :117-150
+    {
+        const uint32_t range = (hai - low) / total;
+        uint32_t lo = low + range * from, hi = low + range * to;
+        unsigned k = 0;
+        for (;;) {
+            if (((lo ^ hi) & 0xff000000u) != 0) {
+                if (hi - lo > (1u << 14)) break;
+                const uint32_t lim = hi & 0xff000000u;
+                if (hi - lim >= lim - lo) lo = lim; else hi = lim - 1;
+            }
+            o4[k++] = (uint8_t)(lo >> 24);
+            lo <<= 8; hi <<= 8;
+        }
+        low = lo; hai = hi;
+        return k;
+    }
+};
+
+__global__ __launch_bounds__(64) void k_ari_byte(rcx_kargs a, int decode)
+{
+    __shared__ uint16_t s_tab[ARI_N * 64];
+    __shared__ uint16_t s_bs[ARI_NB * 64];
+    const unsigned t = threadIdx.x;
+    const uint32_t b = blockIdx.x * 64 + t;
+    if (b >= a.nblocks) return;
+    AriTab T; T.tab = s_tab; T.bs = s_bs; T.t = t; T.init();
+    AriRange R; R.low = 0; R.hai = 0xffffffffu;
+    const uint8_t* in = a.in_base + a.in_off[b];
+    const uint64_t n = a.in_len[b];
+    uint8_t* out = a.out_base + a.out_off[b];
+    const uint64_t cap = a.out_cap[b];
+    uint64_t o = 0, used = 0;
+    int st = RCX_OK;
+    uint8_t tmp[4];
+    if (!decode) {                                             // ByteEncoder::write + finish, table.rs:203-219
+        for (uint64_t i = 0; i <= n; i++) {
+            const uint32_t v = i < n ? in[i] : 256u;           // EOF symbol on finish()
+            uint32_t lo, hi;
+            T.range_of(v, lo, hi);
+            const unsigned k = R.process(T.total, lo, hi, tmp);
+            if (o + k > cap) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
+            for (unsigned j = 0; j < k; j++) out[o + j] = tmp[j];
+            o += k;
+            if (i < n) T.update(v);
+        }
+        if (!st) {                                             // Encoder::finish: 4-byte BE tail of `low`, mod.rs:230-237
+            if (o + 4 > cap) st = RCX_E_OUTPUT_TOO_SMALL;
+            else { out[o] = (uint8_t)(R.low >> 24); out[o + 1] = (uint8_t)(R.low >> 16); out[o + 2] = (uint8_t)(R.low >> 8); out[o + 3] = (uint8_t)R.low; o += 4; }
+        }
+        used = n;
+    } else {                                                   // ByteDecoder::read to EOF + finish, table.rs:256-272
+        uint32_t code = 0; unsigned pending = 4; uint64_t p = 0;
+        for (;;) {
+            while (pending) {                                  // feed(), mod.rs:271-278
+                if (p >= n) { st = RCX_E_MALFORMED; break; }   // mod.rs:282 feed().unwrap() panics
+                code = (code << 8) + in[p++]; pending--;
+            }
+            if (st) break;
+            const uint32_t total = T.total;
+            const uint32_t range = (R.hai - R.low) / total;    // query(), mod.rs:153-159
+            const uint32_t offset = (code - R.low) / range;
+            if (offset >= total) { st = RCX_E_MALFORMED; break; }   // table.rs:106 assert
+            uint32_t lo, hi;
+            const uint32_t v = T.find(offset, lo, hi);
+            pending = R.process(total, lo, hi, tmp);
+            if (v == 256) break;
+            if (o >= cap) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
+            T.update(v);
+            out[o++] = (uint8_t)v;
+        }
+        if (!st) { while (pending) { if (p >= n) { st = RCX_E_EOF; break; } p++; pending--; } }   // finish(), mod.rs:289-292
+        used = p;
+    }
+    a.status[b] = st; a.out_len[b] = o; if (a.in_used) a.in_used[b] = used;
+}
+
+// -------------------------------------------------------------------------------------------------
+static void launch_serial(hipStream_t s, int codec, rcx_kargs& k, int v)
+{
+    const uint32_t n = k.nblocks;
+    (void)v;
+    switch (codec) {
+    case RCX_MTF_ENCODE: hipLaunchKernelGGL((k_mtf<4>), dim3((n + 3) / 4), dim3(256), 0, s, k, 0); break;
+    case RCX_MTF_DECODE: hipLaunchKernelGGL((k_mtf<4>), dim3((n + 3) / 4), dim3(256), 0, s, k, 1); break;
+    case RCX_DC_ENCODE: hipLaunchKernelGGL((k_dc_encode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k); break;
+    case RCX_DC_DECODE: hipLaunchKernelGGL((k_dc_decode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k); break;
+    case RCX_RLE_ENCODE: hipLaunchKernelGGL((k_rle_encode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k); break;
+    case RCX_RLE_DECODE: hipLaunchKernelGGL((k_rle_decode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k); break;
+    case RCX_ARI_BYTE_ENCODE: hipLaunchKernelGGL(k_ari_byte, dim3((n + 63) / 64), dim3(64), 0, s, k, 0); break;
+    case RCX_ARI_BYTE_DECODE: hipLaunchKernelGGL(k_ari_byte, dim3((n + 63) / 64), dim3(64), 0, s, k, 1); break;
+    default: break;
+    }
+}

@@ -77,7 +77,7 @@ extern "C" void rcx_ctx_destroy(rcx_ctx* c)
 extern "C" int rcx_ctx_set_stream(rcx_ctx* c, void* s)
 {
     if (!c) return RCX_RC_BAD_ARG;
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = (hipStream_t)s;          // NULL = the HIP null (legacy default) stream
     return RCX_RC_OK;
 }
 
@@ -145,10 +145,11 @@ static int launch_codec(rcx_ctx* c, int codec, rcx_kargs& k)
     switch (codec) {
     case RCX_LZ4_DECODE:
         if (v == 1) hipLaunchKernelGGL(k_lz4_decode_v1, dim3(n), dim3(64), 0, s, k);
-        else if (v == 2) hipLaunchKernelGGL((k_lz4_decode_v2<4096, 2048, 64, 64, 4>), dim3((n + 3) / 4), dim3(256), 0, s, k);
-        else if (v == 3) hipLaunchKernelGGL((k_lz4_decode_v2<4096, 2048, 32, 32, 1>), dim3(n), dim3(64), 0, s, k);
-        else if (v == 4) hipLaunchKernelGGL((k_lz4_decode_v2<8192, 2048, 128, 128, 1>), dim3(n), dim3(64), 0, s, k);
-        else hipLaunchKernelGGL((k_lz4_decode_v2<4096, 2048, 64, 64, 1>), dim3(n), dim3(64), 0, s, k);
+        else if (v == 2) hipLaunchKernelGGL((k_lz4_decode_v3<2048, 2048, 64, 64, 4>), dim3((n + 3) / 4), dim3(256), 0, s, k);
+        else if (v == 3) hipLaunchKernelGGL((k_lz4_decode_v3<4096, 2048, 64, 64, 1>), dim3(n), dim3(64), 0, s, k);
+        else if (v == 4) hipLaunchKernelGGL((k_lz4_decode_v3<2048, 2048, 32, 32, 1>), dim3(n), dim3(64), 0, s, k);
+        else if (v == 5) hipLaunchKernelGGL((k_lz4_decode_v2<4096, 2048, 64, 64, 1>), dim3(n), dim3(64), 0, s, k);
+        else hipLaunchKernelGGL((k_lz4_decode_v3<2048, 2048, 64, 64, 1>), dim3(n), dim3(64), 0, s, k);
         break;
     case RCX_LZ4_ENCODE: {
         if (k.scratch_bytes < rcx_scratch_bytes(codec, n, 0)) { c->err = "lz4 encode: scratch too small"; return RCX_RC_BAD_ARG; }

@@ -29,15 +29,19 @@ typedef rcx_u32x4 __attribute__((aligned(1))) rcx_u32x4_u;
 
 __device__ __forceinline__ unsigned rcx_lane() { return threadIdx.x & 63u; }
 
-// wave64 inclusive prefix sum (6 shuffle steps)
+// DPP move: lanes whose source is outside the row / masked off get 0.  ctrl: row_shr:n = 0x110+n,
+// row_bcast:15 = 0x142, row_bcast:31 = 0x143 (gfx9 encodings).
+#define RCX_DPP0(v, ctrl, row_mask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (row_mask), 0xf, false))
+
+// wave64 inclusive prefix sum on the VALU (6 DPP adds, no LDS crossbar round trips)
 __device__ __forceinline__ uint32_t rcx_wave_incl_scan(uint32_t v)
 {
-    const unsigned lane = rcx_lane();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d);
-        if (lane >= (unsigned)d) v += t;
-    }
+    v += RCX_DPP0(v, 0x111, 0xf);      // row_shr:1
+    v += RCX_DPP0(v, 0x112, 0xf);      // row_shr:2
+    v += RCX_DPP0(v, 0x114, 0xf);      // row_shr:4
+    v += RCX_DPP0(v, 0x118, 0xf);      // row_shr:8   -> inclusive scan inside each row of 16
+    v += RCX_DPP0(v, 0x142, 0xa);      // row_bcast:15 into rows 1 and 3
+    v += RCX_DPP0(v, 0x143, 0xc);      // row_bcast:31 into rows 2 and 3
     return v;
 }
 __device__ __forceinline__ uint32_t rcx_wave_max(uint32_t v)

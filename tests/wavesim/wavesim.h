@@ -138,6 +138,23 @@ template <class T> inline T readfirstlane(T x)
     for (int i = 0; i < 64; i++) if (v[i]) return from_u64<T>(o[i]);
     return x;
 }
+// __builtin_amdgcn_update_dpp for the controls the kernels use (row_shr/row_shl/row_bcast15/31/wave_shr1)
+inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
+{
+    uint64_t o[64]; bool v[64];
+    wave_exchange(to_u64(src), o, v);
+    const int l = (int)(cur->tid & 63), row = l >> 4, pos = l & 15;
+    if (!((row_mask >> row) & 1) || !((bank_mask >> (pos >> 2)) & 1)) return old;
+    int s = -1;
+    if (ctrl >= 0x111 && ctrl <= 0x11f) { int n = ctrl - 0x110; if (pos >= n) s = l - n; }
+    else if (ctrl >= 0x101 && ctrl <= 0x10f) { int n = ctrl - 0x100; if (pos + n < 16) s = l + n; }
+    else if (ctrl == 0x142) { if (row >= 1) s = row * 16 - 1; }
+    else if (ctrl == 0x143) { if (row >= 2) s = 31; }
+    else if (ctrl == 0x138) { if (l >= 1) s = l - 1; }
+    else { fprintf(stderr, "wavesim: unsupported dpp ctrl 0x%x\n", ctrl); abort(); }
+    if (s < 0 || !v[s]) return bound_ctrl ? 0 : old;
+    return from_u64<int>(o[s]);
+}
 inline int bpermute(int byte_addr, int x) { return shfl<int>(x, (byte_addr >> 2) & 63); }
 
 struct tid_proxy { unsigned x, y, z; };
@@ -196,6 +213,7 @@ static inline unsigned __byte_perm_(unsigned a, unsigned b, unsigned s) { (void)
 #define __builtin_amdgcn_readfirstlane(x) ws::readfirstlane((x))
 #define __builtin_amdgcn_readlane(x, l) ws::shfl((x), (int)(l))
 #define __builtin_amdgcn_writelane(v, l, o) (((int)(ws::cur->tid & 63) == (int)(l)) ? (int)(v) : (int)(o))
+#define __builtin_amdgcn_update_dpp(o, s, c, rm, bm, bc) ws::update_dpp((o), (s), (c), (rm), (bm), (bc))
 #define __builtin_amdgcn_ds_bpermute(a, x) ws::bpermute((a), (x))
 #define __builtin_amdgcn_wave_barrier() ws::wave_barrier()
 #define __builtin_amdgcn_s_barrier() ws::block_barrier()
