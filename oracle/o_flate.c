@@ -260,8 +260,10 @@ int o_zlib_decode(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t*
     if (flags) *flags = 0;
     if (n < 1) return RCX_E_EOF;
     uint8_t cmf = in[0];
+    if (in_used) *in_used = 1;
     if (n < 2) return RCX_E_EOF;
     uint8_t flg = in[1];
+    if (in_used) *in_used = 2;                                        /* both bytes are read before the checks */
     if ((cmf & 0xf) != 0x8) return RCX_E_ZLIB_FORMAT;                 /* :58 */
     if ((cmf & 0xf0) != 0x70) return RCX_E_ZLIB_WINDOW;               /* :65 */
     if (flg & 0x20) return RCX_E_ZLIB_DICT;                           /* :72 */

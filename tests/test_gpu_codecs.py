@@ -1,0 +1,104 @@
+"""GPU parity through the C-ABI vs the oracle, bit-exact, for every codec besides LZ4:
+inflate / zlib / Adler-32, BWT forward + inverse, MTF, DC, adaptive byte range coder, RLE."""
+import zlib
+
+import numpy as np
+import pytest
+
+import corpus
+from rust_compress_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+
+
+def _raws(oracle):
+    raws = corpus.small_corpus(sizes=(17, 1000, 20000, 262144))
+    return raws + [oracle.bwt_encode(r)[0] for r in raws[:20]]
+
+
+def test_inflate_zlib_fixtures_and_python_zlib(ctx, oracle, golden):
+    txt = golden("test.txt")
+    raws = corpus.small_corpus(sizes=(17, 1000, 40000, 300000))
+    zs, exp = [], []
+    for r in raws:
+        for lvl in (0, 1, 6, 9):
+            zs.append(zlib.compress(r, lvl)); exp.append(r)
+        c = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+        zs.append(c.compress(r) + c.flush()); exp.append(r)
+    for i in range(10):
+        zs.append(golden("test.z.%d" % i)); exp.append(txt)                 # zlib.rs:151-164
+    res = ctx.zlib_decode(zs, [len(e) for e in exp]).check()
+    assert res.outputs == exp and list(res.in_used) == [len(z) for z in zs]
+    raw = [z[2:-4] for z in zs] + [golden("test.z.go")]                      # flate.rs:528-542
+    res = ctx.inflate(raw, [len(e) for e in exp] + [len(txt)]).check()
+    assert res.outputs == exp + [txt] and res.aux[-1] == 1
+
+
+def test_inflate_malformed_statuses(ctx, oracle, golden):
+    zs = [zlib.compress(r, 6) for r in corpus.small_corpus(sizes=(17, 1000, 5000))] + [golden("test.z.5")]
+    blobs, caps = corpus.mutate(zs, 1500, 2, [50, 3000, 50000])
+    res = ctx.zlib_decode(blobs, caps)
+    for i, (b, c) in enumerate(zip(blobs, caps)):
+        eo, eu, _, es = oracle.zlib_decode(b, cap=c, raise_on_error=False)
+        assert es == res.status[i] and eu == res.in_used[i], (i, es, res.status[i])
+        if es == 0:
+            assert eo == res.outputs[i]
+    res = ctx.inflate(blobs, caps)
+    for i, (b, c) in enumerate(zip(blobs, caps)):
+        eo, eu, _, es = oracle.inflate(b, cap=c, raise_on_error=False)
+        assert es == res.status[i] and eu == res.in_used[i] and eo == res.outputs[i], i
+
+
+def test_adler32(ctx, oracle):
+    raws = corpus.small_corpus(sizes=(17, 1000, 70000, 1 << 20))
+    res = ctx.adler32(raws).check()
+    assert list(res.aux) == [oracle.adler32(r) for r in raws] == [zlib.adler32(r) for r in raws]
+
+
+def test_bwt_forward_and_inverse(ctx, oracle):
+    raws = corpus.small_corpus(sizes=(17, 1000, 20000, 262144))
+    fw = ctx.bwt_forward(raws).check()
+    for r, L, og in zip(raws, fw.outputs, fw.aux):
+        eL, eo = oracle.bwt_encode(r)
+        assert L == eL and (not r or og == eo)
+    nz = [i for i, r in enumerate(raws) if r]
+    inv = ctx.bwt_inverse([fw.outputs[i] for i in nz], [int(fw.aux[i]) for i in nz]).check()
+    assert inv.outputs == [raws[i] for i in nz]
+    bad = ctx.bwt_inverse([b"abc"], [3])                    # origin >= n: bwt/mod.rs:230 panics
+    assert bad.status[0] == 3
+
+
+def test_mtf_dc_ari_rle(ctx, oracle):
+    raws = _raws(oracle)
+    lens = [len(r) for r in raws]
+    e = ctx.mtf_encode(raws).check()
+    assert e.outputs == [oracle.mtf_encode(r) for r in raws]
+    assert ctx.mtf_decode(e.outputs).check().outputs == raws
+    e = ctx.rle_encode(raws).check()
+    assert e.outputs == [oracle.rle_encode(r) for r in raws]
+    assert ctx.rle_decode(e.outputs, lens).check().outputs == raws
+    e = ctx.ari_byte_encode(raws).check()
+    assert e.outputs == [oracle.ari_byte_encode(r) for r in raws]
+    d = ctx.ari_byte_decode([x + b"tail" for x in e.outputs], lens).check()
+    assert d.outputs == raws and list(d.in_used) == [len(x) for x in e.outputs]
+    e = ctx.dc_encode(raws).check()
+    assert e.outputs == [oracle.dc_encode(r).tobytes() for r in raws]
+    assert ctx.dc_decode(e.outputs, lens).check().outputs == raws
+
+
+def test_rle_ari_malformed(ctx, oracle):
+    rng = np.random.default_rng(2)
+    arb = [bytes(rng.integers(0, 4, rng.integers(0, 200), dtype=np.uint8) * rng.integers(1, 100)) for _ in range(200)]
+    arb += [b"aa", b"aab", b"aa" + bytes(10), b"a", b"aaa\x80b"]
+    res = ctx.rle_decode(arb, [5000] * len(arb))
+    for i, b in enumerate(arb):
+        eo, es = oracle.rle_decode(b, cap=5000, raise_on_error=False)
+        assert es == res.status[i] and (es != 0 or eo == res.outputs[i])
+    enc = [oracle.ari_byte_encode(r) for r in corpus.small_corpus(sizes=(17, 1000))]
+    blobs, caps = corpus.mutate(enc, 400, 9, [10, 2000])
+    res = ctx.ari_byte_decode(blobs, caps)
+    for i, (b, c) in enumerate(zip(blobs, caps)):
+        eo, eu, es = oracle.ari_byte_decode(b, cap=c, raise_on_error=False)
+        assert es == res.status[i], (i, es, res.status[i])
+        if es == 0:
+            assert eo == res.outputs[i] and eu == res.in_used[i]

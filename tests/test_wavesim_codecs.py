@@ -1,0 +1,94 @@
+"""CPU suite: the unmodified .hip kernels of every codec on the wave64 simulator vs the oracle
+(kernel-logic debugging aid; the real parity tests are the -m gpu ones)."""
+import zlib
+
+import numpy as np
+
+import corpus
+from rust_compress_amd import _native as N
+
+
+def _raws(oracle):
+    raws = corpus.small_corpus()
+    return raws + [oracle.bwt_encode(r)[0] for r in raws]     # BWT outputs: long runs
+
+
+def test_lz4_encode(oracle):
+    import simrun
+    raws = _raws(oracle)
+    outs, _, _, st, _ = simrun.run(N.LZ4_ENCODE, 0, raws, [oracle.lz4_compression_bound(len(r)) for r in raws],
+                                   scratch_bytes=len(raws) * (1 << 19))
+    assert not st.any() and outs == [oracle.lz4_encode_block(r) for r in raws]
+
+
+def test_mtf_rle_ari_dc(oracle):
+    import simrun
+    raws = _raws(oracle)
+    lens = [len(r) for r in raws]
+    enc, _, _, st, _ = simrun.run(N.MTF_ENCODE, 0, raws, lens)
+    assert not st.any() and enc == [oracle.mtf_encode(r) for r in raws]
+    dec, _, _, st, _ = simrun.run(N.MTF_DECODE, 0, enc, lens)
+    assert not st.any() and dec == raws
+
+    enc, _, _, st, _ = simrun.run(N.RLE_ENCODE, 0, raws, [oracle.lib().o_rle_encode_bound(n) for n in lens])
+    assert not st.any() and enc == [oracle.rle_encode(r) for r in raws]
+    dec, _, _, st, _ = simrun.run(N.RLE_DECODE, 0, enc, lens)
+    assert not st.any() and dec == raws
+    rng = np.random.default_rng(2)
+    arb = [bytes(rng.integers(0, 4, rng.integers(0, 200), dtype=np.uint8) * rng.integers(1, 100)) for _ in range(40)]
+    arb += [b"aa", b"aab", b"aa" + bytes(10), b"a", b"aaa\x80b"]
+    exp = [oracle.rle_decode(b, cap=5000, raise_on_error=False) for b in arb]
+    outs, _, _, st, _ = simrun.run(N.RLE_DECODE, 0, arb, [5000] * len(arb))
+    for (eo, es), s, o_ in zip(exp, st, outs):
+        assert es == s and (s != 0 or eo == o_)
+
+    enc, _, _, st, _ = simrun.run(N.ARI_BYTE_ENCODE, 0, raws, [2 * n + 16 for n in lens])
+    assert not st.any() and enc == [oracle.ari_byte_encode(r) for r in raws]
+    dec, _, used, st, _ = simrun.run(N.ARI_BYTE_DECODE, 0, [e + b"xyz" for e in enc], lens)
+    assert not st.any() and dec == raws and list(used) == [len(e) for e in enc]   # stops exactly at the stream end
+
+    enc, _, _, st, _ = simrun.run(N.DC_ENCODE, 0, raws, [4 * (256 + n) for n in lens])
+    assert not st.any() and enc == [oracle.dc_encode(r).tobytes() for r in raws]
+    dec, _, _, st, _ = simrun.run(N.DC_DECODE, 0, enc, lens, n_out=np.array(lens, dtype=np.uint64))
+    assert not st.any() and dec == raws
+
+
+def test_inflate_zlib_adler(oracle, golden):
+    import simrun
+    txt = golden("test.txt")
+    raws = corpus.small_corpus(sizes=(17, 1000, 40000))
+    zs, exp = [], []
+    for r in raws:
+        for lvl in (0, 1, 6, 9):
+            zs.append(zlib.compress(r, lvl)); exp.append(r)
+        c = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+        zs.append(c.compress(r) + c.flush()); exp.append(r)
+    for i in range(10):
+        zs.append(golden("test.z.%d" % i)); exp.append(txt)
+    outs, _, used, st, _ = simrun.run(N.ZLIB_DECODE, 0, zs, [len(e) for e in exp])
+    assert not st.any() and outs == exp and list(used) == [len(z) for z in zs]
+    raw = [z[2:-4] for z in zs] + [golden("test.z.go")]
+    outs, _, _, st, aux = simrun.run(N.INFLATE, 0, raw, [len(e) for e in exp] + [len(txt)])
+    assert not st.any() and outs == exp + [txt] and aux[len(raw) - 1] == 1
+    blobs, caps = corpus.mutate(zs, 300, 2, [50, 3000, 50000])
+    ex = [oracle.zlib_decode(b, cap=c, raise_on_error=False) for b, c in zip(blobs, caps)]
+    outs, _, used, st, _ = simrun.run(N.ZLIB_DECODE, 0, blobs, caps)
+    for i, e in enumerate(ex):
+        assert e[-1] == st[i] and e[1] == used[i] and (st[i] != 0 or e[0] == outs[i]), i
+    ex = [oracle.inflate(b, cap=c, raise_on_error=False) for b, c in zip(blobs, caps)]
+    outs, _, used, st, _ = simrun.run(N.INFLATE, 0, blobs, caps)
+    for i, e in enumerate(ex):
+        assert e[-1] == st[i] and e[1] == used[i] and e[0] == outs[i], i
+    big = raws + [b"x" * 70000]
+    _, _, _, _, aux = simrun.run(N.ADLER32, 0, big, [0] * len(big))
+    assert list(aux[: len(big)]) == [oracle.adler32(r) for r in big]
+
+
+def test_bwt_inverse(oracle):
+    import simrun
+    raws = corpus.small_corpus(sizes=(17, 1000, 20000, 70000), with_empty=False)
+    Ls, orgs = zip(*[oracle.bwt_encode(r) for r in raws])
+    maxn = max(len(r) for r in raws)
+    outs, _, _, st, _ = simrun.run(N.BWT_INVERSE, 0, list(Ls), [len(r) for r in raws], aux=np.array(orgs, dtype=np.uint32),
+                                   scratch_bytes=len(raws) * ((maxn * 4 + 255) & ~255) + 256)
+    assert not st.any() and outs == raws

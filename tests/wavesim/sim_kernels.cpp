@@ -1,6 +1,16 @@
 // sim_kernels.cpp -- runs the UNMODIFIED .hip kernel sources on the wave64 simulator (TEST INFRASTRUCTURE).
 // Built by tests/wavesim/build.py with:  g++ -include wavesim.h sim_kernels.cpp wavesim.cpp
 #include "../../rust_compress_amd/csrc/k_lz4_decode.hip"
+#include "../../rust_compress_amd/csrc/k_lz4_encode.hip"
+#define hipStream_t int
+#define hipLaunchKernelGGL(kern, grid, block, shm, stream, ...) ws::launch(grid, block, [&] { kern(__VA_ARGS__); })
+#include "../../rust_compress_amd/csrc/k_serial.hip"
+#include "../../rust_compress_amd/csrc/k_inflate.hip"
+#define hipSuccess 0
+#define hipMemcpyDeviceToHost 0
+static inline int hipMemcpyAsync(void* d, const void* s, size_t n, int, int) { memcpy(d, s, n); return 0; }
+static inline int hipStreamSynchronize(int) { return 0; }
+#include "../../rust_compress_amd/csrc/k_bwt_inverse.hip"
 
 extern "C" int sim_launch(int codec, int variant, const rcx_kargs* a)
 {
@@ -14,6 +24,17 @@ extern "C" int sim_launch(int codec, int variant, const rcx_kargs* a)
         else if (variant == 5) ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_decode_v2<4096, 2048, 64, 64, 1>(k); });
         else ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_decode_v3<2048, 2048, 64, 64, 1>(k); });
         return 0;
+    case RCX_LZ4_ENCODE:
+        ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_encode(k, 0); });
+        return 0;
+    case RCX_MTF_ENCODE: case RCX_MTF_DECODE: case RCX_DC_ENCODE: case RCX_DC_DECODE:
+    case RCX_ARI_BYTE_ENCODE: case RCX_ARI_BYTE_DECODE: case RCX_RLE_ENCODE: case RCX_RLE_DECODE:
+        launch_serial(0, codec, k, variant);
+        return 0;
+    case RCX_INFLATE: launch_inflate(0, k, false, variant); return 0;
+    case RCX_ZLIB_DECODE: launch_inflate(0, k, true, variant); return 0;
+    case RCX_ADLER32: launch_adler32(0, k); return 0;
+    case RCX_BWT_INVERSE: { std::string err; int st = 0; return launch_bwt_inverse(st, k, variant, err); }
     default:
         return -1;
     }
