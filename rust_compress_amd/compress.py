@@ -1,0 +1,440 @@
+"""Host-side mirror of the reference crate's per-algorithm Reader/Writer surface (`compress::*`), over the
+batch C-ABI.  Same names, argument meaning and error behaviour as the Rust types so the parity tests read
+like the reference's own tests:
+
+    compress::lz4::{Decoder, Encoder, decode_block, encode_block, compression_bound}   src/lz4.rs
+    compress::flate::Decoder, compress::zlib::Decoder                                 src/flate.rs, src/zlib.rs
+    compress::bwt::{Encoder, Decoder, encode_simple, decode_simple}                   src/bwt/mod.rs
+    compress::bwt::mtf::{Encoder, Decoder}, compress::bwt::dc::{encode_simple, decode_simple}
+    compress::entropy::ari::{ByteEncoder, ByteDecoder}                                src/entropy/ari/table.rs
+    compress::rle::{Encoder, Decoder}                                                 src/rle.rs
+    compress::Adler32                                                                 src/checksum/adler.rs
+
+A `Decoder(r)` wraps any object with `.read(n) -> bytes` (io.BytesIO, a file, ...) and itself has
+`.read(n)` returning at most n bytes (chunk-size independent, like std::io::Read); an `Encoder(w)` wraps
+any object with `.write(bytes)` and has `.write(buf)` / `.finish()`.  Framing (LZ4 frame, BWT stream,
+zlib header/trailer position) is parsed on the host; every block kernel call is ONE batch FFI call.
+io::Error kinds map to Python exceptions: InvalidInput -> InvalidInput, "unexpected end of file" ->
+UnexpectedEof, a reference panic -> Malformed.
+"""
+import io
+import struct
+
+from . import _native as N
+from .api import BlockError, Context
+
+_ctx = None
+
+
+def context():
+    global _ctx
+    if _ctx is None:
+        _ctx = Context()
+    return _ctx
+
+
+def set_context(ctx):
+    global _ctx
+    _ctx = ctx
+
+
+class CompressError(IOError):
+    def __init__(self, status, msg=None):
+        self.status = int(status)
+        super().__init__(msg if msg is not None else N.lib().rcx_status_string(int(status)).decode())
+
+
+class InvalidInput(CompressError):       # io::ErrorKind::InvalidInput
+    pass
+
+
+class UnexpectedEof(CompressError):      # io::ErrorKind::Other("unexpected end of file") / UnexpectedEof
+    pass
+
+
+class Malformed(CompressError):          # the reference panics here
+    pass
+
+
+def _raise(status):
+    if status == 0:
+        return
+    if status == 1:
+        raise UnexpectedEof(status)
+    if status in (2, 3):
+        raise Malformed(status)
+    raise InvalidInput(status)
+
+
+def _check(res):
+    for s in res.status:
+        _raise(int(s))
+    return res
+
+
+def _read_all(r):
+    chunks = []
+    while True:
+        c = r.read(1 << 20)
+        if not c:
+            break
+        chunks.append(c)
+    return b"".join(chunks)
+
+
+class _BufferedDecoder:
+    """Serves self._out through read(n); subclasses fill it in _decode_all() on first use."""
+
+    def __init__(self, r):
+        self.r = r
+        self._out = None
+        self._pos = 0
+
+    def _ensure(self):
+        if self._out is None:
+            self._raw = _read_all(self.r)
+            self._out = self._decode_all(self._raw)
+            self._pos = 0
+
+    def read(self, n=-1):
+        self._ensure()
+        if n is None or n < 0:
+            n = len(self._out) - self._pos
+        chunk = self._out[self._pos:self._pos + n]
+        self._pos += len(chunk)
+        return chunk
+
+    def read_to_end(self):
+        return self.read(-1)
+
+    def eof(self):
+        self._ensure()
+        return self._pos == len(self._out)
+
+    def reset(self):
+        self._out = None
+        self._pos = 0
+
+
+# ------------------------------------------------------------------------------------------------ lz4
+class lz4:
+    MAGIC = 0x184D2204
+
+    @staticmethod
+    def compression_bound(size):                      # lz4.rs:175-181 -> None | int
+        v = int(N.lib().rcx_lz4_compression_bound(size))
+        return v if v else None
+
+    @staticmethod
+    def decode_block(input, output, max_output=None):  # lz4.rs:602-611: appends to `output`, returns the count
+        cap = max_output if max_output is not None else max(64, 255 * len(input) + 64)
+        res = _check(context().lz4_decode_blocks([bytes(input)], [cap]))
+        output += res.outputs[0]
+        return len(res.outputs[0])
+
+    @staticmethod
+    def encode_block(input, output):                  # lz4.rs:616-627
+        res = context().lz4_encode_blocks([bytes(input)])
+        if res.status[0] == 42:                       # compression_bound() == None -> encode returns 0
+            return 0
+        _check(res)
+        output += res.outputs[0]
+        return len(res.outputs[0])
+
+    class Decoder(_BufferedDecoder):                  # lz4.rs:316-500 (frame reader)
+        MAX_SIZES = [0, 0, 0, 0, 64 << 10, 256 << 10, 1 << 20, 4 << 20]
+
+        def _decode_all(self, data):
+            p, n = 0, len(data)
+            if n - p < 4:
+                raise UnexpectedEof(1)
+            if struct.unpack_from("<I", data, p)[0] != lz4.MAGIC:            # :365-367
+                raise InvalidInput(40, "")
+            p += 4
+            bits = data[p:p + 2] + b"\0\0"                                    # :369-372 short read tolerated
+            p = min(p + 2, n)
+            flg, bd = bits[0], bits[1]
+            if (flg >> 6) != 1:                                               # :375-377
+                raise InvalidInput(41, "")
+            blk_checksum, stream_size, preset = bool(flg & 0x10), bool(flg & 0x08), bool(flg & 0x01)
+            self.max_block_size = self.MAX_SIZES[(bd >> 4) & 7]
+            if stream_size:
+                if n - p < 8:
+                    raise UnexpectedEof(1)
+                p += 8
+            if preset:                                                         # :407 assert!
+                raise Malformed(3, "preset dictionaries not supported yet")
+            if p >= n:
+                raise UnexpectedEof(1)
+            p += 1                                                             # header checksum, ignored :417
+            parts = []                                                         # (kind, payload)
+            while True:
+                if n - p < 4:
+                    raise UnexpectedEof(1)
+                v = struct.unpack_from("<I", data, p)[0]
+                p += 4
+                if v == 0:
+                    break
+                amt = v & 0x7FFFFFFF
+                if n - p < amt:
+                    raise UnexpectedEof(1)
+                parts.append((bool(v & 0x80000000), data[p:p + amt]))
+                p += amt
+                if blk_checksum:
+                    if n - p < 4:
+                        raise UnexpectedEof(1)
+                    p += 4
+            self.consumed = p                                                  # content checksum is never read
+            comp = [d for stored, d in parts if not stored]
+            outs = iter(())
+            if comp:                                                           # ONE batch call for every compressed block
+                caps = [max(self.max_block_size, 255 * len(d) + 64) for d in comp]
+                outs = iter(_check(context().lz4_decode_blocks(comp, caps)).outputs)
+            return b"".join(d if stored else next(outs) for stored, d in parts)
+
+    class Encoder:                                     # lz4.rs:505-597: stored blocks only (compress() is false)
+        def __init__(self, w):
+            self.w = w
+            self.buf = bytearray()
+            self.wrote_header = False
+            self.limit = 256 * 1024
+
+        def _encode_block(self):
+            self.w.write(struct.pack("<I", len(self.buf) | 0x80000000))
+            self.w.write(bytes(self.buf))
+            self.buf.clear()
+
+        def write(self, buf):
+            if not self.wrote_header:
+                self.w.write(struct.pack("<I", lz4.MAGIC) + bytes([0b01100000, 0b01010000, 0]))
+                self.wrote_header = True
+            buf = memoryview(bytes(buf))
+            while len(buf):
+                amt = min(self.limit - len(self.buf), len(buf))
+                self.buf += buf[:amt]
+                if len(self.buf) == self.limit:
+                    self._encode_block()
+                buf = buf[amt:]
+            return 0                                   # the reference returns Ok(buf.len()) of the EMPTIED slice (:588)
+
+        def flush(self):
+            if self.buf:
+                self._encode_block()
+
+        def finish(self):
+            self.flush()
+            self.w.write(b"\0" * 8)
+            return self.w
+
+
+# ------------------------------------------------------------------------------------------------ flate / zlib
+class flate:
+    class Decoder(_BufferedDecoder):                   # flate.rs:164-488; batch semantics: decoded to BFINAL
+        def _decode_all(self, data):
+            cap = 1 << 16
+            while True:
+                res = context().inflate([data], [cap])
+                if res.status[0] == 2 and cap < (1 << 31):
+                    cap *= 8
+                    continue
+                _check(res)
+                self.consumed = int(res.in_used[0])
+                self.flags = int(res.aux[0])
+                return res.outputs[0]
+
+
+class zlib:
+    class Decoder(_BufferedDecoder):                   # zlib.rs:32-127
+        def _decode_all(self, data):
+            cap = 1 << 16
+            while True:
+                res = context().zlib_decode([data], [cap])
+                if res.status[0] == 2 and cap < (1 << 31):
+                    cap *= 8
+                    continue
+                _check(res)
+                self.consumed = int(res.in_used[0])
+                return res.outputs[0]
+
+        def unwrap(self):
+            return self.r
+
+
+class Adler32:                                         # checksum/adler.rs:22-51
+    def __init__(self):
+        self.reset()
+
+    def feed(self, buf):
+        self._data += bytes(buf)
+
+    def result(self):
+        return int(context().adler32([bytes(self._data)]).aux[0])
+
+    def reset(self):
+        self._data = bytearray()
+
+
+# ------------------------------------------------------------------------------------------------ bwt
+class _mtf:
+    class Encoder:                                     # mtf.rs:95-129
+        def __init__(self, w):
+            self.w, self._buf = w, bytearray()
+
+        def write(self, buf):
+            self._buf += bytes(buf)
+            return len(buf)
+
+        def finish(self):
+            self.w.write(_check(context().mtf_encode([bytes(self._buf)])).outputs[0])
+            return self.w
+
+    class Decoder(_BufferedDecoder):                   # mtf.rs:133-169
+        def _decode_all(self, data):
+            return _check(context().mtf_decode([data])).outputs[0]
+
+        def finish(self):
+            return self.r
+
+
+class _dc:
+    @staticmethod
+    def encode_simple(input):                          # dc.rs:153-159 -> list of ints (256 init + distances)
+        out = _check(context().dc_encode([bytes(input)])).outputs[0]
+        return list(struct.unpack("<%dI" % (len(out) // 4), out))
+
+    @staticmethod
+    def decode_simple(n, distances):                   # dc.rs:236-252
+        blob = struct.pack("<%dI" % len(distances), *distances)
+        return _check(context().dc_decode([blob], [n])).outputs[0]
+
+
+class bwt:
+    mtf = _mtf
+    dc = _dc
+
+    @staticmethod
+    def encode_simple(input):                          # bwt/mod.rs:214-219 -> (L, origin)
+        res = _check(context().bwt_forward([bytes(input)]))
+        return res.outputs[0], int(res.aux[0])
+
+    @staticmethod
+    def decode_simple(input, origin):                  # bwt/mod.rs:291-294
+        if len(input) == 0:
+            return b""
+        return _check(context().bwt_inverse([bytes(input)], [origin])).outputs[0]
+
+    class Encoder:                                     # bwt/mod.rs:437-518
+        def __init__(self, w, block_size):
+            self.w, self.block_size, self._buf, self.wrote_header = w, block_size, bytearray(), False
+
+        def write(self, buf):
+            if not self.wrote_header:
+                self.w.write(struct.pack("<I", self.block_size & 0xFFFFFFFF))
+                self.wrote_header = True
+            self._buf += bytes(buf)
+            return 0                                   # same Ok(0) quirk as lz4 (:507)
+
+        def finish(self):
+            data, bs = bytes(self._buf), self.block_size
+            blocks = [data[i:i + bs] for i in range(0, len(data), bs)]
+            if blocks:                                 # ONE batch call for all blocks of the stream
+                res = _check(context().bwt_forward(blocks))
+                for blk, L, origin in zip(blocks, res.outputs, res.aux):
+                    self.w.write(struct.pack("<I", len(blk)) + L + struct.pack("<I", int(origin)))
+            self._buf.clear()
+            return self.w
+
+    class Decoder(_BufferedDecoder):                   # bwt/mod.rs:321-432 (extra_mem = True path)
+        def __init__(self, r, extra_mem=True):
+            super().__init__(r)
+            self.extra_memory = extra_mem
+
+        def _decode_all(self, data):
+            p, n = 0, len(data)
+            if n - p < 4:
+                raise UnexpectedEof(1)                 # :369
+            self.max_block_size = struct.unpack_from("<I", data, p)[0]
+            p += 4
+            Ls, origins = [], []
+            while n - p >= 4:                          # EOF at a block boundary ends the stream, :374-377
+                bn = struct.unpack_from("<I", data, p)[0]
+                p += 4
+                if n - p < bn:
+                    raise UnexpectedEof(1)
+                L = data[p:p + bn]
+                p += bn
+                if n - p < 4:
+                    raise UnexpectedEof(1)
+                origins.append(struct.unpack_from("<I", data, p)[0])
+                p += 4
+                if bn == 0:
+                    raise Malformed(3)                 # input[origin] panics, :230
+                Ls.append(L)
+            if not Ls:
+                return b""
+            return b"".join(_check(context().bwt_inverse(Ls, origins)).outputs)
+
+
+# ------------------------------------------------------------------------------------------------ ari
+class _ari:
+    class ByteEncoder:                                 # table.rs:185-224
+        def __init__(self, w):
+            self.w, self._buf = w, bytearray()
+
+        def write(self, buf):
+            self._buf += bytes(buf)
+            return len(buf)
+
+        def finish(self):
+            self.w.write(_check(context().ari_byte_encode([bytes(self._buf)])).outputs[0])
+            return self.w
+
+    class ByteDecoder(_BufferedDecoder):               # table.rs:229-273; stops exactly at the stream's end
+        def _decode_all(self, data):
+            cap = max(1 << 12, 4 * len(data))
+            while True:
+                res = context().ari_byte_decode([data], [cap])
+                if res.status[0] == 2 and cap < (1 << 31):
+                    cap *= 8
+                    continue
+                _check(res)
+                self.consumed = int(res.in_used[0])
+                return res.outputs[0]
+
+        def finish(self):
+            self._ensure()                             # mod.rs:289-292: the reader ends exactly after this stream
+            return io.BytesIO(self._raw[self.consumed:])
+
+
+class entropy:
+    ari = _ari
+
+
+# ------------------------------------------------------------------------------------------------ rle
+class rle:
+    class Encoder:                                     # rle.rs:40-123 (one-shot semantics)
+        def __init__(self, w):
+            self.w, self._buf = w, bytearray()
+
+        def write(self, buf):
+            self._buf += bytes(buf)
+            return len(buf)
+
+        write_all = write
+
+        def finish(self):
+            self.w.write(_check(context().rle_encode([bytes(self._buf)])).outputs[0])
+            return self.w
+
+    class Decoder(_BufferedDecoder):                   # rle.rs:176-281
+        def _decode_all(self, data):
+            cap = max(1 << 12, 64 * len(data))
+            while True:
+                res = context().rle_decode([data], [cap])
+                if res.status[0] == 2 and cap < (1 << 33):
+                    cap *= 16
+                    continue
+                if res.status[0] == 30:
+                    raise CompressError(30)            # io::ErrorKind::Other "Overly long run"
+                _check(res)
+                return res.outputs[0]

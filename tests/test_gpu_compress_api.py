@@ -1,0 +1,155 @@
+"""GPU: the reference crate's OWN tests, re-stated against the host-side mirror of its Reader/Writer surface
+(rust_compress_amd.compress).  Each test cites the Rust test it restates."""
+import io
+import random
+
+import pytest
+
+import corpus
+from rust_compress_amd import compress as C
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _use_ctx(ctx):
+    C.set_context(ctx)
+
+
+def _one_byte_at_a_time(d):
+    out = bytearray()
+    assert not d.eof()
+    while True:
+        b = d.read(1)
+        if not b:
+            break
+        out += b
+    assert d.eof()
+    return bytes(out)
+
+
+def _random_lengths(d):
+    out = bytearray()
+    while True:
+        b = d.read(1 + random.randrange(40))
+        if not b:
+            break
+        out += b
+    return bytes(out)
+
+
+def test_lz4_decode_fixtures(golden):                      # lz4.rs:647-659 decode
+    ref = golden("test.txt")
+    for i in range(1, 10):
+        assert C.lz4.Decoder(io.BytesIO(golden("test.lz4.%d" % i))).read_to_end() == ref
+
+
+def test_lz4_raw_encode_block(golden):                     # lz4.rs:661-672
+    data = golden("test.txt")
+    enc, dec = bytearray(), bytearray()
+    C.lz4.encode_block(data, enc)
+    C.lz4.decode_block(enc, dec)
+    assert bytes(dec) == data
+
+
+def test_lz4_streaming(golden):                            # lz4.rs:674-706
+    assert _one_byte_at_a_time(C.lz4.Decoder(io.BytesIO(golden("test.lz4.1")))) == golden("test.txt")
+    assert _random_lengths(C.lz4.Decoder(io.BytesIO(golden("test.lz4.1")))) == golden("test.txt")
+
+
+def test_lz4_frame_roundtrips(golden, oracle):             # lz4.rs:708-726 some_roundtrips
+    for data in (b"test", b"", golden("test.txt"), corpus.small_corpus()[-1] * 20):
+        w = io.BytesIO()
+        e = C.lz4.Encoder(w)
+        e.write(data)
+        e.finish()
+        assert w.getvalue() == oracle.lz4_frame_encode(data)
+        assert C.lz4.Decoder(io.BytesIO(w.getvalue())).read_to_end() == data
+    assert C.lz4.compression_bound(0x7E000001) is None and C.lz4.compression_bound(100) == 120
+    with pytest.raises(C.InvalidInput):
+        C.lz4.Decoder(io.BytesIO(b"\x00\x01\x02\x03rest")).read(1)          # bad magic, lz4.rs:366
+    with pytest.raises(C.UnexpectedEof):
+        C.lz4.Decoder(io.BytesIO(golden("test.lz4.1")[:100])).read(1)
+
+
+def test_flate_fixtures_and_streaming(golden):             # flate.rs:528-582
+    ref = golden("test.txt")
+    fix = lambda b: b[2:-4]                                 # flate.rs:504-506
+    for i in range(10):
+        assert C.flate.Decoder(io.BytesIO(fix(golden("test.z.%d" % i)))).read_to_end() == ref
+    assert C.flate.Decoder(io.BytesIO(golden("test.z.go"))).read_to_end() == ref
+    assert _one_byte_at_a_time(C.flate.Decoder(io.BytesIO(fix(golden("test.z.1"))))) == ref
+    assert _random_lengths(C.flate.Decoder(io.BytesIO(fix(golden("test.z.1"))))) == ref
+    with pytest.raises(C.InvalidInput) as e:
+        C.flate.Decoder(io.BytesIO(b"\x07")).read(1)
+    assert str(e.value) == "invalid block code"             # flate.rs:58
+
+
+def test_zlib_fixtures_and_errors(golden):                 # zlib.rs:151-203
+    ref = golden("test.txt")
+    for i in range(10):
+        assert C.zlib.Decoder(io.BytesIO(golden("test.z.%d" % i))).read_to_end() == ref
+    assert _one_byte_at_a_time(C.zlib.Decoder(io.BytesIO(golden("test.z.1")))) == ref
+    bad = bytearray(golden("test.z.1")); bad[-1] ^= 1
+    with pytest.raises(C.InvalidInput) as e:
+        C.zlib.Decoder(io.BytesIO(bytes(bad))).read_to_end()
+    assert str(e.value) == "invalid checksum on zlib stream"   # zlib.rs:111-114
+    a = C.Adler32(); a.feed(b"abra"); a.feed(b"cadabra")
+    assert a.result() == 0x19F20455
+
+
+def test_bwt_mtf_dc_roundtrips(golden, oracle):            # bwt/mod.rs:528-551, mtf.rs:179-197, dc.rs:259-302
+    for data in (b"abracadabra", golden("test.txt")):
+        w = io.BytesIO()
+        e = C.bwt.Encoder(w, 1024)
+        e.write(data)
+        e.finish()
+        assert w.getvalue() == oracle.bwt_stream_encode(data, 1024)
+        assert C.bwt.Decoder(io.BytesIO(w.getvalue()), True).read_to_end() == data
+        L, origin = C.bwt.encode_simple(data)
+        assert (L, origin) == oracle.bwt_encode(data) and C.bwt.decode_simple(L, origin) == data
+        w = io.BytesIO()
+        m = C.bwt.mtf.Encoder(w); m.write(data); m.finish()
+        assert w.getvalue() == oracle.mtf_encode(data)
+        assert C.bwt.mtf.Decoder(io.BytesIO(w.getvalue())).read_to_end() == data
+    for data in (b"teeesst_dc", b"", golden("test.txt")):
+        d = C.bwt.dc.encode_simple(data)
+        assert d == list(map(int, oracle.dc_encode(data)))
+        assert C.bwt.dc.decode_simple(len(data), d) == data
+    assert C.bwt.encode_simple(b"abracadabra") == (b"rdarcaaaabb", 2)          # doctest bwt/mod.rs:26-43
+    with pytest.raises(C.UnexpectedEof):
+        C.bwt.Decoder(io.BytesIO(b"\x00\x04")).read(1)
+
+
+def test_ari_roundtrips(golden, oracle):                   # ari/test.rs:8-20, 52-89, 185-212
+    for data in (b"abracadabra", b"", golden("test.txt")):
+        w = io.BytesIO()
+        e = C.entropy.ari.ByteEncoder(w); e.write(data); e.finish()
+        assert w.getvalue() == oracle.ari_byte_encode(data)
+        assert C.entropy.ari.ByteDecoder(io.BytesIO(w.getvalue())).read_to_end() == data
+    w = io.BytesIO()                                        # roundtrip_term: two terminated streams back to back
+    for part in (b"abra", b"cadabra"):
+        e = C.entropy.ari.ByteEncoder(w); e.write(part); e.finish()
+    d1 = C.entropy.ari.ByteDecoder(io.BytesIO(w.getvalue()))
+    assert d1.read_to_end() == b"abra"
+    rest = d1.finish()
+    assert C.entropy.ari.ByteDecoder(rest).read_to_end() == b"cadabra"
+
+
+def test_rle_known_answers():                              # rle.rs:320-361
+    def enc(b):
+        w = io.BytesIO(); e = C.rle.Encoder(w); e.write_all(b); e.finish(); return w.getvalue()
+    dec = lambda b: C.rle.Decoder(io.BytesIO(b)).read_to_end()
+    assert enc(b"") == b"" and enc(b"a") == b"a" and enc(b"abca123") == b"abca123"
+    assert enc(bytes([20] * 5 + [15])) == bytes([20, 20, 131, 15]) and enc(bytes([0, 0])) == bytes([0, 0, 128])
+    assert enc(bytes([5] * 129)) == bytes([5, 5, 255])
+    data = bytes([1, 3, 4, 4]) + bytes([100] * 182)
+    assert enc(data) == bytes([1, 3, 4, 4, 128, 100, 100, 52, 129]) and dec(enc(data)) == data
+    assert dec(bytes([20, 20, 131, 15])) == bytes([20] * 5 + [15]) and dec(bytes([0, 0, 128])) == bytes([0, 0])
+    rng = random.Random(7)
+    for _ in range(20):
+        buf = bytes(rng.randrange(256) for _ in range(13579))
+        assert dec(enc(buf)) == buf
+    with pytest.raises(C.CompressError) as e:
+        dec(b"aa" + bytes(10))
+    assert str(e.value) == "Overly long run"
