@@ -1,0 +1,148 @@
+"""BWT -> DC -> adaptive range coder pipeline (BASELINE config 5, "bzip-like"), device resident.
+
+The reference provides the three STAGES (bwt::encode, dc::encode_simple order, ari::ByteEncoder) but no
+wiring and no byte serialisation of the DC output (hard part 8), so this module defines the
+container; parity is per stage:
+    (L, origin)                      == bwt::encode_simple               (src/bwt/mod.rs:214-219)
+    (init[256], distances[k])        == dc::encode_simple::<u32> order   (src/bwt/dc.rs:153-159)
+    Ari bytes                        == ari::ByteEncoder over the block record below
+Block record fed to the range coder (little-endian u32 words):  n, origin, k, init[256], dist[k]
+Stream container:  b"RCXP" u32 block_size u32 nblocks, then per block u32 n, u32 comp_len, then the payloads.
+Blocks are independent in every stage, so a stream shards across GPUs by block ranges (dist.partition).
+"""
+import struct
+
+import numpy as np
+
+from . import _native as N
+from .api import DeviceBatch
+
+MAGIC = b"RCXP"
+HDR_WORDS = 3
+
+
+class BwtDcAri:
+    def __init__(self, ctx, device):
+        import torch
+        self.ctx, self.dev, self.torch = ctx, device, torch
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def _i64(self, a):
+        return self.torch.as_tensor(np.asarray(a, dtype=np.int64), device=self.dev)
+
+    def _scratch(self, codec, nb, maxn):
+        return self.torch.empty(self.ctx.scratch_bytes(codec, nb, maxn) + 256, dtype=self.torch.uint8, device=self.dev)
+
+    def encode(self, raw, lens, keep_stages=False):
+        """raw: uint8 tensor holding the blocks back to back; lens: block lengths (numpy).
+        -> (comp tensor, comp_off, comp_len numpy, stages dict)"""
+        torch = self.torch
+        lens = np.asarray(lens, dtype=np.int64)
+        nb = len(lens)
+        maxn = int(lens.max()) if nb else 0
+        off = np.concatenate([[0], np.cumsum(lens)[:-1]]) if nb else np.zeros(0, np.int64)
+        # 1. BWT
+        bw = DeviceBatch(raw, self._i64(off), self._i64(lens), torch.empty(int(lens.sum()) + 64, dtype=torch.uint8, device=self.dev),
+                         self._i64(off), self._i64(lens))
+        sc = self._scratch(N.BWT_FORWARD, nb, maxn)
+        self.ctx.launch_dev(N.BWT_FORWARD, bw, sc)
+        del sc
+        # 2. DC into the record slot, 12 bytes in (n, origin, k go in front)
+        slot = (4 * (HDR_WORDS + 256 + maxn) + 63) // 64 * 64
+        rec = torch.zeros(nb * slot + 64, dtype=torch.uint8, device=self.dev)
+        roff = np.arange(nb, dtype=np.int64) * slot
+        dc = DeviceBatch(bw.out_base, bw.out_off, bw.out_len, rec, self._i64(roff + 4 * HDR_WORDS),
+                         self._i64(np.full(nb, slot - 4 * HDR_WORDS)))
+        self.ctx.launch_dev(N.DC_ENCODE, dc)
+        # 3. header words n, origin, k
+        k = (dc.out_len[:nb] // 4 - 256).to(torch.int32)
+        hdr = torch.stack([self._i64(lens).to(torch.int32), bw.aux[:nb].to(torch.int32), k], dim=1).contiguous()
+        rec32 = rec[: nb * slot].view(torch.int32).view(nb, slot // 4)
+        rec32[:, :HDR_WORDS] = hdr
+        rec_len = dc.out_len[:nb] + 4 * HDR_WORDS
+        # 4. range coder
+        cslot = (2 * slot + 16 + 63) // 64 * 64
+        ar = DeviceBatch(rec, self._i64(roff), rec_len.clone(), torch.empty(nb * cslot + 64, dtype=torch.uint8, device=self.dev),
+                         self._i64(np.arange(nb, dtype=np.int64) * cslot), self._i64(np.full(nb, cslot)))
+        self.ctx.launch_dev(N.ARI_BYTE_ENCODE, ar)
+        torch.cuda.synchronize()
+        for b_ in (bw, dc, ar):
+            assert int(b_.status[:nb].abs().max()) == 0, "pipeline stage failed"
+        stages = {"bwt": bw, "dc": dc, "rec": rec, "rec_off": roff, "rec_len": rec_len, "ari": ar} if keep_stages else None
+        return ar.out_base, np.arange(nb, dtype=np.int64) * cslot, ar.out_len[:nb].cpu().numpy().astype(np.int64), stages
+
+    def decode(self, comp, comp_off, comp_len, lens):
+        """-> uint8 tensor with the blocks back to back"""
+        torch = self.torch
+        lens = np.asarray(lens, dtype=np.int64)
+        nb = len(lens)
+        maxn = int(lens.max()) if nb else 0
+        slot = (4 * (HDR_WORDS + 256 + maxn) + 63) // 64 * 64
+        roff = np.arange(nb, dtype=np.int64) * slot
+        ar = DeviceBatch(comp, self._i64(comp_off), self._i64(comp_len), torch.zeros(nb * slot + 64, dtype=torch.uint8, device=self.dev),
+                         self._i64(roff), self._i64(np.full(nb, slot)))
+        self.ctx.launch_dev(N.ARI_BYTE_DECODE, ar)
+        torch.cuda.synchronize()
+        assert int(ar.status[:nb].abs().max()) == 0, "ari decode failed"
+        rec32 = ar.out_base[: nb * slot].view(torch.int32).view(nb, slot // 4)
+        hdr = rec32[:, :HDR_WORDS].cpu().numpy()
+        n, origin, k = hdr[:, 0].astype(np.int64), hdr[:, 1].astype(np.uint32), hdr[:, 2].astype(np.int64)
+        assert (n == lens).all(), "container length mismatch"
+        ooff = np.concatenate([[0], np.cumsum(lens)[:-1]]) if nb else np.zeros(0, np.int64)
+        total = int(lens.sum())
+        # DC decode through the host-descriptor entry point (it needs n_out)
+        import ctypes as C
+        L = torch.empty(total + 64, dtype=torch.uint8, device=self.dev)
+        u64 = lambda a: np.ascontiguousarray(a, dtype=np.uint64)
+        in_off, in_len = u64(roff + 4 * HDR_WORDS), u64(4 * (256 + k))
+        out_off, out_cap, n_out = u64(ooff), u64(lens), u64(lens)
+        out_len, in_used, status = np.zeros(nb, np.uint64), np.zeros(nb, np.uint64), np.zeros(nb, np.int32)
+        p = lambda a: a.ctypes.data
+        b = N.Batch(ar.out_base.data_ptr(), p(in_off), p(in_len), L.data_ptr(), p(out_off), p(out_cap), p(out_len), p(in_used),
+                    p(status), nb, N.MEM_DEVICE)
+        self.ctx._chk(N.lib().rcx_dc_decode_batch(self.ctx._h, C.byref(b), C.c_void_p(p(n_out))))
+        assert not status.any(), "dc decode failed"
+        inv = DeviceBatch(L, self._i64(ooff), self._i64(lens), torch.empty(total + 64, dtype=torch.uint8, device=self.dev),
+                          self._i64(ooff), self._i64(lens), aux=torch.as_tensor(origin.astype(np.int32), device=self.dev))
+        sc = self._scratch(N.BWT_INVERSE, nb, maxn)
+        self.ctx.launch_dev(N.BWT_INVERSE, inv, sc)
+        torch.cuda.synchronize()
+        assert int(inv.status[:nb].abs().max()) == 0, "bwt inverse failed"
+        return inv.out_base[:total]
+
+
+def encode_stream(ctx, data, block_size=256 * 1024, device=None):
+    """bytes -> container bytes"""
+    import torch
+    dev = device or torch.device("cuda", torch.cuda.current_device())
+    data = bytes(data)
+    lens = [min(block_size, len(data) - i) for i in range(0, len(data), block_size)]
+    out = [MAGIC, struct.pack("<II", block_size, len(lens))]
+    if lens:
+        raw = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+        comp, coff, clen, _ = BwtDcAri(ctx, dev).encode(raw, lens)
+        comp = comp.cpu().numpy()
+        for n, cl in zip(lens, clen):
+            out.append(struct.pack("<II", n, int(cl)))
+        for o, cl in zip(coff, clen):
+            out.append(comp[int(o):int(o) + int(cl)].tobytes())
+    return b"".join(out)
+
+
+def decode_stream(ctx, blob, device=None):
+    import torch
+    dev = device or torch.device("cuda", torch.cuda.current_device())
+    assert blob[:4] == MAGIC, "not an RCXP container"
+    block_size, nb = struct.unpack_from("<II", blob, 4)
+    p = 12
+    lens, clen = [], []
+    for _ in range(nb):
+        n, cl = struct.unpack_from("<II", blob, p)
+        p += 8
+        lens.append(n); clen.append(cl)
+    if not nb:
+        return b""
+    coff = np.concatenate([[0], np.cumsum(clen)[:-1]]).astype(np.int64)
+    comp = torch.frombuffer(bytearray(blob[p:p + int(sum(clen))] + b"\0" * 64), dtype=torch.uint8).to(dev)
+    out = BwtDcAri(ctx, dev).decode(comp, coff, np.asarray(clen, dtype=np.int64), lens)
+    return out.cpu().numpy().tobytes()

@@ -1,0 +1,112 @@
+"""GPU: BASELINE.json configs 3, 4, 5 at (or near) full size, device resident, checked through
+size-independent properties (decode(x) == source, inverse(forward(x)) == x) plus oracle parity on samples."""
+import zlib
+from multiprocessing import Pool
+
+import numpy as np
+import pytest
+
+from rust_compress_amd import _native as N
+from rust_compress_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _zmember(args):
+    i, data = args
+    if i % 16 == 15:
+        c = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)          # fixed-Huffman blocks too
+        return c.compress(data) + c.flush()
+    return zlib.compress(data, (1, 6, 9, 0)[i % 4] if i % 64 else 0)
+
+
+def test_config3_zlib_65536_members(ctx, oracle):
+    """65536 independent zlib members of 16 KiB (levels 0/1/6/9 + Z_FIXED), Adler-32 verified on the GPU."""
+    import torch
+    import rust_compress_amd as R
+    nb, BLOCK = 65536, 16384
+    dev = torch.device("cuda", 0)
+    raw_np = np.concatenate([synth.gen_blocks(k, nb // 4, BLOCK, 0x5A11 + j) for j, k in enumerate(("text", "text", "runs", "dna4"))])
+    blocks = [raw_np[i * BLOCK:(i + 1) * BLOCK].tobytes() for i in range(nb)]
+    with Pool(32) as pool:
+        members = pool.map(_zmember, list(enumerate(blocks)), chunksize=512)
+    from rust_compress_amd import batch as B
+    base, off, lens = B.pack(members)
+    ar = np.arange(nb, dtype=np.int64)
+    db = R.DeviceBatch.from_host(base, off, lens, nb * BLOCK, (ar * BLOCK).astype(np.uint64), np.full(nb, BLOCK, dtype=np.uint64), dev)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.launch_dev(N.ZLIB_DECODE, db)
+    torch.cuda.synchronize()
+    assert int(db.status[:nb].abs().max()) == 0
+    assert bool((db.out_len[:nb] == BLOCK).all())
+    assert bool((db.in_used[:nb].cpu() == torch.from_numpy(lens.astype(np.int64))).all())
+    assert torch.equal(db.out_base[: nb * BLOCK].cpu(), torch.from_numpy(raw_np))
+    for i in range(0, nb, 4099):
+        out, used, _ = oracle.zlib_decode(members[i], cap=BLOCK)
+        assert out == blocks[i] and used == len(members[i])
+    ctx.set_stream(0)
+
+
+def test_config4_bwt_1024x256k(ctx, oracle):
+    """1024 blocks x 256 KiB: forward then inverse; inverse(forward(x)) == x; samples == oracle (L, origin)."""
+    import torch
+    import rust_compress_amd as R
+    nb, BLOCK = 1024, 262144
+    dev = torch.device("cuda", 0)
+    raw_np = np.concatenate([synth.gen_blocks("text", nb // 2, BLOCK, 0xB77), synth.gen_blocks("dna4", nb // 2, BLOCK, 0xB78)])
+    raw = torch.from_numpy(raw_np).to(dev)
+    i64 = lambda a: torch.tensor(a, dtype=torch.int64, device=dev)
+    ar = np.arange(nb, dtype=np.int64)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    fw = R.DeviceBatch(raw, i64(ar * BLOCK), i64(np.full(nb, BLOCK)), torch.zeros(nb * BLOCK + 64, dtype=torch.uint8, device=dev),
+                       i64(ar * BLOCK), i64(np.full(nb, BLOCK)))
+    sc = torch.empty(ctx.scratch_bytes(N.BWT_FORWARD, nb, BLOCK) + 256, dtype=torch.uint8, device=dev)
+    ctx.launch_dev(N.BWT_FORWARD, fw, sc)
+    torch.cuda.synchronize()
+    del sc
+    assert int(fw.status[:nb].abs().max()) == 0
+    inv = R.DeviceBatch(fw.out_base, fw.out_off, fw.out_len, torch.zeros(nb * BLOCK + 64, dtype=torch.uint8, device=dev),
+                        i64(ar * BLOCK), i64(np.full(nb, BLOCK)), aux=fw.aux)
+    sc = torch.empty(ctx.scratch_bytes(N.BWT_INVERSE, nb, BLOCK) + 256, dtype=torch.uint8, device=dev)
+    ctx.launch_dev(N.BWT_INVERSE, inv, sc)
+    torch.cuda.synchronize()
+    assert int(inv.status[:nb].abs().max()) == 0
+    assert torch.equal(inv.out_base[: nb * BLOCK], raw)
+    L = fw.out_base.cpu().numpy()
+    og = fw.aux.cpu().numpy()
+    for i in (0, 511, 512, 1023):
+        eL, eo = oracle.bwt_encode(raw_np[i * BLOCK:(i + 1) * BLOCK].tobytes())
+        assert L[i * BLOCK:(i + 1) * BLOCK].tobytes() == eL and int(og[i]) == eo
+    ctx.set_stream(0)
+
+
+def test_config5_pipeline_roundtrip_and_stage_parity(ctx, oracle):
+    """BWT -> DC -> Ari over 96 blocks x 256 KiB (+ a ragged tail): decode(encode(x)) == x, per-stage parity on samples."""
+    import struct
+    import torch
+    from rust_compress_amd import pipeline as P
+    BLOCK = 262144
+    dev = torch.device("cuda", 0)
+    data = synth.gen("text", 96 * BLOCK + 182784, 0xC0FFEE)
+    lens = [BLOCK] * 96 + [182784]
+    pipe = P.BwtDcAri(ctx, dev)
+    raw = torch.from_numpy(data).to(dev)
+    comp, coff, clen, st = pipe.encode(raw, lens, keep_stages=True)
+    back = pipe.decode(comp, coff, clen, lens)
+    assert torch.equal(back, raw)
+    assert clen.sum() < 0.45 * data.size                               # it does compress text
+    Lall = st["bwt"].out_base.cpu().numpy()
+    rec = st["rec"].cpu().numpy()
+    compn = comp.cpu().numpy()
+    for i in (0, 50, 96):
+        src = data[i * BLOCK:i * BLOCK + lens[i]].tobytes()
+        eL, eo = oracle.bwt_encode(src)
+        assert Lall[i * BLOCK:i * BLOCK + lens[i]].tobytes() == eL
+        words = oracle.dc_encode(eL)
+        record = struct.pack("<III", lens[i], eo, len(words) - 256) + words.tobytes()
+        o = int(st["rec_off"][i])
+        assert rec[o:o + len(record)].tobytes() == record
+        assert compn[int(coff[i]):int(coff[i]) + int(clen[i])].tobytes() == oracle.ari_byte_encode(record)
+    blob = P.encode_stream(ctx, data[: 3 * BLOCK + 17].tobytes())
+    assert P.decode_stream(ctx, blob) == data[: 3 * BLOCK + 17].tobytes()
+    ctx.set_stream(0)
