@@ -1,0 +1,422 @@
+// compress.hpp -- C++17 host-side mirror of the reference crate's per-algorithm Reader/Writer surface
+// (`compress::*`, rusty-shell/rust-compress) over the batch C-ABI of include/rcx.h.
+//
+// The reference is Rust and no Rust toolchain exists in this image, so the host side above the C-ABI is
+// written in C++ with the SAME names, argument meaning and error behaviour (INTEGRATION.md shows the Rust
+// binding a maintainer would add).  A reader R is anything with `size_t read(uint8_t* dst, size_t n)`
+// (returns 0 at end of stream, like std::io::Read); a writer W anything with `void write(const uint8_t*,
+// size_t)`.  Decoders buffer their whole input, parse the framing on the host and make ONE batch FFI call
+// per stream; `read()` then serves the decoded bytes in whatever chunk sizes the caller asks for.
+//
+//   compress::lz4::{Decoder,Encoder,decode_block,encode_block,compression_bound}   src/lz4.rs
+//   compress::flate::Decoder, compress::zlib::Decoder, compress::Adler32           src/flate.rs, zlib.rs, adler.rs
+//   compress::bwt::{Encoder,Decoder,encode_simple,decode_simple}, bwt::mtf, bwt::dc src/bwt/*.rs
+//   compress::entropy::ari::{ByteEncoder,ByteDecoder}                              src/entropy/ari/table.rs
+//   compress::rle::{Encoder,Decoder}                                               src/rle.rs
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/rcx.h"
+
+namespace compress {
+
+enum class ErrorKind { InvalidInput, UnexpectedEof, Other, Panic };
+
+struct io_error : std::runtime_error {          // std::io::Error
+    ErrorKind kind; int status;
+    io_error(ErrorKind k, int st, const std::string& m) : std::runtime_error(m), kind(k), status(st) {}
+};
+
+inline void raise_status(int st)
+{
+    if (st == RCX_OK) return;
+    const std::string msg = rcx_status_string(st);
+    if (st == RCX_E_EOF) throw io_error(ErrorKind::UnexpectedEof, st, msg);
+    if (st == RCX_E_MALFORMED || st == RCX_E_OUTPUT_TOO_SMALL) throw io_error(ErrorKind::Panic, st, msg);
+    if (st == RCX_E_RLE_LONG_RUN) throw io_error(ErrorKind::Other, st, msg);
+    throw io_error(ErrorKind::InvalidInput, st, msg);
+}
+
+// ---- plumbing --------------------------------------------------------------------------------------
+class Context {                                   // one rcx_ctx; no CPU fallback: throws without a GPU
+public:
+    explicit Context(int device = -1)
+    {
+        const int rc = rcx_ctx_create(device, &h_);
+        if (rc != RCX_RC_OK) throw std::runtime_error("rcx_ctx_create failed (no HIP device? there is no CPU fallback)");
+    }
+    ~Context() { rcx_ctx_destroy(h_); }
+    Context(const Context&) = delete;
+    rcx_ctx* get() const { return h_; }
+    static Context& global() { static Context c; return c; }
+private:
+    rcx_ctx* h_ = nullptr;
+};
+
+struct BatchResult {
+    std::vector<std::vector<uint8_t>> out;
+    std::vector<uint64_t> in_used;
+    std::vector<int32_t> status;
+    std::vector<uint32_t> aux;
+};
+
+// Pack blobs into one host buffer, call a batch entry point, unpack.  `call` gets (ctx, &batch).
+template <class Call>
+BatchResult run_batch(const std::vector<std::vector<uint8_t>>& blobs, const std::vector<uint64_t>& caps, Call call)
+{
+    const uint32_t n = (uint32_t)blobs.size();
+    std::vector<uint64_t> in_off(n), in_len(n), out_off(n), out_cap(n), out_len(n), in_used(n);
+    std::vector<int32_t> status(n);
+    uint64_t it = 0, ot = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        in_off[i] = it; in_len[i] = blobs[i].size(); it += (blobs[i].size() + 15) & ~15ull;
+        out_off[i] = ot; out_cap[i] = caps[i]; ot += (caps[i] + 15) & ~15ull;
+    }
+    std::vector<uint8_t> in(it + 16), out(ot + 16);
+    for (uint32_t i = 0; i < n; i++) if (!blobs[i].empty()) std::memcpy(in.data() + in_off[i], blobs[i].data(), blobs[i].size());
+    rcx_batch b{in.data(), in_off.data(), in_len.data(), out.data(), out_off.data(), out_cap.data(), out_len.data(),
+                in_used.data(), status.data(), n, RCX_MEM_HOST};
+    BatchResult r;
+    r.aux.assign(n, 0);
+    const int rc = call(Context::global().get(), &b, r.aux.data());
+    if (rc != RCX_RC_OK) throw std::runtime_error(std::string("rcx batch call failed: ") + rcx_last_error(Context::global().get()));
+    r.out.resize(n);
+    for (uint32_t i = 0; i < n; i++) r.out[i].assign(out.begin() + out_off[i], out.begin() + out_off[i] + out_len[i]);
+    r.in_used = in_used; r.status = status;
+    return r;
+}
+inline void check(const BatchResult& r) { for (int st : r.status) raise_status(st); }
+
+struct SliceReader {                              // BufReader::new(&[u8])
+    const uint8_t* p; size_t n, pos = 0;
+    SliceReader(const uint8_t* d, size_t len) : p(d), n(len) {}
+    explicit SliceReader(const std::vector<uint8_t>& v) : p(v.data()), n(v.size()) {}
+    size_t read(uint8_t* dst, size_t k) { k = k < n - pos ? k : n - pos; std::memcpy(dst, p + pos, k); pos += k; return k; }
+};
+struct VecWriter {                                // BufWriter::new(Vec::new())
+    std::vector<uint8_t> v;
+    void write(const uint8_t* d, size_t n) { v.insert(v.end(), d, d + n); }
+};
+template <class R> std::vector<uint8_t> read_all(R& r)
+{
+    std::vector<uint8_t> v; uint8_t buf[65536]; size_t k;
+    while ((k = r.read(buf, sizeof buf)) != 0) v.insert(v.end(), buf, buf + k);
+    return v;
+}
+inline uint32_t le32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline void put32(std::vector<uint8_t>& v, uint32_t x) { for (int i = 0; i < 4; i++) v.push_back((uint8_t)(x >> (8 * i))); }
+
+// common part of every buffered decoder: decode everything on first read, then serve chunks
+template <class R, class Derived>
+class BufferedDecoder {
+public:
+    R r;                                          // `pub r: R`
+    explicit BufferedDecoder(R rd) : r(std::move(rd)) {}
+    size_t read(uint8_t* dst, size_t n)
+    {
+        ensure();
+        const size_t k = n < out_.size() - pos_ ? n : out_.size() - pos_;
+        std::memcpy(dst, out_.data() + pos_, k);
+        pos_ += k;
+        return k;
+    }
+    std::vector<uint8_t> read_to_end() { ensure(); std::vector<uint8_t> v(out_.begin() + pos_, out_.end()); pos_ = out_.size(); return v; }
+    bool eof() { ensure(); return pos_ == out_.size(); }
+    void reset() { done_ = false; out_.clear(); pos_ = 0; }
+    size_t consumed = 0;                          // input bytes this stream used (in_used)
+protected:
+    void ensure() { if (!done_) { raw_ = read_all(r); out_ = static_cast<Derived*>(this)->decode_all(raw_); pos_ = 0; done_ = true; } }
+    std::vector<uint8_t> raw_, out_; size_t pos_ = 0; bool done_ = false;
+};
+
+// ---- lz4 ---------------------------------------------------------------------------------------------
+namespace lz4 {
+inline std::optional<uint32_t> compression_bound(uint32_t size)                      // lz4.rs:175-181
+{
+    const uint64_t v = rcx_lz4_compression_bound(size);
+    return v ? std::optional<uint32_t>((uint32_t)v) : std::nullopt;
+}
+inline size_t decode_block(const std::vector<uint8_t>& input, std::vector<uint8_t>& output)   // lz4.rs:602-611
+{
+    auto r = run_batch({input}, {255 * input.size() + 64}, [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_lz4_decode_batch(c, b); });
+    check(r);
+    output.insert(output.end(), r.out[0].begin(), r.out[0].end());
+    return r.out[0].size();
+}
+inline size_t encode_block(const std::vector<uint8_t>& input, std::vector<uint8_t>& output)   // lz4.rs:616-627
+{
+    auto r = run_batch({input}, {rcx_lz4_compression_bound(input.size()) + 1}, [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_lz4_encode_batch(c, b); });
+    if (r.status[0] == RCX_E_LZ4_INPUT_TOO_LARGE) return 0;
+    check(r);
+    output.insert(output.end(), r.out[0].begin(), r.out[0].end());
+    return r.out[0].size();
+}
+template <class R>
+class Decoder : public BufferedDecoder<R, Decoder<R>> {                              // lz4.rs:316-500
+public:
+    using BufferedDecoder<R, Decoder<R>>::BufferedDecoder;
+    std::vector<uint8_t> decode_all(const std::vector<uint8_t>& d)
+    {
+        size_t p = 0; const size_t n = d.size();
+        auto need = [&](size_t k) { if (n - p < k) raise_status(RCX_E_EOF); };
+        need(4);
+        if (le32(&d[p]) != 0x184d2204u) throw io_error(ErrorKind::InvalidInput, RCX_E_LZ4_MAGIC, "");   // :365-367
+        p += 4;
+        uint8_t flg = p < n ? d[p] : 0, bd = p + 1 < n ? d[p + 1] : 0;               // :369-372
+        p = p + 2 < n ? p + 2 : n;
+        if ((flg >> 6) != 1) throw io_error(ErrorKind::InvalidInput, RCX_E_LZ4_VERSION, "");           // :375-377
+        const bool blk_ck = flg & 0x10, ssize = flg & 0x08, preset = flg & 0x01;
+        static const size_t MAXS[8] = {0, 0, 0, 0, 64u << 10, 256u << 10, 1u << 20, 4u << 20};
+        const size_t max_block = MAXS[(bd >> 4) & 7];
+        if (ssize) { need(8); p += 8; }
+        if (preset) raise_status(RCX_E_MALFORMED);                                    // :407 assert!
+        need(1); p += 1;                                                              // header checksum ignored, :417
+        std::vector<std::pair<bool, std::vector<uint8_t>>> parts;
+        for (;;) {
+            need(4);
+            const uint32_t v = le32(&d[p]); p += 4;
+            if (v == 0) break;
+            const size_t amt = v & 0x7fffffffu;
+            need(amt);
+            parts.emplace_back((v & 0x80000000u) != 0, std::vector<uint8_t>(d.begin() + p, d.begin() + p + amt));
+            p += amt;
+            if (blk_ck) { need(4); p += 4; }
+        }
+        this->consumed = p;
+        std::vector<std::vector<uint8_t>> comp; std::vector<uint64_t> caps;
+        for (auto& pr : parts) if (!pr.first) { comp.push_back(pr.second); caps.push_back(std::max(max_block, 255 * pr.second.size() + 64)); }
+        BatchResult r;
+        if (!comp.empty()) { r = run_batch(comp, caps, [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_lz4_decode_batch(c, b); }); check(r); }
+        std::vector<uint8_t> out; size_t ci = 0;
+        for (auto& pr : parts) { const auto& src = pr.first ? pr.second : r.out[ci++]; out.insert(out.end(), src.begin(), src.end()); }
+        return out;
+    }
+};
+template <class W>
+class Encoder {                                                                       // lz4.rs:505-597 (stored blocks)
+public:
+    explicit Encoder(W w) : w_(std::move(w)) {}
+    size_t write(const uint8_t* buf, size_t n)
+    {
+        if (!wrote_header_) { const uint8_t h[7] = {0x04, 0x22, 0x4d, 0x18, 0x60, 0x50, 0x00}; w_.write(h, 7); wrote_header_ = true; }
+        while (n) {
+            const size_t amt = std::min(limit_ - buf_.size(), n);
+            buf_.insert(buf_.end(), buf, buf + amt);
+            if (buf_.size() == limit_) encode_block();
+            buf += amt; n -= amt;
+        }
+        return 0;                                                                     // Ok(0) quirk, :588
+    }
+    W finish() { if (!buf_.empty()) encode_block(); const uint8_t z[8] = {0}; w_.write(z, 8); return std::move(w_); }
+private:
+    void encode_block() { std::vector<uint8_t> h; put32(h, (uint32_t)buf_.size() | 0x80000000u); w_.write(h.data(), 4); w_.write(buf_.data(), buf_.size()); buf_.clear(); }
+    W w_; std::vector<uint8_t> buf_; bool wrote_header_ = false; size_t limit_ = 256 * 1024;
+};
+}  // namespace lz4
+
+// ---- flate / zlib / Adler32 ------------------------------------------------------------------------------
+namespace detail {
+template <class Fn> std::vector<uint8_t> grow_decode(const std::vector<uint8_t>& d, size_t& consumed, Fn fn, uint32_t* flags = nullptr)
+{
+    for (uint64_t cap = 1u << 16;; cap *= 8) {
+        auto r = run_batch({d}, {cap}, fn);
+        if (r.status[0] == RCX_E_OUTPUT_TOO_SMALL && cap < (1ull << 33)) continue;
+        check(r);
+        consumed = r.in_used[0];
+        if (flags) *flags = r.aux[0];
+        return r.out[0];
+    }
+}
+}  // namespace detail
+namespace flate {
+template <class R>
+class Decoder : public BufferedDecoder<R, Decoder<R>> {                              // flate.rs:164-488
+public:
+    using BufferedDecoder<R, Decoder<R>>::BufferedDecoder;
+    uint32_t flags = 0;
+    std::vector<uint8_t> decode_all(const std::vector<uint8_t>& d)
+    { return detail::grow_decode(d, this->consumed, [](rcx_ctx* c, rcx_batch* b, uint32_t* f) { return rcx_inflate_batch(c, b, f); }, &flags); }
+};
+}  // namespace flate
+namespace zlib {
+template <class R>
+class Decoder : public BufferedDecoder<R, Decoder<R>> {                              // zlib.rs:32-127
+public:
+    using BufferedDecoder<R, Decoder<R>>::BufferedDecoder;
+    std::vector<uint8_t> decode_all(const std::vector<uint8_t>& d)
+    { return detail::grow_decode(d, this->consumed, [](rcx_ctx* c, rcx_batch* b, uint32_t* f) { return rcx_zlib_decode_batch(c, b, f); }); }
+    R unwrap() { return std::move(this->r); }
+};
+}  // namespace zlib
+class Adler32 {                                                                       // checksum/adler.rs:22-51
+public:
+    void feed(const uint8_t* p, size_t n) { data_.insert(data_.end(), p, p + n); }
+    uint32_t result() const
+    {
+        auto r = run_batch({data_}, {0}, [](rcx_ctx* c, rcx_batch* b, uint32_t* a) { return rcx_adler32_batch(c, b, a); });
+        return r.aux[0];
+    }
+    void reset() { data_.clear(); }
+private:
+    std::vector<uint8_t> data_;
+};
+
+// ---- bwt ------------------------------------------------------------------------------------------------
+namespace bwt {
+inline std::pair<std::vector<uint8_t>, size_t> encode_simple(const std::vector<uint8_t>& input)   // bwt/mod.rs:214-219
+{
+    auto r = run_batch({input}, {input.size()}, [](rcx_ctx* c, rcx_batch* b, uint32_t* o) { return rcx_bwt_forward_batch(c, b, o); });
+    check(r);
+    return {r.out[0], r.aux[0]};
+}
+inline std::vector<uint8_t> decode_simple(const std::vector<uint8_t>& input, size_t origin)       // bwt/mod.rs:291-294
+{
+    if (input.empty()) return {};
+    uint32_t og = (uint32_t)origin;
+    auto r = run_batch({input}, {input.size()}, [&](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_bwt_inverse_batch(c, b, &og); });
+    check(r);
+    return r.out[0];
+}
+template <class W>
+class Encoder {                                                                       // bwt/mod.rs:437-518
+public:
+    Encoder(W w, size_t block_size) : w_(std::move(w)), bs_(block_size) {}
+    size_t write(const uint8_t* buf, size_t n)
+    {
+        if (!wrote_header_) { std::vector<uint8_t> h; put32(h, (uint32_t)bs_); w_.write(h.data(), 4); wrote_header_ = true; }
+        buf_.insert(buf_.end(), buf, buf + n);
+        return 0;                                                                     // Ok(0) quirk, :507
+    }
+    W finish()
+    {
+        std::vector<std::vector<uint8_t>> blocks; std::vector<uint64_t> caps;
+        for (size_t i = 0; i < buf_.size(); i += bs_) { blocks.emplace_back(buf_.begin() + i, buf_.begin() + std::min(buf_.size(), i + bs_)); caps.push_back(blocks.back().size()); }
+        if (!blocks.empty()) {                                                        // ONE batch call for the whole stream
+            auto r = run_batch(blocks, caps, [](rcx_ctx* c, rcx_batch* b, uint32_t* o) { return rcx_bwt_forward_batch(c, b, o); });
+            check(r);
+            for (size_t i = 0; i < blocks.size(); i++) {
+                std::vector<uint8_t> h; put32(h, (uint32_t)blocks[i].size()); w_.write(h.data(), 4);
+                w_.write(r.out[i].data(), r.out[i].size());
+                h.clear(); put32(h, r.aux[i]); w_.write(h.data(), 4);
+            }
+        }
+        return std::move(w_);
+    }
+private:
+    W w_; size_t bs_; std::vector<uint8_t> buf_; bool wrote_header_ = false;
+};
+template <class R>
+class Decoder : public BufferedDecoder<R, Decoder<R>> {                              // bwt/mod.rs:321-432
+public:
+    Decoder(R r, bool extra_mem) : BufferedDecoder<R, Decoder<R>>(std::move(r)), extra_memory(extra_mem) {}
+    bool extra_memory; size_t max_block_size = 0;
+    std::vector<uint8_t> decode_all(const std::vector<uint8_t>& d)
+    {
+        size_t p = 0; const size_t n = d.size();
+        if (n - p < 4) raise_status(RCX_E_EOF);                                       // :369
+        max_block_size = le32(&d[p]); p += 4;
+        std::vector<std::vector<uint8_t>> Ls; std::vector<uint64_t> caps; std::vector<uint32_t> origins;
+        while (n - p >= 4) {                                                          // EOF at a block boundary ends, :374-377
+            const size_t bn = le32(&d[p]); p += 4;
+            if (n - p < bn) raise_status(RCX_E_EOF);
+            Ls.emplace_back(d.begin() + p, d.begin() + p + bn); p += bn;
+            if (n - p < 4) raise_status(RCX_E_EOF);
+            origins.push_back(le32(&d[p])); p += 4;
+            if (bn == 0) raise_status(RCX_E_MALFORMED);                               // :230 panic
+            caps.push_back(bn);
+        }
+        std::vector<uint8_t> out;
+        if (Ls.empty()) return out;
+        auto r = run_batch(Ls, caps, [&](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_bwt_inverse_batch(c, b, origins.data()); });
+        check(r);
+        for (auto& o : r.out) out.insert(out.end(), o.begin(), o.end());
+        return out;
+    }
+};
+namespace mtf {
+inline std::vector<uint8_t> encode(const std::vector<uint8_t>& in)                   // mtf::Encoder over a whole stream, mtf.rs:95-129
+{ auto r = run_batch({in}, {in.size()}, [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_mtf_encode_batch(c, b); }); check(r); return r.out[0]; }
+inline std::vector<uint8_t> decode(const std::vector<uint8_t>& in)                   // mtf::Decoder, mtf.rs:133-169
+{ auto r = run_batch({in}, {in.size()}, [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_mtf_decode_batch(c, b); }); check(r); return r.out[0]; }
+}  // namespace mtf
+namespace dc {
+inline std::vector<uint32_t> encode_simple(const std::vector<uint8_t>& in)           // dc.rs:153-159
+{
+    auto r = run_batch({in}, {4 * (256 + in.size())}, [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_dc_encode_batch(c, b); });
+    check(r);
+    std::vector<uint32_t> w(r.out[0].size() / 4);
+    for (size_t i = 0; i < w.size(); i++) w[i] = le32(&r.out[0][4 * i]);
+    return w;
+}
+inline std::vector<uint8_t> decode_simple(size_t n, const std::vector<uint32_t>& distances)   // dc.rs:236-252
+{
+    std::vector<uint8_t> blob; for (uint32_t x : distances) put32(blob, x);
+    uint64_t nn = n;
+    auto r = run_batch({blob}, {n}, [&](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_dc_decode_batch(c, b, &nn); });
+    check(r);
+    return r.out[0];
+}
+}  // namespace dc
+}  // namespace bwt
+
+// ---- entropy::ari ----------------------------------------------------------------------------------------
+namespace entropy { namespace ari {
+template <class W>
+class ByteEncoder {                                                                   // table.rs:185-224
+public:
+    explicit ByteEncoder(W w) : w_(std::move(w)) {}
+    size_t write(const uint8_t* p, size_t n) { buf_.insert(buf_.end(), p, p + n); return n; }
+    W finish()
+    {
+        auto r = run_batch({buf_}, {rcx_ari_byte_encode_bound(buf_.size())}, [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_ari_byte_encode_batch(c, b); });
+        check(r);
+        w_.write(r.out[0].data(), r.out[0].size());
+        return std::move(w_);
+    }
+private:
+    W w_; std::vector<uint8_t> buf_;
+};
+template <class R>
+class ByteDecoder : public BufferedDecoder<R, ByteDecoder<R>> {                      // table.rs:229-273
+public:
+    using BufferedDecoder<R, ByteDecoder<R>>::BufferedDecoder;
+    std::vector<uint8_t> decode_all(const std::vector<uint8_t>& d)
+    { return detail::grow_decode(d, this->consumed, [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_ari_byte_decode_batch(c, b); }); }
+    // finish(): the reader ends exactly after this stream (mod.rs:289-292)
+    std::vector<uint8_t> finish() { this->ensure(); return std::vector<uint8_t>(this->raw_.begin() + this->consumed, this->raw_.end()); }
+};
+}}  // namespace entropy::ari
+
+// ---- rle ------------------------------------------------------------------------------------------------
+namespace rle {
+template <class W>
+class Encoder {                                                                       // rle.rs:40-123 (one-shot write_all + finish)
+public:
+    explicit Encoder(W w) : w_(std::move(w)) {}
+    void write_all(const uint8_t* p, size_t n) { buf_.insert(buf_.end(), p, p + n); }
+    W finish()
+    {
+        auto r = run_batch({buf_}, {rcx_rle_encode_bound(buf_.size())}, [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_rle_encode_batch(c, b); });
+        check(r);
+        w_.write(r.out[0].data(), r.out[0].size());
+        return std::move(w_);
+    }
+private:
+    W w_; std::vector<uint8_t> buf_;
+};
+template <class R>
+class Decoder : public BufferedDecoder<R, Decoder<R>> {                              // rle.rs:176-281
+public:
+    using BufferedDecoder<R, Decoder<R>>::BufferedDecoder;
+    std::vector<uint8_t> decode_all(const std::vector<uint8_t>& d)
+    { return detail::grow_decode(d, this->consumed, [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_rle_decode_batch(c, b); }); }
+};
+}  // namespace rle
+
+}  // namespace compress
