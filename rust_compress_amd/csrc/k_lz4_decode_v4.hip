@@ -1,0 +1,575 @@
+// k_lz4_decode_v4.hip -- LZ4 block decode, fourth iteration of the batched design (see k_lz4_decode.hip
+// for v1-v3 and the reference citations: BlockDecoder::decode, src/lz4.rs:67-140).
+//
+// What changed against v3, each item from the rocprof PMC profile of v3 on MI355X (40.6 instructions and
+// 458 cycles per sequence, 40 % of the wave's time in memory waits, 9.2 K static instructions):
+//   * one emit() call site (state machine) instead of nine inlined copies: the hot loop fits the I-cache;
+//   * the token walk is 9 scalar instructions per hop: v_readlane of the hop distance, a visited-position
+//     bit mask (s_lshl/s_or), and ONE vector compaction per 64-byte window (mbcnt + ds_write of the token
+//     positions into an LDS list) instead of a v_cndmask per hop;
+//   * matches older than the LDS window are fetched with one 16-byte HBM load per lane into a per-lane
+//     32-byte LDS staging slot and then ride the same byte-copy rounds as window matches (v3 spent
+//     ~130 instructions per batch extracting those bytes);
+//   * a copy round reads up to 32 bytes per lane into registers, then writes them: one LDS round trip
+//     per dependency level instead of one per 8-byte chunk;
+//   * sequences longer than the per-lane caps but <= 1 KiB are copied by the whole wave INSIDE the LDS
+//     window (periodic source for overlapping matches): run-heavy data no longer drains/refills through HBM;
+//   * the window slides lazily (only when the next batch would not fit), which also lengthens the history.
+#include "rcx_dev.h"
+
+#ifndef RCX_U
+#define RCX_U(x) ((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x)))
+#endif
+
+// PROF: phase timers (s_memtime via __builtin_readcyclecounter) accumulated per block into scratch; A/B builds only
+#define LZ4P_T0() uint64_t t0_ = PROF ? (uint64_t)__builtin_readcyclecounter() : 0
+#define LZ4P_ADD(slot) do { if (PROF) { const uint64_t t1_ = (uint64_t)__builtin_readcyclecounter(); prof[slot] += t1_ - t0_; t0_ = t1_; } } while (0)
+
+template <int CB, bool PROF = false>
+struct Lz4V4 {
+    uint64_t prof[12];
+    static constexpr int H = 2048;                 // history kept when the window slides
+    static constexpr int LCAP = 32, MCAP = 32;     // per-lane caps of a batched sequence
+    static constexpr int TFAST = 64 * 32;          // 64 plain tokens: <= 14 literals + 18 match bytes each
+    static constexpr int TSLOW = 1024;
+    static constexpr int TCAP = TFAST + TSLOW;
+    static constexpr int SOLO = 1024;              // wave-cooperative in-window copy up to this many bytes
+    static constexpr int LIN = H + 16 + TCAP + 768;
+    static constexpr int TRASH = LIN + 64;         // 64 bytes of read slack, then 64 trash bytes
+    static constexpr int STAGE = TRASH + 64;       // 64 lanes x 32 bytes of old-match staging
+    static constexpr int WBUF = STAGE + 64 * 32;
+    static constexpr int RH = 128;
+    static constexpr int MARGIN = LCAP + 16;
+    static constexpr uint32_t FLAG = 0x80000000u;
+    static_assert(SOLO <= TCAP && (CB % 1024) == 0 && (STAGE % 16) == 0, "geometry");
+
+    const uint8_t* in; uint8_t* out; uint32_t n, cap;
+    uint8_t* cbuf; uint8_t* wb_;          // wb_: [lin | slack | trash | staging]
+    uint32_t* epos;                        // token positions of the batch (LDS, 64 entries)
+    int32_t cbase; uint32_t cend;
+    int32_t lbase;
+    uint32_t oend, gflush, rlo, omis;
+    unsigned lane;
+
+    __device__ __forceinline__ int32_t lbase_for(uint32_t pos) const
+    {
+        return (((int32_t)pos - H + (int32_t)omis) & ~15) - (int32_t)omis;
+    }
+    __device__ __forceinline__ uint32_t rlo_eff() const
+    {
+        const uint32_t lb0 = lbase > 0 ? (uint32_t)lbase : 0u;
+        return rlo > lb0 ? rlo : lb0;
+    }
+
+    __device__ void stage(uint32_t cur)
+    {
+        const uint32_t inmis = (uint32_t)((uintptr_t)in & 15u);
+        cbase = (int32_t)RCX_U((int32_t)((cur + inmis) & ~15u) - (int32_t)inmis);
+#pragma unroll
+        for (int r = 0; r < CB / 1024; r++) {
+            const int j = r * 64 + (int)lane;
+            const int32_t pos = cbase + 16 * j;
+            if (pos >= 0 && (uint32_t)pos + 16 <= n) {
+                *(rcx_u32x4*)(cbuf + 16 * j) = *(const rcx_u32x4*)(in + pos);
+            } else {
+                for (int t = 0; t < 16; t++) {
+                    const int32_t q = pos + t;
+                    cbuf[16 * j + t] = (q >= 0 && (uint32_t)q < n) ? in[q] : (uint8_t)0;
+                }
+            }
+        }
+        const uint32_t lim = (uint32_t)(cbase + CB);
+        cend = RCX_U(n < lim ? n : lim);
+        rcx_wave_sync();
+    }
+
+    __device__ __forceinline__ uint32_t peek(uint32_t q) const
+    {
+        const int32_t idx = (int32_t)q - cbase;
+        uint32_t v = (idx >= 0 && q < cend) ? (uint32_t)cbuf[idx] : (uint32_t)in[q];
+        return RCX_U(v);
+    }
+
+    // make room for `need` more output bytes in the window; slides by a multiple of 16, keeps H bytes
+    __device__ void make_room(uint32_t need)
+    {
+        if ((int32_t)oend - lbase + (int32_t)need + 16 <= LIN) return;
+        const int32_t nb = (int32_t)RCX_U(lbase_for(oend));
+        const int32_t delta = nb - lbase;
+        if (delta <= 0) return;
+        const int32_t keep = ((int32_t)oend - nb + 15) & ~15;
+        if (delta < LIN) {
+            rcx_u32x4 v[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {                      // keep <= H+16 <= 3 x 1024: all reads, then all writes
+                const int32_t j = 1024 * k + 16 * (int32_t)lane;
+                v[k] = rcx_u32x4{0, 0, 0, 0};
+                if (j < keep && j + delta + 16 <= LIN + 64) v[k] = *(const rcx_u32x4*)(wb_ + j + delta);
+            }
+            rcx_wave_sync();
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int32_t j = 1024 * k + 16 * (int32_t)lane;
+                if (j < keep && j + delta + 16 <= LIN + 64) *(rcx_u32x4*)(wb_ + j) = v[k];
+            }
+            rcx_wave_sync();
+        }
+        lbase = nb;
+    }
+
+    __device__ void flush(uint32_t to, bool final)
+    {
+        uint32_t from = gflush;
+        if (to <= from) return;
+        const uint32_t mis = (uint32_t)((uintptr_t)(out + from) & 15u);
+        uint32_t head = mis ? 16u - mis : 0u;
+        if (head > to - from) head = final ? to - from : 0u;
+        if (mis && head == 0 && !final) return;
+        if (head) {
+            if (lane < head) out[from + lane] = wb_[(int32_t)(from + lane) - lbase];
+            from += head;
+        }
+        const uint32_t nch = (to - from) >> 4;
+        for (uint32_t c = lane; c < nch; c += 64) {
+            const uint32_t p = from + 16 * c;
+            *(rcx_u32x4*)(out + p) = *(const rcx_u32x4*)(wb_ + ((int32_t)p - lbase));
+        }
+        from += nch * 16;
+        if (final) {
+            const uint32_t tail = to - from;
+            if (lane < tail) out[from + lane] = wb_[(int32_t)(from + lane) - lbase];
+            from = to;
+        }
+        gflush = RCX_U(from);
+    }
+
+    __device__ void repair()
+    {
+        lbase = (int32_t)RCX_U(lbase_for(oend));
+        rlo = oend > (uint32_t)RH ? oend - RH : 0u;
+        rcx_wave_sync();
+        for (uint32_t p = rlo + lane; p < oend; p += 64) wb_[(int32_t)p - lbase] = out[p];
+        rcx_wave_sync();
+    }
+
+    __device__ void wide_literals(uint32_t src, uint32_t len)
+    {
+        uint8_t* d = out + oend;
+        const uint8_t* s = in + src;
+        const uint32_t mis = (uint32_t)((uintptr_t)d & 15u);
+        uint32_t head = mis ? 16u - mis : 0u;
+        if (head > len) head = len;
+        if (lane < head) d[lane] = s[lane];
+        const uint32_t nb = (len - head) >> 4;
+        for (uint32_t c = lane; c < nb; c += 64)
+            *(rcx_u32x4*)(d + head + 16 * c) = *(const rcx_u32x4_u*)(s + head + 16 * c);
+        const uint32_t done = head + nb * 16;
+        if (lane < len - done) d[done + lane] = s[done + lane];
+    }
+
+    __device__ void wide_match(uint32_t off, uint32_t len)
+    {
+        uint32_t e = off, d = oend, rem = len;
+        while (rem) {
+            uint32_t C = rem < e ? rem : e;
+            if (C > 1024) C = 1024;
+            const uint32_t i0 = 16 * lane;
+            if (i0 + 16 <= C) {
+                *(rcx_u32x4_u*)(out + d + i0) = *(const rcx_u32x4_u*)(out + d - e + i0);
+            } else if (i0 < C) {
+                for (uint32_t t = i0; t < C; t++) out[d + t] = out[d - e + t];
+            }
+            rcx_wave_sync();
+            d += C; rem -= C;
+            if (C == e && e < 1024) e *= 2;
+        }
+    }
+
+    // one long sequence, copied by the whole wave inside the LDS window.  Returns 0 or an rcx_status.
+    __device__ int solo(uint32_t lit_src, uint32_t L, uint32_t off, uint32_t M)
+    {
+        if (L > cap - oend) return RCX_E_OUTPUT_TOO_SMALL;
+        const uint32_t mdst = oend + L;
+        if (M) {
+            if (off == 0 || off > mdst) return RCX_E_MALFORMED;
+            if (M > cap - mdst) return RCX_E_OUTPUT_TOO_SMALL;
+            // a source that starts before the window must lie entirely in drained HBM; else take the wide path
+            const uint32_t slo0 = mdst - off;
+            const uint32_t need = off < M ? off : M;
+            if (slo0 < rlo_eff() && slo0 + need > gflush) return -2;
+        }
+        make_room(L + M);
+        const int32_t li = (int32_t)oend - lbase;
+        for (uint32_t i = lane; i < L; i += 64) wb_[li + (int32_t)i] = in[lit_src + i];
+        rcx_wave_sync();
+        if (M) {
+            const uint32_t slo = mdst - off;
+            const int32_t lm = li + (int32_t)L;
+            if (slo >= rlo_eff()) {                                   // source in the window (may overlap itself)
+                const int32_t ls = (int32_t)slo - lbase;
+                if (off >= M) {
+                    for (uint32_t i = lane; i < M; i += 64) wb_[lm + (int32_t)i] = wb_[ls + (int32_t)i];
+                } else {                                              // periodic: only finished bytes are read
+                    for (uint32_t i = lane; i < M; i += 64) wb_[lm + (int32_t)i] = wb_[ls + (int32_t)(i % off)];
+                }
+            } else if (off >= M) {                                    // drained long ago: HBM -> window
+                for (uint32_t i = lane; i < M; i += 64) wb_[lm + (int32_t)i] = out[slo + i];
+            } else {
+                for (uint32_t i = lane; i < M; i += 64) wb_[lm + (int32_t)i] = out[slo + (i % off)];
+            }
+            rcx_wave_sync();
+        }
+        oend = RCX_U(oend + L + M);
+        flush(oend, false);
+        return 0;
+    }
+
+    __device__ __forceinline__ uint32_t lane_of(uint32_t ostart, uint32_t x) const
+    {
+        uint32_t lo = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const uint32_t c = lo + step;
+            const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)ostart);
+            if (c < 64 && v <= x) lo = c;
+        }
+        return lo;
+    }
+
+    // 32 bytes per lane from wb_[sb ...] (period `per`: index wraps to 0 at `per`) into wb_[db ...], for
+    // lanes in `on`, only the first M bytes are stored.  Reads first, then writes.
+    template <bool PERIODIC>
+    __device__ __forceinline__ void copy32(bool on, uint32_t M, int32_t sb, int32_t db, uint32_t per)
+    {
+        const unsigned long long m8 = __ballot(on && M > 8), m16 = __ballot(on && M > 16), m24 = __ballot(on && M > 24);
+        const int32_t trash = TRASH + (int32_t)lane;
+        const int32_t rb = on ? sb : 0;
+        uint8_t v[32];
+        uint32_t r = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (c == 1 && !m8) break;
+            if (c == 2 && !m16) break;
+            if (c == 3 && !m24) break;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (PERIODIC) { v[8 * c + u] = wb_[rb + (int32_t)r]; r = (r + 1 == per) ? 0u : r + 1; }
+                else v[8 * c + u] = wb_[rb + 8 * c + u];
+            }
+        }
+        rcx_wave_sync();
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (c == 1 && !m8) break;
+            if (c == 2 && !m16) break;
+            if (c == 3 && !m24) break;
+#pragma unroll
+            for (int u = 0; u < 8; u++) wb_[(on && (uint32_t)(8 * c + u) < M) ? db + 8 * c + u : trash] = v[8 * c + u];
+        }
+        rcx_wave_sync();
+    }
+
+    __device__ int emit(int ns, uint32_t s_L, uint32_t s_M, uint32_t s_off, uint32_t s_src)
+    {
+        LZ4P_T0();
+        make_room(TCAP);
+        LZ4P_ADD(1);
+        const bool act = (int)lane < ns;
+        uint32_t L = 0, M = 0, off = 0, src = (uint32_t)cbase;
+        if (act) {
+            const uint32_t e = epos[lane];
+            if (e & FLAG) { L = s_L; M = s_M; off = s_off; src = s_src; }
+            else {
+                const uint32_t t = cbuf[(int32_t)e - cbase];
+                L = t >> 4; M = (t & 15u) + 4u; src = e + 1;
+                const int32_t oi = (int32_t)(src + L) - cbase;
+                off = (uint32_t)cbuf[oi] | ((uint32_t)cbuf[oi + 1] << 8);
+            }
+        }
+        const uint32_t len = L + M;
+        const uint32_t incl = rcx_wave_incl_scan(len);
+        const uint32_t T = RCX_U(__builtin_amdgcn_readlane(incl, 63));
+        const uint32_t oend0 = oend;
+        const uint32_t ostart = oend0 + incl - len;
+        const uint32_t mdst = ostart + L;
+        int err = 0;
+        if (act) {
+            if (L > cap - ostart || ostart > cap) err = RCX_E_OUTPUT_TOO_SMALL;
+            else if (M && (off == 0 || off > mdst)) err = RCX_E_MALFORMED;
+            else if (M && M > cap - mdst) err = RCX_E_OUTPUT_TOO_SMALL;
+        }
+        const unsigned long long bad = __ballot(err != 0);
+        if (bad) return __builtin_amdgcn_readlane(err, __ffsll(bad) - 1);
+        LZ4P_ADD(2);
+
+        const uint32_t re = rlo_eff();
+        const int32_t li_o = (int32_t)ostart - lbase;
+        const int32_t li_m = li_o + (int32_t)L;
+        const int32_t trash = TRASH + (int32_t)lane;
+        const uint32_t slo = mdst - off;
+        const uint32_t shi = (slo + M < mdst) ? slo + M : mdst;
+        const bool isfar = M && slo < re;                            // source drained and slid out of the window
+
+        // ---- old matches: one or two 16-byte HBM gathers per lane into the lane's staging slot
+        rcx_u32x4 f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0};
+        const unsigned long long anyfar = __ballot(isfar);
+        const bool far16 = isfar && (uint64_t)slo + 32u <= (uint64_t)cap;
+        const bool farb = isfar && !far16;                           // within 32 bytes of the slot end: byte loads
+        if (anyfar) {
+            // the slot end is within the block's output slot: slo + 32 <= cap is not guaranteed near the end
+            if (far16) { f0 = *(const rcx_u32x4_u*)(out + slo); if (M > 16) f1 = *(const rcx_u32x4_u*)(out + slo + 16); }
+        }
+
+        // ---- literals: compressed window -> output window (4 bytes, then 8 per step; reads before writes)
+        {
+            const int32_t sb = (int32_t)src - cbase;
+            if (__ballot(L != 0)) {
+                uint8_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = cbuf[sb + u];
+#pragma unroll
+                for (int u = 0; u < 4; u++) wb_[((uint32_t)u < L) ? li_o + u : trash] = v[u];
+                for (uint32_t i0 = 4; __ballot(i0 < L); i0 += 8) {
+                    const int32_t rb = i0 < L ? sb + (int32_t)i0 : 0;
+                    uint8_t x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) x[u] = cbuf[rb + u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) wb_[(i0 + u < L) ? li_o + (int32_t)i0 + u : trash] = x[u];
+                }
+            }
+        }
+        if (anyfar) {
+            if (far16) { *(rcx_u32x4*)(wb_ + STAGE + 32 * (int32_t)lane) = f0; *(rcx_u32x4*)(wb_ + STAGE + 32 * (int32_t)lane + 16) = f1; }
+            for (uint32_t i = 0; __ballot(farb && i < M); i++)
+                if (farb && i < M) wb_[STAGE + 32 * (int32_t)lane + (int32_t)i] = out[slo + i];
+        }
+        rcx_wave_sync();
+        LZ4P_ADD(3);
+
+        // ---- matches.  Producer lanes of [slo, shi) inside this batch = lanes ka..kb; copy when none is pending.
+        if (__ballot(M != 0)) {
+            unsigned long long dep = 0;
+            const bool inb = M && !isfar && shi > oend0;
+            if (__ballot(inb)) {
+                const uint32_t ka = lane_of(ostart, slo > oend0 ? slo : oend0);
+                const uint32_t kb = lane_of(ostart, shi > oend0 ? shi - 1 : oend0);
+                if (inb) {
+                    const unsigned long long upto = (kb >= 63) ? ~0ull : ((2ull << kb) - 1ull);
+                    dep = upto & ~((1ull << ka) - 1ull) & ((1ull << lane) - 1ull);
+                }
+            }
+            LZ4P_ADD(4);
+            const int32_t sbase = isfar ? STAGE + 32 * (int32_t)lane : (int32_t)slo - lbase;
+            const bool ovl = M && !isfar && off < M;
+            // 8 bytes per ready lane per iteration: "the next 8 bytes of a long match" and "the next dependency
+            // level" share iterations, so an iteration is 8 LDS reads + 8 LDS writes whatever the mix.
+            bool pending = M != 0;
+            uint32_t prog = 0, r = 0;
+            for (;;) {
+                const unsigned long long pm = __ballot(pending);
+                if (!pm) break;
+                const bool ready = pending && (pm & dep) == 0;
+                const bool rn = ready && !ovl;
+                uint8_t v[8];
+                bool did;
+                if (__ballot(rn)) {
+                    const int32_t rb = rn ? sbase + (int32_t)prog : 0;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) v[u] = wb_[rb + u];
+                    did = rn;
+                } else {                                   // self-overlapping matches: periodic source, batched up
+                    const bool ro = ready && ovl;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { v[u] = wb_[ro ? sbase + (int32_t)r : 0]; r = !ro ? r : (r + 1 == off) ? 0u : r + 1; }
+                    did = ro;
+                }
+                rcx_wave_sync();
+                const int32_t db = li_m + (int32_t)prog;
+#pragma unroll
+                for (int u = 0; u < 8; u++) wb_[(did && prog + u < M) ? db + u : trash] = v[u];
+                rcx_wave_sync();
+                if (did) { prog += 8; if (prog >= M) pending = false; }
+            }
+        }
+        LZ4P_ADD(5);
+        oend = RCX_U(oend0 + T);
+        flush(oend, false);
+        LZ4P_ADD(6);
+        if (PROF) prof[10] += 1;
+        return 0;
+    }
+
+    __device__ void run(int32_t* st_out, uint32_t* len_out)
+    {
+        lane = rcx_lane();
+        omis = (uint32_t)((uintptr_t)out & 15u);
+        oend = 0; gflush = 0; rlo = 0;
+        lbase = (int32_t)RCX_U(lbase_for(0));
+        int st = RCX_OK;
+        uint32_t cur = 0;
+        if (n) stage(0); else { cbase = 0; cend = 0; }
+
+        uint32_t s_L = 0, s_M = 0, s_off = 0, s_src = 0;      // fields of general-path entries (per lane)
+        int ns = 0;
+        uint32_t tslow = 0;
+        enum { GO = 0, STAGE_ = 1, SOLO_ = 2, WIDE_ = 3, END_ = 4, ERR_ = 5 };
+        if (PROF) for (int i = 0; i < 12; i++) prof[i] = 0;
+        for (;;) {
+            LZ4P_T0();
+            // ------------------------------------------------------------------ collect a batch
+            int why = GO;
+            int perr = 0;
+            uint32_t gL = 0, gM = 0, goff = 0, gsrc = 0, gnext = 0;
+            while (why == GO) {
+                cur = RCX_U(cur); ns = (int)RCX_U(ns); tslow = RCX_U(tslow);
+                if (cur >= n) { why = END_; break; }
+                if (cend < n && cur + (uint32_t)MARGIN > cend) { why = STAGE_; break; }
+                if (ns > 42) break;                               // a window may add up to 22 entries
+                // register window: hop distance of the candidate token at cur+lane (0 = general path)
+                const uint32_t q = cur + lane;
+                const uint32_t fast_lim = cend >= 20 ? cend - 20 : 0;
+                uint32_t dv = 128;
+                if (q < fast_lim) {
+                    const uint32_t t = cbuf[(int32_t)q - cbase];
+                    const uint32_t L = t >> 4, M = t & 15u;
+                    dv = (L == 15u || M == 15u) ? 128u : 3u + L;
+                }
+                uint32_t rel = 0, mark = 0;
+                RCX_HOP_WALK(dv, lane, rel, mark);                // the serial token chain
+                const bool general = rel >= 128;                  // stopped at a token that needs the general path
+                if (general) { rel -= 128; mark = (lane == rel) ? 0u : mark; }
+                // compaction: a marked lane p is a token start -> epos[ns + rank]
+                const unsigned long long vis = __ballot(mark != 0);
+                if (vis) {
+                    const uint32_t rank = (uint32_t)__popcll(vis & ((1ull << lane) - 1ull));
+                    if (mark) epos[ns + (int)rank] = q;
+                    ns += (int)__popcll(vis);
+                }
+                cur += rel;
+                if (!general) continue;                           // window ran out: next window
+                if (cur >= n) { why = END_; break; }
+                if (cend < n && cur + (uint32_t)MARGIN > cend) { why = STAGE_; break; }
+
+                // ---- general path for the token at `cur`
+                const uint32_t t = peek(cur);
+                uint32_t p = cur + 1;
+                uint32_t L = t >> 4;
+                if (L == 15) {
+                    for (;;) {
+                        if (p >= n) { perr = RCX_E_MALFORMED; break; }
+                        const uint32_t x = peek(p); p++;
+                        L += x;
+                        if (x != 255) break;
+                    }
+                    if (perr) { why = ERR_; break; }
+                }
+                const uint32_t lit_src = p;
+                if (L > n - p) { perr = RCX_E_MALFORMED; why = ERR_; break; }
+                p += L;
+                uint32_t M = 0, off = 0;
+                if (p != n) {
+                    if (n - p < 2) { perr = -1; gL = L; why = ERR_; break; }     // literals copy, then the offset read panics
+                    off = peek(p) | (peek(p + 1) << 8);
+                    p += 2;
+                    M = t & 15u;
+                    if (M == 15) {
+                        for (;;) {
+                            if (p >= n) { perr = -1; gL = L; break; }            // same order: literal overflow first
+                            const uint32_t x = peek(p); p++;
+                            M += x;
+                            if (x != 255) break;
+                        }
+                        if (perr) { why = ERR_; break; }
+                    }
+                    M += 4;
+                }
+                const bool eligible = L <= (uint32_t)LCAP && M <= (uint32_t)MCAP && lit_src + L <= cend && (int32_t)lit_src >= cbase;
+                if (eligible && tslow + L + M <= (uint32_t)TSLOW && ns < 64) {
+                    if (lane == 0) epos[ns] = FLAG;
+                    s_L = ((int)lane == ns) ? L : s_L;
+                    s_M = ((int)lane == ns) ? M : s_M;
+                    s_off = ((int)lane == ns) ? off : s_off;
+                    s_src = ((int)lane == ns) ? lit_src : s_src;
+                    ns++; tslow += L + M;
+                    cur = p;
+                } else if (eligible) {
+                    break;                                        // batch full: emit, then this token is parsed again
+                } else {
+                    gL = L; gM = M; goff = off; gsrc = lit_src; gnext = p;
+                    why = (L + M <= (uint32_t)SOLO) ? SOLO_ : WIDE_;
+                }
+            }
+            // ------------------------------------------------------------------ emit it (the one call site)
+            rcx_wave_sync();
+            LZ4P_ADD(0);
+            if (PROF) prof[11] += (uint64_t)ns;
+            if (ns) {
+                const int e = emit(ns, s_L, s_M, s_off, s_src);
+                ns = 0; tslow = 0;
+                if (e) { st = e; break; }
+            }
+            // ------------------------------------------------------------------ then what stopped the batch
+            if (PROF) t0_ = (uint64_t)__builtin_readcyclecounter();
+            if (why == END_) break;
+            if (why == STAGE_) { stage(cur); LZ4P_ADD(7); continue; }
+            if (why == ERR_) { st = perr > 0 ? perr : ((gL > cap - oend) ? RCX_E_OUTPUT_TOO_SMALL : RCX_E_MALFORMED); break; }
+            if (why == SOLO_) {
+                const int e = solo(gsrc, gL, goff, gM);
+                if (e == -2) why = WIDE_;
+                else if (e) { st = e; break; }
+                else cur = gnext;
+                LZ4P_ADD(8);
+            }
+            if (why == WIDE_) {
+                flush(oend, true);
+                if (gL > cap - oend) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
+                if (gL) { wide_literals(gsrc, gL); oend += gL; }
+                if (gM) {
+                    if (goff == 0 || goff > oend) { st = RCX_E_MALFORMED; break; }
+                    if (gM > cap - oend) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
+                    rcx_wave_sync();
+                    wide_match(goff, gM);
+                    oend += gM;
+                }
+                oend = RCX_U(oend);
+                gflush = oend;
+                repair();
+                cur = gnext;
+                LZ4P_ADD(9);
+            }
+        }
+        if (!st) flush(oend, true);
+        *st_out = st;
+        *len_out = st ? 0u : oend;
+    }
+};
+
+template <int CB, int WAVES, bool PROF = false>
+__global__ __launch_bounds__(64 * WAVES) void k_lz4_decode_v4(rcx_kargs a)
+{
+    typedef Lz4V4<CB, PROF> S;
+    __shared__ __align__(16) uint8_t s_cbuf[WAVES][CB + 64];
+    __shared__ __align__(16) uint8_t s_wbuf[WAVES][S::WBUF];
+    __shared__ uint32_t s_epos[WAVES][64];
+    const unsigned w = threadIdx.x >> 6;
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + w));
+    if (b >= a.nblocks) return;
+    S s;
+    s.in = a.in_base + a.in_off[b];
+    s.n = (uint32_t)a.in_len[b];
+    s.out = a.out_base + a.out_off[b];
+    const uint64_t cap64 = a.out_cap[b];
+    s.cap = cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)cap64;
+    s.cbuf = s_cbuf[w];
+    s.wb_ = s_wbuf[w];
+    s.epos = s_epos[w];
+    int32_t st; uint32_t olen;
+    s.run(&st, &olen);
+    if ((threadIdx.x & 63u) == 0) {
+        a.status[b] = st;
+        a.out_len[b] = olen;
+        if (a.in_used) a.in_used[b] = s.n;
+        if (PROF && a.scratch) for (int i = 0; i < 12; i++) ((uint64_t*)a.scratch)[(size_t)b * 12 + i] = s.prof[i];
+    }
+}

@@ -10,6 +10,7 @@
 
 #include "rcx_dev.h"
 #include "k_lz4_decode.hip"
+#include "k_lz4_decode_v4.hip"
 #include "k_lz4_encode.hip"
 #include "k_inflate.hip"
 #include "k_bwt.hip"
@@ -150,7 +151,11 @@ static int launch_codec(rcx_ctx* c, int codec, rcx_kargs& k)
         else if (v == 3) hipLaunchKernelGGL((k_lz4_decode_v3<4096, 2048, 64, 64, 1>), dim3(n), dim3(64), 0, s, k);
         else if (v == 4) hipLaunchKernelGGL((k_lz4_decode_v3<2048, 2048, 32, 32, 1>), dim3(n), dim3(64), 0, s, k);
         else if (v == 5) hipLaunchKernelGGL((k_lz4_decode_v2<4096, 2048, 64, 64, 1>), dim3(n), dim3(64), 0, s, k);
-        else hipLaunchKernelGGL((k_lz4_decode_v3<2048, 2048, 64, 64, 1>), dim3(n), dim3(64), 0, s, k);
+        else if (v == 6) hipLaunchKernelGGL((k_lz4_decode_v3<2048, 2048, 64, 64, 1>), dim3(n), dim3(64), 0, s, k);
+        else if (v == 7) hipLaunchKernelGGL((k_lz4_decode_v4<2048, 1>), dim3(n), dim3(64), 0, s, k);
+        else if (v == 9) hipLaunchKernelGGL((k_lz4_decode_v4<1024, 1, true>), dim3(n), dim3(64), 0, s, k);   // phase timers -> scratch
+        else if (v == 8) hipLaunchKernelGGL((k_lz4_decode_v4<1024, 4>), dim3((n + 3) / 4), dim3(256), 0, s, k);
+        else hipLaunchKernelGGL((k_lz4_decode_v4<1024, 1>), dim3(n), dim3(64), 0, s, k);
         break;
     case RCX_LZ4_ENCODE: {
         if (k.scratch_bytes < rcx_scratch_bytes(codec, n, 0)) { c->err = "lz4 encode: scratch too small"; return RCX_RC_BAD_ARG; }

@@ -60,6 +60,40 @@ __device__ __forceinline__ uint32_t rcx_wave_sum(uint32_t v)
     return v;
 }
 
+// LZ4 token walk over one 64-position register window.  dv: lane p holds the hop distance of the candidate
+// token at window position p, or 128 if that token needs the general path.  Starting at `rel`, follows the
+// chain while it stays inside the window and sets mark = 1 in the lane of every token start visited.
+// On return rel >= 128 means: stopped at a general-path token at window position rel-128 (its lane is
+// marked too); otherwise 64 <= rel < 128 is where the chain left the window.
+// Hand-scheduled because the CU's single scalar unit is the bottleneck of the parse (rocprof + phase timers:
+// hipcc's loop cost 11 SALU per hop, ~168 cycles with 16 waves per CU): 3 SALU + 3 VALU per hop, no taken
+// branch for 4 hops.  SALU reads of a VALU-written SGPR interlock in hardware; the lane select is SALU-written.
+// The wave simulator supplies a portable version through this hook.
+#ifndef RCX_HOP_WALK
+__device__ __forceinline__ void rcx_hop_walk(uint32_t dv, uint32_t lanev, uint32_t& rel, uint32_t& mark)
+{
+    uint32_t d;
+#define RCX_HOP1                                              \
+        "v_readlane_b32 %[d], %[dv], %[rel]\n\t"              \
+        "v_cmp_eq_u32_e32 vcc, %[rel], %[lanev]\n\t"          \
+        "v_cndmask_b32_e64 %[mark], %[mark], 1, vcc\n\t"      \
+        "s_add_u32 %[rel], %[rel], %[d]\n\t"                  \
+        "s_cmp_gt_u32 %[rel], 63\n\t"
+    asm volatile(
+        "L_hop_%=:\n\t"
+        RCX_HOP1 "s_cbranch_scc1 L_done_%=\n\t"
+        RCX_HOP1 "s_cbranch_scc1 L_done_%=\n\t"
+        RCX_HOP1 "s_cbranch_scc1 L_done_%=\n\t"
+        RCX_HOP1 "s_cbranch_scc0 L_hop_%=\n\t"
+        "L_done_%=:\n\t"
+        : [d] "=&s"(d), [rel] "+s"(rel), [mark] "+v"(mark)
+        : [dv] "v"(dv), [lanev] "v"(lanev)
+        : "scc", "vcc");
+#undef RCX_HOP1
+}
+#define RCX_HOP_WALK rcx_hop_walk
+#endif
+
 // Cross-lane ordering inside one wave for traffic through LDS/global: hardware executes a wave's
 // memory instructions in order, so this only has to stop the COMPILER from reordering (no ISA emitted).
 __device__ __forceinline__ void rcx_wave_sync()

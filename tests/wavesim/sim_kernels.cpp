@@ -1,6 +1,7 @@
 // sim_kernels.cpp -- runs the UNMODIFIED .hip kernel sources on the wave64 simulator (TEST INFRASTRUCTURE).
 // Built by tests/wavesim/build.py with:  g++ -include wavesim.h sim_kernels.cpp wavesim.cpp
 #include "../../rust_compress_amd/csrc/k_lz4_decode.hip"
+#include "../../rust_compress_amd/csrc/k_lz4_decode_v4.hip"
 #include "../../rust_compress_amd/csrc/k_lz4_encode.hip"
 #define hipStream_t int
 #define hipLaunchKernelGGL(kern, grid, block, shm, stream, ...) ws::launch(grid, block, [&] { kern(__VA_ARGS__); })
@@ -22,7 +23,10 @@ extern "C" int sim_launch(int codec, int variant, const rcx_kargs* a)
         else if (variant == 3) ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_decode_v3<4096, 2048, 64, 64, 1>(k); });
         else if (variant == 4) ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_decode_v3<2048, 2048, 32, 32, 1>(k); });
         else if (variant == 5) ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_decode_v2<4096, 2048, 64, 64, 1>(k); });
-        else ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_decode_v3<2048, 2048, 64, 64, 1>(k); });
+        else if (variant == 6) ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_decode_v3<2048, 2048, 64, 64, 1>(k); });
+        else if (variant == 7) ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_decode_v4<2048, 1>(k); });
+        else if (variant == 8) ws::launch(dim3((k.nblocks + 3) / 4), dim3(256), [&] { k_lz4_decode_v4<1024, 4>(k); });
+        else ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_decode_v4<1024, 1>(k); });
         return 0;
     case RCX_LZ4_ENCODE:
         ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_encode(k, 0); });

@@ -225,6 +225,18 @@ static inline unsigned __byte_perm_(unsigned a, unsigned b, unsigned s) { (void)
 #define __builtin_amdgcn_mbcnt_hi(m, b) ((int)(ws::cur->tid & 63) < 32 ? (b) : (int)(ws::cur->tid & 63) - 32 + (b))
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
+// portable version of rcx_dev.h's hand-scheduled LZ4 token walk (the product uses inline gfx950 asm)
+static inline void ws_hop_walk(uint32_t dv, uint32_t lanev, uint32_t& rel, uint32_t& mark)
+{
+    for (;;) {
+        const uint32_t d = (uint32_t)ws::shfl((int)dv, (int)rel);
+        if (lanev == rel) mark = 1;
+        rel += d;
+        if (rel > 63) break;
+    }
+}
+#define RCX_HOP_WALK ws_hop_walk
+#define __builtin_readcyclecounter() 0ull
 #define __threadfence() ((void)0)
 #define __threadfence_block() ((void)0)
 
