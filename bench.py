@@ -183,7 +183,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(dec, raw, torch, args.nblocks)
         if args.extras and world == 1:
             extras = {}
-            for kind in ("text", "runs", "rand", "mix"):
+            for kind in ("text", "words", "runs", "rand", "mix"):
                 d2, r2, cb, ob = make_workload(R, ctx, torch, dev, kind, args.nblocks, 0x77 + len(kind))
                 for v in (0, 1, 6, 7, 8):
                     ctx.set_variant(N.LZ4_DECODE, v)

@@ -333,10 +333,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_adler32(rcx_kargs a)
     }
 }
 
+__global__ void k_inflate2(rcx_kargs a, int zlib);
 static void launch_inflate(hipStream_t s, rcx_kargs& k, bool zlib, int v)
 {
-    (void)v;
-    hipLaunchKernelGGL(k_inflate, dim3((k.nblocks + 63) / 64), dim3(64), 0, s, k, zlib ? 1 : 0);
+    if (v == 1) hipLaunchKernelGGL(k_inflate, dim3((k.nblocks + 63) / 64), dim3(64), 0, s, k, zlib ? 1 : 0);   // first version (A/B)
+    else hipLaunchKernelGGL(k_inflate2, dim3((k.nblocks + 63) / 64), dim3(64), 0, s, k, zlib ? 1 : 0);
 }
 static void launch_adler32(hipStream_t s, rcx_kargs& k)
 {

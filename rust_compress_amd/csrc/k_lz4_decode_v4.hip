@@ -29,15 +29,14 @@ template <int CB, bool PROF = false>
 struct Lz4V4 {
     uint64_t prof[12];
     static constexpr int H = 2048;                 // history kept when the window slides
-    static constexpr int LCAP = 32, MCAP = 32;     // per-lane caps of a batched sequence
-    static constexpr int TFAST = 64 * 32;          // 64 plain tokens: <= 14 literals + 18 match bytes each
-    static constexpr int TSLOW = 1024;
-    static constexpr int TCAP = TFAST + TSLOW;
+    static constexpr int LCAP = 32, MCAP = 64;     // per-lane caps of a batched sequence
+    static constexpr int WINMAX = 22 * (14 + MCAP);// most output one 64-byte token window can add (22 tokens)
+    static constexpr int TCAP = 2560;              // output bytes per batch
     static constexpr int SOLO = 1024;              // wave-cooperative in-window copy up to this many bytes
-    static constexpr int LIN = H + 16 + TCAP + 768;
+    static constexpr int LIN = H + 16 + TCAP;
     static constexpr int TRASH = LIN + 64;         // 64 bytes of read slack, then 64 trash bytes
-    static constexpr int STAGE = TRASH + 64;       // 64 lanes x 32 bytes of old-match staging
-    static constexpr int WBUF = STAGE + 64 * 32;
+    static constexpr int STAGE = TRASH + 64;       // 64 lanes x MCAP bytes of old-match staging
+    static constexpr int WBUF = STAGE + 64 * MCAP;
     static constexpr int RH = 128;
     static constexpr int MARGIN = LCAP + 16;
     static constexpr uint32_t FLAG = 0x80000000u;
@@ -284,6 +283,7 @@ struct Lz4V4 {
                 L = t >> 4; M = (t & 15u) + 4u; src = e + 1;
                 const int32_t oi = (int32_t)(src + L) - cbase;
                 off = (uint32_t)cbuf[oi] | ((uint32_t)cbuf[oi + 1] << 8);
+                if (M == 19u) M += cbuf[oi + 2];                         // one match-length extension byte (< 255, lz4.rs:112-122)
             }
         }
         const uint32_t len = L + M;
@@ -311,13 +311,17 @@ struct Lz4V4 {
         const bool isfar = M && slo < re;                            // source drained and slid out of the window
 
         // ---- old matches: one or two 16-byte HBM gathers per lane into the lane's staging slot
-        rcx_u32x4 f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0};
+        rcx_u32x4 f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0}, f2 = {0, 0, 0, 0}, f3 = {0, 0, 0, 0};
         const unsigned long long anyfar = __ballot(isfar);
-        const bool far16 = isfar && (uint64_t)slo + 32u <= (uint64_t)cap;
-        const bool farb = isfar && !far16;                           // within 32 bytes of the slot end: byte loads
+        const bool far16 = isfar && (uint64_t)slo + (uint32_t)MCAP <= (uint64_t)cap;
+        const bool farb = isfar && !far16;                           // within MCAP bytes of the slot end: byte loads
         if (anyfar) {
-            // the slot end is within the block's output slot: slo + 32 <= cap is not guaranteed near the end
-            if (far16) { f0 = *(const rcx_u32x4_u*)(out + slo); if (M > 16) f1 = *(const rcx_u32x4_u*)(out + slo + 16); }
+            if (far16) {
+                f0 = *(const rcx_u32x4_u*)(out + slo);
+                if (M > 16) f1 = *(const rcx_u32x4_u*)(out + slo + 16);
+                if (M > 32) f2 = *(const rcx_u32x4_u*)(out + slo + 32);
+                if (M > 48) f3 = *(const rcx_u32x4_u*)(out + slo + 48);
+            }
         }
 
         // ---- literals: compressed window -> output window (4 bytes, then 8 per step; reads before writes)
@@ -340,9 +344,13 @@ struct Lz4V4 {
             }
         }
         if (anyfar) {
-            if (far16) { *(rcx_u32x4*)(wb_ + STAGE + 32 * (int32_t)lane) = f0; *(rcx_u32x4*)(wb_ + STAGE + 32 * (int32_t)lane + 16) = f1; }
+            uint8_t* sl = wb_ + STAGE + MCAP * (int32_t)lane;
+            if (far16) {
+                *(rcx_u32x4*)(sl) = f0; *(rcx_u32x4*)(sl + 16) = f1;
+                if (M > 32) { *(rcx_u32x4*)(sl + 32) = f2; *(rcx_u32x4*)(sl + 48) = f3; }
+            }
             for (uint32_t i = 0; __ballot(farb && i < M); i++)
-                if (farb && i < M) wb_[STAGE + 32 * (int32_t)lane + (int32_t)i] = out[slo + i];
+                if (farb && i < M) sl[i] = out[slo + i];
         }
         rcx_wave_sync();
         LZ4P_ADD(3);
@@ -360,7 +368,7 @@ struct Lz4V4 {
                 }
             }
             LZ4P_ADD(4);
-            const int32_t sbase = isfar ? STAGE + 32 * (int32_t)lane : (int32_t)slo - lbase;
+            const int32_t sbase = isfar ? STAGE + MCAP * (int32_t)lane : (int32_t)slo - lbase;
             const bool ovl = M && !isfar && off < M;
             // 8 bytes per ready lane per iteration: "the next 8 bytes of a long match" and "the next dependency
             // level" share iterations, so an iteration is 8 LDS reads + 8 LDS writes whatever the mix.
@@ -412,7 +420,7 @@ struct Lz4V4 {
 
         uint32_t s_L = 0, s_M = 0, s_off = 0, s_src = 0;      // fields of general-path entries (per lane)
         int ns = 0;
-        uint32_t tslow = 0;
+        uint32_t tsum = 0;
         enum { GO = 0, STAGE_ = 1, SOLO_ = 2, WIDE_ = 3, END_ = 4, ERR_ = 5 };
         if (PROF) for (int i = 0; i < 12; i++) prof[i] = 0;
         for (;;) {
@@ -422,30 +430,49 @@ struct Lz4V4 {
             int perr = 0;
             uint32_t gL = 0, gM = 0, goff = 0, gsrc = 0, gnext = 0;
             while (why == GO) {
-                cur = RCX_U(cur); ns = (int)RCX_U(ns); tslow = RCX_U(tslow);
+                cur = RCX_U(cur); ns = (int)RCX_U(ns); tsum = RCX_U(tsum);
                 if (cur >= n) { why = END_; break; }
                 if (cend < n && cur + (uint32_t)MARGIN > cend) { why = STAGE_; break; }
                 if (ns > 42) break;                               // a window may add up to 22 entries
-                // register window: hop distance of the candidate token at cur+lane (0 = general path)
+                // register window: hop distance of the candidate token at cur+lane (128 = general path) and the
+                // output bytes it produces.  A match-length nibble of 15 followed by ONE extension byte that keeps
+                // the match within MCAP stays on the vector path (second, dependent LDS read).
                 const uint32_t q = cur + lane;
                 const uint32_t fast_lim = cend >= 20 ? cend - 20 : 0;
-                uint32_t dv = 128;
+                uint32_t dv = 128, lenv = 0;
                 if (q < fast_lim) {
-                    const uint32_t t = cbuf[(int32_t)q - cbase];
+                    const int32_t qi = (int32_t)q - cbase;
+                    const uint32_t t = cbuf[qi];
                     const uint32_t L = t >> 4, M = t & 15u;
-                    dv = (L == 15u || M == 15u) ? 128u : 3u + L;
+                    const uint32_t x = cbuf[qi + 3 + (int32_t)L];
+                    const bool ext = M == 15u;
+                    const bool ok = L != 15u && (!ext || x <= (uint32_t)(MCAP - 19));
+                    dv = ok ? (ext ? 4u : 3u) + L : 128u;
+                    lenv = L + M + 4u + (ext ? x : 0u);
                 }
                 uint32_t rel = 0, mark = 0;
                 RCX_HOP_WALK(dv, lane, rel, mark);                // the serial token chain
-                const bool general = rel >= 128;                  // stopped at a token that needs the general path
+                bool general = rel >= 128;                        // stopped at a token that needs the general path
                 if (general) { rel -= 128; mark = (lane == rel) ? 0u : mark; }
-                // compaction: a marked lane p is a token start -> epos[ns + rank]
-                const unsigned long long vis = __ballot(mark != 0);
+                // compaction: a marked lane p is a token start -> epos[ns + rank]; the batch's output is capped
+                unsigned long long vis = __ballot(mark != 0);
+                bool full = false;
                 if (vis) {
+                    const uint32_t inc = rcx_wave_incl_scan(mark ? lenv : 0u);
+                    const uint32_t wsum = RCX_U(__builtin_amdgcn_readlane(inc, 63));
+                    if (tsum + wsum > (uint32_t)TCAP) {           // keep the prefix that fits, emit, resume at the first rejected token
+                        const unsigned long long rej = __ballot(mark && tsum + inc > (uint32_t)TCAP);
+                        rel = (uint32_t)__ffsll(rej) - 1u;
+                        vis &= (1ull << rel) - 1ull;
+                        mark = (lane < rel) ? mark : 0u;
+                        general = false; full = true;
+                    }
                     const uint32_t rank = (uint32_t)__popcll(vis & ((1ull << lane) - 1ull));
                     if (mark) epos[ns + (int)rank] = q;
                     ns += (int)__popcll(vis);
+                    tsum += wsum;
                 }
+                if (full) { cur += rel; break; }
                 cur += rel;
                 if (!general) continue;                           // window ran out: next window
                 if (cur >= n) { why = END_; break; }
@@ -485,13 +512,13 @@ struct Lz4V4 {
                     M += 4;
                 }
                 const bool eligible = L <= (uint32_t)LCAP && M <= (uint32_t)MCAP && lit_src + L <= cend && (int32_t)lit_src >= cbase;
-                if (eligible && tslow + L + M <= (uint32_t)TSLOW && ns < 64) {
+                if (eligible && tsum + L + M <= (uint32_t)TCAP && ns < 64) {
                     if (lane == 0) epos[ns] = FLAG;
                     s_L = ((int)lane == ns) ? L : s_L;
                     s_M = ((int)lane == ns) ? M : s_M;
                     s_off = ((int)lane == ns) ? off : s_off;
                     s_src = ((int)lane == ns) ? lit_src : s_src;
-                    ns++; tslow += L + M;
+                    ns++; tsum += L + M;
                     cur = p;
                 } else if (eligible) {
                     break;                                        // batch full: emit, then this token is parsed again
@@ -506,7 +533,7 @@ struct Lz4V4 {
             if (PROF) prof[11] += (uint64_t)ns;
             if (ns) {
                 const int e = emit(ns, s_L, s_M, s_off, s_src);
-                ns = 0; tslow = 0;
+                ns = 0; tsum = 0;
                 if (e) { st = e; break; }
             }
             // ------------------------------------------------------------------ then what stopped the batch

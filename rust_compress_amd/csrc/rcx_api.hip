@@ -13,6 +13,7 @@
 #include "k_lz4_decode_v4.hip"
 #include "k_lz4_encode.hip"
 #include "k_inflate.hip"
+#include "k_inflate2.hip"
 #include "k_bwt.hip"
 #include "k_bwt_inverse.hip"
 #include "k_serial.hip"

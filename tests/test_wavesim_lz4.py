@@ -18,6 +18,14 @@ def _raws():
     raws += [b"\0" * 65536, b"ab" * 30000, bytes(range(256)) * 100,
              b"x" * 100 + bytes(rng.integers(0, 256, 3000, dtype=np.uint8)) + b"x" * 5000,
              (b"abcdefghijklmnopqrstuvwxyz0123456789" * 3 + b"Q") * 500]
+    # matches of 19..70 bytes at near and far offsets, 0-3 literals between them: the one-extension-byte vector
+    # path of the v4 decoder, its 64-byte staging slots and the per-batch output cap
+    bank = [bytes(rng.integers(0, 256, int(rng.integers(19, 71)), dtype=np.uint8)) for _ in range(300)]
+    parts = []
+    while sum(map(len, parts)) < 65536:
+        parts.append(bank[int(rng.integers(0, 300))])
+        parts.append(bytes(rng.integers(0, 256, int(rng.integers(0, 4)), dtype=np.uint8)))
+    raws.append(b"".join(parts)[:65536])
     return raws
 
 

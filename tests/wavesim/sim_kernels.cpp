@@ -7,6 +7,7 @@
 #define hipLaunchKernelGGL(kern, grid, block, shm, stream, ...) ws::launch(grid, block, [&] { kern(__VA_ARGS__); })
 #include "../../rust_compress_amd/csrc/k_serial.hip"
 #include "../../rust_compress_amd/csrc/k_inflate.hip"
+#include "../../rust_compress_amd/csrc/k_inflate2.hip"
 #define hipSuccess 0
 #define hipMemcpyDeviceToHost 0
 static inline int hipMemcpyAsync(void* d, const void* s, size_t n, int, int) { memcpy(d, s, n); return 0; }

@@ -207,6 +207,7 @@ static inline int __ffsll(unsigned long long x) { return x ? __builtin_ctzll(x) 
 static inline int __ffs(unsigned x) { return x ? __builtin_ctz(x) + 1 : 0; }
 static inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
 static inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
+static inline unsigned __brev(unsigned x) { unsigned r = 0; for (int i = 0; i < 32; i++) if (x & (1u << i)) r |= 1u << (31 - i); return r; }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline unsigned __byte_perm_(unsigned a, unsigned b, unsigned s) { (void)a; (void)b; (void)s; return 0; }
 
