@@ -13,12 +13,13 @@ dev = torch.device("cuda", 0)
 ctx = R.Context(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 dec, raw, cb, ob = bench.make_workload(R, ctx, torch, dev, kind, 4096, 0x4C5A3401)
 ctx.set_variant(N.LZ4_DECODE, 9)
-sc = torch.zeros(4096 * 12 * 8 + 64, dtype=torch.uint8, device=dev)
+sc = torch.zeros(4096 * 16 * 8 + 64, dtype=torch.uint8, device=dev)
 ctx.launch_dev(N.LZ4_DECODE, dec, sc); torch.cuda.synchronize()
 ctx.launch_dev(N.LZ4_DECODE, dec, sc); torch.cuda.synchronize()
-p = sc[: 4096 * 96].view(torch.int64).view(4096, 12).cpu().numpy().astype(np.float64)
+p = sc[: 4096 * 128].view(torch.int64).view(4096, 16).cpu().numpy().astype(np.float64)
 names = ["parse", "make_room", "head+scan+valid", "far+literals", "dep masks", "copy rounds", "flush", "stage", "solo", "wide", "#batches", "#entries"]
 tot = p[:, :10].sum(axis=1).mean()
 print("kind", kind, "mean cycles/block (sum of phases)", int(tot), "batches/block", p[:, 10].mean(), "entries/batch", p[:, 11].mean() / max(p[:, 10].mean(), 1))
 for i in range(10):
     print("%-18s %10.0f cycles/block  %5.1f%%" % (names[i], p[:, i].mean(), 100 * p[:, i].mean() / tot))
+print("copy iterations/batch %.2f   parse windows/batch %.2f" % (p[:, 12].mean() / p[:, 10].mean(), p[:, 13].mean() / p[:, 10].mean()))

@@ -17,6 +17,12 @@
 //   * the window slides lazily (only when the next batch would not fit), which also lengthens the history.
 #include "rcx_dev.h"
 
+#ifndef RCX_INV_BALLOT
+#define RCX_INV_BALLOT(m) __builtin_amdgcn_inverse_ballot_w64(m)      // uniform 64-bit mask -> per-lane predicate, no VALU
+#endif
+#ifndef RCX_ALIGNBYTE
+#define RCX_ALIGNBYTE(hi, lo, sh) __builtin_amdgcn_alignbyte((hi), (lo), (sh))   // ({hi,lo} >> 8*sh) & 0xffffffff
+#endif
 #ifndef RCX_U
 #define RCX_U(x) ((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x)))
 #endif
@@ -27,29 +33,34 @@
 
 template <int CB, bool PROF = false>
 struct Lz4V4 {
-    uint64_t prof[12];
+    uint64_t prof[16];
     static constexpr int H = 2048;                 // history kept when the window slides
     static constexpr int LCAP = 32, MCAP = 64;     // per-lane caps of a batched sequence
     static constexpr int WINMAX = 22 * (14 + MCAP);// most output one 64-byte token window can add (22 tokens)
     static constexpr int TCAP = 2560;              // output bytes per batch
     static constexpr int SOLO = 1024;              // wave-cooperative in-window copy up to this many bytes
     static constexpr int LIN = H + 16 + TCAP;
-    static constexpr int TRASH = LIN + 64;         // 64 bytes of read slack, then 64 trash bytes
-    static constexpr int STAGE = TRASH + 64;       // 64 lanes x MCAP bytes of old-match staging
+    static constexpr int STAGE = LIN + 64;         // 64 bytes of read slack, then 64 lanes x MCAP bytes of old-match staging
     static constexpr int WBUF = STAGE + 64 * MCAP;
     static constexpr int RH = 128;
     static constexpr int MARGIN = LCAP + 16;
     static constexpr uint32_t FLAG = 0x80000000u;
-    static_assert(SOLO <= TCAP && (CB % 1024) == 0 && (STAGE % 16) == 0, "geometry");
+    static_assert(SOLO <= TCAP && (CB % 1024) == 0 && RH >= 2 * MCAP && (STAGE % 16) == 0, "geometry");
 
     const uint8_t* in; uint8_t* out; uint32_t n, cap;
-    uint8_t* cbuf; uint8_t* wb_;          // wb_: [lin | slack | trash | staging]
+    uint8_t* cbuf; uint8_t* wb_;          // wb_: [lin | slack | staging]
     uint32_t* epos;                        // token positions of the batch (LDS, 64 entries)
     int32_t cbase; uint32_t cend;
     int32_t lbase;
     uint32_t oend, gflush, rlo, omis;
     unsigned lane;
 
+    // 4 bytes at any LDS address as two aligned dword reads + v_alignbyte (an unaligned ds_read costs ~24 cycles)
+    static __device__ __forceinline__ uint32_t lds_load4u(const uint8_t* p)
+    {
+        const uint32_t* q = (const uint32_t*)((uintptr_t)p & ~(uintptr_t)3);
+        return RCX_ALIGNBYTE(q[1], q[0], (uint32_t)(uintptr_t)p & 3u);
+    }
     __device__ __forceinline__ int32_t lbase_for(uint32_t pos) const
     {
         return (((int32_t)pos - H + (int32_t)omis) & ~15) - (int32_t)omis;
@@ -235,39 +246,6 @@ struct Lz4V4 {
         return lo;
     }
 
-    // 32 bytes per lane from wb_[sb ...] (period `per`: index wraps to 0 at `per`) into wb_[db ...], for
-    // lanes in `on`, only the first M bytes are stored.  Reads first, then writes.
-    template <bool PERIODIC>
-    __device__ __forceinline__ void copy32(bool on, uint32_t M, int32_t sb, int32_t db, uint32_t per)
-    {
-        const unsigned long long m8 = __ballot(on && M > 8), m16 = __ballot(on && M > 16), m24 = __ballot(on && M > 24);
-        const int32_t trash = TRASH + (int32_t)lane;
-        const int32_t rb = on ? sb : 0;
-        uint8_t v[32];
-        uint32_t r = 0;
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            if (c == 1 && !m8) break;
-            if (c == 2 && !m16) break;
-            if (c == 3 && !m24) break;
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                if (PERIODIC) { v[8 * c + u] = wb_[rb + (int32_t)r]; r = (r + 1 == per) ? 0u : r + 1; }
-                else v[8 * c + u] = wb_[rb + 8 * c + u];
-            }
-        }
-        rcx_wave_sync();
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            if (c == 1 && !m8) break;
-            if (c == 2 && !m16) break;
-            if (c == 3 && !m24) break;
-#pragma unroll
-            for (int u = 0; u < 8; u++) wb_[(on && (uint32_t)(8 * c + u) < M) ? db + 8 * c + u : trash] = v[8 * c + u];
-        }
-        rcx_wave_sync();
-    }
-
     __device__ int emit(int ns, uint32_t s_L, uint32_t s_M, uint32_t s_off, uint32_t s_src)
     {
         LZ4P_T0();
@@ -281,9 +259,9 @@ struct Lz4V4 {
             else {
                 const uint32_t t = cbuf[(int32_t)e - cbase];
                 L = t >> 4; M = (t & 15u) + 4u; src = e + 1;
-                const int32_t oi = (int32_t)(src + L) - cbase;
-                off = (uint32_t)cbuf[oi] | ((uint32_t)cbuf[oi + 1] << 8);
-                if (M == 19u) M += cbuf[oi + 2];                         // one match-length extension byte (< 255, lz4.rs:112-122)
+                const uint32_t w = lds_load4u(cbuf + ((int32_t)(src + L) - cbase));   // offset lo, hi, extension byte
+                off = w & 0xffffu;
+                if (M == 19u) M += (w >> 16) & 0xffu;                    // one match-length extension byte (< 255, lz4.rs:112-122)
             }
         }
         const uint32_t len = L + M;
@@ -305,12 +283,11 @@ struct Lz4V4 {
         const uint32_t re = rlo_eff();
         const int32_t li_o = (int32_t)ostart - lbase;
         const int32_t li_m = li_o + (int32_t)L;
-        const int32_t trash = TRASH + (int32_t)lane;
         const uint32_t slo = mdst - off;
         const uint32_t shi = (slo + M < mdst) ? slo + M : mdst;
         const bool isfar = M && slo < re;                            // source drained and slid out of the window
 
-        // ---- old matches: one or two 16-byte HBM gathers per lane into the lane's staging slot
+        // ---- old matches: up to four 16-byte HBM gathers per lane into the lane's staging slot
         rcx_u32x4 f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0}, f2 = {0, 0, 0, 0}, f3 = {0, 0, 0, 0};
         const unsigned long long anyfar = __ballot(isfar);
         const bool far16 = isfar && (uint64_t)slo + (uint32_t)MCAP <= (uint64_t)cap;
@@ -324,26 +301,18 @@ struct Lz4V4 {
             }
         }
 
-        // ---- literals: compressed window -> output window (4 bytes, then 8 per step; reads before writes)
+        // ---- literals: compressed window -> output window, 16 bytes per step (exec-narrowing byte stores)
         {
             const int32_t sb = (int32_t)src - cbase;
-            if (__ballot(L != 0)) {
-                uint8_t v[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) v[u] = cbuf[sb + u];
-#pragma unroll
-                for (int u = 0; u < 4; u++) wb_[((uint32_t)u < L) ? li_o + u : trash] = v[u];
-                for (uint32_t i0 = 4; __ballot(i0 < L); i0 += 8) {
-                    const int32_t rb = i0 < L ? sb + (int32_t)i0 : 0;
-                    uint8_t x[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) x[u] = cbuf[rb + u];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) wb_[(i0 + u < L) ? li_o + (int32_t)i0 + u : trash] = x[u];
-                }
+            for (uint32_t i0 = 0; __ballot(i0 < L); i0 += 16) {
+                const bool on = i0 < L;
+                const int32_t rb = on ? sb + (int32_t)i0 : 0;
+                const uint64_t x0 = *(const rcx_u64_u*)(cbuf + rb), x1 = *(const rcx_u64_u*)(cbuf + rb + 8);
+                const uint32_t nv = on ? (L - i0 < 16u ? L - i0 : 16u) : 0u;
+                RCX_LDS_STORE16(wb_ + li_o + (int32_t)i0, (uint32_t)x0, (uint32_t)(x0 >> 32), (uint32_t)x1, (uint32_t)(x1 >> 32), nv);
             }
         }
-        if (anyfar) {
+        if (anyfar) {                                                // gathered bytes -> the lane's staging slot
             uint8_t* sl = wb_ + STAGE + MCAP * (int32_t)lane;
             if (far16) {
                 *(rcx_u32x4*)(sl) = f0; *(rcx_u32x4*)(sl + 16) = f1;
@@ -369,35 +338,37 @@ struct Lz4V4 {
             }
             LZ4P_ADD(4);
             const int32_t sbase = isfar ? STAGE + MCAP * (int32_t)lane : (int32_t)slo - lbase;
-            const bool ovl = M && !isfar && off < M;
-            // 8 bytes per ready lane per iteration: "the next 8 bytes of a long match" and "the next dependency
-            // level" share iterations, so an iteration is 8 LDS reads + 8 LDS writes whatever the mix.
+            // A chunk of 16 bytes only needs its source to be 16 bytes behind: matches with off >= 16 ride the
+            // plain path even when they overlap themselves; off < 16 reads a periodic source 8 bytes at a time.
+            const bool ovl = M && !isfar && off < 16u && off < M;
             bool pending = M != 0;
             uint32_t prog = 0, r = 0;
             for (;;) {
                 const unsigned long long pm = __ballot(pending);
                 if (!pm) break;
+                if (PROF) prof[12] += 1;
                 const bool ready = pending && (pm & dep) == 0;
                 const bool rn = ready && !ovl;
-                uint8_t v[8];
-                bool did;
+                uint32_t v0, v1, v2 = 0, v3 = 0, nv;
                 if (__ballot(rn)) {
                     const int32_t rb = rn ? sbase + (int32_t)prog : 0;
-#pragma unroll
-                    for (int u = 0; u < 8; u++) v[u] = wb_[rb + u];
-                    did = rn;
-                } else {                                   // self-overlapping matches: periodic source, batched up
+                    const uint64_t x0 = *(const rcx_u64_u*)(wb_ + rb), x1 = *(const rcx_u64_u*)(wb_ + rb + 8);
+                    v0 = (uint32_t)x0; v1 = (uint32_t)(x0 >> 32); v2 = (uint32_t)x1; v3 = (uint32_t)(x1 >> 32);
+                    nv = rn ? (M - prog < 16u ? M - prog : 16u) : 0u;
+                } else {                                   // self-overlapping short-period matches, batched up
                     const bool ro = ready && ovl;
+                    uint32_t b[8];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) { v[u] = wb_[ro ? sbase + (int32_t)r : 0]; r = !ro ? r : (r + 1 == off) ? 0u : r + 1; }
-                    did = ro;
+                    for (int u = 0; u < 8; u++) { b[u] = wb_[ro ? sbase + (int32_t)r : 0]; r = !ro ? r : (r + 1 == off) ? 0u : r + 1; }
+                    v0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+                    v1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+                    nv = ro ? (M - prog < 8u ? M - prog : 8u) : 0u;
                 }
                 rcx_wave_sync();
-                const int32_t db = li_m + (int32_t)prog;
-#pragma unroll
-                for (int u = 0; u < 8; u++) wb_[(did && prog + u < M) ? db + u : trash] = v[u];
+                RCX_LDS_STORE16(wb_ + li_m + (int32_t)prog, v0, v1, v2, v3, nv);
                 rcx_wave_sync();
-                if (did) { prog += 8; if (prog >= M) pending = false; }
+                prog += nv;
+                pending = pending && prog < M;
             }
         }
         LZ4P_ADD(5);
@@ -422,7 +393,7 @@ struct Lz4V4 {
         int ns = 0;
         uint32_t tsum = 0;
         enum { GO = 0, STAGE_ = 1, SOLO_ = 2, WIDE_ = 3, END_ = 4, ERR_ = 5 };
-        if (PROF) for (int i = 0; i < 12; i++) prof[i] = 0;
+        if (PROF) for (int i = 0; i < 16; i++) prof[i] = 0;
         for (;;) {
             LZ4P_T0();
             // ------------------------------------------------------------------ collect a batch
@@ -433,7 +404,7 @@ struct Lz4V4 {
                 cur = RCX_U(cur); ns = (int)RCX_U(ns); tsum = RCX_U(tsum);
                 if (cur >= n) { why = END_; break; }
                 if (cend < n && cur + (uint32_t)MARGIN > cend) { why = STAGE_; break; }
-                if (ns > 42) break;                               // a window may add up to 22 entries
+                if (ns >= 64) break;
                 // register window: hop distance of the candidate token at cur+lane (128 = general path) and the
                 // output bytes it produces.  A match-length nibble of 15 followed by ONE extension byte that keeps
                 // the match within MCAP stays on the vector path (second, dependent LDS read).
@@ -450,24 +421,27 @@ struct Lz4V4 {
                     dv = ok ? (ext ? 4u : 3u) + L : 128u;
                     lenv = L + M + 4u + (ext ? x : 0u);
                 }
-                uint32_t rel = 0, mark = 0;
-                RCX_HOP_WALK(dv, lane, rel, mark);                // the serial token chain
+                uint32_t rel = 0;
+                uint64_t vis = 0;
+                RCX_HOP_WALK(dv, rel, vis);                       // the serial token chain
+                if (PROF) prof[13] += 1;
                 bool general = rel >= 128;                        // stopped at a token that needs the general path
-                if (general) { rel -= 128; mark = (lane == rel) ? 0u : mark; }
-                // compaction: a marked lane p is a token start -> epos[ns + rank]; the batch's output is capped
-                unsigned long long vis = __ballot(mark != 0);
+                if (general) { rel -= 128; vis &= ~(1ull << rel); }
+                // compaction: a visited position p is a token start -> epos[ns + rank]; the batch's output is capped
+                bool mark = RCX_INV_BALLOT(vis);
                 bool full = false;
                 if (vis) {
                     const uint32_t inc = rcx_wave_incl_scan(mark ? lenv : 0u);
                     const uint32_t wsum = RCX_U(__builtin_amdgcn_readlane(inc, 63));
-                    if (tsum + wsum > (uint32_t)TCAP) {           // keep the prefix that fits, emit, resume at the first rejected token
-                        const unsigned long long rej = __ballot(mark && tsum + inc > (uint32_t)TCAP);
+                    uint32_t rank = (uint32_t)__popcll(vis & ((1ull << lane) - 1ull));
+                    if (tsum + wsum > (uint32_t)TCAP || ns + (int)__popcll(vis) > 64) {
+                        // keep the prefix that fits (64 entries, TCAP bytes), emit, resume at the first rejected token
+                        const unsigned long long rej = __ballot(mark && (tsum + inc > (uint32_t)TCAP || ns + (int)rank >= 64));
                         rel = (uint32_t)__ffsll(rej) - 1u;
                         vis &= (1ull << rel) - 1ull;
-                        mark = (lane < rel) ? mark : 0u;
+                        mark = mark && lane < rel;
                         general = false; full = true;
                     }
-                    const uint32_t rank = (uint32_t)__popcll(vis & ((1ull << lane) - 1ull));
                     if (mark) epos[ns + (int)rank] = q;
                     ns += (int)__popcll(vis);
                     tsum += wsum;
@@ -597,6 +571,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_lz4_decode_v4(rcx_kargs a)
         a.status[b] = st;
         a.out_len[b] = olen;
         if (a.in_used) a.in_used[b] = s.n;
-        if (PROF && a.scratch) for (int i = 0; i < 12; i++) ((uint64_t*)a.scratch)[(size_t)b * 12 + i] = s.prof[i];
+        if (PROF && a.scratch) for (int i = 0; i < 16; i++) ((uint64_t*)a.scratch)[(size_t)b * 16 + i] = s.prof[i];
     }
 }

@@ -26,6 +26,7 @@ struct rcx_kargs {
 // 16-byte vector; the _u flavour may sit at any byte address (global memory only: unaligned DS is slow)
 typedef unsigned int rcx_u32x4 __attribute__((vector_size(16)));
 typedef rcx_u32x4 __attribute__((aligned(1))) rcx_u32x4_u;
+typedef uint64_t __attribute__((aligned(1))) rcx_u64_u;
 
 __device__ __forceinline__ unsigned rcx_lane() { return threadIdx.x & 63u; }
 
@@ -62,23 +63,23 @@ __device__ __forceinline__ uint32_t rcx_wave_sum(uint32_t v)
 
 // LZ4 token walk over one 64-position register window.  dv: lane p holds the hop distance of the candidate
 // token at window position p, or 128 if that token needs the general path.  Starting at `rel`, follows the
-// chain while it stays inside the window and sets mark = 1 in the lane of every token start visited.
-// On return rel >= 128 means: stopped at a general-path token at window position rel-128 (its lane is
-// marked too); otherwise 64 <= rel < 128 is where the chain left the window.
-// Hand-scheduled because the CU's single scalar unit is the bottleneck of the parse (rocprof + phase timers:
-// hipcc's loop cost 11 SALU per hop, ~168 cycles with 16 waves per CU): 3 SALU + 3 VALU per hop, no taken
-// branch for 4 hops.  SALU reads of a VALU-written SGPR interlock in hardware; the lane select is SALU-written.
+// chain while it stays inside the window and sets bit p of `vis` for every token start p visited.
+// On return rel >= 128 means: stopped at a general-path token at window position rel-128 (its bit is set
+// too); otherwise 64 <= rel < 128 is where the chain left the window.
+// Hand-scheduled: the decoder is VALU-issue bound on MI355X (rocprof: SQ_ACTIVE_INST_VALU ~84 % of SIMD time
+// with 4 waves per SIMD), so the visited set is kept in an SGPR pair (s_bitset1_b64) and the only vector
+// instruction per hop is the v_readlane of the hop distance; the position is biased by -64 so that the s_add's
+// carry is the window-exit test: 1 VALU + 3 SALU per hop, no taken branch for 4 hops.  SALU reads of a VALU-written SGPR interlock in hardware; the lane select is SALU-written.
 // The wave simulator supplies a portable version through this hook.
 #ifndef RCX_HOP_WALK
-__device__ __forceinline__ void rcx_hop_walk(uint32_t dv, uint32_t lanev, uint32_t& rel, uint32_t& mark)
+__device__ __forceinline__ void rcx_hop_walk(uint32_t dv, uint32_t& rel, uint64_t& vis)
 {
     uint32_t d;
+    rel -= 64u;                      // biased so that leaving the window is the carry of the s_add (no s_cmp)
 #define RCX_HOP1                                              \
         "v_readlane_b32 %[d], %[dv], %[rel]\n\t"              \
-        "v_cmp_eq_u32_e32 vcc, %[rel], %[lanev]\n\t"          \
-        "v_cndmask_b32_e64 %[mark], %[mark], 1, vcc\n\t"      \
-        "s_add_u32 %[rel], %[rel], %[d]\n\t"                  \
-        "s_cmp_gt_u32 %[rel], 63\n\t"
+        "s_bitset1_b64 %[vis], %[rel]\n\t"                    \
+        "s_add_u32 %[rel], %[rel], %[d]\n\t"
     asm volatile(
         "L_hop_%=:\n\t"
         RCX_HOP1 "s_cbranch_scc1 L_done_%=\n\t"
@@ -86,12 +87,48 @@ __device__ __forceinline__ void rcx_hop_walk(uint32_t dv, uint32_t lanev, uint32
         RCX_HOP1 "s_cbranch_scc1 L_done_%=\n\t"
         RCX_HOP1 "s_cbranch_scc0 L_hop_%=\n\t"
         "L_done_%=:\n\t"
-        : [d] "=&s"(d), [rel] "+s"(rel), [mark] "+v"(mark)
-        : [dv] "v"(dv), [lanev] "v"(lanev)
-        : "scc", "vcc");
+        : [d] "=&s"(d), [rel] "+s"(rel), [vis] "+s"(vis)
+        : [dv] "v"(dv)
+        : "scc");
+    rel += 64u;
 #undef RCX_HOP1
 }
 #define RCX_HOP_WALK rcx_hop_walk
+#endif
+
+// Store the low `nv` (0..16, per lane) bytes of the 128-bit value {v0,v1,v2,v3} at LDS pointer p.
+// EXEC is narrowed byte by byte (v_cmpx) and the byte index rides in the DS offset field, so a byte costs one
+// VALU compare + one ds_write_b8 (plus a shift for odd bytes) and the sequence ends at the first multiple of
+// four that no lane reaches.  Byte stores because gfx950 serialises unaligned wider LDS accesses (measured:
+// ~24 cycles per unaligned ds_write_b16/b32/b64 against 2-3 per ds_write_b8, benchmarks/micro/lds_cost.hip).
+#ifndef RCX_LDS_STORE16
+__device__ __forceinline__ void rcx_lds_store16(uint8_t* p, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t nv)
+{
+    const uint32_t a = (uint32_t)(uintptr_t)p;       // low half of a generic LDS pointer = the LDS byte address
+    uint32_t t; uint64_t sv;
+#define RCX_ST4(V, O0, O1, O2, O3)                                        \
+        "v_cmpx_lt_u32_e32 vcc, " #O0 ", %[nv]\n\t"                       \
+        "s_cbranch_execz L_end_%=\n\t"                                    \
+        "ds_write_b8 %[a], %[" V "] offset:" #O0 "\n\t"                    \
+        "v_cmpx_lt_u32_e32 vcc, " #O1 ", %[nv]\n\t"                       \
+        "v_lshrrev_b32_e32 %[t], 8, %[" V "]\n\t"                         \
+        "ds_write_b8 %[a], %[t] offset:" #O1 "\n\t"                       \
+        "v_cmpx_lt_u32_e32 vcc, " #O2 ", %[nv]\n\t"                       \
+        "ds_write_b8_d16_hi %[a], %[" V "] offset:" #O2 "\n\t"             \
+        "v_cmpx_lt_u32_e32 vcc, " #O3 ", %[nv]\n\t"                       \
+        "v_lshrrev_b32_e32 %[t], 24, %[" V "]\n\t"                        \
+        "ds_write_b8 %[a], %[t] offset:" #O3 "\n\t"
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        RCX_ST4("v0", 0, 1, 2, 3) RCX_ST4("v1", 4, 5, 6, 7) RCX_ST4("v2", 8, 9, 10, 11) RCX_ST4("v3", 12, 13, 14, 15)
+        "L_end_%=:\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        : [t] "=&v"(t), [sv] "=&s"(sv)
+        : [a] "v"(a), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [nv] "v"(nv)
+        : "vcc", "memory");
+#undef RCX_ST4
+}
+#define RCX_LDS_STORE16 rcx_lds_store16
 #endif
 
 // Cross-lane ordering inside one wave for traffic through LDS/global: hardware executes a wave's

@@ -227,15 +227,24 @@ static inline unsigned __byte_perm_(unsigned a, unsigned b, unsigned s) { (void)
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 // portable version of rcx_dev.h's hand-scheduled LZ4 token walk (the product uses inline gfx950 asm)
-static inline void ws_hop_walk(uint32_t dv, uint32_t lanev, uint32_t& rel, uint32_t& mark)
+static inline void ws_hop_walk(uint32_t dv, uint32_t& rel, uint64_t& vis)
 {
     for (;;) {
         const uint32_t d = (uint32_t)ws::shfl((int)dv, (int)rel);
-        if (lanev == rel) mark = 1;
+        vis |= 1ull << rel;
         rel += d;
         if (rel > 63) break;
     }
 }
+// portable version of rcx_dev.h's exec-narrowing LDS byte store
+static inline void ws_lds_store16(uint8_t* p, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t nv)
+{
+    const uint32_t v[4] = {v0, v1, v2, v3};
+    for (uint32_t i = 0; i < nv && i < 16; i++) p[i] = (uint8_t)(v[i >> 2] >> (8 * (i & 3)));
+}
+#define RCX_LDS_STORE16 ws_lds_store16
+#define RCX_ALIGNBYTE(hi, lo, sh) ((uint32_t)(((((uint64_t)(hi)) << 32) | (uint32_t)(lo)) >> (8 * ((sh) & 3u))))
+#define RCX_INV_BALLOT(m) ((((m) >> (threadIdx.x & 63u)) & 1ull) != 0)
 #define RCX_HOP_WALK ws_hop_walk
 #define __builtin_readcyclecounter() 0ull
 #define __threadfence() ((void)0)
