@@ -43,6 +43,7 @@ struct Lz4V4 {
     static constexpr int STAGE = LIN + 64;         // 64 bytes of read slack, then 64 lanes x MCAP bytes of old-match staging
     static constexpr int WBUF = STAGE + 64 * MCAP;
     static constexpr int RH = 128;
+    static constexpr int RR = 2;                   // redirection rounds (pointer doubling) before the copy rounds
     static constexpr int MARGIN = LCAP + 16;
     static constexpr uint32_t FLAG = 0x80000000u;
     static_assert(SOLO <= TCAP && (CB % 1024) == 0 && RH >= 2 * MCAP && (STAGE % 16) == 0, "geometry");
@@ -326,18 +327,38 @@ struct Lz4V4 {
 
         // ---- matches.  Producer lanes of [slo, shi) inside this batch = lanes ka..kb; copy when none is pending.
         if (__ballot(M != 0)) {
+            // Chains are the rule in text (the reference's compressor always points at the MOST RECENT occurrence,
+            // so the 5th " the " of a batch copies from the 4th, which copies from the 3rd ...): a match whose
+            // source lies wholly inside ONE earlier match of the batch is redirected to that match's own source
+            // (bytes x of match j equal bytes x - S_j), with pointer doubling: RR rounds cut 2^RR levels.
             unsigned long long dep = 0;
-            const bool inb = M && !isfar && shi > oend0;
+            bool inb = M && !isfar && shi > oend0;
+            uint32_t S = off;                                         // current shift: the source is [mdst - S, +M)
             if (__ballot(inb)) {
-                const uint32_t ka = lane_of(ostart, slo > oend0 ? slo : oend0);
-                const uint32_t kb = lane_of(ostart, shi > oend0 ? shi - 1 : oend0);
+                uint32_t ka = lane_of(ostart, slo > oend0 ? slo : oend0);
+                uint32_t kb = lane_of(ostart, shi > oend0 ? shi - 1 : oend0);
+                // producer usable for redirection: its match is in the window and does not overlap itself
+                const uint32_t pmd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ka << 2), (int)((isfar || off < M) ? 0xffffffffu : mdst));
+                uint32_t prod = (inb && ka == kb && slo >= pmd && off >= M) ? ka : 64u;
+#pragma unroll
+                for (int rr = 0; rr < RR; rr++) {
+                    if (!__ballot(prod < 64u)) break;
+                    const uint32_t j = prod < 64u ? prod : lane;
+                    const uint32_t Sj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)S);
+                    const uint32_t pk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)(prod | (ka << 7) | (kb << 13) | ((uint32_t)inb << 19)));
+                    if (prod < 64u) {
+                        if (mdst - S - Sj >= re && S + Sj <= mdst) {
+                            S += Sj; prod = pk & 127u; ka = (pk >> 7) & 63u; kb = (pk >> 13) & 63u; inb = (pk >> 19) & 1u;
+                        } else prod = 64u;                            // would leave the window: wait for the producer instead
+                    }
+                }
                 if (inb) {
                     const unsigned long long upto = (kb >= 63) ? ~0ull : ((2ull << kb) - 1ull);
                     dep = upto & ~((1ull << ka) - 1ull) & ((1ull << lane) - 1ull);
                 }
             }
             LZ4P_ADD(4);
-            const int32_t sbase = isfar ? STAGE + MCAP * (int32_t)lane : (int32_t)slo - lbase;
+            const int32_t sbase = isfar ? STAGE + MCAP * (int32_t)lane : (int32_t)(mdst - S) - lbase;
             // A chunk of 16 bytes only needs its source to be 16 bytes behind: matches with off >= 16 ride the
             // plain path even when they overlap themselves; off < 16 reads a periodic source 8 bytes at a time.
             const bool ovl = M && !isfar && off < 16u && off < M;
