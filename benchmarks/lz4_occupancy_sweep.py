@@ -15,7 +15,7 @@ ctx = R.Context(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 names = ["parse", "room", "head", "far+lit", "dep", "copy", "flush", "stage", "solo", "wide"]
 for nb in (256, 1024, 2048, 4096, 8192, 16384):
     dec, raw, cb, ob = bench.make_workload(R, ctx, torch, dev, kind, nb, 0x4C5A3401)
-    for variant in (0, 9):
+    for variant in (0, 10):
         ctx.set_variant(N.LZ4_DECODE, variant)
         sc = torch.zeros(nb * 16 * 8 + 64, dtype=torch.uint8, device=dev)
         for _ in range(2):
@@ -28,7 +28,7 @@ for nb in (256, 1024, 2048, 4096, 8192, 16384):
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
         line = "blocks %6d variant %d  %.3f ms  %.1f GiB/s" % (nb, variant, ms, nb * 65536 / ms / 1e-3 / 2**30)
-        if variant == 9:
+        if variant == 99:
             p = sc[: nb * 128].view(torch.int64).view(nb, 16).cpu().numpy().astype(np.float64)
             tot = p[:, :10].sum(axis=1).mean()
             line += "  cyc/block %.0fK: " % (tot / 1e3) + " ".join("%s %.0fK" % (names[i], p[:, i].mean() / 1e3) for i in range(10))

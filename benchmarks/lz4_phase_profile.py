@@ -23,3 +23,4 @@ print("kind", kind, "mean cycles/block (sum of phases)", int(tot), "batches/bloc
 for i in range(10):
     print("%-18s %10.0f cycles/block  %5.1f%%" % (names[i], p[:, i].mean(), 100 * p[:, i].mean() / tot))
 print("copy iterations/batch %.2f   parse windows/batch %.2f" % (p[:, 12].mean() / p[:, 10].mean(), p[:, 13].mean() / p[:, 10].mean()))
+print("parse split: window setup %.0f  walk %.0f  (cycles/block)" % (p[:, 14].mean(), p[:, 15].mean()))

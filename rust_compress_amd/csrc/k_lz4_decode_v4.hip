@@ -400,166 +400,186 @@ struct Lz4V4 {
         return 0;
     }
 
-    __device__ void run(int32_t* st_out, uint32_t* len_out)
-    {
-        lane = rcx_lane();
-        omis = (uint32_t)((uintptr_t)out & 15u);
-        oend = 0; gflush = 0; rlo = 0;
-        lbase = (int32_t)RCX_U(lbase_for(0));
-        int st = RCX_OK;
-        uint32_t cur = 0;
-        if (n) stage(0); else { cbase = 0; cend = 0; }
+    // What stopped a batch, and the one long sequence that goes with SOLO_/WIDE_ (or the error with ERR_).
+    enum { GO = 0, STAGE_ = 1, SOLO_ = 2, WIDE_ = 3, END_ = 4, ERR_ = 5 };
+    struct Batch { int ns, why, perr; uint32_t gL, gM, goff, gsrc, gnext; };
 
-        uint32_t s_L = 0, s_M = 0, s_off = 0, s_src = 0;      // fields of general-path entries (per lane)
+    // Parse side: walk tokens from `cur`, filling epos[0..ns) (and the s_* fields of general-path entries).
+    __device__ __forceinline__ Batch collect(uint32_t& cur, uint32_t& s_L, uint32_t& s_M, uint32_t& s_off, uint32_t& s_src)
+    {
         int ns = 0;
         uint32_t tsum = 0;
-        enum { GO = 0, STAGE_ = 1, SOLO_ = 2, WIDE_ = 3, END_ = 4, ERR_ = 5 };
-        if (PROF) for (int i = 0; i < 16; i++) prof[i] = 0;
-        for (;;) {
-            LZ4P_T0();
-            // ------------------------------------------------------------------ collect a batch
-            int why = GO;
-            int perr = 0;
-            uint32_t gL = 0, gM = 0, goff = 0, gsrc = 0, gnext = 0;
-            while (why == GO) {
-                cur = RCX_U(cur); ns = (int)RCX_U(ns); tsum = RCX_U(tsum);
-                if (cur >= n) { why = END_; break; }
-                if (cend < n && cur + (uint32_t)MARGIN > cend) { why = STAGE_; break; }
-                if (ns >= 64) break;
-                // register window: hop distance of the candidate token at cur+lane (128 = general path) and the
-                // output bytes it produces.  A match-length nibble of 15 followed by ONE extension byte that keeps
-                // the match within MCAP stays on the vector path (second, dependent LDS read).
-                const uint32_t q = cur + lane;
-                const uint32_t fast_lim = cend >= 20 ? cend - 20 : 0;
-                uint32_t dv = 128, lenv = 0;
-                if (q < fast_lim) {
-                    const int32_t qi = (int32_t)q - cbase;
-                    const uint32_t t = cbuf[qi];
-                    const uint32_t L = t >> 4, M = t & 15u;
-                    const uint32_t x = cbuf[qi + 3 + (int32_t)L];
-                    const bool ext = M == 15u;
-                    const bool ok = L != 15u && (!ext || x <= (uint32_t)(MCAP - 19));
-                    dv = ok ? (ext ? 4u : 3u) + L : 128u;
-                    lenv = L + M + 4u + (ext ? x : 0u);
+        int why = GO;
+        int perr = 0;
+        uint32_t gL = 0, gM = 0, goff = 0, gsrc = 0, gnext = 0;
+        while (why == GO) {
+            cur = RCX_U(cur); ns = (int)RCX_U(ns); tsum = RCX_U(tsum);
+            if (cur >= n) { why = END_; break; }
+            if (cend < n && cur + (uint32_t)MARGIN > cend) { why = STAGE_; break; }
+            if (ns >= 64) break;
+            // register window: hop distance of the candidate token at cur+lane (128 = general path) and the
+            // output bytes it produces.  A match-length nibble of 15 followed by ONE extension byte that keeps
+            // the match within MCAP stays on the vector path (second, dependent LDS read).
+            uint64_t tw0_ = PROF ? (uint64_t)__builtin_readcyclecounter() : 0;
+            const uint32_t q = cur + lane;
+            const uint32_t fast_lim = cend >= 20 ? cend - 20 : 0;
+            uint32_t dv = 128, lenv = 0;
+            if (q < fast_lim) {
+                const int32_t qi = (int32_t)q - cbase;
+                const uint32_t t = cbuf[qi];
+                const uint32_t L = t >> 4, M = t & 15u;
+                const uint32_t x = cbuf[qi + 3 + (int32_t)L];
+                const bool ext = M == 15u;
+                const bool ok = L != 15u && (!ext || x <= (uint32_t)(MCAP - 19));
+                dv = ok ? (ext ? 4u : 3u) + L : 128u;
+                lenv = L + M + 4u + (ext ? x : 0u);
+            }
+            uint32_t rel = 0;
+            uint64_t vis = 0;
+            if (PROF) { dv = RCX_U(dv) * 0u + dv; const uint64_t t = (uint64_t)__builtin_readcyclecounter(); prof[14] += t - tw0_; tw0_ = t; }
+            RCX_HOP_WALK(dv, rel, vis);                       // the serial token chain
+            if (PROF) { const uint64_t t = (uint64_t)__builtin_readcyclecounter(); prof[15] += t - tw0_; }
+            if (PROF) prof[13] += 1;
+            bool general = rel >= 128;                        // stopped at a token that needs the general path
+            if (general) { rel -= 128; vis &= ~(1ull << rel); }
+            // compaction: a visited position p is a token start -> epos[ns + rank]; the batch's output is capped
+            bool mark = RCX_INV_BALLOT(vis);
+            bool full = false;
+            if (vis) {
+                const uint32_t inc = rcx_wave_incl_scan(mark ? lenv : 0u);
+                const uint32_t wsum = RCX_U(__builtin_amdgcn_readlane(inc, 63));
+                uint32_t rank = (uint32_t)__popcll(vis & ((1ull << lane) - 1ull));
+                if (tsum + wsum > (uint32_t)TCAP || ns + (int)__popcll(vis) > 64) {
+                    // keep the prefix that fits (64 entries, TCAP bytes), emit, resume at the first rejected token
+                    const unsigned long long rej = __ballot(mark && (tsum + inc > (uint32_t)TCAP || ns + (int)rank >= 64));
+                    rel = (uint32_t)__ffsll(rej) - 1u;
+                    vis &= (1ull << rel) - 1ull;
+                    mark = mark && lane < rel;
+                    general = false; full = true;
                 }
-                uint32_t rel = 0;
-                uint64_t vis = 0;
-                RCX_HOP_WALK(dv, rel, vis);                       // the serial token chain
-                if (PROF) prof[13] += 1;
-                bool general = rel >= 128;                        // stopped at a token that needs the general path
-                if (general) { rel -= 128; vis &= ~(1ull << rel); }
-                // compaction: a visited position p is a token start -> epos[ns + rank]; the batch's output is capped
-                bool mark = RCX_INV_BALLOT(vis);
-                bool full = false;
-                if (vis) {
-                    const uint32_t inc = rcx_wave_incl_scan(mark ? lenv : 0u);
-                    const uint32_t wsum = RCX_U(__builtin_amdgcn_readlane(inc, 63));
-                    uint32_t rank = (uint32_t)__popcll(vis & ((1ull << lane) - 1ull));
-                    if (tsum + wsum > (uint32_t)TCAP || ns + (int)__popcll(vis) > 64) {
-                        // keep the prefix that fits (64 entries, TCAP bytes), emit, resume at the first rejected token
-                        const unsigned long long rej = __ballot(mark && (tsum + inc > (uint32_t)TCAP || ns + (int)rank >= 64));
-                        rel = (uint32_t)__ffsll(rej) - 1u;
-                        vis &= (1ull << rel) - 1ull;
-                        mark = mark && lane < rel;
-                        general = false; full = true;
-                    }
-                    if (mark) epos[ns + (int)rank] = q;
-                    ns += (int)__popcll(vis);
-                    tsum += wsum;
-                }
-                if (full) { cur += rel; break; }
-                cur += rel;
-                if (!general) continue;                           // window ran out: next window
-                if (cur >= n) { why = END_; break; }
-                if (cend < n && cur + (uint32_t)MARGIN > cend) { why = STAGE_; break; }
+                if (mark) epos[ns + (int)rank] = q;
+                ns += (int)__popcll(vis);
+                tsum += wsum;
+            }
+            if (full) { cur += rel; break; }
+            cur += rel;
+            if (!general) continue;                           // window ran out: next window
+            if (cur >= n) { why = END_; break; }
+            if (cend < n && cur + (uint32_t)MARGIN > cend) { why = STAGE_; break; }
 
-                // ---- general path for the token at `cur`
-                const uint32_t t = peek(cur);
-                uint32_t p = cur + 1;
-                uint32_t L = t >> 4;
-                if (L == 15) {
+            // ---- general path for the token at `cur`
+            const uint32_t t = peek(cur);
+            uint32_t p = cur + 1;
+            uint32_t L = t >> 4;
+            if (L == 15) {
+                for (;;) {
+                    if (p >= n) { perr = RCX_E_MALFORMED; break; }
+                    const uint32_t x = peek(p); p++;
+                    L += x;
+                    if (x != 255) break;
+                }
+                if (perr) { why = ERR_; break; }
+            }
+            const uint32_t lit_src = p;
+            if (L > n - p) { perr = RCX_E_MALFORMED; why = ERR_; break; }
+            p += L;
+            uint32_t M = 0, off = 0;
+            if (p != n) {
+                if (n - p < 2) { perr = -1; gL = L; why = ERR_; break; }     // literals copy, then the offset read panics
+                off = peek(p) | (peek(p + 1) << 8);
+                p += 2;
+                M = t & 15u;
+                if (M == 15) {
                     for (;;) {
-                        if (p >= n) { perr = RCX_E_MALFORMED; break; }
+                        if (p >= n) { perr = -1; gL = L; break; }            // same order: literal overflow first
                         const uint32_t x = peek(p); p++;
-                        L += x;
+                        M += x;
                         if (x != 255) break;
                     }
                     if (perr) { why = ERR_; break; }
                 }
-                const uint32_t lit_src = p;
-                if (L > n - p) { perr = RCX_E_MALFORMED; why = ERR_; break; }
-                p += L;
-                uint32_t M = 0, off = 0;
-                if (p != n) {
-                    if (n - p < 2) { perr = -1; gL = L; why = ERR_; break; }     // literals copy, then the offset read panics
-                    off = peek(p) | (peek(p + 1) << 8);
-                    p += 2;
-                    M = t & 15u;
-                    if (M == 15) {
-                        for (;;) {
-                            if (p >= n) { perr = -1; gL = L; break; }            // same order: literal overflow first
-                            const uint32_t x = peek(p); p++;
-                            M += x;
-                            if (x != 255) break;
-                        }
-                        if (perr) { why = ERR_; break; }
-                    }
-                    M += 4;
-                }
-                const bool eligible = L <= (uint32_t)LCAP && M <= (uint32_t)MCAP && lit_src + L <= cend && (int32_t)lit_src >= cbase;
-                if (eligible && tsum + L + M <= (uint32_t)TCAP && ns < 64) {
-                    if (lane == 0) epos[ns] = FLAG;
-                    s_L = ((int)lane == ns) ? L : s_L;
-                    s_M = ((int)lane == ns) ? M : s_M;
-                    s_off = ((int)lane == ns) ? off : s_off;
-                    s_src = ((int)lane == ns) ? lit_src : s_src;
-                    ns++; tsum += L + M;
-                    cur = p;
-                } else if (eligible) {
-                    break;                                        // batch full: emit, then this token is parsed again
-                } else {
-                    gL = L; gM = M; goff = off; gsrc = lit_src; gnext = p;
-                    why = (L + M <= (uint32_t)SOLO) ? SOLO_ : WIDE_;
-                }
+                M += 4;
             }
-            // ------------------------------------------------------------------ emit it (the one call site)
+            const bool eligible = L <= (uint32_t)LCAP && M <= (uint32_t)MCAP && lit_src + L <= cend && (int32_t)lit_src >= cbase;
+            if (eligible && tsum + L + M <= (uint32_t)TCAP && ns < 64) {
+                if (lane == 0) epos[ns] = FLAG;
+                s_L = ((int)lane == ns) ? L : s_L;
+                s_M = ((int)lane == ns) ? M : s_M;
+                s_off = ((int)lane == ns) ? off : s_off;
+                s_src = ((int)lane == ns) ? lit_src : s_src;
+                ns++; tsum += L + M;
+                cur = p;
+            } else if (eligible) {
+                break;                                        // batch full: emit, then this token is parsed again
+            } else {
+                gL = L; gM = M; goff = off; gsrc = lit_src; gnext = p;
+                why = (L + M <= (uint32_t)SOLO) ? SOLO_ : WIDE_;
+            }
+        }
+        Batch bt; bt.ns = ns; bt.why = why; bt.perr = perr; bt.gL = gL; bt.gM = gM; bt.goff = goff; bt.gsrc = gsrc; bt.gnext = gnext;
+        return bt;
+    }
+
+    // Execute side: what follows a batch.  Returns 0 to go on, 1 when the block is finished (st holds the status).
+    __device__ __forceinline__ int after_batch(const Batch& bt, int& st)
+    {
+        int why = bt.why;
+        if (why == END_) return 1;
+        if (why == ERR_) { st = bt.perr > 0 ? bt.perr : ((bt.gL > cap - oend) ? RCX_E_OUTPUT_TOO_SMALL : RCX_E_MALFORMED); return 1; }
+        if (why == SOLO_) {
+            const int e = solo(bt.gsrc, bt.gL, bt.goff, bt.gM);
+            if (e == -2) why = WIDE_;
+            else if (e) { st = e; return 1; }
+        }
+        if (why == WIDE_) {
+            flush(oend, true);
+            if (bt.gL > cap - oend) { st = RCX_E_OUTPUT_TOO_SMALL; return 1; }
+            if (bt.gL) { wide_literals(bt.gsrc, bt.gL); oend += bt.gL; }
+            if (bt.gM) {
+                if (bt.goff == 0 || bt.goff > oend) { st = RCX_E_MALFORMED; return 1; }
+                if (bt.gM > cap - oend) { st = RCX_E_OUTPUT_TOO_SMALL; return 1; }
+                rcx_wave_sync();
+                wide_match(bt.goff, bt.gM);
+                oend += bt.gM;
+            }
+            oend = RCX_U(oend);
+            gflush = oend;
+            repair();
+        }
+        return 0;
+    }
+
+    __device__ void init_window()
+    {
+        omis = (uint32_t)((uintptr_t)out & 15u);
+        oend = 0; gflush = 0; rlo = 0;
+        lbase = (int32_t)RCX_U(lbase_for(0));
+    }
+
+    __device__ void run(int32_t* st_out, uint32_t* len_out)
+    {
+        lane = rcx_lane();
+        init_window();
+        int st = RCX_OK;
+        uint32_t cur = 0;
+        if (n) stage(0); else { cbase = 0; cend = 0; }
+        uint32_t s_L = 0, s_M = 0, s_off = 0, s_src = 0;      // fields of general-path entries (per lane)
+        if (PROF) for (int i = 0; i < 16; i++) prof[i] = 0;
+        for (;;) {
+            LZ4P_T0();
+            const Batch bt = collect(cur, s_L, s_M, s_off, s_src);
             rcx_wave_sync();
             LZ4P_ADD(0);
-            if (PROF) prof[11] += (uint64_t)ns;
-            if (ns) {
-                const int e = emit(ns, s_L, s_M, s_off, s_src);
-                ns = 0; tsum = 0;
+            if (PROF) prof[11] += (uint64_t)bt.ns;
+            if (bt.ns) {
+                const int e = emit(bt.ns, s_L, s_M, s_off, s_src);
                 if (e) { st = e; break; }
             }
-            // ------------------------------------------------------------------ then what stopped the batch
             if (PROF) t0_ = (uint64_t)__builtin_readcyclecounter();
-            if (why == END_) break;
-            if (why == STAGE_) { stage(cur); LZ4P_ADD(7); continue; }
-            if (why == ERR_) { st = perr > 0 ? perr : ((gL > cap - oend) ? RCX_E_OUTPUT_TOO_SMALL : RCX_E_MALFORMED); break; }
-            if (why == SOLO_) {
-                const int e = solo(gsrc, gL, goff, gM);
-                if (e == -2) why = WIDE_;
-                else if (e) { st = e; break; }
-                else cur = gnext;
-                LZ4P_ADD(8);
-            }
-            if (why == WIDE_) {
-                flush(oend, true);
-                if (gL > cap - oend) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
-                if (gL) { wide_literals(gsrc, gL); oend += gL; }
-                if (gM) {
-                    if (goff == 0 || goff > oend) { st = RCX_E_MALFORMED; break; }
-                    if (gM > cap - oend) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
-                    rcx_wave_sync();
-                    wide_match(goff, gM);
-                    oend += gM;
-                }
-                oend = RCX_U(oend);
-                gflush = oend;
-                repair();
-                cur = gnext;
-                LZ4P_ADD(9);
-            }
+            if (bt.why == STAGE_) { stage(cur); LZ4P_ADD(7); continue; }
+            if (after_batch(bt, st)) break;
+            if (bt.why == SOLO_ || bt.why == WIDE_) cur = bt.gnext;
+            LZ4P_ADD(8);
         }
         if (!st) flush(oend, true);
         *st_out = st;

@@ -1,0 +1,277 @@
+// k_lz4_decode_v5.hip -- LZ4 block decode, two waves per block: a PARSER wave and an EXECUTOR wave in one
+// workgroup, coupled by a ring of batch descriptors in LDS (reference: BlockDecoder::decode, src/lz4.rs:67-140).
+//
+// Why: v4 (one wave per block) is latency bound, not throughput bound.  Measured on MI355X with 4096 blocks
+// (16 waves per CU): a wave waits on s_waitcnt 45 % of its life while VALU, SALU and LDS are each 50-60 % busy,
+// and the token walk (a serial SALU chain) and the copy rounds (LDS round trips) never overlap inside one wave.
+// BASELINE configs[1] offers 4096 blocks = 16 waves per CU, so the only way to more waves in flight is inside
+// a block.  The walk needs nothing from the output side, so it runs ahead in its own wave:
+//
+//   parser   (wave 0): stages the compressed bytes in LDS, walks the tokens (Lz4V4::collect, unchanged),
+//                      extracts each entry's fields and posts {literal source, L, M, offset} descriptors;
+//   executor (wave 1): scan, validation, literals (fetched from HBM/L2, the parser's staging buffer is private),
+//                      old-match gathers, dependency masks, redirection, copy rounds, flush (Lz4V4's window code).
+//
+// Both waves are always co-resident (same workgroup), so the LDS hand-off cannot deadlock: the parser only blocks
+// on a full ring, the executor only on an empty one, and an executor-side error raises `abort` for the parser.
+// LDS operations of one wave are performed in issue order, so "write data, then write head" / "read data, then
+// write tail" need no more than compiler ordering.  64 VGPRs (launch bound) keep 8 waves per SIMD = 16 blocks per CU.
+#include "rcx_dev.h"
+
+template <int CB>
+struct Lz4V5 : Lz4V4<CB, false> {
+    typedef Lz4V4<CB, false> B;
+    static constexpr int NSLOT = 3;
+    struct Slot { uint32_t hdr[16]; uint32_t desc[64][2]; };
+    struct Ring { Slot slot[NSLOT]; volatile uint32_t head, tail, abort_, pad; };
+    static constexpr int WBUF5 = B::LIN + 64;          // no staging slots: gathered bytes go straight to their place
+    Ring* ring;
+
+    // ------------------------------------------------------------------------------------------ parser wave
+    __device__ void run_parser()
+    {
+        this->lane = rcx_lane();
+        const unsigned lane = this->lane;
+        uint32_t cur = 0;
+        if (this->n) this->stage(0); else { this->cbase = 0; this->cend = 0; }
+        uint32_t s_L = 0, s_M = 0, s_off = 0, s_src = 0;
+        uint32_t head = 0;
+        for (;;) {
+            const typename B::Batch bt = this->collect(cur, s_L, s_M, s_off, s_src);
+            rcx_wave_sync();
+            // entry fields (the executor never sees the staging buffer)
+            uint32_t w0 = 0, w1 = 0;
+            if ((int)lane < bt.ns) {
+                const uint32_t e = this->epos[lane];
+                uint32_t L, M, off, src;
+                if (e & B::FLAG) { L = s_L; M = s_M; off = s_off; src = s_src; }
+                else {
+                    const uint32_t t = this->cbuf[(int32_t)e - this->cbase];
+                    L = t >> 4; M = (t & 15u) + 4u; src = e + 1;
+                    const uint32_t w = B::lds_load4u(this->cbuf + ((int32_t)(src + L) - this->cbase));
+                    off = w & 0xffffu;
+                    if (M == 19u) M += (w >> 16) & 0xffu;
+                }
+                w0 = src; w1 = L | (M << 8) | (off << 16);
+            }
+            // a free slot
+            for (;;) {
+                const uint32_t t = RCX_U(ring->tail);
+                if (RCX_U(ring->abort_)) return;
+                if (head - t < (uint32_t)NSLOT) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            rcx_wave_sync();
+            Slot* sl = &ring->slot[head % NSLOT];
+            *(uint64_t*)sl->desc[lane] = (uint64_t)w0 | ((uint64_t)w1 << 32);
+            if (lane == 0) {
+                sl->hdr[0] = (uint32_t)bt.ns; sl->hdr[1] = (uint32_t)bt.why; sl->hdr[2] = (uint32_t)bt.perr;
+                sl->hdr[3] = bt.gL; sl->hdr[4] = bt.gM; sl->hdr[5] = bt.goff; sl->hdr[6] = bt.gsrc;
+            }
+            rcx_wave_sync();
+            head++;
+            if (lane == 0) ring->head = head;
+            if (bt.why == B::END_ || bt.why == B::ERR_) return;
+            if (bt.why == B::STAGE_) { this->stage(cur); continue; }
+            if (bt.why == B::SOLO_ || bt.why == B::WIDE_) cur = bt.gnext;
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------ executor wave
+    // One batch: lane i holds entry i's descriptor (w0 = literal source position, w1 = L | M << 8 | offset << 16).
+    __device__ int emit5(int ns, uint32_t w0, uint32_t w1)
+    {
+        const unsigned lane = this->lane;
+        const uint8_t* in = this->in; uint8_t* out = this->out; uint8_t* wb_ = this->wb_;
+        const uint32_t cap = this->cap, n = this->n;
+        this->make_room(B::TCAP);
+        const uint32_t L = w1 & 0xffu, M = (w1 >> 8) & 0xffu, off = w1 >> 16, src = w0;
+        const bool act = (int)lane < ns;
+        const uint32_t len = L + M;
+        const uint32_t incl = rcx_wave_incl_scan(len);
+        const uint32_t T = RCX_U(__builtin_amdgcn_readlane(incl, 63));
+        const uint32_t oend0 = this->oend;
+        const uint32_t ostart = oend0 + incl - len;
+        const uint32_t mdst = ostart + L;
+        int err = 0;
+        if (act) {
+            if (L > cap - ostart || ostart > cap) err = RCX_E_OUTPUT_TOO_SMALL;
+            else if (M && (off == 0 || off > mdst)) err = RCX_E_MALFORMED;
+            else if (M && M > cap - mdst) err = RCX_E_OUTPUT_TOO_SMALL;
+        }
+        const unsigned long long bad = __ballot(err != 0);
+        if (bad) return __builtin_amdgcn_readlane(err, __ffsll(bad) - 1);
+
+        const int32_t lbase = this->lbase;
+        const uint32_t re = this->rlo_eff();
+        const int32_t li_o = (int32_t)ostart - lbase;
+        const int32_t li_m = li_o + (int32_t)L;
+        const uint32_t slo = mdst - off;
+        const uint32_t shi = (slo + M < mdst) ? slo + M : mdst;
+        const bool isfar = M && slo < re;                            // source drained and slid out of the window
+
+        // ---- loads first: literals (parser staged them a moment ago: L2 hits) and old matches, 16 bytes each
+        rcx_u32x4 g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0};
+        const bool lit16 = L && (uint64_t)src + 32u <= (uint64_t)n;
+        const bool litb = L && !lit16;                               // within 32 bytes of the block's end: byte loads
+        if (lit16) { g0 = *(const rcx_u32x4_u*)(in + src); if (L > 16) g1 = *(const rcx_u32x4_u*)(in + src + 16); }
+        rcx_u32x4 f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0}, f2 = {0, 0, 0, 0}, f3 = {0, 0, 0, 0};
+        const bool far16 = isfar && (uint64_t)slo + (uint32_t)B::MCAP <= (uint64_t)cap;
+        const bool farb = isfar && !far16;
+        if (far16) {
+            f0 = *(const rcx_u32x4_u*)(out + slo);
+            if (M > 16) f1 = *(const rcx_u32x4_u*)(out + slo + 16);
+            if (M > 32) f2 = *(const rcx_u32x4_u*)(out + slo + 32);
+            if (M > 48) f3 = *(const rcx_u32x4_u*)(out + slo + 48);
+        }
+
+        // ---- producer lanes of [slo, shi) inside this batch, chains redirected (see Lz4V4::emit) while the loads fly
+        unsigned long long dep = 0;
+        bool inb = M && !isfar && shi > oend0;
+        uint32_t S = off;
+        if (__ballot(inb)) {
+            uint32_t ka = this->lane_of(ostart, slo > oend0 ? slo : oend0);
+            uint32_t kb = this->lane_of(ostart, shi > oend0 ? shi - 1 : oend0);
+            const uint32_t pmd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ka << 2), (int)((isfar || off < M) ? 0xffffffffu : mdst));
+            uint32_t prod = (inb && ka == kb && slo >= pmd && off >= M) ? ka : 64u;
+#pragma unroll
+            for (int rr = 0; rr < B::RR; rr++) {
+                if (!__ballot(prod < 64u)) break;
+                const uint32_t j = prod < 64u ? prod : lane;
+                const uint32_t Sj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)S);
+                const uint32_t pk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)(prod | (ka << 7) | (kb << 13) | ((uint32_t)inb << 19)));
+                if (prod < 64u) {
+                    if (mdst - S - Sj >= re && S + Sj <= mdst) {
+                        S += Sj; prod = pk & 127u; ka = (pk >> 7) & 63u; kb = (pk >> 13) & 63u; inb = (pk >> 19) & 1u;
+                    } else prod = 64u;
+                }
+            }
+            if (inb) {
+                const unsigned long long upto = (kb >= 63) ? ~0ull : ((2ull << kb) - 1ull);
+                dep = upto & ~((1ull << ka) - 1ull) & ((1ull << lane) - 1ull);
+            }
+        }
+
+        // ---- literals, then gathered matches: registers -> their place in the window
+        if (__ballot(L != 0)) {
+            RCX_LDS_STORE16(wb_ + li_o, g0[0], g0[1], g0[2], g0[3], lit16 ? (L < 16u ? L : 16u) : 0u);
+            if (__ballot(lit16 && L > 16)) RCX_LDS_STORE16(wb_ + li_o + 16, g1[0], g1[1], g1[2], g1[3], (lit16 && L > 16u) ? L - 16u : 0u);
+            for (uint32_t i = 0; __ballot(litb && i < L); i++)
+                if (litb && i < L) wb_[li_o + (int32_t)i] = in[src + i];
+        }
+        if (__ballot(isfar)) {
+            uint8_t* d = wb_ + li_m;
+            const uint32_t mf = far16 ? M : 0u;
+            RCX_LDS_STORE16(d, f0[0], f0[1], f0[2], f0[3], mf < 16u ? mf : 16u);
+            if (__ballot(mf > 16)) RCX_LDS_STORE16(d + 16, f1[0], f1[1], f1[2], f1[3], mf > 16u ? (mf < 32u ? mf - 16u : 16u) : 0u);
+            if (__ballot(mf > 32)) RCX_LDS_STORE16(d + 32, f2[0], f2[1], f2[2], f2[3], mf > 32u ? (mf < 48u ? mf - 32u : 16u) : 0u);
+            if (__ballot(mf > 48)) RCX_LDS_STORE16(d + 48, f3[0], f3[1], f3[2], f3[3], mf > 48u ? mf - 48u : 0u);
+            for (uint32_t i = 0; __ballot(farb && i < M); i++)
+                if (farb && i < M) d[i] = out[slo + i];
+        }
+        rcx_wave_sync();
+
+        // ---- window matches: copy rounds (16 bytes per ready lane), see Lz4V4::emit
+        {
+            const int32_t sbase = (int32_t)(mdst - S) - lbase;
+            const bool ovl = M && !isfar && off < 16u && off < M;
+            bool pending = M != 0 && !isfar;
+            uint32_t prog = 0, r = 0;
+            for (;;) {
+                const unsigned long long pm = __ballot(pending);
+                if (!pm) break;
+                const bool ready = pending && (pm & dep) == 0;
+                const bool rn = ready && !ovl;
+                uint32_t v0, v1, v2 = 0, v3 = 0, nv;
+                if (__ballot(rn)) {
+                    const int32_t rb = rn ? sbase + (int32_t)prog : 0;
+                    const uint64_t x0 = *(const rcx_u64_u*)(wb_ + rb), x1 = *(const rcx_u64_u*)(wb_ + rb + 8);
+                    v0 = (uint32_t)x0; v1 = (uint32_t)(x0 >> 32); v2 = (uint32_t)x1; v3 = (uint32_t)(x1 >> 32);
+                    nv = rn ? (M - prog < 16u ? M - prog : 16u) : 0u;
+                } else {
+                    const bool ro = ready && ovl;
+                    uint32_t b[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { b[u] = wb_[ro ? sbase + (int32_t)r : 0]; r = !ro ? r : (r + 1 == off) ? 0u : r + 1; }
+                    v0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+                    v1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+                    nv = ro ? (M - prog < 8u ? M - prog : 8u) : 0u;
+                }
+                rcx_wave_sync();
+                RCX_LDS_STORE16(wb_ + li_m + (int32_t)prog, v0, v1, v2, v3, nv);
+                rcx_wave_sync();
+                prog += nv;
+                pending = pending && prog < M;
+            }
+        }
+        this->oend = RCX_U(oend0 + T);
+        this->flush(this->oend, false);
+        return 0;
+    }
+
+    __device__ void run_executor(int32_t* st_out, uint32_t* len_out)
+    {
+        this->lane = rcx_lane();
+        const unsigned lane = this->lane;
+        this->init_window();
+        int st = RCX_OK;
+        uint32_t tail = 0;
+        for (;;) {
+            while (RCX_U(ring->head) == tail) __builtin_amdgcn_s_sleep(1);
+            rcx_wave_sync();
+            const Slot* sl = &ring->slot[tail % NSLOT];
+            typename B::Batch bt;
+            bt.ns = (int)RCX_U(sl->hdr[0]); bt.why = (int)RCX_U(sl->hdr[1]); bt.perr = (int)RCX_U(sl->hdr[2]);
+            bt.gL = RCX_U(sl->hdr[3]); bt.gM = RCX_U(sl->hdr[4]); bt.goff = RCX_U(sl->hdr[5]); bt.gsrc = RCX_U(sl->hdr[6]);
+            bt.gnext = 0;
+            const uint64_t d = *(const uint64_t*)sl->desc[lane];
+            const uint32_t w0 = (uint32_t)d, w1 = (uint32_t)(d >> 32);
+            rcx_wave_sync();
+            tail++;
+            if (lane == 0) ring->tail = tail;             // the slot is in registers: hand it back
+            if (bt.ns) {
+                const int e = emit5(bt.ns, w0, w1);
+                if (e) { st = e; break; }
+            }
+            if (bt.why == B::STAGE_) continue;
+            if (this->after_batch(bt, st)) break;
+        }
+        if (st && lane == 0) ring->abort_ = 1;
+        if (!st) this->flush(this->oend, true);
+        *st_out = st;
+        *len_out = st ? 0u : this->oend;
+    }
+};
+
+template <int CB>
+__global__ __launch_bounds__(128, 8) void k_lz4_decode_v5(rcx_kargs a)
+{
+    typedef Lz4V5<CB> S;
+    __shared__ __align__(16) uint8_t s_cbuf[CB + 64];
+    __shared__ __align__(16) uint8_t s_wbuf[S::WBUF5];
+    __shared__ uint32_t s_epos[64];
+    __shared__ __align__(16) typename S::Ring s_ring;
+    const uint32_t b = blockIdx.x;
+    if (b >= a.nblocks) return;
+    if (threadIdx.x == 0) { s_ring.head = 0; s_ring.tail = 0; s_ring.abort_ = 0; }
+    __syncthreads();
+    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    S s;
+    s.in = a.in_base + a.in_off[b];
+    s.n = (uint32_t)a.in_len[b];
+    s.out = a.out_base + a.out_off[b];
+    const uint64_t cap64 = a.out_cap[b];
+    s.cap = cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)cap64;
+    s.cbuf = s_cbuf;
+    s.wb_ = s_wbuf;
+    s.epos = s_epos;
+    s.ring = &s_ring;
+    if (role == 0) { s.run_parser(); return; }
+    int32_t st; uint32_t olen;
+    s.run_executor(&st, &olen);
+    if ((threadIdx.x & 63u) == 0) {
+        a.status[b] = st;
+        a.out_len[b] = olen;
+        if (a.in_used) a.in_used[b] = s.n;
+    }
+}

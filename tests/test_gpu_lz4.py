@@ -30,7 +30,7 @@ def test_encode_bit_exact_vs_oracle(ctx, oracle, golden):
     assert list(res.in_used) == [len(r) for r in raws]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11])
 def test_decode_bit_exact_vs_oracle(ctx, oracle, golden, variant):
     ctx.set_variant(N.LZ4_DECODE, variant)
     raws = _raws(golden)
@@ -46,7 +46,7 @@ def test_decode_bit_exact_vs_oracle(ctx, oracle, golden, variant):
     ctx.set_variant(N.LZ4_DECODE, 0)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 5])
+@pytest.mark.parametrize("variant", [0, 1, 5, 10, 11])
 def test_decode_malformed_statuses(ctx, oracle, variant):
     ctx.set_variant(N.LZ4_DECODE, variant)
     rng = np.random.default_rng(5)
