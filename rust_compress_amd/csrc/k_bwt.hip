@@ -5,7 +5,8 @@
 // byte), so the suffix array is unique and any correct sorter gives bit-identical (L, origin).  Here:
 // prefix doubling over the WHOLE batch at once -- one 64-bit key per suffix (block | rank[i] | rank[i+h],
 // rank 0 = "past the end"), a device-wide LSD radix sort per round (rocPRIM primitive), re-ranking by
-// head flags + max-scan, h = 4, 8, 16, ... until every suffix is alone in its group.
+// group flags + max-scan, h = 4, 8, 16, ...; a suffix that is alone in its group is written to the suffix
+// array and dropped, so round k sorts only what h = 2^(k+1) bytes could not separate.
 //
 // INVERSE replaces compute_inversion_table + InverseIterator (src/bwt/mod.rs:223-282).  The reference's
 // n-step pointer chase is replaced by list ranking: the jump table is built with a stable wave-parallel
@@ -41,51 +42,76 @@ __global__ void k_bwtf_init(BwtfArgs a, uint64_t* keys, uint32_t* vals, uint32_t
         vals[g0 + i] = g0 + i;
     }
 }
-// head[j] = j if a new (block, key) group starts at sorted position j, else 0
-__global__ void k_bwtf_heads(const uint64_t* keys, uint32_t* head, uint32_t N, uint32_t* ngroups)
+// ---- one refinement round over the still-unresolved suffixes U (sorted by key = block | rank | next rank) ----
+// pair[j] = (index of the first element of j's OLD group, index of the first element of j's NEW group), as
+// "j if a group starts here else 0" for a component-wise max-scan.  `so`: key >> so identifies the old group.
+struct BwtfPair { uint32_t s, g; };
+struct BwtfPairMax {
+    __device__ __host__ BwtfPair operator()(const BwtfPair& a, const BwtfPair& b) const
+    {
+        BwtfPair r; r.s = a.s > b.s ? a.s : b.s; r.g = a.g > b.g ? a.g : b.g; return r;
+    }
+};
+__global__ void k_bwtf_flags(const uint64_t* keys, BwtfPair* pair, uint32_t n, uint32_t so)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    bool h = false;
-    if (j < N) { h = (j == 0) || keys[j] != keys[j - 1]; head[j] = h ? j : 0u; }
-    const unsigned long long m = __ballot(h);
-    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(ngroups, (uint32_t)__popcll(m));
+    if (j >= n) return;
+    const uint64_t k = keys[j], kp = j ? keys[j - 1] : ~k;
+    BwtfPair p; p.s = (j && (k >> so) == (kp >> so)) ? 0u : j; p.g = (j && k == kp) ? 0u : j;
+    pair[j] = p;
 }
-// rank[suffix] = (group start - block start) + 1
-__global__ void k_bwtf_rank(const uint64_t* keys, const uint32_t* vals, const uint32_t* gs, const uint32_t* bstart,
-                            uint32_t* rank, uint32_t N, uint32_t blk_shift)
+// new rank of element j = rank of its old group + (start of its new group - start of its old group); a new group
+// of one element is final: its suffix goes to SA[new rank] and leaves U.
+__global__ void k_bwtf_rank(const uint64_t* keys, const uint32_t* vals, const BwtfPair* pair, const uint32_t* bstart,
+                            uint32_t* rank, uint32_t* sa, uint32_t* keep, uint32_t n, uint32_t sb, uint32_t br, int round0)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= N) return;
-    const uint32_t b = (uint32_t)(keys[j] >> blk_shift);
-    rank[vals[j]] = gs[j] - bstart[b] + 1u;
-}
-__global__ void k_bwtf_next(const uint64_t* keys, const uint32_t* vals, const uint32_t* rank, const uint32_t* bstart,
-                            uint64_t* keys_out, uint32_t N, uint32_t blk_shift_old, uint32_t br, uint32_t h)
-{
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= N) return;
-    const uint32_t b = (uint32_t)(keys[j] >> blk_shift_old);
+    if (j >= n) return;
+    const uint64_t k = keys[j];
+    const BwtfPair p = pair[j];
+    const uint32_t b = (uint32_t)(k >> sb);
+    const uint32_t base = round0 ? bstart[b] : bstart[b] + (uint32_t)((k >> br) & ((1ull << br) - 1ull)) - 1u;
+    const uint32_t nr = base + (p.g - p.s);
     const uint32_t g = vals[j];
-    const uint32_t e = bstart[b + 1];
-    const uint64_t r1 = rank[g];
-    const uint64_t r2 = (g + h < e) ? rank[g + h] : 0u;
-    keys_out[j] = ((uint64_t)b << (2 * br)) | (r1 << br) | r2;
+    rank[g] = nr;
+    const bool single = p.g == j && (j + 1 == n || keys[j + 1] != k);
+    if (single) sa[nr] = g;
+    keep[j] = single ? 0u : 1u;
+}
+// compact the survivors and give them their next key: block | new local rank + 1 | local rank + 1 of suffix + h (0 = past the end)
+__global__ void k_bwtf_next(const uint64_t* keys, const uint32_t* vals, const uint32_t* keep, const uint32_t* pos,
+                            const uint32_t* rank, const uint32_t* bstart, uint64_t* keys_out, uint32_t* vals_out,
+                            uint32_t n, uint32_t sb, uint32_t br, uint32_t h)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n || !keep[j]) return;
+    const uint32_t b = (uint32_t)(keys[j] >> sb);
+    const uint32_t g = vals[j];
+    const uint32_t g0 = bstart[b], e = bstart[b + 1];
+    const uint64_t r1 = rank[g] - g0 + 1u;
+    const uint64_t r2 = (g + h < e) ? rank[g + h] - g0 + 1u : 0u;
+    const uint32_t o = pos[j];
+    keys_out[o] = ((uint64_t)b << (2 * br)) | (r1 << br) | r2;
+    vals_out[o] = g;
+}
+__global__ void k_bwtf_count(const uint32_t* keep, const uint32_t* pos, uint32_t n, uint32_t* out)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out = n ? pos[n - 1] + keep[n - 1] : 0u;
 }
 // L[j] = T[SA[j]-1], or T[n-1] where SA[j] == 0 (that j is `origin`), mod.rs:193-203
-__global__ void k_bwtf_emit(BwtfArgs a, const uint64_t* keys, const uint32_t* vals, uint32_t N, uint32_t blk_shift,
-                            uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap, uint32_t* origin)
+__global__ void k_bwtf_emit(BwtfArgs a, const uint32_t* sa, uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap, uint32_t* origin)
 {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= N) return;
-    const uint32_t b = (uint32_t)(keys[j] >> blk_shift);
-    const uint32_t g0 = a.bstart[b];
+    const uint32_t b = blockIdx.y;
     const uint32_t n = (uint32_t)a.in_len[b];
     if (out_cap[b] < n) return;
+    const uint32_t g0 = a.bstart[b];
     const uint8_t* T = a.in_base + a.in_off[b];
-    const uint32_t i = vals[j] - g0, jl = j - g0;
     uint8_t* out = out_base + out_off[b];
-    if (i == 0) { out[jl] = T[n - 1]; if (origin) origin[b] = jl; }
-    else out[jl] = T[i - 1];
+    for (uint32_t jl = blockIdx.x * blockDim.x + threadIdx.x; jl < n; jl += gridDim.x * blockDim.x) {
+        const uint32_t i = sa[g0 + jl] - g0;
+        if (i == 0) { out[jl] = T[n - 1]; if (origin) origin[b] = jl; }
+        else out[jl] = T[i - 1];
+    }
 }
 __global__ void k_bwtf_finish(rcx_kargs a)
 {
@@ -104,8 +130,8 @@ static inline uint32_t bits_for(uint64_t v) { uint32_t b = 1; while ((1ull << b)
 static uint64_t bwt_forward_scratch_bytes(uint32_t nblocks, uint64_t max_block)
 {
     const uint64_t N = (uint64_t)nblocks * max_block;
-    // keys 2x8N, vals 2x4N, rank 4N, heads 4N, bstart, counters, sort/scan temp
-    return 32 * N + N / 16 + (uint64_t)(nblocks + 2) * 4 + (64ull << 20);
+    // keys 2x8N, vals 2x4N, rank 4N, SA 4N, group pairs 8N, keep 4N, positions 4N, bstart, counters, sort/scan temp
+    return 48 * N + N / 16 + (uint64_t)(nblocks + 2) * 4 + (64ull << 20);
 }
 
 static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::string& err)
@@ -129,15 +155,19 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
         auto carve = [&](size_t bytes) { uint8_t* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
         uint64_t* keysA = (uint64_t*)carve(8ull * N); uint64_t* keysB = (uint64_t*)carve(8ull * N);
         uint32_t* valsA = (uint32_t*)carve(4ull * N); uint32_t* valsB = (uint32_t*)carve(4ull * N);
-        uint32_t* rank = (uint32_t*)carve(4ull * N);  uint32_t* head = (uint32_t*)carve(4ull * N);
+        uint32_t* rank = (uint32_t*)carve(4ull * N);  uint32_t* sa = (uint32_t*)carve(4ull * N);
+        BwtfPair* pair = (BwtfPair*)carve(8ull * N);
+        uint32_t* keep = (uint32_t*)carve(4ull * N);  uint32_t* pos = (uint32_t*)carve(4ull * N);
         uint32_t* bstart = (uint32_t*)carve(4ull * (nb + 1)); uint32_t* counter = (uint32_t*)carve(256);
-        size_t sort_tmp = 0, scan_tmp = 0;
+        size_t sort_tmp = 0, scan_tmp = 0, scan2_tmp = 0;
         {
             rocprim::double_buffer<uint64_t> dk(keysA, keysB); rocprim::double_buffer<uint32_t> dv(valsA, valsB);
-            rocprim::radix_sort_pairs(nullptr, sort_tmp, dk, dv, N, 0, 64, s);
-            rocprim::inclusive_scan(nullptr, scan_tmp, head, head, N, rocprim::maximum<uint32_t>(), s);
+            (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, dk, dv, N, 0, 64, s);
+            (void)rocprim::inclusive_scan(nullptr, scan_tmp, pair, pair, N, BwtfPairMax(), s);
+            (void)rocprim::exclusive_scan(nullptr, scan2_tmp, keep, pos, 0u, N, rocprim::plus<uint32_t>(), s);
         }
-        const size_t tmp_bytes = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
+        size_t tmp_bytes = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
+        if (scan2_tmp > tmp_bytes) tmp_bytes = scan2_tmp;
         void* tmp = carve(tmp_bytes);
         if ((uint64_t)(p - (uint8_t*)k.scratch) > k.scratch_bytes) { err = "bwt forward: scratch too small"; return RCX_RC_BAD_ARG; }
         if (hipMemcpyAsync(bstart, h_bstart.data(), 4ull * (nb + 1), hipMemcpyHostToDevice, s) != hipSuccess) { err = "bwt forward: H2D"; return RCX_RC_HIP_ERROR; }
@@ -145,26 +175,30 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
         const uint32_t gx = (uint32_t)((maxn + 255) / 256 < 1024 ? (maxn + 255) / 256 : 1024);
         hipLaunchKernelGGL(k_bwtf_init, dim3(gx ? gx : 1, nb), dim3(256), 0, s, fa, keysA, valsA, (uint32_t)maxn);
         rocprim::double_buffer<uint64_t> dk(keysA, keysB); rocprim::double_buffer<uint32_t> dv(valsA, valsB);
-        uint32_t blk_shift = 36, end_bit = 36 + bblk, h = 4;
-        const uint32_t gN = (N + 255) / 256;
-        for (int round = 0; round < 40; round++) {
+        // Round 0 sorts every suffix by its first 4 bytes; each later round sorts only the suffixes whose group
+        // is still larger than one (Larsson-Sadakane style discarding) by (group rank, rank of suffix + h).
+        uint32_t sb = 36, so = 36, end_bit = 36 + bblk, h = 4, n = N;
+        for (int round = 0; round < 40 && n; round++) {
+            const uint32_t gn = (n + 255) / 256;
             size_t tb = tmp_bytes;
-            if (rocprim::radix_sort_pairs(tmp, tb, dk, dv, N, 0, end_bit, s) != hipSuccess) { err = "bwt forward: radix sort failed"; return RCX_RC_HIP_ERROR; }
-            (void)hipMemsetAsync(counter, 0, 4, s);
-            hipLaunchKernelGGL(k_bwtf_heads, dim3(gN), dim3(256), 0, s, dk.current(), head, N, counter);
-            uint32_t groups = 0;
-            (void)hipMemcpyAsync(&groups, counter, 4, hipMemcpyDeviceToHost, s);
-            if (hipStreamSynchronize(s) != hipSuccess) { err = "bwt forward: sync failed"; return RCX_RC_HIP_ERROR; }
-            if (groups == N) break;                                      // every suffix is alone: SA is final
+            if (rocprim::radix_sort_pairs(tmp, tb, dk, dv, n, 0, end_bit, s) != hipSuccess) { err = "bwt forward: radix sort failed"; return RCX_RC_HIP_ERROR; }
+            hipLaunchKernelGGL(k_bwtf_flags, dim3(gn), dim3(256), 0, s, dk.current(), pair, n, so);
             tb = tmp_bytes;
-            rocprim::inclusive_scan(tmp, tb, head, head, N, rocprim::maximum<uint32_t>(), s);
-            hipLaunchKernelGGL(k_bwtf_rank, dim3(gN), dim3(256), 0, s, dk.current(), dv.current(), head, bstart, rank, N, blk_shift);
-            hipLaunchKernelGGL(k_bwtf_next, dim3(gN), dim3(256), 0, s, dk.current(), dv.current(), rank, bstart, dk.alternate(), N, blk_shift, br, h);
-            dk.swap();                                                   // new keys, same value order
-            blk_shift = 2 * br; end_bit = 2 * br + bblk; h *= 2;
+            if (rocprim::inclusive_scan(tmp, tb, pair, pair, n, BwtfPairMax(), s) != hipSuccess) { err = "bwt forward: scan failed"; return RCX_RC_HIP_ERROR; }
+            hipLaunchKernelGGL(k_bwtf_rank, dim3(gn), dim3(256), 0, s, dk.current(), dv.current(), pair, bstart, rank, sa, keep, n, sb, br, round == 0 ? 1 : 0);
+            tb = tmp_bytes;
+            if (rocprim::exclusive_scan(tmp, tb, keep, pos, 0u, n, rocprim::plus<uint32_t>(), s) != hipSuccess) { err = "bwt forward: scan failed"; return RCX_RC_HIP_ERROR; }
+            hipLaunchKernelGGL(k_bwtf_count, dim3(1), dim3(64), 0, s, keep, pos, n, counter);
+            hipLaunchKernelGGL(k_bwtf_next, dim3(gn), dim3(256), 0, s, dk.current(), dv.current(), keep, pos, rank, bstart,
+                               dk.alternate(), dv.alternate(), n, sb, br, h);
+            uint32_t left = 0;
+            (void)hipMemcpyAsync(&left, counter, 4, hipMemcpyDeviceToHost, s);
+            if (hipStreamSynchronize(s) != hipSuccess) { err = "bwt forward: sync failed"; return RCX_RC_HIP_ERROR; }
+            dk.swap(); dv.swap();
+            n = left; sb = 2 * br; so = br; end_bit = 2 * br + bblk; h *= 2;
         }
-        hipLaunchKernelGGL(k_bwtf_emit, dim3(gN), dim3(256), 0, s, fa, dk.current(), dv.current(), N, blk_shift,
-                           k.out_base, k.out_off, k.out_cap, k.aux);
+        if (n) { err = "bwt forward: did not converge"; return RCX_RC_HIP_ERROR; }
+        hipLaunchKernelGGL(k_bwtf_emit, dim3(gx ? gx : 1, nb), dim3(256), 0, s, fa, sa, k.out_base, k.out_off, k.out_cap, k.aux);
     }
     hipLaunchKernelGGL(k_bwtf_finish, dim3((nb + 255) / 256), dim3(256), 0, s, k);
     return RCX_RC_OK;
