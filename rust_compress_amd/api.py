@@ -51,7 +51,11 @@ class Context:
             N.lib().rcx_ctx_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:           # interpreter shutdown: the module globals may already be gone
+            pass
 
     def _chk(self, rc):
         if rc != N.RC_OK:

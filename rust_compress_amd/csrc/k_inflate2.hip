@@ -29,6 +29,7 @@ struct F2Huff {                   // one canonical code, register resident
 struct F2 {
     // LDS views (lane-interleaved)
     uint8_t* lsym; uint32_t* lbit; uint8_t* dsym; uint32_t* ring; unsigned t;
+    uint32_t lg;                      // log2(streams per wave): the interleave stride of the LDS views
     // stream state
     const uint8_t* in; uint64_t n, p;
     uint8_t* out; uint64_t cap, end, flushed;
@@ -36,13 +37,13 @@ struct F2 {
     uint32_t nx; bool nxv;            // prefetched input word at p
     uint32_t a, b, pend, omis;
 
-    __device__ __forceinline__ uint8_t& LS(uint32_t i) { return lsym[i * 64 + t]; }
-    __device__ __forceinline__ uint32_t& LB(uint32_t i) { return lbit[i * 64 + t]; }
-    __device__ __forceinline__ uint8_t& DS(uint32_t i) { return dsym[i * 64 + t]; }
+    __device__ __forceinline__ uint8_t& LS(uint32_t i) { return lsym[(i << lg) + t]; }
+    __device__ __forceinline__ uint32_t& LB(uint32_t i) { return lbit[(i << lg) + t]; }
+    __device__ __forceinline__ uint8_t& DS(uint32_t i) { return dsym[(i << lg) + t]; }
     __device__ __forceinline__ uint8_t* RB(uint64_t pos)          // ring byte of absolute output position
     {
         const uint32_t q = (uint32_t)(pos + omis) & (F2_W - 1u);
-        return (uint8_t*)ring + (((q >> 2) * 64u + t) << 2) + (q & 3u);
+        return (uint8_t*)ring + ((((q >> 2) << lg) + t) << 2) + (q & 3u);
     }
 
     // ---- input bits ------------------------------------------------------------------------------
@@ -74,8 +75,8 @@ struct F2 {
             const uint64_t pos = flushed;
             if ((((uintptr_t)(out + pos)) & 15u) == 0 && upto - pos >= 16) {
                 const uint32_t q = (uint32_t)(pos + omis) & (F2_W - 1u);
-                const uint32_t w0 = (q >> 2) * 64u + t;
-                rcx_u32x4 v = {ring[w0], ring[w0 + 64], ring[w0 + 128], ring[w0 + 192]};
+                const uint32_t w0 = ((q >> 2) << lg) + t, sw = 1u << lg;
+                rcx_u32x4 v = {ring[w0], ring[w0 + sw], ring[w0 + 2 * sw], ring[w0 + 3 * sw]};
                 *(rcx_u32x4*)(out + pos) = v;
                 flushed += 16;
             } else { out[pos] = *RB(pos); flushed += 1; }
@@ -352,18 +353,24 @@ __device__ int f2_dynamic(F2& s, F2Huff& HL, F2Huff& HD, uint8_t* lens)
     return f2_codes(s, HL, HD);
 }
 
-// LDS per 64-stream wave: lsym 288 B + 9th-bit bitmap 9 words + dsym 32 B + ring 128 B, per lane
-#define F2_LDS (288 * 64 + 9 * 4 * 64 + 32 * 64 + 128 * 64)
+// LDS per stream: lsym 288 B + 9th-bit bitmap 9 words + dsym 32 B + ring 128 B = 484 B.
+// SPW = streams (active lanes) per wave.  A lane's instruction stream is the union of what its wave's lanes do and a
+// wave issues one instruction per >= 4 cycles, so with 65 536 members a full wave (SPW 64) means 4 waves per CU,
+// one per SIMD, nothing to hide latency behind; SPW 16 gives 16 waves per CU with a quarter of the divergence each.
+#define F2_LDS_PER_STREAM (288 + 9 * 4 + 32 + 128)
 
+template <int SPW, int LG>
 __global__ __launch_bounds__(64) void k_inflate2(rcx_kargs a, int zlib)
 {
-    __shared__ __align__(16) uint8_t s_mem[F2_LDS];
+    static_assert((1 << LG) == SPW && SPW <= 64, "streams per wave");
+    __shared__ __align__(16) uint8_t s_mem[F2_LDS_PER_STREAM * SPW];
     const unsigned t = threadIdx.x;
-    const uint32_t b = blockIdx.x * 64 + t;
+    const uint32_t b = blockIdx.x * SPW + t;
     if (b >= a.nblocks) return;
     F2 s;
-    s.lsym = s_mem; s.lbit = (uint32_t*)(s_mem + 288 * 64); s.dsym = s_mem + 288 * 64 + 9 * 4 * 64;
-    s.ring = (uint32_t*)(s_mem + 288 * 64 + 9 * 4 * 64 + 32 * 64); s.t = t;
+    s.lg = LG;
+    s.lsym = s_mem; s.lbit = (uint32_t*)(s_mem + 288 * SPW); s.dsym = s_mem + 288 * SPW + 9 * 4 * SPW;
+    s.ring = (uint32_t*)(s_mem + 288 * SPW + 9 * 4 * SPW + 32 * SPW); s.t = t;
     s.in = a.in_base + a.in_off[b]; s.n = a.in_len[b]; s.p = 0;
     s.out = a.out_base + a.out_off[b]; s.cap = a.out_cap[b]; s.end = 0; s.flushed = 0;
     s.bb = 0; s.bc = 0; s.nx = 0; s.nxv = false; s.a = 1; s.b = 0; s.pend = 0;

@@ -65,8 +65,9 @@ def test_inflate_zlib_adler(oracle, golden):
         zs.append(c.compress(r) + c.flush()); exp.append(r)
     for i in range(10):
         zs.append(golden("test.z.%d" % i)); exp.append(txt)
-    outs, _, used, st, _ = simrun.run(N.ZLIB_DECODE, 0, zs, [len(e) for e in exp])
-    assert not st.any() and outs == exp and list(used) == [len(z) for z in zs]
+    for variant in (0, 2, 3, 4, 1):                 # auto (8 streams per wave here), 64, 32, 16, first kernel
+        outs, _, used, st, _ = simrun.run(N.ZLIB_DECODE, variant, zs, [len(e) for e in exp])
+        assert not st.any() and outs == exp and list(used) == [len(z) for z in zs], variant
     raw = [z[2:-4] for z in zs] + [golden("test.z.go")]
     outs, _, _, st, aux = simrun.run(N.INFLATE, 0, raw, [len(e) for e in exp] + [len(txt)])
     assert not st.any() and outs == exp + [txt] and aux[len(raw) - 1] == 1
