@@ -8,7 +8,7 @@ def _z(a): return zlib.compress(a[1], (1,6,9)[a[0]%3])
 if __name__ == "__main__":
     dev = torch.device("cuda", 0)
     ctx = R.Context(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    for nb in (65536, 16384, 262144):
+    for nb in (65536,):
         BLOCK = 16384
         raw_np = synth.gen_blocks("text", nb, BLOCK, 0x5A11)
         with Pool(32) as pool:
@@ -16,7 +16,7 @@ if __name__ == "__main__":
         base, off, lens = B.pack(members)
         ar = np.arange(nb, dtype=np.int64)
         db = R.DeviceBatch.from_host(base, off, lens, nb*BLOCK, (ar*BLOCK).astype(np.uint64), np.full(nb, BLOCK, dtype=np.uint64), dev)
-        for v in (0, 1, 2, 3, 4, 5):
+        for v in (0, 3, 4, 6, 7, 8):
             ctx.set_variant(N.ZLIB_DECODE, v)
             for _ in range(2): ctx.launch_dev(N.ZLIB_DECODE, db)
             torch.cuda.synchronize()

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_adler32(rcx_kargs a)
     }
 }
 
-template <int SPW, int LG> __global__ void k_inflate2(rcx_kargs a, int zlib);
+template <int SPW, int LG, int MINW> __global__ void k_inflate2(rcx_kargs a, int zlib);
 static void launch_inflate(hipStream_t s, rcx_kargs& k, bool zlib, int v)
 {
     if (v == 1) hipLaunchKernelGGL(k_inflate, dim3((k.nblocks + 63) / 64), dim3(64), 0, s, k, zlib ? 1 : 0);   // first version (A/B)
@@ -343,10 +343,13 @@ static void launch_inflate(hipStream_t s, rcx_kargs& k, bool zlib, int v)
         const uint32_t n = k.nblocks;
         int spw = v == 2 ? 64 : v == 3 ? 32 : v == 4 ? 16 : v == 5 ? 8 : (n >= 32u * 2048u ? 32 : n >= 16u * 2048u ? 16 : 8);
         const int z = zlib ? 1 : 0;
-        if (spw == 64) hipLaunchKernelGGL((k_inflate2<64, 6>), dim3((n + 63) / 64), dim3(64), 0, s, k, z);
-        else if (spw == 32) hipLaunchKernelGGL((k_inflate2<32, 5>), dim3((n + 31) / 32), dim3(32), 0, s, k, z);
-        else if (spw == 16) hipLaunchKernelGGL((k_inflate2<16, 4>), dim3((n + 15) / 16), dim3(16), 0, s, k, z);
-        else hipLaunchKernelGGL((k_inflate2<8, 3>), dim3((n + 7) / 8), dim3(8), 0, s, k, z);
+        if (v == 6) hipLaunchKernelGGL((k_inflate2<16, 4, 4>), dim3((n + 15) / 16), dim3(16), 0, s, k, z);
+        else if (v == 7) hipLaunchKernelGGL((k_inflate2<32, 5, 3>), dim3((n + 31) / 32), dim3(32), 0, s, k, z);
+        else if (v == 8) hipLaunchKernelGGL((k_inflate2<16, 4, 3>), dim3((n + 15) / 16), dim3(16), 0, s, k, z);
+        else if (spw == 64) hipLaunchKernelGGL((k_inflate2<64, 6, 1>), dim3((n + 63) / 64), dim3(64), 0, s, k, z);
+        else if (spw == 32) hipLaunchKernelGGL((k_inflate2<32, 5, 1>), dim3((n + 31) / 32), dim3(32), 0, s, k, z);
+        else if (spw == 16) hipLaunchKernelGGL((k_inflate2<16, 4, 1>), dim3((n + 15) / 16), dim3(16), 0, s, k, z);
+        else hipLaunchKernelGGL((k_inflate2<8, 3, 1>), dim3((n + 7) / 8), dim3(8), 0, s, k, z);
     }
 }
 static void launch_adler32(hipStream_t s, rcx_kargs& k)

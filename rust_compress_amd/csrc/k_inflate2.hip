@@ -359,8 +359,8 @@ __device__ int f2_dynamic(F2& s, F2Huff& HL, F2Huff& HD, uint8_t* lens)
 // one per SIMD, nothing to hide latency behind; SPW 16 gives 16 waves per CU with a quarter of the divergence each.
 #define F2_LDS_PER_STREAM (288 + 9 * 4 + 32 + 128)
 
-template <int SPW, int LG>
-__global__ __launch_bounds__(64) void k_inflate2(rcx_kargs a, int zlib)
+template <int SPW, int LG, int MINW>
+__global__ __launch_bounds__(64, MINW) void k_inflate2(rcx_kargs a, int zlib)
 {
     static_assert((1 << LG) == SPW && SPW <= 64, "streams per wave");
     __shared__ __align__(16) uint8_t s_mem[F2_LDS_PER_STREAM * SPW];
