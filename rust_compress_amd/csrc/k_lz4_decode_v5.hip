@@ -24,7 +24,8 @@ struct Lz4V5 : Lz4V4<CB, false> {
     static constexpr int NSLOT = 3;
     struct Slot { uint32_t hdr[16]; uint32_t desc[64][2]; };
     struct Ring { Slot slot[NSLOT]; volatile uint32_t head, tail, abort_, pad; };
-    static constexpr int WBUF5 = B::LIN + 64;          // no staging slots: gathered bytes go straight to their place
+    static constexpr int STAGE5 = B::LIN + 64;         // 64 lanes x 32 bytes of old-match staging (bytes 32.. of a longer
+    static constexpr int WBUF5 = STAGE5 + 64 * 32;     // gathered match go straight to their place): 16 blocks per CU fit
     Ring* ring;
 
     // ------------------------------------------------------------------------------------------ parser wave
@@ -59,7 +60,7 @@ struct Lz4V5 : Lz4V4<CB, false> {
                 const uint32_t t = RCX_U(ring->tail);
                 if (RCX_U(ring->abort_)) return;
                 if (head - t < (uint32_t)NSLOT) break;
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(16);                        // ~1K cycles: an executor batch takes ~20K
             }
             rcx_wave_sync();
             Slot* sl = &ring->slot[head % NSLOT];
@@ -162,8 +163,7 @@ struct Lz4V5 : Lz4V4<CB, false> {
         if (__ballot(isfar)) {
             uint8_t* d = wb_ + li_m;
             const uint32_t mf = far16 ? M : 0u;
-            RCX_LDS_STORE16(d, f0[0], f0[1], f0[2], f0[3], mf < 16u ? mf : 16u);
-            if (__ballot(mf > 16)) RCX_LDS_STORE16(d + 16, f1[0], f1[1], f1[2], f1[3], mf > 16u ? (mf < 32u ? mf - 16u : 16u) : 0u);
+            if (far16) { uint8_t* sl = wb_ + STAGE5 + 32 * (int32_t)lane; *(rcx_u32x4*)sl = f0; *(rcx_u32x4*)(sl + 16) = f1; }
             if (__ballot(mf > 32)) RCX_LDS_STORE16(d + 32, f2[0], f2[1], f2[2], f2[3], mf > 32u ? (mf < 48u ? mf - 32u : 16u) : 0u);
             if (__ballot(mf > 48)) RCX_LDS_STORE16(d + 48, f3[0], f3[1], f3[2], f3[3], mf > 48u ? mf - 48u : 0u);
             for (uint32_t i = 0; __ballot(farb && i < M); i++)
@@ -173,9 +173,10 @@ struct Lz4V5 : Lz4V4<CB, false> {
 
         // ---- window matches: copy rounds (16 bytes per ready lane), see Lz4V4::emit
         {
-            const int32_t sbase = (int32_t)(mdst - S) - lbase;
+            const int32_t sbase = far16 ? STAGE5 + 32 * (int32_t)lane : (int32_t)(mdst - S) - lbase;
             const bool ovl = M && !isfar && off < 16u && off < M;
-            bool pending = M != 0 && !isfar;
+            const uint32_t Mc = far16 ? (M < 32u ? M : 32u) : M;     // staged gathers ride the rounds for their first 32 bytes
+            bool pending = M != 0 && !farb;
             uint32_t prog = 0, r = 0;
             for (;;) {
                 const unsigned long long pm = __ballot(pending);
@@ -187,7 +188,7 @@ struct Lz4V5 : Lz4V4<CB, false> {
                     const int32_t rb = rn ? sbase + (int32_t)prog : 0;
                     const uint64_t x0 = *(const rcx_u64_u*)(wb_ + rb), x1 = *(const rcx_u64_u*)(wb_ + rb + 8);
                     v0 = (uint32_t)x0; v1 = (uint32_t)(x0 >> 32); v2 = (uint32_t)x1; v3 = (uint32_t)(x1 >> 32);
-                    nv = rn ? (M - prog < 16u ? M - prog : 16u) : 0u;
+                    nv = rn ? (Mc - prog < 16u ? Mc - prog : 16u) : 0u;
                 } else {
                     const bool ro = ready && ovl;
                     uint32_t b[8];
@@ -201,7 +202,7 @@ struct Lz4V5 : Lz4V4<CB, false> {
                 RCX_LDS_STORE16(wb_ + li_m + (int32_t)prog, v0, v1, v2, v3, nv);
                 rcx_wave_sync();
                 prog += nv;
-                pending = pending && prog < M;
+                pending = pending && prog < Mc;
             }
         }
         this->oend = RCX_U(oend0 + T);
@@ -217,7 +218,7 @@ struct Lz4V5 : Lz4V4<CB, false> {
         int st = RCX_OK;
         uint32_t tail = 0;
         for (;;) {
-            while (RCX_U(ring->head) == tail) __builtin_amdgcn_s_sleep(1);
+            while (RCX_U(ring->head) == tail) __builtin_amdgcn_s_sleep(4);
             rcx_wave_sync();
             const Slot* sl = &ring->slot[tail % NSLOT];
             typename B::Batch bt;

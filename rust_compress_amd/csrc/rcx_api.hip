@@ -140,10 +140,9 @@ extern "C" uint64_t rcx_scratch_bytes(int codec, uint32_t nblocks, uint64_t max_
 }
 
 // ---- kernel dispatch ----------------------------------------------------------------------------
-// LZ4 decode, default variant: below ~12 blocks per CU the chip is latency bound and the two-wave kernel
-// (parser || executor) is 1.2-1.4x faster; from 16 blocks per CU on both kernels saturate the CU's scalar/LDS
-// issue and the single-wave kernel is the cheaper one (measured: benchmarks/lz4_occupancy_sweep.py).
-static constexpr uint32_t LZ4D_TWO_WAVE_MAX_BLOCKS = 3072;
+// LZ4 decode, default variant: the two-wave kernel (parser || executor).  It is 1.2-1.4x faster than the
+// single-wave kernel below ~12 blocks per CU (latency bound) and still 5-7 % faster at 16 and more blocks per CU
+// (measured: benchmarks/lz4_occupancy_sweep.py); variant 11 selects the single-wave kernel.
 static int launch_codec(rcx_ctx* c, int codec, rcx_kargs& k)
 {
     hipStream_t s = c->stream;
@@ -161,9 +160,9 @@ static int launch_codec(rcx_ctx* c, int codec, rcx_kargs& k)
         else if (v == 7) hipLaunchKernelGGL((k_lz4_decode_v4<2048, 1>), dim3(n), dim3(64), 0, s, k);
         else if (v == 9) hipLaunchKernelGGL((k_lz4_decode_v4<1024, 1, true>), dim3(n), dim3(64), 0, s, k);   // phase timers -> scratch
         else if (v == 8) hipLaunchKernelGGL((k_lz4_decode_v4<1024, 4>), dim3((n + 3) / 4), dim3(256), 0, s, k);
-        else if (v == 10 || (v == 0 && n <= LZ4D_TWO_WAVE_MAX_BLOCKS))
+        else if (v == 10 || v == 0)
             hipLaunchKernelGGL((k_lz4_decode_v5<1024>), dim3(n), dim3(128), 0, s, k);   // parser + executor waves
-        else hipLaunchKernelGGL((k_lz4_decode_v4<1024, 1>), dim3(n), dim3(64), 0, s, k); // v == 0 (large batch) or 11
+        else hipLaunchKernelGGL((k_lz4_decode_v4<1024, 1>), dim3(n), dim3(64), 0, s, k); // v == 11
         break;
     case RCX_LZ4_ENCODE: {
         if (k.scratch_bytes < rcx_scratch_bytes(codec, n, 0)) { c->err = "lz4 encode: scratch too small"; return RCX_RC_BAD_ARG; }
