@@ -412,25 +412,27 @@ struct Lz4V4 {
         int why = GO;
         int perr = 0;
         uint32_t gL = 0, gM = 0, goff = 0, gsrc = 0, gnext = 0;
-        while (why == GO) {
+        // positions from which a token may not fit the staged bytes any more (re-stage first); none once the tail is staged
+        const uint32_t stage_lim = RCX_U(cend < n ? cend - (uint32_t)MARGIN : 0xffffffffu);
+        const uint32_t fast_lim = RCX_U(cend >= 20 ? cend - 20 : 0);
+        for (;;) {
             cur = RCX_U(cur); ns = (int)RCX_U(ns); tsum = RCX_U(tsum);
             if (cur >= n) { why = END_; break; }
-            if (cend < n && cur + (uint32_t)MARGIN > cend) { why = STAGE_; break; }
+            if (cur > stage_lim) { why = STAGE_; break; }
             if (ns >= 64) break;
             // register window: hop distance of the candidate token at cur+lane (128 = general path) and the
             // output bytes it produces.  A match-length nibble of 15 followed by ONE extension byte that keeps
             // the match within MCAP stays on the vector path (second, dependent LDS read).
             uint64_t tw0_ = PROF ? (uint64_t)__builtin_readcyclecounter() : 0;
             const uint32_t q = cur + lane;
-            const uint32_t fast_lim = cend >= 20 ? cend - 20 : 0;
-            uint32_t dv = 128, lenv = 0;
-            if (q < fast_lim) {
+            uint32_t dv, lenv;
+            {                                                     // every lane reads (the staging buffer has slack); selects, no EXEC games
                 const int32_t qi = (int32_t)q - cbase;
                 const uint32_t t = cbuf[qi];
                 const uint32_t L = t >> 4, M = t & 15u;
                 const uint32_t x = cbuf[qi + 3 + (int32_t)L];
                 const bool ext = M == 15u;
-                const bool ok = L != 15u && (!ext || x <= (uint32_t)(MCAP - 19));
+                const bool ok = q < fast_lim && L != 15u && (!ext || x <= (uint32_t)(MCAP - 19));
                 dv = ok ? (ext ? 4u : 3u) + L : 128u;
                 lenv = L + M + 4u + (ext ? x : 0u);
             }
@@ -440,8 +442,8 @@ struct Lz4V4 {
             RCX_HOP_WALK(dv, rel, vis);                       // the serial token chain
             if (PROF) { const uint64_t t = (uint64_t)__builtin_readcyclecounter(); prof[15] += t - tw0_; }
             if (PROF) prof[13] += 1;
-            bool general = rel >= 128;                        // stopped at a token that needs the general path
-            if (general) { rel -= 128; vis &= ~(1ull << rel); }
+            bool general = false;                             // stopped at a token that needs the general path?
+            if (__builtin_expect(rel >= 128, 0)) { general = true; rel -= 128; vis &= ~(1ull << rel); }
             // compaction: a visited position p is a token start -> epos[ns + rank]; the batch's output is capped
             bool mark = RCX_INV_BALLOT(vis);
             bool full = false;
@@ -465,7 +467,7 @@ struct Lz4V4 {
             cur += rel;
             if (!general) continue;                           // window ran out: next window
             if (cur >= n) { why = END_; break; }
-            if (cend < n && cur + (uint32_t)MARGIN > cend) { why = STAGE_; break; }
+            if (cur > stage_lim) { why = STAGE_; break; }
 
             // ---- general path for the token at `cur`
             const uint32_t t = peek(cur);
@@ -514,6 +516,7 @@ struct Lz4V4 {
             } else {
                 gL = L; gM = M; goff = off; gsrc = lit_src; gnext = p;
                 why = (L + M <= (uint32_t)SOLO) ? SOLO_ : WIDE_;
+                break;
             }
         }
         Batch bt; bt.ns = ns; bt.why = why; bt.perr = perr; bt.gL = gL; bt.gM = gM; bt.goff = goff; bt.gsrc = gsrc; bt.gnext = gnext;
@@ -591,7 +594,7 @@ template <int CB, int WAVES, bool PROF = false>
 __global__ __launch_bounds__(64 * WAVES) void k_lz4_decode_v4(rcx_kargs a)
 {
     typedef Lz4V4<CB, PROF> S;
-    __shared__ __align__(16) uint8_t s_cbuf[WAVES][CB + 64];
+    __shared__ __align__(16) uint8_t s_cbuf[WAVES][CB + 96];
     __shared__ __align__(16) uint8_t s_wbuf[WAVES][S::WBUF];
     __shared__ uint32_t s_epos[WAVES][64];
     const unsigned w = threadIdx.x >> 6;

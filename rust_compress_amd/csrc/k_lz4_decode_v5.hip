@@ -248,7 +248,7 @@ template <int CB>
 __global__ __launch_bounds__(128, 8) void k_lz4_decode_v5(rcx_kargs a)
 {
     typedef Lz4V5<CB> S;
-    __shared__ __align__(16) uint8_t s_cbuf[CB + 64];
+    __shared__ __align__(16) uint8_t s_cbuf[CB + 96];
     __shared__ __align__(16) uint8_t s_wbuf[S::WBUF5];
     __shared__ uint32_t s_epos[64];
     __shared__ __align__(16) typename S::Ring s_ring;
