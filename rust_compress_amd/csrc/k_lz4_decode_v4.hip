@@ -247,12 +247,14 @@ struct Lz4V4 {
         return lo;
     }
 
-    __device__ int emit(int ns, uint32_t s_L, uint32_t s_M, uint32_t s_off, uint32_t s_src)
+    // Emits entries [lo, hi) of the batch, hi = ns unless their output exceeds TCAP bytes (then the prefix that
+    // fits; the caller comes back for the rest), and advances lo to hi.  Returns 0 or an rcx_status.
+    __device__ int emit(int ns, int& lo, uint32_t s_L, uint32_t s_M, uint32_t s_off, uint32_t s_src)
     {
         LZ4P_T0();
         make_room(TCAP);
         LZ4P_ADD(1);
-        const bool act = (int)lane < ns;
+        bool act = (int)lane >= lo && (int)lane < ns;
         uint32_t L = 0, M = 0, off = 0, src = (uint32_t)cbase;
         if (act) {
             const uint32_t e = epos[lane];
@@ -267,7 +269,15 @@ struct Lz4V4 {
         }
         const uint32_t len = L + M;
         const uint32_t incl = rcx_wave_incl_scan(len);
-        const uint32_t T = RCX_U(__builtin_amdgcn_readlane(incl, 63));
+        uint32_t T = RCX_U(__builtin_amdgcn_readlane(incl, 63));
+        int hi = ns;
+        if (T > (uint32_t)TCAP) {                                     // rare: take the prefix that fits (an entry is <= 96 bytes)
+            hi = lo + (int)__popcll(__ballot(act && incl <= (uint32_t)TCAP));
+            act = act && (int)lane < hi;
+            if (!act) { L = 0; M = 0; off = 0; }
+            T = RCX_U(__builtin_amdgcn_readlane(incl, hi - 1));
+        }
+        lo = hi;
         const uint32_t oend0 = oend;
         const uint32_t ostart = oend0 + incl - len;
         const uint32_t mdst = ostart + L;
@@ -408,7 +418,6 @@ struct Lz4V4 {
     __device__ __forceinline__ Batch collect(uint32_t& cur, uint32_t& s_L, uint32_t& s_M, uint32_t& s_off, uint32_t& s_src)
     {
         int ns = 0;
-        uint32_t tsum = 0;
         int why = GO;
         int perr = 0;
         uint32_t gL = 0, gM = 0, goff = 0, gsrc = 0, gnext = 0;
@@ -416,7 +425,7 @@ struct Lz4V4 {
         const uint32_t stage_lim = RCX_U(cend < n ? cend - (uint32_t)MARGIN : 0xffffffffu);
         const uint32_t fast_lim = RCX_U(cend >= 20 ? cend - 20 : 0);
         for (;;) {
-            cur = RCX_U(cur); ns = (int)RCX_U(ns); tsum = RCX_U(tsum);
+            cur = RCX_U(cur); ns = (int)RCX_U(ns);
             if (cur >= n) { why = END_; break; }
             if (cur > stage_lim) { why = STAGE_; break; }
             if (ns >= 64) break;
@@ -425,7 +434,7 @@ struct Lz4V4 {
             // the match within MCAP stays on the vector path (second, dependent LDS read).
             uint64_t tw0_ = PROF ? (uint64_t)__builtin_readcyclecounter() : 0;
             const uint32_t q = cur + lane;
-            uint32_t dv, lenv;
+            uint32_t dv;
             {                                                     // every lane reads (the staging buffer has slack); selects, no EXEC games
                 const int32_t qi = (int32_t)q - cbase;
                 const uint32_t t = cbuf[qi];
@@ -434,7 +443,6 @@ struct Lz4V4 {
                 const bool ext = M == 15u;
                 const bool ok = q < fast_lim && L != 15u && (!ext || x <= (uint32_t)(MCAP - 19));
                 dv = ok ? (ext ? 4u : 3u) + L : 128u;
-                lenv = L + M + 4u + (ext ? x : 0u);
             }
             uint32_t rel = 0;
             uint64_t vis = 0;
@@ -448,12 +456,9 @@ struct Lz4V4 {
             bool mark = RCX_INV_BALLOT(vis);
             bool full = false;
             if (vis) {
-                const uint32_t inc = rcx_wave_incl_scan(mark ? lenv : 0u);
-                const uint32_t wsum = RCX_U(__builtin_amdgcn_readlane(inc, 63));
                 uint32_t rank = (uint32_t)__popcll(vis & ((1ull << lane) - 1ull));
-                if (tsum + wsum > (uint32_t)TCAP || ns + (int)__popcll(vis) > 64) {
-                    // keep the prefix that fits (64 entries, TCAP bytes), emit, resume at the first rejected token
-                    const unsigned long long rej = __ballot(mark && (tsum + inc > (uint32_t)TCAP || ns + (int)rank >= 64));
+                if (ns + (int)__popcll(vis) > 64) {               // keep the first 64 - ns tokens, emit, resume at the first rejected one
+                    const unsigned long long rej = __ballot(mark && ns + (int)rank >= 64);
                     rel = (uint32_t)__ffsll(rej) - 1u;
                     vis &= (1ull << rel) - 1ull;
                     mark = mark && lane < rel;
@@ -461,7 +466,6 @@ struct Lz4V4 {
                 }
                 if (mark) epos[ns + (int)rank] = q;
                 ns += (int)__popcll(vis);
-                tsum += wsum;
             }
             if (full) { cur += rel; break; }
             cur += rel;
@@ -503,13 +507,13 @@ struct Lz4V4 {
                 M += 4;
             }
             const bool eligible = L <= (uint32_t)LCAP && M <= (uint32_t)MCAP && lit_src + L <= cend && (int32_t)lit_src >= cbase;
-            if (eligible && tsum + L + M <= (uint32_t)TCAP && ns < 64) {
+            if (eligible && ns < 64) {
                 if (lane == 0) epos[ns] = FLAG;
                 s_L = ((int)lane == ns) ? L : s_L;
                 s_M = ((int)lane == ns) ? M : s_M;
                 s_off = ((int)lane == ns) ? off : s_off;
                 s_src = ((int)lane == ns) ? lit_src : s_src;
-                ns++; tsum += L + M;
+                ns++;
                 cur = p;
             } else if (eligible) {
                 break;                                        // batch full: emit, then this token is parsed again
@@ -574,10 +578,9 @@ struct Lz4V4 {
             rcx_wave_sync();
             LZ4P_ADD(0);
             if (PROF) prof[11] += (uint64_t)bt.ns;
-            if (bt.ns) {
-                const int e = emit(bt.ns, s_L, s_M, s_off, s_src);
-                if (e) { st = e; break; }
-            }
+            int lo = 0, e = 0;
+            while (lo < bt.ns && !e) e = emit(bt.ns, lo, s_L, s_M, s_off, s_src);
+            if (e) { st = e; break; }
             if (PROF) t0_ = (uint64_t)__builtin_readcyclecounter();
             if (bt.why == STAGE_) { stage(cur); LZ4P_ADD(7); continue; }
             if (after_batch(bt, st)) break;

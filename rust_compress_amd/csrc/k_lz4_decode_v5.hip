@@ -80,17 +80,27 @@ struct Lz4V5 : Lz4V4<CB, false> {
 
     // ------------------------------------------------------------------------------------------ executor wave
     // One batch: lane i holds entry i's descriptor (w0 = literal source position, w1 = L | M << 8 | offset << 16).
-    __device__ int emit5(int ns, uint32_t w0, uint32_t w1)
+    // Entries [lo, hi) as in Lz4V4::emit (hi < ns only when the batch's output exceeds TCAP bytes); advances lo.
+    __device__ int emit5(int ns, int& lo, uint32_t w0, uint32_t w1)
     {
         const unsigned lane = this->lane;
         const uint8_t* in = this->in; uint8_t* out = this->out; uint8_t* wb_ = this->wb_;
         const uint32_t cap = this->cap, n = this->n;
         this->make_room(B::TCAP);
-        const uint32_t L = w1 & 0xffu, M = (w1 >> 8) & 0xffu, off = w1 >> 16, src = w0;
-        const bool act = (int)lane < ns;
+        bool act = (int)lane >= lo && (int)lane < ns;
+        uint32_t L = act ? w1 & 0xffu : 0u, M = act ? (w1 >> 8) & 0xffu : 0u, off = act ? w1 >> 16 : 0u;
+        const uint32_t src = w0;
         const uint32_t len = L + M;
         const uint32_t incl = rcx_wave_incl_scan(len);
-        const uint32_t T = RCX_U(__builtin_amdgcn_readlane(incl, 63));
+        uint32_t T = RCX_U(__builtin_amdgcn_readlane(incl, 63));
+        int hi = ns;
+        if (T > (uint32_t)B::TCAP) {                                  // rare: take the prefix that fits (an entry is <= 96 bytes)
+            hi = lo + (int)__popcll(__ballot(act && incl <= (uint32_t)B::TCAP));
+            act = act && (int)lane < hi;
+            if (!act) { L = 0; M = 0; off = 0; }
+            T = RCX_U(__builtin_amdgcn_readlane(incl, hi - 1));
+        }
+        lo = hi;
         const uint32_t oend0 = this->oend;
         const uint32_t ostart = oend0 + incl - len;
         const uint32_t mdst = ostart + L;
@@ -230,10 +240,9 @@ struct Lz4V5 : Lz4V4<CB, false> {
             rcx_wave_sync();
             tail++;
             if (lane == 0) ring->tail = tail;             // the slot is in registers: hand it back
-            if (bt.ns) {
-                const int e = emit5(bt.ns, w0, w1);
-                if (e) { st = e; break; }
-            }
+            int lo = 0, e = 0;
+            while (lo < bt.ns && !e) e = emit5(bt.ns, lo, w0, w1);
+            if (e) { st = e; break; }
             if (bt.why == B::STAGE_) continue;
             if (this->after_batch(bt, st)) break;
         }
