@@ -235,16 +235,18 @@ struct Lz4V4 {
         return 0;
     }
 
+    // Largest lane k with ostart[k] <= x (ostart is non-decreasing over the lanes): binary search with ds_bpermute.
+    // The probe lo + step never exceeds 63, and the byte address (lane * 4) is what is carried.
     __device__ __forceinline__ uint32_t lane_of(uint32_t ostart, uint32_t x) const
     {
-        uint32_t lo = 0;
+        uint32_t lo4 = 0;
 #pragma unroll
         for (int step = 32; step >= 1; step >>= 1) {
-            const uint32_t c = lo + step;
-            const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)ostart);
-            if (c < 64 && v <= x) lo = c;
+            const uint32_t c4 = lo4 + 4u * (uint32_t)step;
+            const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)c4, (int)ostart);
+            lo4 = v <= x ? c4 : lo4;
         }
-        return lo;
+        return lo4 >> 2;
     }
 
     // Emits entries [lo, hi) of the batch, hi = ns unless their output exceeds TCAP bytes (then the prefix that

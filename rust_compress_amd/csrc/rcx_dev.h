@@ -66,20 +66,21 @@ __device__ __forceinline__ uint32_t rcx_wave_sum(uint32_t v)
 // chain while it stays inside the window and sets bit p of `vis` for every token start p visited.
 // On return rel >= 128 means: stopped at a general-path token at window position rel-128 (its bit is set
 // too); otherwise 64 <= rel < 128 is where the chain left the window.
-// Hand-scheduled: the decoder is VALU-issue bound on MI355X (rocprof: SQ_ACTIVE_INST_VALU ~84 % of SIMD time
-// with 4 waves per SIMD) AND the CU's scalar unit retires one instruction per cycle for all its waves
-// (benchmarks/micro/issue_rate.hip: SALU, VOPC and v_readlane each cap at ~1 per cycle per CU), so a hop is
-// v_readlane (distance) + v_writelane (visited mark, plain VALU rate) + ONE s_add; the position is biased by
-// -64 so that the s_add's carry is the window-exit test.  No taken branch for 4 hops.  SALU reads of a VALU-written SGPR interlock in hardware; the lane select is SALU-written.
+// Hand-scheduled (hipcc's loop cost 11 SALU per hop): a hop is v_readlane (distance) + s_bitset1_b64 (visited
+// mark, kept in an SGPR pair) + ONE s_add whose carry is the window-exit test (position biased by -64); no taken
+// branch for 4 hops.  A v_writelane mark (plain VALU rate, one SALU less) measured the same: per CU the scalar
+// unit retires ~1 instruction per cycle and VALU is the busier pipe (benchmarks/micro/issue_rate.hip, rocprof).
+// SALU reads of a VALU-written SGPR interlock in hardware; the lane select is SALU-written.
 // The wave simulator supplies a portable version through this hook.
 #ifndef RCX_HOP_WALK
 __device__ __forceinline__ void rcx_hop_walk(uint32_t dv, uint32_t& rel, uint64_t& vis)
 {
-    uint32_t d, mk = 0;
+    uint32_t d;
+    uint64_t mk = 0;
     rel -= 64u;                      // biased so that leaving the window is the carry of the s_add (no s_cmp)
 #define RCX_HOP1                                              \
         "v_readlane_b32 %[d], %[dv], %[rel]\n\t"              \
-        "v_writelane_b32 %[mk], 1, %[rel]\n\t"                \
+        "s_bitset1_b64 %[mk], %[rel]\n\t"                     \
         "s_add_u32 %[rel], %[rel], %[d]\n\t"
     asm volatile(
         "L_hop_%=:\n\t"
@@ -88,11 +89,11 @@ __device__ __forceinline__ void rcx_hop_walk(uint32_t dv, uint32_t& rel, uint64_
         RCX_HOP1 "s_cbranch_scc1 L_done_%=\n\t"
         RCX_HOP1 "s_cbranch_scc0 L_hop_%=\n\t"
         "L_done_%=:\n\t"
-        : [d] "=&s"(d), [rel] "+s"(rel), [mk] "+v"(mk)
+        : [d] "=&s"(d), [rel] "+s"(rel), [mk] "+s"(mk)
         : [dv] "v"(dv)
         : "scc");
     rel += 64u;
-    vis = __ballot(mk != 0);
+    vis = mk;
 #undef RCX_HOP1
 }
 #define RCX_HOP_WALK rcx_hop_walk
