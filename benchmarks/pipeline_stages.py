@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Per-stage times of the BWT -> DC -> Ari pipeline (config 5 shape, --scale of 10^9 bytes)."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import rust_compress_amd as R
+from rust_compress_amd import _native as N, synth, pipeline as P
+
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.25
+total = int(1e9 * scale)
+BS = 256 * 1024
+dev = torch.device("cuda", 0)
+ctx = R.Context(0)
+lens = [min(BS, total - i) for i in range(0, total, BS)]
+raw = torch.from_numpy(synth.gen_blocks("text", (total + BS - 1) // BS, BS, 0xE9)[:total]).to(dev)
+pipe = P.BwtDcAri(ctx, dev)
+orig = ctx.launch_dev
+names = {N.BWT_FORWARD: "bwt_forward", N.DC_ENCODE: "dc_encode", N.ARI_BYTE_ENCODE: "ari_encode", N.ARI_BYTE_DECODE: "ari_decode",
+         N.BWT_INVERSE: "bwt_inverse"}
+acc = {}
+def timed(codec, *a, **k):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    r = orig(codec, *a, **k)
+    torch.cuda.synchronize(); acc[names.get(codec, str(codec))] = acc.get(names.get(codec, str(codec)), 0.0) + time.perf_counter() - t0
+    return r
+ctx.launch_dev = timed
+for rep in range(2):
+    acc.clear()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    comp, coff, clen, stg = pipe.encode(raw, lens, keep_stages=(rep == 1))
+    torch.cuda.synchronize(); te = time.perf_counter() - t0
+    if stg: print("range coder input: %.0f bytes per block (record = 4 x (3 + 256 + k) bytes)" % float(stg["rec_len"].float().mean()))
+    t0 = time.perf_counter()
+    out = pipe.decode(comp, coff, clen, lens)
+    torch.cuda.synchronize(); td = time.perf_counter() - t0
+assert torch.equal(out, raw)
+print("bytes %d blocks %d  encode %.3f s  decode %.3f s  ratio %.2f" % (total, len(lens), te, td, total / clen.sum()))
+for k, v in acc.items():
+    print("  %-12s %.1f ms" % (k, v * 1e3))

@@ -415,30 +415,61 @@ struct AriTab {
         total += add;
         if (total >= 4096) {                                  // downscale, table.rs:82-91 (cut_shift = 1)
             total = 0;
-            for (uint32_t k = 0; k < ARI_NB; k++) {
-                uint32_t bsum = 0;
-                const uint32_t e1 = k == 16 ? ARI_N : 16 * k + 16;
-                for (uint32_t e = 16 * k; e < e1; e++) { const uint16_t x = (uint16_t)((f(e) + 1) >> 1); f(e) = x; bsum += x; }
+            for (uint32_t k = 0; k < 16; k++) {
+                uint32_t x[16], bsum = 0;
+#pragma unroll
+                for (int j = 0; j < 16; j++) x[j] = f(16 * k + (uint32_t)j);
+#pragma unroll
+                for (int j = 0; j < 16; j++) { x[j] = (x[j] + 1) >> 1; f(16 * k + (uint32_t)j) = (uint16_t)x[j]; bsum += x[j]; }
                 s(k) = (uint16_t)bsum;
                 total += bsum;
             }
+            { const uint32_t x = ((uint32_t)f(256) + 1) >> 1; f(256) = (uint16_t)x; s(16) = (uint16_t)x; total += x; }
         }
     }
-    __device__ void range_of(uint32_t v, uint32_t& lo, uint32_t& hi)      // get_range, table.rs:100-103
+    // Both lookups read the 16 block sums and the 16 entries of one block UNCONDITIONALLY (two batches of
+    // independent LDS reads = two round trips per symbol) and select with predicates; a data-dependent loop of
+    // dependent reads cost ~30 round trips per symbol.
+    __device__ __forceinline__ void range_of(uint32_t v, uint32_t& lo, uint32_t& hi)      // get_range, table.rs:100-103
     {
-        uint32_t l = 0;
-        for (uint32_t k = 0; k < (v >> 4); k++) l += s(k);
-        for (uint32_t e = v & ~15u; e < v; e++) l += f(e);
-        lo = l; hi = l + f(v);
+        const uint32_t kb = v >> 4, jb = v & 15u, e0 = v & ~15u;
+        uint32_t sk[16], fe[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) sk[k] = s((uint32_t)k);
+#pragma unroll
+        for (int j = 0; j < 16; j++) { const uint32_t e = e0 + (uint32_t)j; fe[j] = f(e < ARI_N ? e : ARI_N - 1); }
+        uint32_t l = 0, fv = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) l += (uint32_t)k < kb ? sk[k] : 0u;
+#pragma unroll
+        for (int j = 0; j < 16; j++) { l += (uint32_t)j < jb ? fe[j] : 0u; fv = (uint32_t)j == jb ? fe[j] : fv; }
+        lo = l; hi = l + fv;
     }
-    __device__ uint32_t find(uint32_t offset, uint32_t& lo, uint32_t& hi)  // find_value, table.rs:105-117
+    __device__ __forceinline__ uint32_t find(uint32_t offset, uint32_t& lo, uint32_t& hi)  // find_value, table.rs:105-117
     {
-        uint32_t l = 0, k = 0;
-        for (; k < 16; k++) { const uint32_t x = s(k); if (l + x > offset) break; l += x; }
-        uint32_t e = 16 * k, h;
-        for (;;) { h = l + f(e); if (h > offset) break; l = h; e++; }
-        lo = l; hi = h;
-        return e;
+        uint32_t sk[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) sk[k] = s((uint32_t)k);
+        uint32_t c = 0, l = 0, kb = 0;                        // kb = first block whose cumulative end exceeds offset (16: the EOF entry)
+#pragma unroll
+        for (int k = 0; k < 16; k++) { c += sk[k]; const bool below = c <= offset; kb += below ? 1u : 0u; l = below ? c : l; }
+        const uint32_t e0 = 16u * kb;
+        uint32_t fe[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) { const uint32_t e = e0 + (uint32_t)j; fe[j] = f(e < ARI_N ? e : ARI_N - 1); }
+        uint32_t jb = 0, h = 0;
+        c = l;
+        bool found = false;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t nc = c + fe[j];
+            const bool hit = !found && nc > offset;
+            if (hit) { lo = c; h = nc; jb = (uint32_t)j; }
+            found = found || hit;
+            c = nc;
+        }
+        hi = h;
+        return e0 + jb;
     }
 };
 struct AriRange {                                              // RangeEncoder, mod.rs:67-91
@@ -462,6 +493,27 @@ struct AriRange {                                              // RangeEncoder, 
     }
 };
 
+// Sequential byte source for one lane: 8 bytes per global load, the next word requested 8 bytes ahead of its use
+// (a dependent byte load per symbol is ~1 us of latency per symbol).
+struct AriBytes {
+    const uint8_t* in; uint64_t n, p; uint64_t cw, nw;
+    __device__ __forceinline__ uint64_t load8(uint64_t q) const
+    {
+        if (q + 8 <= n) return *(const rcx_u64_u*)(in + q);
+        uint64_t w = 0;
+        for (uint64_t i = q; i < n; i++) w |= (uint64_t)in[i] << (8 * (i - q));
+        return w;
+    }
+    __device__ __forceinline__ void start(const uint8_t* in_, uint64_t n_) { in = in_; n = n_; p = 0; cw = 0; nw = load8(0); }
+    __device__ __forceinline__ uint32_t next()                 // caller checks p < n
+    {
+        if ((p & 7u) == 0) { cw = nw; nw = load8(p + 8); }
+        const uint32_t v = (uint32_t)(cw >> (8 * (p & 7u))) & 0xffu;
+        p++;
+        return v;
+    }
+};
+
 __global__ __launch_bounds__(64) void k_ari_byte(rcx_kargs a, int decode)
 {
     __shared__ uint16_t s_tab[ARI_N * 64];
@@ -478,9 +530,10 @@ __global__ __launch_bounds__(64) void k_ari_byte(rcx_kargs a, int decode)
     uint64_t o = 0, used = 0;
     int st = RCX_OK;
     uint8_t tmp[4];
+    AriBytes src; src.start(in, n);
     if (!decode) {                                             // ByteEncoder::write + finish, table.rs:203-219
         for (uint64_t i = 0; i <= n; i++) {
-            const uint32_t v = i < n ? in[i] : 256u;           // EOF symbol on finish()
+            const uint32_t v = i < n ? src.next() : 256u;      // EOF symbol on finish()
             uint32_t lo, hi;
             T.range_of(v, lo, hi);
             const unsigned k = R.process(T.total, lo, hi, tmp);
@@ -495,11 +548,11 @@ __global__ __launch_bounds__(64) void k_ari_byte(rcx_kargs a, int decode)
         }
         used = n;
     } else {                                                   // ByteDecoder::read to EOF + finish, table.rs:256-272
-        uint32_t code = 0; unsigned pending = 4; uint64_t p = 0;
+        uint32_t code = 0; unsigned pending = 4;
         for (;;) {
             while (pending) {                                  // feed(), mod.rs:271-278
-                if (p >= n) { st = RCX_E_MALFORMED; break; }   // mod.rs:282 feed().unwrap() panics
-                code = (code << 8) + in[p++]; pending--;
+                if (src.p >= n) { st = RCX_E_MALFORMED; break; }   // mod.rs:282 feed().unwrap() panics
+                code = (code << 8) + src.next(); pending--;
             }
             if (st) break;
             const uint32_t total = T.total;
@@ -514,6 +567,7 @@ __global__ __launch_bounds__(64) void k_ari_byte(rcx_kargs a, int decode)
             T.update(v);
             out[o++] = (uint8_t)v;
         }
+        uint64_t p = src.p;
         if (!st) { while (pending) { if (p >= n) { st = RCX_E_EOF; break; } p++; pending--; } }   // finish(), mod.rs:289-292
         used = p;
     }
@@ -521,10 +575,161 @@ __global__ __launch_bounds__(64) void k_ari_byte(rcx_kargs a, int decode)
 }
 
 // -------------------------------------------------------------------------------------------------
+// Same coder, one WAVE per stream (the pipeline has a few thousand long streams, not 64 K short ones: with one lane
+// per stream that is 60 waves on the whole chip, each paying ~250 dependent instructions per symbol).  The 256 byte
+// frequencies live in registers, 4 per lane (entry e in lane e>>2), the EOF entry and every coder variable are
+// wave-uniform; each lane keeps the cumulative frequency in front of its entries, patched by `add` after an update
+// (lanes above the updated one) and rebuilt by one DPP scan after a downscale.  (lo, hi) of a symbol are computed by
+// every lane and read from the owner with v_readlane; the decoder finds the owner with a ballot.  Input is held 64
+// bytes at a time across the lanes (next chunk prefetched), output is staged 64 bytes across the lanes and stored
+// coalesced.  All integers equal the reference's (table.rs:69-117, mod.rs:117-159).
+struct AriWave {
+    uint32_t f0, f1, f2, f3, base;        // per lane: entries 4*lane .. 4*lane+3 and the cumulative frequency before them
+    uint32_t f256, total;                 // uniform
+    unsigned lane;
+    __device__ void init() { f0 = f1 = f2 = f3 = 1; base = 4 * lane; f256 = 1; total = ARI_N; }
+    __device__ __forceinline__ void rescan()
+    {
+        const uint32_t sl = f0 + f1 + f2 + f3;
+        const uint32_t inc = rcx_wave_incl_scan(sl);
+        base = inc - sl;
+        total = RCX_UNI(__builtin_amdgcn_readlane(inc, 63)) + f256;
+    }
+    __device__ __forceinline__ void range_of(uint32_t v, uint32_t& lo, uint32_t& hi)      // v uniform
+    {
+        if (v == 256u) { lo = total - f256; hi = total; return; }
+        const uint32_t idx = v & 3u, lv = v >> 2;
+        const uint32_t l = base + (idx > 0 ? f0 : 0u) + (idx > 1 ? f1 : 0u) + (idx > 2 ? f2 : 0u);
+        const uint32_t fv = idx == 0 ? f0 : idx == 1 ? f1 : idx == 2 ? f2 : f3;
+        lo = RCX_UNI(__builtin_amdgcn_readlane(l, lv));
+        hi = lo + RCX_UNI(__builtin_amdgcn_readlane(fv, lv));
+    }
+    __device__ __forceinline__ uint32_t find(uint32_t offset, uint32_t& lo, uint32_t& hi)  // offset uniform, < total
+    {
+        const uint32_t c1 = base + f0, c2 = c1 + f1, c3 = c2 + f2, c4 = c3 + f3;
+        const unsigned long long own = __ballot(base <= offset && offset < c4);
+        if (!own) { lo = total - f256; hi = total; return 256u; }
+        const uint32_t lv = (uint32_t)__ffsll(own) - 1u;
+        const uint32_t idx = (c1 <= offset ? 1u : 0u) + (c2 <= offset ? 1u : 0u) + (c3 <= offset ? 1u : 0u);
+        const uint32_t l = idx == 0 ? base : idx == 1 ? c1 : idx == 2 ? c2 : c3;
+        const uint32_t h = idx == 0 ? c1 : idx == 1 ? c2 : idx == 2 ? c3 : c4;
+        lo = RCX_UNI(__builtin_amdgcn_readlane(l, lv));
+        hi = RCX_UNI(__builtin_amdgcn_readlane(h, lv));
+        return 4u * lv + RCX_UNI(__builtin_amdgcn_readlane(idx, lv));
+    }
+    __device__ __forceinline__ void update(uint32_t v)                                     // update(value, 10, 1), v < 256 uniform
+    {
+        const uint32_t add = (total >> 10) + 1, idx = v & 3u, lv = v >> 2;
+        const uint32_t mine = lane == lv ? add : 0u;
+        if (idx == 0) f0 += mine; else if (idx == 1) f1 += mine; else if (idx == 2) f2 += mine; else f3 += mine;
+        base += lane > lv ? add : 0u;
+        total += add;
+        if (total >= 4096) {                                  // downscale, table.rs:82-91 (cut_shift = 1)
+            f0 = (f0 + 1) >> 1; f1 = (f1 + 1) >> 1; f2 = (f2 + 1) >> 1; f3 = (f3 + 1) >> 1; f256 = (f256 + 1) >> 1;
+            rescan();
+        }
+    }
+};
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_ari_byte_wave(rcx_kargs a, int decode)
+{
+    const unsigned w = threadIdx.x >> 6, lane = rcx_lane();
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + w));
+    if (b >= a.nblocks) return;
+    AriWave T; T.lane = lane; T.init();
+    uint32_t low = 0, hai = 0xffffffffu;
+    const uint8_t* in = a.in_base + a.in_off[b];
+    const uint64_t n = a.in_len[b];
+    uint8_t* out = a.out_base + a.out_off[b];
+    const uint64_t cap = a.out_cap[b];
+    uint64_t o = 0, used = 0, p = 0;
+    int st = RCX_OK;
+    uint32_t obuf = 0;                                         // lane j: output byte (o & ~63) + j
+    // input window: lane j holds in[(p & ~63) + j]; `nxt` is the following 64 bytes, requested one window early
+    uint32_t cur = lane < n ? in[lane] : 0u, nxt = 64 + lane < n ? in[64 + lane] : 0u;
+#define ARIW_NEXT_BYTE(dst)                                                                             \
+    do {                                                                                                \
+        dst = RCX_UNI(__builtin_amdgcn_readlane(cur, (uint32_t)p & 63u));                               \
+        p++;                                                                                            \
+        if ((p & 63u) == 0) { cur = nxt; const uint64_t q = p + 64 + lane; nxt = q < n ? in[q] : 0u; }  \
+    } while (0)
+#define ARIW_PUT_BYTE(x)                                                                                \
+    do {                                                                                                \
+        obuf = lane == ((uint32_t)o & 63u) ? (x) : obuf;                                                \
+        o++;                                                                                            \
+        if ((o & 63u) == 0) out[o - 64 + lane] = (uint8_t)obuf;                                         \
+    } while (0)
+    // RangeEncoder::process, mod.rs:117-150, on wave-uniform values: emits 0..4 bytes
+#define ARIW_PROCESS(total_, from_, to_, EMIT)                                                          \
+    do {                                                                                                \
+        const uint32_t range_ = RCX_UNI((hai - low) / (total_));                                        \
+        uint32_t lo_ = low + range_ * (from_), hi_ = low + range_ * (to_);                              \
+        for (;;) {                                                                                      \
+            if (((lo_ ^ hi_) & 0xff000000u) != 0) {                                                     \
+                if (hi_ - lo_ > (1u << 14)) break;                                                      \
+                const uint32_t lim_ = hi_ & 0xff000000u;                                                \
+                if (hi_ - lim_ >= lim_ - lo_) lo_ = lim_; else hi_ = lim_ - 1;                          \
+            }                                                                                           \
+            EMIT(lo_ >> 24);                                                                            \
+            lo_ <<= 8; hi_ <<= 8;                                                                       \
+        }                                                                                               \
+        low = lo_; hai = hi_;                                                                           \
+    } while (0)
+    if (!decode) {                                             // ByteEncoder::write + finish, table.rs:203-219
+        for (uint64_t i = 0; i <= n && !st; i++) {
+            uint32_t v = 256u;                                 // EOF symbol on finish()
+            if (i < n) ARIW_NEXT_BYTE(v);
+            uint32_t lo, hi;
+            T.range_of(v, lo, hi);
+#define ARIW_EMIT_ENC(x) do { if (o >= cap) { st = RCX_E_OUTPUT_TOO_SMALL; } else { ARIW_PUT_BYTE(x); } } while (0)
+            ARIW_PROCESS(T.total, lo, hi, ARIW_EMIT_ENC);
+            if (st) break;
+            if (i < n) T.update(v);
+        }
+        if (!st) {                                             // Encoder::finish: 4-byte BE tail of `low`, mod.rs:230-237
+            if (o + 4 > cap) st = RCX_E_OUTPUT_TOO_SMALL;
+            else { ARIW_PUT_BYTE(low >> 24); ARIW_PUT_BYTE((low >> 16) & 0xffu); ARIW_PUT_BYTE((low >> 8) & 0xffu); ARIW_PUT_BYTE(low & 0xffu); }
+        }
+        used = n;
+    } else {                                                   // ByteDecoder::read to EOF + finish, table.rs:256-272
+        uint32_t code = 0; unsigned pending = 4;
+        for (;;) {
+            while (pending) {                                  // feed(), mod.rs:271-278
+                if (p >= n) { st = RCX_E_MALFORMED; break; }   // mod.rs:282 feed().unwrap() panics
+                uint32_t x; ARIW_NEXT_BYTE(x);
+                code = (code << 8) + x; pending--;
+            }
+            if (st) break;
+            const uint32_t total = T.total;
+            const uint32_t range = RCX_UNI((hai - low) / total);   // query(), mod.rs:153-159
+            const uint32_t offset = RCX_UNI((code - low) / range);
+            if (offset >= total) { st = RCX_E_MALFORMED; break; }  // table.rs:106 assert
+            uint32_t lo, hi;
+            const uint32_t v = T.find(offset, lo, hi);
+#define ARIW_EMIT_DEC(x) do { pending++; } while (0)
+            ARIW_PROCESS(total, lo, hi, ARIW_EMIT_DEC);
+            if (v == 256) break;
+            if (o >= cap) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
+            T.update(v);
+            ARIW_PUT_BYTE(v);
+        }
+        if (!st) { while (pending) { if (p >= n) { st = RCX_E_EOF; break; } p++; pending--; } }   // finish(), mod.rs:289-292
+        used = p;
+    }
+    if ((o & 63u) && lane < (o & 63u)) out[(o & ~(uint64_t)63) + lane] = (uint8_t)obuf;     // the staged tail
+    if (lane == 0) { a.status[b] = st; a.out_len[b] = o; if (a.in_used) a.in_used[b] = used; }
+#undef ARIW_NEXT_BYTE
+#undef ARIW_PUT_BYTE
+#undef ARIW_PROCESS
+#undef ARIW_EMIT_ENC
+#undef ARIW_EMIT_DEC
+}
+
+// -------------------------------------------------------------------------------------------------
 static void launch_serial(hipStream_t s, int codec, rcx_kargs& k, int v)
 {
     const uint32_t n = k.nblocks;
-    (void)v;
     switch (codec) {
     case RCX_MTF_ENCODE: hipLaunchKernelGGL((k_mtf<4>), dim3((n + 3) / 4), dim3(256), 0, s, k, 0); break;
     case RCX_MTF_DECODE: hipLaunchKernelGGL((k_mtf<4>), dim3((n + 3) / 4), dim3(256), 0, s, k, 1); break;
@@ -532,8 +737,14 @@ static void launch_serial(hipStream_t s, int codec, rcx_kargs& k, int v)
     case RCX_DC_DECODE: hipLaunchKernelGGL((k_dc_decode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k); break;
     case RCX_RLE_ENCODE: hipLaunchKernelGGL((k_rle_encode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k); break;
     case RCX_RLE_DECODE: hipLaunchKernelGGL((k_rle_decode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k); break;
-    case RCX_ARI_BYTE_ENCODE: hipLaunchKernelGGL(k_ari_byte, dim3((n + 63) / 64), dim3(64), 0, s, k, 0); break;
-    case RCX_ARI_BYTE_DECODE: hipLaunchKernelGGL(k_ari_byte, dim3((n + 63) / 64), dim3(64), 0, s, k, 1); break;
+    case RCX_ARI_BYTE_ENCODE: case RCX_ARI_BYTE_DECODE: {
+        // one wave per stream until there are enough streams to fill the chip with one LANE per stream (variant 1 / 2 pin it)
+        const int dec = codec == RCX_ARI_BYTE_DECODE ? 1 : 0;
+        const bool per_wave = v == 2 ? true : v == 1 ? false : n < 32768u;
+        if (per_wave) hipLaunchKernelGGL((k_ari_byte_wave<4>), dim3((n + 3) / 4), dim3(256), 0, s, k, dec);
+        else hipLaunchKernelGGL(k_ari_byte, dim3((n + 63) / 64), dim3(64), 0, s, k, dec);
+        break;
+    }
     default: break;
     }
 }

@@ -134,6 +134,10 @@ __device__ __forceinline__ void rcx_lds_store16(uint8_t* p, uint32_t v0, uint32_
 #define RCX_LDS_STORE16 rcx_lds_store16
 #endif
 
+#ifndef RCX_UNI
+#define RCX_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x)))   // wave-uniform value -> SGPR
+#endif
+
 // Cross-lane ordering inside one wave for traffic through LDS/global: hardware executes a wave's
 // memory instructions in order, so this only has to stop the COMPILER from reordering (no ISA emitted).
 __device__ __forceinline__ void rcx_wave_sync()

@@ -42,10 +42,18 @@ def test_mtf_rle_ari_dc(oracle):
     for (eo, es), s, o_ in zip(exp, st, outs):
         assert es == s and (s != 0 or eo == o_)
 
-    enc, _, _, st, _ = simrun.run(N.ARI_BYTE_ENCODE, 0, raws, [2 * n + 16 for n in lens])
-    assert not st.any() and enc == [oracle.ari_byte_encode(r) for r in raws]
-    dec, _, used, st, _ = simrun.run(N.ARI_BYTE_DECODE, 0, [e + b"xyz" for e in enc], lens)
-    assert not st.any() and dec == raws and list(used) == [len(e) for e in enc]   # stops exactly at the stream end
+    for variant in (1, 2):                         # one lane per stream, one wave per stream
+        enc, _, _, st, _ = simrun.run(N.ARI_BYTE_ENCODE, variant, raws, [2 * n + 16 for n in lens])
+        assert not st.any() and enc == [oracle.ari_byte_encode(r) for r in raws], variant
+        dec, _, used, st, _ = simrun.run(N.ARI_BYTE_DECODE, variant, [e + b"xyz" for e in enc], lens)
+        assert not st.any() and dec == raws and list(used) == [len(e) for e in enc], variant   # stops exactly at the stream end
+        # truncated / corrupted streams and short output slots: statuses as the oracle's
+        bad = [e[: max(0, len(e) - k)] for e in enc[:6] for k in (1, 3, 5)] + [bytes([255] * 40), b"", b"\x00\x01"]
+        caps = [len(r) // 2 + 1 for r in raws[:6] for _ in range(3)] + [100, 10, 10]
+        exp = [oracle.ari_byte_decode(b_, cap=c, raise_on_error=False) for b_, c in zip(bad, caps)]
+        outs, _, used, st, _ = simrun.run(N.ARI_BYTE_DECODE, variant, bad, caps)
+        for i, e in enumerate(exp):
+            assert e[-1] == st[i], (variant, i, e[-1], st[i])
 
     enc, _, _, st, _ = simrun.run(N.DC_ENCODE, 0, raws, [4 * (256 + n) for n in lens])
     assert not st.any() and enc == [oracle.dc_encode(r).tobytes() for r in raws]
