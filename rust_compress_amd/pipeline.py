@@ -31,7 +31,13 @@ class BwtDcAri:
         return self.torch.as_tensor(np.asarray(a, dtype=np.int64), device=self.dev)
 
     def _scratch(self, codec, nb, maxn):
-        return self.torch.empty(self.ctx.scratch_bytes(codec, nb, maxn) + 256, dtype=self.torch.uint8, device=self.dev)
+        """One scratch buffer per pipeline object, grown on demand: the suffix sort wants 48 B per input byte, and a
+        fresh 48 GB hipMalloc per call costs about a second."""
+        need = self.ctx.scratch_bytes(codec, nb, maxn) + 256
+        if getattr(self, "_sc", None) is None or self._sc.numel() < need:
+            self._sc = None
+            self._sc = self.torch.empty(need, dtype=self.torch.uint8, device=self.dev)
+        return self._sc
 
     def encode(self, raw, lens, keep_stages=False):
         """raw: uint8 tensor holding the blocks back to back; lens: block lengths (numpy).
@@ -46,7 +52,6 @@ class BwtDcAri:
                          self._i64(off), self._i64(lens))
         sc = self._scratch(N.BWT_FORWARD, nb, maxn)
         self.ctx.launch_dev(N.BWT_FORWARD, bw, sc)
-        del sc
         # 2. DC into the record slot, 12 bytes in (n, origin, k go in front)
         slot = (4 * (HDR_WORDS + 256 + maxn) + 63) // 64 * 64
         rec = torch.zeros(nb * slot + 64, dtype=torch.uint8, device=self.dev)
