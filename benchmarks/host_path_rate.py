@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the host-memory entry point (rcx_lz4_decode_batch with RCX_MEM_HOST) on the headline
+workload: descriptors and data on the host, one H2D of the compressed bytes + one D2H of the decoded bytes inside
+the call.  bench.py's `value` is the HBM-resident rate; this is the number DESIGN.md quotes beside it."""
+import ctypes as C
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import rust_compress_amd as R
+from rust_compress_amd import _native as N
+import bench
+
+dev = torch.device("cuda", 0)
+ctx = R.Context(0)
+nb = 4096
+dec, raw, cb, ob = bench.make_workload(R, ctx, torch, dev, "text", nb, 0x4C5A3401)
+u64 = lambda t: np.ascontiguousarray(t.cpu().numpy().astype(np.uint64))
+in_base = np.ascontiguousarray(dec.in_base.cpu().numpy())
+in_off, in_len, out_off, out_cap = u64(dec.in_off), u64(dec.in_len), u64(dec.out_off), u64(dec.out_cap)
+for pinned in (False, True):
+    if pinned:
+        inb = torch.from_numpy(in_base).pin_memory(); outb = torch.empty(nb * bench.BLOCK + 64, dtype=torch.uint8).pin_memory()
+        ip, op = inb.data_ptr(), outb.data_ptr()
+    else:
+        outn = np.zeros(nb * bench.BLOCK + 64, dtype=np.uint8)
+        ip, op = in_base.ctypes.data, outn.ctypes.data
+    out_len, in_used, status = np.zeros(nb, np.uint64), np.zeros(nb, np.uint64), np.zeros(nb, np.int32)
+    p = lambda a: a.ctypes.data
+    b = N.Batch(ip, p(in_off), p(in_len), op, p(out_off), p(out_cap), p(out_len), p(in_used), p(status), nb, N.MEM_HOST)
+    ts = []
+    for it in range(6):
+        t0 = time.perf_counter()
+        rc = N.lib().rcx_lz4_decode_batch(ctx._h, C.byref(b))
+        ts.append(time.perf_counter() - t0)
+    assert rc == 0 and not status.any()
+    got = outb.numpy() if pinned else outn
+    assert np.array_equal(got[: nb * bench.BLOCK], raw.cpu().numpy()[: nb * bench.BLOCK])
+    t = float(np.median(ts[1:]))
+    print("host path (%s host buffers): %.2f ms per 4096 x 64 KiB  -> %.1f GiB/s decoded, PCIe-inclusive (%.0f MB in, %.0f MB out)"
+          % ("pinned" if pinned else "pageable", t * 1e3, ob / t / 2**30, cb / 1e6, ob / 1e6))
