@@ -70,7 +70,13 @@ enum rcx_status {
     RCX_E_LZ4_MAGIC = 40,
     RCX_E_LZ4_VERSION = 41,
     /* lz4.rs:229-230: compression_bound() == None -> encode returns 0 */
-    RCX_E_LZ4_INPUT_TOO_LARGE = 42
+    RCX_E_LZ4_INPUT_TOO_LARGE = 42,
+    /* gzip member framing (RFC 1952; extension, see rcx_gzip_decode_batch) */
+    RCX_E_GZIP_MAGIC = 50,          /* ID1 ID2 != 1f 8b */
+    RCX_E_GZIP_METHOD = 51,         /* CM != 8 */
+    RCX_E_GZIP_FLAGS = 52,          /* reserved FLG bits set */
+    RCX_E_GZIP_CRC = 53,            /* CRC32 trailer mismatch */
+    RCX_E_GZIP_ISIZE = 54           /* ISIZE trailer mismatch */
 };
 
 /* ---- batch-level return codes --------------------------------------------- */
@@ -135,6 +141,13 @@ int rcx_zlib_decode_batch(rcx_ctx*, const rcx_batch*, uint32_t* flags);
 /* reference: src/checksum/adler.rs:22-51; out_len/out_base unused,
  * adler[i] = State32::result() of block i */
 int rcx_adler32_batch(rcx_ctx*, const rcx_batch*, uint32_t* adler);
+/* ---- extension beyond the reference ("gzip members" of BASELINE config 3) ----
+ * The reference has RFC 1950 (zlib) framing only, src/zlib.rs:55-126; these two follow its structure for RFC 1952.
+ * crc[i] = CRC-32 (IEEE 802.3, as in the gzip trailer) of block i; out_len/out_base unused. */
+int rcx_crc32_batch(rcx_ctx*, const rcx_batch*, uint32_t* crc);
+/* one gzip member per block: header (FEXTRA/FNAME/FCOMMENT/FHCRC skipped), DEFLATE stream decoded to BFINAL,
+ * CRC32 + ISIZE trailer verified; in_used[i] = bytes of the member.  flags as rcx_inflate_batch. */
+int rcx_gzip_decode_batch(rcx_ctx*, const rcx_batch*, uint32_t* flags);
 
 /* ---- BWT / MTF / DC --------------------------------------------------------- */
 /* reference: src/bwt/mod.rs:136-219 compute_suffixes + TransformIterator.
@@ -190,7 +203,7 @@ enum rcx_codec {
     RCX_LZ4_DECODE = 0, RCX_LZ4_ENCODE, RCX_INFLATE, RCX_ZLIB_DECODE, RCX_ADLER32,
     RCX_BWT_FORWARD, RCX_BWT_INVERSE, RCX_MTF_ENCODE, RCX_MTF_DECODE,
     RCX_DC_ENCODE, RCX_DC_DECODE, RCX_ARI_BYTE_ENCODE, RCX_ARI_BYTE_DECODE,
-    RCX_RLE_ENCODE, RCX_RLE_DECODE, RCX_CODEC_COUNT
+    RCX_RLE_ENCODE, RCX_RLE_DECODE, RCX_CRC32, RCX_GZIP_DECODE, RCX_CODEC_COUNT
 };
 /* scratch bytes (HBM) the codec needs for nblocks blocks of <= max_block bytes */
 uint64_t rcx_scratch_bytes(int codec, uint32_t nblocks, uint64_t max_block);

@@ -11,15 +11,18 @@ LIB_PATH = os.path.join(_HERE, "csrc", "librcx.so")
 
 # enum rcx_codec
 (LZ4_DECODE, LZ4_ENCODE, INFLATE, ZLIB_DECODE, ADLER32, BWT_FORWARD, BWT_INVERSE, MTF_ENCODE, MTF_DECODE,
- DC_ENCODE, DC_DECODE, ARI_BYTE_ENCODE, ARI_BYTE_DECODE, RLE_ENCODE, RLE_DECODE, CODEC_COUNT) = range(16)
+ DC_ENCODE, DC_DECODE, ARI_BYTE_ENCODE, ARI_BYTE_DECODE, RLE_ENCODE, RLE_DECODE, CRC32, GZIP_DECODE, CODEC_COUNT) = range(18)
 MEM_HOST, MEM_DEVICE = 0, 1
+# enum rcx_status (the ones Python code names; include/rcx.h has them all)
+E_EOF, E_OUTPUT_TOO_SMALL, E_MALFORMED = 1, 2, 3
+E_GZIP_MAGIC, E_GZIP_METHOD, E_GZIP_FLAGS, E_GZIP_CRC, E_GZIP_ISIZE = 50, 51, 52, 53, 54
 RC_OK, RC_BAD_ARG, RC_NO_DEVICE, RC_HIP_ERROR, RC_NO_MEMORY = 0, -1, -2, -3, -4
 
 EXPORTS = [
     "rcx_version", "rcx_ctx_create", "rcx_ctx_destroy", "rcx_ctx_set_stream", "rcx_ctx_set_variant", "rcx_last_error",
     "rcx_status_string", "rcx_lz4_decode_batch", "rcx_lz4_encode_batch", "rcx_lz4_compression_bound",
-    "rcx_inflate_batch", "rcx_zlib_decode_batch", "rcx_adler32_batch", "rcx_bwt_forward_batch",
-    "rcx_bwt_inverse_batch", "rcx_mtf_encode_batch", "rcx_mtf_decode_batch", "rcx_dc_encode_batch",
+    "rcx_inflate_batch", "rcx_zlib_decode_batch", "rcx_adler32_batch", "rcx_crc32_batch", "rcx_gzip_decode_batch",
+    "rcx_bwt_forward_batch", "rcx_bwt_inverse_batch", "rcx_mtf_encode_batch", "rcx_mtf_decode_batch", "rcx_dc_encode_batch",
     "rcx_dc_decode_batch", "rcx_ari_byte_encode_batch", "rcx_ari_byte_decode_batch", "rcx_ari_byte_encode_bound",
     "rcx_rle_encode_batch", "rcx_rle_decode_batch", "rcx_rle_encode_bound", "rcx_scratch_bytes", "rcx_launch_dev",
 ]
@@ -69,7 +72,8 @@ def lib():
                      "rcx_dc_encode_batch", "rcx_ari_byte_encode_batch", "rcx_ari_byte_decode_batch",
                      "rcx_rle_encode_batch", "rcx_rle_decode_batch"):
             getattr(L, name).argtypes = [C.c_void_p, C.POINTER(Batch)]
-        for name in ("rcx_inflate_batch", "rcx_zlib_decode_batch", "rcx_adler32_batch", "rcx_bwt_forward_batch",
+        for name in ("rcx_inflate_batch", "rcx_zlib_decode_batch", "rcx_adler32_batch", "rcx_crc32_batch",
+                     "rcx_gzip_decode_batch", "rcx_bwt_forward_batch",
                      "rcx_bwt_inverse_batch", "rcx_dc_decode_batch"):
             getattr(L, name).argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p]
         _lib = L

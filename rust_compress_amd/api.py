@@ -109,6 +109,14 @@ class Context:
     def adler32(self, blobs):
         return self._run_host("rcx_adler32_batch", blobs, None, extra_out=True, needs_out=False)
 
+    def crc32(self, blobs):
+        """CRC-32 as in the gzip trailer (extension beyond the reference)."""
+        return self._run_host("rcx_crc32_batch", blobs, None, extra_out=True, needs_out=False)
+
+    def gzip_decode(self, blobs, caps):
+        """One gzip member (RFC 1952) per blob: header, DEFLATE, CRC32 + ISIZE (extension)."""
+        return self._run_host("rcx_gzip_decode_batch", blobs, caps, extra_out=True)
+
     def bwt_forward(self, blobs):
         return self._run_host("rcx_bwt_forward_batch", blobs, [len(b) for b in blobs], extra_out=True)
 

@@ -260,6 +260,49 @@ class zlib:
             return self.r
 
 
+class gzip:
+    """RFC 1952 members on top of the same DEFLATE kernel.  EXTENSION: the reference has zlib framing only
+    (SURVEY.md 8f rank 3); the shape follows zlib::Decoder.  A stream of concatenated members decodes member by member
+    (the ISIZE trailer sizes each output exactly; CRC-32 is verified on the device)."""
+
+    class Decoder(_BufferedDecoder):
+        def _decode_all(self, data):
+            out, pos = [], 0
+            self.members = 0
+            while pos < len(data):
+                member = data[pos:]
+                cap = 1 << 16
+                while True:
+                    res = context().gzip_decode([member], [cap])
+                    if res.status[0] == 2 and cap < (1 << 31):
+                        cap *= 8
+                        continue
+                    break
+                _check(res)
+                out.append(res.outputs[0])
+                pos += int(res.in_used[0])
+                self.members += 1
+            self.consumed = pos
+            return b"".join(out)
+
+        def unwrap(self):
+            return self.r
+
+
+class Crc32:                                           # extension, mirrors Adler32 below
+    def __init__(self):
+        self.reset()
+
+    def feed(self, buf):
+        self._data += bytes(buf)
+
+    def result(self):
+        return int(context().crc32([bytes(self._data)]).aux[0])
+
+    def reset(self):
+        self._data = bytearray()
+
+
 class Adler32:                                         # checksum/adler.rs:22-51
     def __init__(self):
         self.reset()

@@ -18,6 +18,8 @@
 #include "k_bwt.hip"
 #include "k_bwt_inverse.hip"
 #include "k_serial.hip"
+#include "k_crc32.hip"
+#include "k_gzip.hip"
 
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
@@ -118,6 +120,11 @@ extern "C" const char* rcx_status_string(int s)
     case RCX_E_LZ4_MAGIC: return "";
     case RCX_E_LZ4_VERSION: return "";
     case RCX_E_LZ4_INPUT_TOO_LARGE: return "input too large";
+    case RCX_E_GZIP_MAGIC: return "not a gzip member";
+    case RCX_E_GZIP_METHOD: return "unsupported gzip compression method";
+    case RCX_E_GZIP_FLAGS: return "reserved gzip flags set";
+    case RCX_E_GZIP_CRC: return "invalid CRC-32 on gzip member";
+    case RCX_E_GZIP_ISIZE: return "invalid length on gzip member";
     default: return "unknown status";
     }
 }
@@ -135,6 +142,7 @@ extern "C" uint64_t rcx_scratch_bytes(int codec, uint32_t nblocks, uint64_t max_
     case RCX_LZ4_ENCODE: return (uint64_t)(nblocks < LZ4E_CHUNK ? nblocks : LZ4E_CHUNK) * LZ4E_TABLE * 4ull;
     case RCX_BWT_FORWARD: return bwt_forward_scratch_bytes(nblocks, max_block);
     case RCX_BWT_INVERSE: return bwt_inverse_scratch_bytes(nblocks, max_block);
+    case RCX_GZIP_DECODE: return gzip_scratch_bytes(nblocks);
     default: return 0;
     }
 }
@@ -178,6 +186,13 @@ static int launch_codec(rcx_ctx* c, int codec, rcx_kargs& k)
         break;
     case RCX_ADLER32:
         launch_adler32(s, k);
+        break;
+    case RCX_CRC32:
+        launch_crc32(s, k);
+        break;
+    case RCX_GZIP_DECODE:
+        if (k.scratch_bytes < gzip_scratch_bytes(n)) { c->err = "gzip decode: scratch too small"; return RCX_RC_BAD_ARG; }
+        launch_gzip_decode(s, k, v);
         break;
     case RCX_BWT_FORWARD: {
         int rc = launch_bwt_forward(s, k, v, c->err);
@@ -295,6 +310,8 @@ extern "C" int rcx_lz4_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run
 extern "C" int rcx_inflate_batch(rcx_ctx* c, const rcx_batch* b, uint32_t* flags) { return run_batch(c, RCX_INFLATE, b, nullptr, flags, nullptr, true); }
 extern "C" int rcx_zlib_decode_batch(rcx_ctx* c, const rcx_batch* b, uint32_t* flags) { return run_batch(c, RCX_ZLIB_DECODE, b, nullptr, flags, nullptr, true); }
 extern "C" int rcx_adler32_batch(rcx_ctx* c, const rcx_batch* b, uint32_t* adler) { return run_batch(c, RCX_ADLER32, b, nullptr, adler, nullptr, false); }
+extern "C" int rcx_crc32_batch(rcx_ctx* c, const rcx_batch* b, uint32_t* crc) { return run_batch(c, RCX_CRC32, b, nullptr, crc, nullptr, false); }
+extern "C" int rcx_gzip_decode_batch(rcx_ctx* c, const rcx_batch* b, uint32_t* flags) { return run_batch(c, RCX_GZIP_DECODE, b, nullptr, flags, nullptr, true); }
 extern "C" int rcx_bwt_forward_batch(rcx_ctx* c, const rcx_batch* b, uint32_t* origin) { return run_batch(c, RCX_BWT_FORWARD, b, nullptr, origin, nullptr, true); }
 extern "C" int rcx_bwt_inverse_batch(rcx_ctx* c, const rcx_batch* b, const uint32_t* origin) { return run_batch(c, RCX_BWT_INVERSE, b, origin, nullptr, nullptr, true); }
 extern "C" int rcx_mtf_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_MTF_ENCODE, b, nullptr, nullptr, nullptr, true); }

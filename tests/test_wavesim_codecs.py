@@ -101,3 +101,46 @@ def test_bwt_inverse(oracle):
     outs, _, _, st, _ = simrun.run(N.BWT_INVERSE, 0, list(Ls), [len(r) for r in raws], aux=np.array(orgs, dtype=np.uint32),
                                    scratch_bytes=len(raws) * ((maxn * 4 + 255) & ~255) + 256)
     assert not st.any() and outs == raws
+
+
+def _gzip_members(raws):
+    """gzip members with every optional header field (RFC 1952), made with Python's gzip/zlib (the checker here:
+    the reference crate has no gzip code, see include/rcx.h)."""
+    import gzip, struct
+    out = []
+    for i, r in enumerate(raws):
+        plain = gzip.compress(r, compresslevel=(1, 6, 9)[i % 3], mtime=0)
+        if i % 4 == 0:
+            out.append(plain)
+            continue
+        body = plain[10:]                                        # deflate stream + CRC32 + ISIZE
+        flg, hdr = 0, b""
+        if i % 4 in (1, 3):
+            flg |= 4; x = b"ab" + struct.pack("<H", 3) + b"xyz"; hdr += struct.pack("<H", len(x)) + x      # FEXTRA
+        if i % 4 in (2, 3):
+            flg |= 8 | 16; hdr += b"name.txt\0" + b"a comment\0"                                          # FNAME, FCOMMENT
+        if i % 4 == 3:
+            flg |= 2; hdr += b"\x12\x34"                                                                   # FHCRC (skipped)
+        out.append(b"\x1f\x8b\x08" + bytes([flg]) + plain[4:10] + hdr + body)
+    return out
+
+
+def test_crc32_gzip(golden):
+    import gzip
+    import simrun
+    raws = corpus.small_corpus(sizes=(17, 63, 64, 65, 1000, 40000)) + [golden("test.txt"), b"x" * 70000]
+    _, _, _, st, aux = simrun.run(N.CRC32, 0, raws, [0] * len(raws))
+    assert not st.any() and list(aux[: len(raws)]) == [zlib.crc32(r) for r in raws]
+    gz = _gzip_members(raws)
+    for g, r in zip(gz, raws):
+        assert gzip.decompress(g) == r                           # the members are valid for the independent decoder
+    outs, _, used, st, _ = simrun.run(N.GZIP_DECODE, 0, [g + b"tail" for g in gz], [len(r) for r in raws],
+                                      scratch_bytes=48 * len(gz) + 256)
+    assert not st.any() and outs == raws and list(used) == [len(g) for g in gz]
+    # framing errors
+    g0 = gz[4]
+    bad = [b"\x1f\x8c" + g0[2:], g0[:2] + b"\x07" + g0[3:], g0[:3] + b"\x20" + g0[4:], g0[:-8] + bytes(4) + g0[-4:],
+           g0[:-4] + bytes(4), g0[:-3], g0[:5], b""]
+    exp = [N.E_GZIP_MAGIC, N.E_GZIP_METHOD, N.E_GZIP_FLAGS, N.E_GZIP_CRC, N.E_GZIP_ISIZE, N.E_EOF, N.E_EOF, N.E_EOF]
+    _, _, _, st, _ = simrun.run(N.GZIP_DECODE, 0, bad, [len(raws[4])] * len(bad), scratch_bytes=48 * len(bad) + 256)
+    assert list(st) == exp

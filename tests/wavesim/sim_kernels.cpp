@@ -9,6 +9,8 @@
 #include "../../rust_compress_amd/csrc/k_serial.hip"
 #include "../../rust_compress_amd/csrc/k_inflate.hip"
 #include "../../rust_compress_amd/csrc/k_inflate2.hip"
+#include "../../rust_compress_amd/csrc/k_crc32.hip"
+#include "../../rust_compress_amd/csrc/k_gzip.hip"
 #define hipSuccess 0
 #define hipMemcpyDeviceToHost 0
 static inline int hipMemcpyAsync(void* d, const void* s, size_t n, int, int) { memcpy(d, s, n); return 0; }
@@ -41,6 +43,8 @@ extern "C" int sim_launch(int codec, int variant, const rcx_kargs* a)
     case RCX_INFLATE: launch_inflate(0, k, false, variant); return 0;
     case RCX_ZLIB_DECODE: launch_inflate(0, k, true, variant); return 0;
     case RCX_ADLER32: launch_adler32(0, k); return 0;
+    case RCX_CRC32: launch_crc32(0, k); return 0;
+    case RCX_GZIP_DECODE: launch_gzip_decode(0, k, variant); return 0;
     case RCX_BWT_INVERSE: { std::string err; int st = 0; return launch_bwt_inverse(st, k, variant, err); }
     default:
         return -1;
