@@ -59,7 +59,8 @@ def main():
             base, off, lens = B.pack(members)
             ar = np.arange(nb, dtype=np.int64)
             db = R.DeviceBatch.from_host(base, off, lens, nb * BLOCK, (ar * BLOCK).astype(np.uint64), np.full(nb, BLOCK, dtype=np.uint64), dev)
-            t = timeit(lambda: ctx.launch_dev(N.ZLIB_DECODE, db), torch)
+            sc = torch.empty(ctx.scratch_bytes(N.ZLIB_DECODE, nb, BLOCK) + 256, dtype=torch.uint8, device=dev)
+            t = timeit(lambda: ctx.launch_dev(N.ZLIB_DECODE, db, sc), torch)
             assert int(db.status[:nb].abs().max()) == 0 and torch.equal(db.out_base[: nb * BLOCK].cpu(), torch.from_numpy(raw_np))
             alg = int(lens.sum()) + nb * BLOCK
             print(json.dumps({"config": 3, "workload": "zlib decode, %d members x 16 KiB (G-text, levels 1/6/9)" % nb, "GiB/s": round(nb * BLOCK / t / 2**30, 2),

@@ -105,6 +105,8 @@ static void launch_gzip_decode(hipStream_t s, rcx_kargs& k, int v)
     hipLaunchKernelGGL(k_gzip_head, dim3((n + 255) / 256), dim3(256), 0, s, k, g);
     rcx_kargs ki = k;                                      // the raw DEFLATE payloads
     ki.in_off = g.off2; ki.in_len = g.len2; ki.in_used = g.used2; ki.status = g.st_infl; ki.aux = g.fl;
+    ki.scratch = (uint8_t*)k.scratch + ((gzip_scratch_bytes(n) + 255) & ~255ull);                     // the inflate path's own scratch
+    ki.scratch_bytes = k.scratch_bytes > gzip_scratch_bytes(n) + 256 ? k.scratch_bytes - gzip_scratch_bytes(n) - 256 : 0;
     launch_inflate(s, ki, false, v);
     rcx_kargs kc = k;                                      // CRC-32 of what was decoded
     kc.in_base = k.out_base; kc.in_off = k.out_off; kc.in_len = k.out_len; kc.out_len = nullptr; kc.in_used = nullptr;

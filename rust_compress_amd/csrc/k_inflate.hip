@@ -327,30 +327,61 @@ __global__ __launch_bounds__(64 * WAVES) void k_adler32(rcx_kargs a)
         const uint32_t ra = (1u + sa) % 65521u;
         const uint32_t rb = (uint32_t)((n % 65521u + sb) % 65521u);
         if (a.aux) a.aux[b] = (rb << 16) | ra;
-        a.status[b] = RCX_OK;
+        if (a.status) a.status[b] = RCX_OK;
         if (a.out_len) a.out_len[b] = 0;
         if (a.in_used) a.in_used[b] = n;
     }
 }
 
 template <int SPW, int LG, int MINW> __global__ void k_inflate2(rcx_kargs a, int zlib);
+template <int CB> __global__ void k_inflate3(rcx_kargs a, int zlib);
+__global__ void k_zlib_tail3(rcx_kargs a, const uint32_t* adler);
+template <int WAVES> __global__ void k_adler32(rcx_kargs a);
+
+// one lane per stream (k_inflate2); `flags`: bit 0 zlib framing, bit 1 only the blocks k_inflate3 handed back
+static void launch_inflate2(hipStream_t s, rcx_kargs& k, int flags, int v)
+{
+    // streams per wave: the largest of 32/16/8 that still gives 2048 waves (measured: benchmarks/inflate_spw_sweep.py;
+    // full waves are never the fastest); variants 2..5 pin it (A/B)
+    const uint32_t n = k.nblocks;
+    int spw = v == 2 ? 64 : v == 3 ? 32 : v == 4 ? 16 : v == 5 ? 8 : (n >= 32u * 2048u ? 32 : n >= 16u * 2048u ? 16 : 8);
+    const int z = flags;
+    if (v == 6) hipLaunchKernelGGL((k_inflate2<16, 4, 4>), dim3((n + 15) / 16), dim3(16), 0, s, k, z);
+    else if (v == 7) hipLaunchKernelGGL((k_inflate2<32, 5, 3>), dim3((n + 31) / 32), dim3(32), 0, s, k, z);
+    else if (v == 8) hipLaunchKernelGGL((k_inflate2<16, 4, 3>), dim3((n + 15) / 16), dim3(16), 0, s, k, z);
+    else if (spw == 64) hipLaunchKernelGGL((k_inflate2<64, 6, 1>), dim3((n + 63) / 64), dim3(64), 0, s, k, z);
+    else if (spw == 32) hipLaunchKernelGGL((k_inflate2<32, 5, 1>), dim3((n + 31) / 32), dim3(32), 0, s, k, z);
+    else if (spw == 16) hipLaunchKernelGGL((k_inflate2<16, 4, 1>), dim3((n + 15) / 16), dim3(16), 0, s, k, z);
+    else hipLaunchKernelGGL((k_inflate2<8, 3, 1>), dim3((n + 7) / 8), dim3(8), 0, s, k, z);
+}
+
+static constexpr uint32_t INF3_MAX_STREAMS = 32768;
+// scratch the default path wants: Adler-32 values (zlib) and a stand-in for a null in_used
+static uint64_t inflate_scratch_bytes(uint32_t nblocks) { return 12ull * nblocks + 256; }
+
+// Variant 0: one wave per stream (k_inflate3), then k_inflate2 over the blocks it handed back (every error status and
+// every unusual stream comes from the kernel that reproduces the reference case by case).  Variants 1..8: k_inflate /
+// k_inflate2 only; 9: k_inflate2 with its automatic geometry.  Without the scratch (older callers) variant 0 is 9.
 static void launch_inflate(hipStream_t s, rcx_kargs& k, bool zlib, int v)
 {
-    if (v == 1) hipLaunchKernelGGL(k_inflate, dim3((k.nblocks + 63) / 64), dim3(64), 0, s, k, zlib ? 1 : 0);   // first version (A/B)
-    else {
-        // streams per wave: the largest of 32/16/8 that still gives 2048 waves (measured: benchmarks/inflate_spw_sweep.py;
-        // full waves are never the fastest); variants 2..5 pin it (A/B)
-        const uint32_t n = k.nblocks;
-        int spw = v == 2 ? 64 : v == 3 ? 32 : v == 4 ? 16 : v == 5 ? 8 : (n >= 32u * 2048u ? 32 : n >= 16u * 2048u ? 16 : 8);
-        const int z = zlib ? 1 : 0;
-        if (v == 6) hipLaunchKernelGGL((k_inflate2<16, 4, 4>), dim3((n + 15) / 16), dim3(16), 0, s, k, z);
-        else if (v == 7) hipLaunchKernelGGL((k_inflate2<32, 5, 3>), dim3((n + 31) / 32), dim3(32), 0, s, k, z);
-        else if (v == 8) hipLaunchKernelGGL((k_inflate2<16, 4, 3>), dim3((n + 15) / 16), dim3(16), 0, s, k, z);
-        else if (spw == 64) hipLaunchKernelGGL((k_inflate2<64, 6, 1>), dim3((n + 63) / 64), dim3(64), 0, s, k, z);
-        else if (spw == 32) hipLaunchKernelGGL((k_inflate2<32, 5, 1>), dim3((n + 31) / 32), dim3(32), 0, s, k, z);
-        else if (spw == 16) hipLaunchKernelGGL((k_inflate2<16, 4, 1>), dim3((n + 15) / 16), dim3(16), 0, s, k, z);
-        else hipLaunchKernelGGL((k_inflate2<8, 3, 1>), dim3((n + 7) / 8), dim3(8), 0, s, k, z);
+    const uint32_t n = k.nblocks;
+    if (v == 1) { hipLaunchKernelGGL(k_inflate, dim3((n + 63) / 64), dim3(64), 0, s, k, zlib ? 1 : 0); return; }   // first version (A/B)
+    // one wave per stream wins while the streams are few (it needs ~12 waves per CU, not 12 x 64 streams per CU): measured
+    // crossover around 32768 streams of 16 KiB (benchmarks/inflate_spw_sweep.py); variant 10 forces it, 9 forces k_inflate2
+    const bool wave_per_stream = v == 10 || (v == 0 && n < INF3_MAX_STREAMS);
+    if (!wave_per_stream || k.scratch == nullptr || k.scratch_bytes < inflate_scratch_bytes(n)) { launch_inflate2(s, k, zlib ? 1 : 0, (v == 9 || v == 10) ? 0 : v); return; }
+    rcx_kargs k3 = k;
+    uint32_t* adler = (uint32_t*)k.scratch;
+    if (!k3.in_used) k3.in_used = (uint64_t*)((uint8_t*)k.scratch + ((4ull * n + 63) & ~63ull));
+    hipLaunchKernelGGL((k_inflate3<1024>), dim3(n), dim3(64), 0, s, k3, zlib ? 1 : 0);
+    if (zlib) {
+        rcx_kargs ka = k3;
+        ka.in_base = k3.out_base; ka.in_off = k3.out_off; ka.in_len = k3.out_len; ka.out_len = nullptr; ka.in_used = nullptr;
+        ka.status = nullptr; ka.aux = adler;
+        hipLaunchKernelGGL((k_adler32<4>), dim3((n + 3) / 4), dim3(256), 0, s, ka);
+        hipLaunchKernelGGL(k_zlib_tail3, dim3((n + 255) / 256), dim3(256), 0, s, k3, adler);
     }
+    if (v != 10) launch_inflate2(s, k, (zlib ? 1 : 0) | 2, 0);                      // 10: A/B, shows what the first pass handed back
 }
 static void launch_adler32(hipStream_t s, rcx_kargs& k)
 {

@@ -367,6 +367,8 @@ __global__ __launch_bounds__(64, MINW) void k_inflate2(rcx_kargs a, int zlib)
     const unsigned t = threadIdx.x;
     const uint32_t b = blockIdx.x * SPW + t;
     if (b >= a.nblocks) return;
+    if ((zlib & 2) && a.status[b] != 0x7ff00001) return;                   // second pass: only what k_inflate3 handed back
+    zlib &= 1;
     F2 s;
     s.lg = LG;
     s.lsym = s_mem; s.lbit = (uint32_t*)(s_mem + 288 * SPW); s.dsym = s_mem + 288 * SPW + 9 * 4 * SPW;

@@ -81,7 +81,10 @@ struct Lz4V5 : Lz4V4<CB, false> {
     // ------------------------------------------------------------------------------------------ executor wave
     // One batch: lane i holds entry i's descriptor (w0 = literal source position, w1 = L | M << 8 | offset << 16).
     // Entries [lo, hi) as in Lz4V4::emit (hi < ns only when the batch's output exceeds TCAP bytes); advances lo.
-    __device__ int emit5(int ns, int& lo, uint32_t w0, uint32_t w1)
+    // LITLDS: the literal bytes sit in an LDS buffer (`litbuf`, with 32 bytes of slack) instead of the input in HBM --
+    // that is how the inflate front end (k_inflate3.hip) feeds this executor.
+    template <bool LITLDS = false>
+    __device__ int emit5(int ns, int& lo, uint32_t w0, uint32_t w1, const uint8_t* litbuf = nullptr)
     {
         const unsigned lane = this->lane;
         const uint8_t* in = this->in; uint8_t* out = this->out; uint8_t* wb_ = this->wb_;
@@ -123,9 +126,19 @@ struct Lz4V5 : Lz4V4<CB, false> {
 
         // ---- loads first: literals (parser staged them a moment ago: L2 hits) and old matches, 16 bytes each
         rcx_u32x4 g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0};
-        const bool lit16 = L && (uint64_t)src + 32u <= (uint64_t)n;
+        const bool lit16 = L && (LITLDS || (uint64_t)src + 32u <= (uint64_t)n);
         const bool litb = L && !lit16;                               // within 32 bytes of the block's end: byte loads
-        if (lit16) { g0 = *(const rcx_u32x4_u*)(in + src); if (L > 16) g1 = *(const rcx_u32x4_u*)(in + src + 16); }
+        if (LITLDS) {
+            if (__ballot(lit16)) {
+                const uint8_t* q = litbuf + (lit16 ? src : 0u);
+                const uint64_t x0 = *(const rcx_u64_u*)q, x1 = *(const rcx_u64_u*)(q + 8);
+                g0 = rcx_u32x4{(uint32_t)x0, (uint32_t)(x0 >> 32), (uint32_t)x1, (uint32_t)(x1 >> 32)};
+                if (__ballot(lit16 && L > 16)) {
+                    const uint64_t y0 = *(const rcx_u64_u*)(q + 16), y1 = *(const rcx_u64_u*)(q + 24);
+                    g1 = rcx_u32x4{(uint32_t)y0, (uint32_t)(y0 >> 32), (uint32_t)y1, (uint32_t)(y1 >> 32)};
+                }
+            }
+        } else if (lit16) { g0 = *(const rcx_u32x4_u*)(in + src); if (L > 16) g1 = *(const rcx_u32x4_u*)(in + src + 16); }
         rcx_u32x4 f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0}, f2 = {0, 0, 0, 0}, f3 = {0, 0, 0, 0};
         const bool far16 = isfar && (uint64_t)slo + (uint32_t)B::MCAP <= (uint64_t)cap;
         const bool farb = isfar && !far16;

@@ -15,6 +15,7 @@
 #include "k_lz4_encode.hip"
 #include "k_inflate.hip"
 #include "k_inflate2.hip"
+#include "k_inflate3.hip"
 #include "k_bwt.hip"
 #include "k_bwt_inverse.hip"
 #include "k_serial.hip"
@@ -142,7 +143,8 @@ extern "C" uint64_t rcx_scratch_bytes(int codec, uint32_t nblocks, uint64_t max_
     case RCX_LZ4_ENCODE: return (uint64_t)(nblocks < LZ4E_CHUNK ? nblocks : LZ4E_CHUNK) * LZ4E_TABLE * 4ull;
     case RCX_BWT_FORWARD: return bwt_forward_scratch_bytes(nblocks, max_block);
     case RCX_BWT_INVERSE: return bwt_inverse_scratch_bytes(nblocks, max_block);
-    case RCX_GZIP_DECODE: return gzip_scratch_bytes(nblocks);
+    case RCX_INFLATE: case RCX_ZLIB_DECODE: return inflate_scratch_bytes(nblocks);
+    case RCX_GZIP_DECODE: return gzip_scratch_bytes(nblocks) + inflate_scratch_bytes(nblocks);
     default: return 0;
     }
 }

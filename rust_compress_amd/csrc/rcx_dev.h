@@ -138,6 +138,13 @@ __device__ __forceinline__ void rcx_lds_store16(uint8_t* p, uint32_t v0, uint32_
 #define RCX_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x)))   // wave-uniform value -> SGPR
 #endif
 
+// Launder a wave-uniform value into a VGPR so that what is computed from it runs on the (idle) vector ALU instead of
+// the CU's single scalar unit; decisions come back through __ballot.  The wave simulator defines it as the identity.
+#ifndef RCX_VGPR
+__device__ __forceinline__ uint32_t rcx_vgpr(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
+#define RCX_VGPR(x) rcx_vgpr(x)
+#endif
+
 // Cross-lane ordering inside one wave for traffic through LDS/global: hardware executes a wave's
 // memory instructions in order, so this only has to stop the COMPILER from reordering (no ISA emitted).
 __device__ __forceinline__ void rcx_wave_sync()

@@ -61,10 +61,16 @@ def test_mtf_rle_ari_dc(oracle):
     assert not st.any() and dec == raws
 
 
+def synth_dna(n):
+    from rust_compress_amd import synth
+    return synth.gen("dna4", n, 5).tobytes()
+
+
 def test_inflate_zlib_adler(oracle, golden):
     import simrun
     txt = golden("test.txt")
     raws = corpus.small_corpus(sizes=(17, 1000, 40000))
+    raws.append(synth_dna(120000))                  # far matches, long distance codes, several dynamic blocks
     zs, exp = [], []
     for r in raws:
         for lvl in (0, 1, 6, 9):
@@ -73,19 +79,20 @@ def test_inflate_zlib_adler(oracle, golden):
         zs.append(c.compress(r) + c.flush()); exp.append(r)
     for i in range(10):
         zs.append(golden("test.z.%d" % i)); exp.append(txt)
-    for variant in (0, 2, 3, 4, 1):                 # auto (8 streams per wave here), 64, 32, 16, first kernel
-        outs, _, used, st, _ = simrun.run(N.ZLIB_DECODE, variant, zs, [len(e) for e in exp])
+    sb = 12 * (len(zs) + 1) + 256                  # variant 0 = wave-per-stream kernel + exact fallback: wants scratch
+    for variant in (0, 9, 2, 3, 4, 1):              # ..., lane-per-stream auto (8 streams per wave here), 64, 32, 16, first kernel
+        outs, _, used, st, _ = simrun.run(N.ZLIB_DECODE, variant, zs, [len(e) for e in exp], scratch_bytes=sb)
         assert not st.any() and outs == exp and list(used) == [len(z) for z in zs], variant
     raw = [z[2:-4] for z in zs] + [golden("test.z.go")]
-    outs, _, _, st, aux = simrun.run(N.INFLATE, 0, raw, [len(e) for e in exp] + [len(txt)])
+    outs, _, _, st, aux = simrun.run(N.INFLATE, 0, raw, [len(e) for e in exp] + [len(txt)], scratch_bytes=sb)
     assert not st.any() and outs == exp + [txt] and aux[len(raw) - 1] == 1
     blobs, caps = corpus.mutate(zs, 300, 2, [50, 3000, 50000])
     ex = [oracle.zlib_decode(b, cap=c, raise_on_error=False) for b, c in zip(blobs, caps)]
-    outs, _, used, st, _ = simrun.run(N.ZLIB_DECODE, 0, blobs, caps)
+    outs, _, used, st, _ = simrun.run(N.ZLIB_DECODE, 0, blobs, caps, scratch_bytes=12 * len(blobs) + 256)
     for i, e in enumerate(ex):
         assert e[-1] == st[i] and e[1] == used[i] and (st[i] != 0 or e[0] == outs[i]), i
     ex = [oracle.inflate(b, cap=c, raise_on_error=False) for b, c in zip(blobs, caps)]
-    outs, _, used, st, _ = simrun.run(N.INFLATE, 0, blobs, caps)
+    outs, _, used, st, _ = simrun.run(N.INFLATE, 0, blobs, caps, scratch_bytes=12 * len(blobs) + 256)
     for i, e in enumerate(ex):
         assert e[-1] == st[i] and e[1] == used[i] and e[0] == outs[i], i
     big = raws + [b"x" * 70000]

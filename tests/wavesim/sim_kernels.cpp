@@ -9,6 +9,7 @@
 #include "../../rust_compress_amd/csrc/k_serial.hip"
 #include "../../rust_compress_amd/csrc/k_inflate.hip"
 #include "../../rust_compress_amd/csrc/k_inflate2.hip"
+#include "../../rust_compress_amd/csrc/k_inflate3.hip"
 #include "../../rust_compress_amd/csrc/k_crc32.hip"
 #include "../../rust_compress_amd/csrc/k_gzip.hip"
 #define hipSuccess 0

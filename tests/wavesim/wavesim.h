@@ -242,7 +242,50 @@ static inline void ws_lds_store16(uint8_t* p, uint32_t v0, uint32_t v1, uint32_t
     const uint32_t v[4] = {v0, v1, v2, v3};
     for (uint32_t i = 0; i < nv && i < 16; i++) p[i] = (uint8_t)(v[i >> 2] >> (8 * (i & 3)));
 }
+
+// portable version of k_inflate3.hip's hand-written symbol pass (same contract; LDS "addresses" are host pointers' low bits
+// there, so the simulator passes real pointers through a side channel: see RCX_LDSADDR below)
+static inline void ws_inf_run(uint32_t& lo, uint32_t& hi, uint32_t& bc, uint32_t& off, uint32_t& cnt, uint32_t& litv, uint32_t& len,
+                              uint32_t& dist, uint32_t& status, uint32_t room, uint32_t lim, uint32_t lane, const uint8_t* cb,
+                              const uint16_t* lutL, const uint16_t* lutD, const uint32_t* ltab, const uint32_t* dtab)
+{
+    uint64_t bb = ((uint64_t)hi << 32) | lo;
+    auto refill = [&] { if (bc <= 32) { uint64_t w; memcpy(&w, cb + off, 8); bb |= w << bc; bc += 32; off += 4; } };
+    len = 0; dist = 0; status = 0;
+    for (;;) {
+        if (off > lim || cnt >= room) break;
+        refill();
+        uint32_t e = lutL[bb & 0x1ff];
+        if (e <= 0x7fff) {
+            const uint32_t l = e & 15; bb >>= l; bc -= l;
+            if (lane == cnt) litv = e >> 4;
+            cnt++;
+            continue;
+        }
+        uint32_t l = e & 15;
+        if (l == 0) { status = 3; break; }
+        uint32_t sym = (e >> 4) & 0x7ff;
+        if (sym == 256) { bb >>= l; bc -= l; status = 2; break; }
+        const uint32_t nn = sym - 257;
+        if (nn > 28) { status = 3; break; }
+        bb >>= l; bc -= l;
+        uint32_t t = ltab[nn], xb = t >> 16;
+        len = (t & 0xffff) + ((uint32_t)bb & ((1u << xb) - 1u)); bb >>= xb; bc -= xb;
+        refill();
+        e = lutD[bb & 0x1ff]; l = e & 15;
+        const uint32_t d = (e >> 4) & 0x7ff;
+        if (l == 0 || d > 29) { status = 5; break; }
+        bb >>= l; bc -= l;
+        t = dtab[d]; xb = t >> 16;
+        dist = (t & 0xffff) + ((uint32_t)bb & ((1u << xb) - 1u)); bb >>= xb; bc -= xb;
+        status = 1;
+        break;
+    }
+    lo = (uint32_t)bb; hi = (uint32_t)(bb >> 32);
+}
 #define RCX_LDS_STORE16 ws_lds_store16
+#define RCX_INF_RUN_CALL ws_inf_run
+#define RCX_VGPR(x) ((uint32_t)(x))
 #define RCX_ALIGNBYTE(hi, lo, sh) ((uint32_t)(((((uint64_t)(hi)) << 32) | (uint32_t)(lo)) >> (8 * ((sh) & 3u))))
 #define RCX_INV_BALLOT(m) ((((m) >> (threadIdx.x & 63u)) & 1ull) != 0)
 #define RCX_HOP_WALK ws_hop_walk
