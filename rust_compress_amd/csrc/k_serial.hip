@@ -631,14 +631,20 @@ struct AriWave {
     }
 };
 
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void k_ari_byte_wave(rcx_kargs a, int decode)
+template <int WAVES, bool DEC>
+__global__ __launch_bounds__(64 * WAVES) void k_ari_byte_wave(rcx_kargs a)
 {
+    const int decode = DEC ? 1 : 0;
+    // ENCODER: low / hai are wave-uniform but kept in VGPRs, so the coder's arithmetic (a 32-bit division per symbol) runs on
+    // the vector ALU instead of the CU's single scalar unit (3815 streams: 148 -> 120 ms).  The DECODER has two dependent
+    // divisions per symbol and is latency bound: the scalar form is faster there (175 vs 194 ms).
+#define ARIW_V(x) (DEC ? (uint32_t)(x) : RCX_VGPR(x))
+#define ARIW_ANY(c) (DEC ? (bool)(c) : (__ballot(c) != 0))
     const unsigned w = threadIdx.x >> 6, lane = rcx_lane();
     const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + w));
     if (b >= a.nblocks) return;
     AriWave T; T.lane = lane; T.init();
-    uint32_t low = 0, hai = 0xffffffffu;
+    uint32_t low = ARIW_V(0), hai = ARIW_V(0xffffffffu);
     const uint8_t* in = a.in_base + a.in_off[b];
     const uint64_t n = a.in_len[b];
     uint8_t* out = a.out_base + a.out_off[b];
@@ -663,13 +669,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_ari_byte_wave(rcx_kargs a, int d
     // RangeEncoder::process, mod.rs:117-150, on wave-uniform values: emits 0..4 bytes
 #define ARIW_PROCESS(total_, from_, to_, EMIT)                                                          \
     do {                                                                                                \
-        const uint32_t range_ = RCX_UNI((hai - low) / (total_));                                        \
+        const uint32_t range_ = DEC ? RCX_UNI((hai - low) / (total_)) : (hai - low) / ARIW_V(total_);   \
         uint32_t lo_ = low + range_ * (from_), hi_ = low + range_ * (to_);                              \
         for (;;) {                                                                                      \
-            if (((lo_ ^ hi_) & 0xff000000u) != 0) {                                                     \
-                if (hi_ - lo_ > (1u << 14)) break;                                                      \
+            if (ARIW_ANY(((lo_ ^ hi_) & 0xff000000u) != 0)) {                                           \
+                if (ARIW_ANY(hi_ - lo_ > (1u << 14))) break;                                            \
                 const uint32_t lim_ = hi_ & 0xff000000u;                                                \
-                if (hi_ - lim_ >= lim_ - lo_) lo_ = lim_; else hi_ = lim_ - 1;                          \
+                const bool up_ = hi_ - lim_ >= lim_ - lo_;                                              \
+                lo_ = up_ ? lim_ : lo_; hi_ = up_ ? hi_ : lim_ - 1;                                     \
             }                                                                                           \
             EMIT(lo_ >> 24);                                                                            \
             lo_ <<= 8; hi_ <<= 8;                                                                       \
@@ -724,6 +731,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_ari_byte_wave(rcx_kargs a, int d
 #undef ARIW_PROCESS
 #undef ARIW_EMIT_ENC
 #undef ARIW_EMIT_DEC
+#undef ARIW_V
+#undef ARIW_ANY
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -741,7 +750,8 @@ static void launch_serial(hipStream_t s, int codec, rcx_kargs& k, int v)
         // one wave per stream until there are enough streams to fill the chip with one LANE per stream (variant 1 / 2 pin it)
         const int dec = codec == RCX_ARI_BYTE_DECODE ? 1 : 0;
         const bool per_wave = v == 2 ? true : v == 1 ? false : n < 32768u;
-        if (per_wave) hipLaunchKernelGGL((k_ari_byte_wave<4>), dim3((n + 3) / 4), dim3(256), 0, s, k, dec);
+        if (per_wave && dec) hipLaunchKernelGGL((k_ari_byte_wave<4, true>), dim3((n + 3) / 4), dim3(256), 0, s, k);
+        else if (per_wave) hipLaunchKernelGGL((k_ari_byte_wave<4, false>), dim3((n + 3) / 4), dim3(256), 0, s, k);
         else hipLaunchKernelGGL(k_ari_byte, dim3((n + 63) / 64), dim3(64), 0, s, k, dec);
         break;
     }
