@@ -27,8 +27,11 @@ def test_inflate_zlib_fixtures_and_python_zlib(ctx, oracle, golden):
         zs.append(c.compress(r) + c.flush()); exp.append(r)
     for i in range(10):
         zs.append(golden("test.z.%d" % i)); exp.append(txt)                 # zlib.rs:151-164
-    res = ctx.zlib_decode(zs, [len(e) for e in exp]).check()
-    assert res.outputs == exp and list(res.in_used) == [len(z) for z in zs]
+    for variant in (0, 9, 10, 1):              # auto (wave per stream + exact fallback here), lane per stream, wave per stream, v1
+        ctx.set_variant(N.ZLIB_DECODE, variant)
+        res = ctx.zlib_decode(zs, [len(e) for e in exp]).check()
+        assert res.outputs == exp and list(res.in_used) == [len(z) for z in zs], variant
+    ctx.set_variant(N.ZLIB_DECODE, 0)
     raw = [z[2:-4] for z in zs] + [golden("test.z.go")]                      # flate.rs:528-542
     res = ctx.inflate(raw, [len(e) for e in exp] + [len(txt)]).check()
     assert res.outputs == exp + [txt] and res.aux[-1] == 1
