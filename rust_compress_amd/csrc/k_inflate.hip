@@ -355,7 +355,7 @@ static void launch_inflate2(hipStream_t s, rcx_kargs& k, int flags, int v)
     else hipLaunchKernelGGL((k_inflate2<8, 3, 1>), dim3((n + 7) / 8), dim3(8), 0, s, k, z);
 }
 
-static constexpr uint32_t INF3_MAX_STREAMS = 32768;
+static constexpr uint32_t INF3_MAX_STREAMS = 49152;
 // scratch the default path wants: Adler-32 values (zlib) and a stand-in for a null in_used
 static uint64_t inflate_scratch_bytes(uint32_t nblocks) { return 12ull * nblocks + 256; }
 
@@ -367,7 +367,7 @@ static void launch_inflate(hipStream_t s, rcx_kargs& k, bool zlib, int v)
     const uint32_t n = k.nblocks;
     if (v == 1) { hipLaunchKernelGGL(k_inflate, dim3((n + 63) / 64), dim3(64), 0, s, k, zlib ? 1 : 0); return; }   // first version (A/B)
     // one wave per stream wins while the streams are few (it needs ~12 waves per CU, not 12 x 64 streams per CU): measured
-    // crossover around 32768 streams of 16 KiB (benchmarks/inflate_spw_sweep.py); variant 10 forces it, 9 forces k_inflate2
+    // 32768 streams of 16 KiB 21 vs 27 ms, 65536 streams 39 vs 34 ms (benchmarks/inflate_spw_sweep.py); variant 10 forces it, 9 forces k_inflate2
     const bool wave_per_stream = v == 10 || (v == 0 && n < INF3_MAX_STREAMS);
     if (!wave_per_stream || k.scratch == nullptr || k.scratch_bytes < inflate_scratch_bytes(n)) { launch_inflate2(s, k, zlib ? 1 : 0, (v == 9 || v == 10) ? 0 : v); return; }
     rcx_kargs k3 = k;

@@ -93,7 +93,7 @@ __device__ __forceinline__ void rcx_inf_run(uint32_t& lo, uint32_t& hi, uint32_t
         "v_add_u32_e32 v90, v89, v87\n\t"
         INF_CONSUME
         INF_REFILL("L_h2_%=")
-        "v_and_b32_e32 v86, 0x1ff, v80\n\t"
+        "v_and_b32_e32 v86, 0xff, v80\n\t"
         "v_lshl_add_u32 v86, v86, 1, %[lutD]\n\t"
         "ds_read_u16 v88, v86\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
@@ -141,10 +141,13 @@ __device__ __forceinline__ void rcx_inf_run(uint32_t& lo, uint32_t& hi, uint32_t
 #endif
 
 template <int CB>
-struct Inf3 : Lz4V5<CB> {
-    typedef Lz4V4<CB, false> B;
-    static constexpr int LITCAP = 1024;      // literal bytes per batch
-    static constexpr int LUTBITS = 9, LUTN = 1 << LUTBITS;
+struct Inf3 : Lz4V5<CB, 1536, 1024> {
+    // LDS per wave must stay below 10 KB for 16 waves per CU: 1536-byte batch output cap, 1 KiB of history in the window,
+    // 512 literal bytes per batch, an 8-bit table for the distance code
+    typedef Lz4V4<CB, false, 1536, 1024> B;
+    static constexpr int LITCAP = 512;       // literal bytes per batch
+    static constexpr int LUTBITS = 9, LUTN = 1 << LUTBITS;     // lit/len table
+    static constexpr int DBITS = 8, DLUTN = 1 << DBITS;        // distance (and code-length) table
     // LDS views
     uint16_t* lutL; uint16_t* lutD; uint16_t* symL; uint16_t* symD;
     uint8_t* lens;                            // [0, 320): lit/len + distance code lengths, [320, 352): code-length code
@@ -181,12 +184,13 @@ struct Inf3 : Lz4V5<CB> {
     // HuffmanTree::construct (flate.rs:83-120) for nsym code lengths at L: 9-bit lookup table (entry = sym << 4 | len,
     // bit 15 set for everything that is not a literal; 0x8000 = no code of <= 9 bits starts like this), symbols in canonical order, limits/bases for the longer codes.
     // Returns 0, 1 (over-subscribed) or 2 (no code at all).
-    __device__ __forceinline__ int build(const uint8_t* L, uint32_t nsym, uint16_t* lut, uint16_t* symtab, uint32_t* lim, uint32_t* base)
+    __device__ __forceinline__ int build(const uint8_t* L, uint32_t nsym, uint16_t* lut, uint32_t lutbits, uint16_t* symtab, uint32_t* lim, uint32_t* base)
     {
+        const uint32_t lutn = 1u << lutbits;
         const unsigned lane = this->lane;
         uint32_t* hist = tab + 64;
         if (lane < 16) hist[lane] = 0;
-        for (uint32_t j = lane; j < (uint32_t)LUTN / 2; j += 64) ((uint32_t*)lut)[j] = 0x80008000u;   // "no short code" (bit 15, length 0)
+        for (uint32_t j = lane; j < lutn / 2; j += 64) ((uint32_t*)lut)[j] = 0x80008000u;   // "no short code" (bit 15, length 0)
         rcx_wave_sync();
         for (uint32_t c0 = 0; c0 < nsym; c0 += 64) {
             const uint32_t s = c0 + lane;
@@ -221,11 +225,11 @@ struct Inf3 : Lz4V5<CB> {
             }
             if (l) {
                 symtab[pos] = (uint16_t)s;
-                if (l <= (uint32_t)LUTBITS) {
+                if (l <= lutbits) {
                     const uint32_t cd = pos - base[l];                          // first[l] + rank
                     const uint32_t r = __brev(cd) >> (32u - l);
                     const uint16_t e = (uint16_t)((s << 4) | l | (s >= 256u ? 0x8000u : 0u));
-                    for (uint32_t k = r; k < (uint32_t)LUTN; k += 1u << l) lut[k] = e;
+                    for (uint32_t k = r; k < lutn; k += 1u << l) lut[k] = e;
                 }
             }
         }
@@ -233,15 +237,15 @@ struct Inf3 : Lz4V5<CB> {
         return 0;
     }
     // HuffmanTree::decode (flate.rs:129-146); false: these bits are no code (the caller falls back)
-    __device__ __forceinline__ bool decode(const uint16_t* lut, const uint16_t* symtab, const uint32_t* lim, const uint32_t* base, uint32_t& sym)
+    __device__ __forceinline__ bool decode(const uint16_t* lut, uint32_t lutbits, const uint16_t* symtab, const uint32_t* lim, const uint32_t* base, uint32_t& sym)
     {
-        const uint32_t e = RCX_U(lut[(uint32_t)bb & (uint32_t)(LUTN - 1)]);
+        const uint32_t e = RCX_U(lut[(uint32_t)bb & ((1u << lutbits) - 1u)]);
         const uint32_t len = e & 15u;
         if (__builtin_expect(len != 0, 1)) { sym = (e >> 4) & 0x7ffu; bb >>= len; bc -= len; return true; }
         const uint32_t rev = __brev((uint32_t)bb) >> 17;
         bool ok = false;
 #pragma unroll 1
-        for (uint32_t l = LUTBITS + 1; l <= 15 && !ok; l++) {
+        for (uint32_t l = lutbits + 1; l <= 15 && !ok; l++) {
             if (rev < RCX_U(lim[l])) {
                 sym = RCX_U(symtab[(rev >> (15u - l)) + RCX_U(base[l])]);
                 bb >>= l; bc -= l;
@@ -388,7 +392,7 @@ struct Inf3 : Lz4V5<CB> {
                     const bool isD = bjob == 0 || j == 1;
                     const uint8_t* Lp = bjob == 0 ? lens + 320 : (j == 0 ? lens : lens + hlit);
                     const uint32_t nsym = bjob == 0 ? 19u : (j == 0 ? hlit : hdist);
-                    const int r = build(Lp, nsym, isD ? lutD : lutL, isD ? symD : symL, isD ? limD : limL, isD ? baseD : baseL);
+                    const int r = build(Lp, nsym, isD ? lutD : lutL, isD ? (uint32_t)DBITS : (uint32_t)LUTBITS, isD ? symD : symL, isD ? limD : limL, isD ? baseD : baseL);
                     // no distance code at all is fine (:447-448, a block of literals only: its table stays empty);
                     // over-subscribed codes and an empty lit/len or code-length code go to the exact kernel
                     if (r == 1 || (r == 2 && !(bjob == 1 && j == 1))) st = RCX_ST_FALLBACK;
@@ -401,7 +405,7 @@ struct Inf3 : Lz4V5<CB> {
                     if (!staged(16)) { want_stage = true; break; }
                     refill();
                     uint32_t symbol = 0;
-                    if (!decode(lutD, symD, limD, baseD, symbol)) { st = RCX_ST_FALLBACK; break; }
+                    if (!decode(lutD, DBITS, symD, limD, baseD, symbol)) { st = RCX_ST_FALLBACK; break; }
                     if (symbol < 16) {
                         if (lane == 0) lens[ci] = (uint8_t)symbol;
                         ci++;
@@ -468,7 +472,7 @@ struct Inf3 : Lz4V5<CB> {
                     if (!staged(16)) { if (fs == 5u) carry_len = flen; want_stage = true; break; }   // the decoded length survives the restage
                     refill();                                          // >= 33 bits: a code (15) + extra (5) and more
                     uint32_t sym = 257;
-                    if (fs != 5u && !decode(lutL, symL, limL, baseL, sym)) { st = RCX_ST_FALLBACK; break; }
+                    if (fs != 5u && !decode(lutL, LUTBITS, symL, limL, baseL, sym)) { st = RCX_ST_FALLBACK; break; }
                     if (sym < 256) {                                   // :289
                         if (lane == 0) litbuf[litn] = (uint8_t)sym;
                         litn = RCX_U(litn + 1); runL = RCX_U(runL + 1); otot = RCX_U(otot + 1);
@@ -488,7 +492,7 @@ struct Inf3 : Lz4V5<CB> {
                     const uint32_t len = fs == 5u ? flen : lbase + bits(lb);
                     refill();                                          // >= 33 bits: a code (15) + extra (13)
                     uint32_t d = 0;
-                    if (!decode(lutD, symD, limD, baseD, d) || d >= 30) { st = RCX_ST_FALLBACK; break; }
+                    if (!decode(lutD, DBITS, symD, limD, baseD, d) || d >= 30) { st = RCX_ST_FALLBACK; break; }
                     const uint32_t db = d < 4 ? 0u : (d - 2u) >> 1;                             // EXTRADIST/EXTRADBITS, :275-284
                     const uint32_t dbase = d < 4 ? 1u + d : 1u + ((2u + (d & 1u)) << db);
                     const uint32_t dist = dbase + bits(db);
@@ -530,7 +534,7 @@ __global__ __launch_bounds__(64) void k_inflate3(rcx_kargs a, int zlib)
     __shared__ __align__(16) uint8_t s_cbuf[CB + 96];
     __shared__ __align__(16) uint8_t s_wbuf[S::WBUF5];
     __shared__ __align__(16) uint16_t s_lutL[512];
-    __shared__ __align__(16) uint16_t s_lutD[512];
+    __shared__ __align__(16) uint16_t s_lutD[S::DLUTN];
     __shared__ uint16_t s_symL[288];
     __shared__ uint16_t s_symD[32];
     __shared__ __align__(16) uint8_t s_lens[352];

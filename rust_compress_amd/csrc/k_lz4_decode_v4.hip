@@ -31,13 +31,13 @@
 #define LZ4P_T0() uint64_t t0_ = PROF ? (uint64_t)__builtin_readcyclecounter() : 0
 #define LZ4P_ADD(slot) do { if (PROF) { const uint64_t t1_ = (uint64_t)__builtin_readcyclecounter(); prof[slot] += t1_ - t0_; t0_ = t1_; } } while (0)
 
-template <int CB, bool PROF = false>
+template <int CB, bool PROF = false, int TC = 2560, int HH = 2048>
 struct Lz4V4 {
     uint64_t prof[16];
-    static constexpr int H = 2048;                 // history kept when the window slides
+    static constexpr int H = HH;                   // history kept when the window slides (2048 for LZ4)
     static constexpr int LCAP = 32, MCAP = 64;     // per-lane caps of a batched sequence
     static constexpr int WINMAX = 22 * (14 + MCAP);// most output one 64-byte token window can add (22 tokens)
-    static constexpr int TCAP = 2560;              // output bytes per batch
+    static constexpr int TCAP = TC;                // output bytes per batch (2560 for LZ4; the inflate front end uses less LDS)
     static constexpr int SOLO = 1024;              // wave-cooperative in-window copy up to this many bytes
     static constexpr int LIN = H + 16 + TCAP;
     static constexpr int STAGE = LIN + 64;         // 64 bytes of read slack, then 64 lanes x MCAP bytes of old-match staging

@@ -18,9 +18,9 @@
 // write tail" need no more than compiler ordering.  64 VGPRs (launch bound) keep 8 waves per SIMD = 16 blocks per CU.
 #include "rcx_dev.h"
 
-template <int CB>
-struct Lz4V5 : Lz4V4<CB, false> {
-    typedef Lz4V4<CB, false> B;
+template <int CB, int TC = 2560, int HH = 2048>
+struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
+    typedef Lz4V4<CB, false, TC, HH> B;
     static constexpr int NSLOT = 3;
     struct Slot { uint32_t hdr[16]; uint32_t desc[64][2]; };
     struct Ring { Slot slot[NSLOT]; volatile uint32_t head, tail, abort_, pad; };

@@ -272,7 +272,7 @@ static inline void ws_inf_run(uint32_t& lo, uint32_t& hi, uint32_t& bc, uint32_t
         uint32_t t = ltab[nn], xb = t >> 16;
         len = (t & 0xffff) + ((uint32_t)bb & ((1u << xb) - 1u)); bb >>= xb; bc -= xb;
         refill();
-        e = lutD[bb & 0x1ff]; l = e & 15;
+        e = lutD[bb & 0xff]; l = e & 15;
         const uint32_t d = (e >> 4) & 0x7ff;
         if (l == 0 || d > 29) { status = 5; break; }
         bb >>= l; bc -= l;
