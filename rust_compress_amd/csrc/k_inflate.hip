@@ -312,9 +312,21 @@ __global__ __launch_bounds__(64 * WAVES) void k_adler32(rcx_kargs a)
     const uint64_t s1 = s0 + per < n ? s0 + per : n;
     // local sums over [s0, s1): A = sum x, B = sum (s1 - i) x_i   (i.e. Adler's b with a starting at 0)
     uint32_t A = 0, B = 0, pend = 0;
-    for (uint64_t i = s0; i < s1; i++) {
+    uint64_t i = s0;
+    for (; i + 16 <= s1; i += 16) {                            // 16 bytes per load (a byte load per byte was the whole cost)
+        const rcx_u32x4 v = *(const rcx_u32x4_u*)(in + i);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t x = v[k];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { A += x & 0xffu; B += A; x >>= 8; }
+        }
+        pend += 16;
+        if (pend >= 5536) { A %= 65521u; B %= 65521u; pend = 0; }
+    }
+    for (; i < s1; i++) {
         A += in[i]; B += A;
-        if (++pend == 5552) { A %= 65521u; B %= 65521u; pend = 0; }
+        if (++pend >= 5536) { A %= 65521u; B %= 65521u; pend = 0; }
     }
     A %= 65521u; B %= 65521u;
     // contribution to the global b: B + (n - s1) * A
@@ -355,7 +367,7 @@ static void launch_inflate2(hipStream_t s, rcx_kargs& k, int flags, int v)
     else hipLaunchKernelGGL((k_inflate2<8, 3, 1>), dim3((n + 7) / 8), dim3(8), 0, s, k, z);
 }
 
-static constexpr uint32_t INF3_MAX_STREAMS = 49152;
+static constexpr uint32_t INF3_MAX_STREAMS = 0xffffffffu;   // every batch size measured (1024 .. 65536 streams) is faster wave-per-stream
 // scratch the default path wants: Adler-32 values (zlib) and a stand-in for a null in_used
 static uint64_t inflate_scratch_bytes(uint32_t nblocks) { return 12ull * nblocks + 256; }
 
@@ -366,8 +378,8 @@ static void launch_inflate(hipStream_t s, rcx_kargs& k, bool zlib, int v)
 {
     const uint32_t n = k.nblocks;
     if (v == 1) { hipLaunchKernelGGL(k_inflate, dim3((n + 63) / 64), dim3(64), 0, s, k, zlib ? 1 : 0); return; }   // first version (A/B)
-    // one wave per stream wins while the streams are few (it needs ~12 waves per CU, not 12 x 64 streams per CU): measured
-    // 32768 streams of 16 KiB 21 vs 27 ms, 65536 streams 39 vs 34 ms (benchmarks/inflate_spw_sweep.py); variant 10 forces it, 9 forces k_inflate2
+    // one wave per stream (16 waves per CU) against one lane per stream: 65536 streams of 16 KiB 28 vs 34 ms, 4096 streams
+    // 2.2 vs 20.7 ms (benchmarks/inflate_spw_sweep.py); variant 10 forces it, 9 forces k_inflate2
     const bool wave_per_stream = v == 10 || (v == 0 && n < INF3_MAX_STREAMS);
     if (!wave_per_stream || k.scratch == nullptr || k.scratch_bytes < inflate_scratch_bytes(n)) { launch_inflate2(s, k, zlib ? 1 : 0, (v == 9 || v == 10) ? 0 : v); return; }
     rcx_kargs k3 = k;
