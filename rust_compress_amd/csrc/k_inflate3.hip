@@ -22,17 +22,22 @@
 
 // One pass of the symbol decoder on the vector ALU (hand-written: hipcc's version of the same loop costs ~17 scalar-unit
 // instructions per literal and ~120 per match, and the CU's single scalar unit is what bounds this kernel).  All
-// operands are wave-uniform values held in VGPRs.  Decodes literals with short codes into `litv` (literal j of the pass
-// in lane j) while cnt < room and at most `lim` staged bytes are consumed, and stops at the first symbol that is not one:
-//   status 0  limits reached (room / staging)          1  a match: len, dist decoded (short codes), all bits consumed
-//          2  end of block (consumed)                  3  the next lit/len code is long or invalid: nothing consumed
+// operands are wave-uniform values held in VGPRs.  The pass decodes symbols with short codes and BOOKS them itself:
+// literals go to `litv` (literal j of the pass in lane j; the caller stores them at litbuf[litn0 + j]), a match of <= 64
+// bytes closes the open literal run as a sequence descriptor {run source, L | M << 8 | dist << 16} at desc[ns], 32
+// literals in a row close a run without a match.  It returns when something needs the caller:
+//   status 0  limits: staging (off > lim), literal register / buffer (cnt >= room) or descriptors (ns >= 64) ran out
+//          1  a match longer than 64 bytes: len, dist decoded, NOT booked (the wave-wide copy path takes it)
+//          2  end of block (consumed)        3  the next lit/len code is long or invalid: nothing consumed
+//          4  a distance beyond the output or 32 KiB (the caller falls back)
 //          5  length decoded into len, the distance code is long or invalid: nothing of the distance consumed
 // Bits: the 64-bit buffer is refilled 8 bytes at a time (only 32 counted; the rest are the same bits the next refill ORs
-// in again).  ltab/dtab: base | extra_bits << 16 per length / distance symbol.  Fixed registers v80-v92 form the pairs.
+// in again).  ltab/dtab: base | extra_bits << 16 per length / distance symbol.  Fixed registers v80-v99, s[90:91].
 #ifndef RCX_INF_RUN_CALL
 __device__ __forceinline__ void rcx_inf_run(uint32_t& lo, uint32_t& hi, uint32_t& bc, uint32_t& off, uint32_t& cnt, uint32_t& litv,
-                                            uint32_t& len, uint32_t& dist, uint32_t& status, uint32_t room, uint32_t lim, uint32_t lane,
-                                            uint32_t cb, uint32_t lutL, uint32_t lutD, uint32_t ltab, uint32_t dtab)
+                                            uint32_t& len, uint32_t& dist, uint32_t& status, uint32_t& ns, uint32_t& runL, uint32_t& runsrc,
+                                            uint32_t& otot, uint32_t room, uint32_t lim, uint32_t lane, uint32_t litn0,
+                                            uint32_t cb, uint32_t lutL, uint32_t lutD, uint32_t ltab, uint32_t dtab, uint32_t descb)
 {
 #define INF_REFILL(L)                                          \
         "v_cmp_gt_u32_e32 vcc, 33, v82\n\t"                    \
@@ -49,14 +54,30 @@ __device__ __forceinline__ void rcx_inf_run(uint32_t& lo, uint32_t& hi, uint32_t
 #define INF_CONSUME                                            \
         "v_lshrrev_b64 v[80:81], v86, v[80:81]\n\t"            \
         "v_sub_u32_e32 v82, v82, v86\n\t"
+    /* desc[ns] = {runsrc, runL | len << 8 | dist << 16} by lane 0; ns++, the next run starts at litn0 + cnt */
+#define INF_POST                                               \
+        "v_mov_b32_e32 v98, v95\n\t"                           \
+        "v_lshl_or_b32 v99, v90, 8, v94\n\t"                   \
+        "v_lshl_or_b32 v99, v91, 16, v99\n\t"                  \
+        "v_lshl_add_u32 v97, v93, 3, %[descb]\n\t"             \
+        "v_cmp_eq_u32_e32 vcc, 0, %[lane]\n\t"                 \
+        "s_and_saveexec_b64 s[90:91], vcc\n\t"                 \
+        "ds_write_b64 v97, v[98:99]\n\t"                       \
+        "s_mov_b64 exec, s[90:91]\n\t"                         \
+        "v_add_u32_e32 v93, 1, v93\n\t"                        \
+        "v_mov_b32_e32 v94, 0\n\t"                             \
+        "v_add_u32_e32 v95, %[litn0], v84\n\t"
     asm volatile(
         "v_mov_b32_e32 v80, %[lo]\n\t" "v_mov_b32_e32 v81, %[hi]\n\t" "v_mov_b32_e32 v82, %[bc]\n\t" "v_mov_b32_e32 v83, %[off]\n\t"
         "v_mov_b32_e32 v84, %[cnt]\n\t" "v_mov_b32_e32 v85, %[litv]\n\t" "v_mov_b32_e32 v90, 0\n\t" "v_mov_b32_e32 v91, 0\n\t"
-        "v_mov_b32_e32 v92, 0\n\t"
+        "v_mov_b32_e32 v92, 0\n\t" "v_mov_b32_e32 v93, %[ns]\n\t" "v_mov_b32_e32 v94, %[runL]\n\t" "v_mov_b32_e32 v95, %[runsrc]\n\t"
+        "v_mov_b32_e32 v96, %[otot]\n\t"
         "L_top_%=:\n\t"
         "v_cmp_lt_u32_e32 vcc, %[lim], v83\n\t"
         "s_cbranch_vccnz L_out_%=\n\t"
         "v_cmp_ge_u32_e32 vcc, v84, %[room]\n\t"
+        "s_cbranch_vccnz L_out_%=\n\t"
+        "v_cmp_lt_u32_e32 vcc, 63, v93\n\t"
         "s_cbranch_vccnz L_out_%=\n\t"
         INF_REFILL("L_h1_%=")
         "v_and_b32_e32 v86, 0x1ff, v80\n\t"
@@ -71,6 +92,13 @@ __device__ __forceinline__ void rcx_inf_run(uint32_t& lo, uint32_t& hi, uint32_t
         "v_cmp_eq_u32_e32 vcc, %[lane], v84\n\t"
         "v_cndmask_b32_e32 v85, v85, v87, vcc\n\t"
         "v_add_u32_e32 v84, 1, v84\n\t"
+        "v_add_u32_e32 v94, 1, v94\n\t"
+        "v_add_u32_e32 v96, 1, v96\n\t"
+        "v_cmp_ne_u32_e32 vcc, 32, v94\n\t"
+        "s_cbranch_vccnz L_top_%=\n\t"
+        "v_mov_b32_e32 v90, 0\n\t"                             /* 32 literals in a row: a run without a match */
+        "v_mov_b32_e32 v91, 0\n\t"
+        INF_POST
         "s_branch L_top_%=\n\t"
         "L_nonlit_%=:\n\t"
         "v_and_b32_e32 v86, 15, v88\n\t"
@@ -113,7 +141,20 @@ __device__ __forceinline__ void rcx_inf_run(uint32_t& lo, uint32_t& hi, uint32_t
         "v_and_b32_e32 v87, v87, v80\n\t"
         "v_add_u32_e32 v91, v89, v87\n\t"
         INF_CONSUME
+        "v_cmp_gt_u32_e32 vcc, v91, v96\n\t"                   /* distance beyond the output so far */
+        "s_cbranch_vccnz L_bad_%=\n\t"
+        "v_cmp_lt_u32_e32 vcc, 0x8000, v91\n\t"
+        "s_cbranch_vccnz L_bad_%=\n\t"
+        "v_cmp_lt_u32_e32 vcc, 64, v90\n\t"
+        "s_cbranch_vccnz L_long_%=\n\t"
+        INF_POST
+        "v_add_u32_e32 v96, v96, v90\n\t"
+        "s_branch L_top_%=\n\t"
+        "L_long_%=:\n\t"
         "v_mov_b32_e32 v92, 1\n\t"
+        "s_branch L_out_%=\n\t"
+        "L_bad_%=:\n\t"
+        "v_mov_b32_e32 v92, 4\n\t"
         "s_branch L_out_%=\n\t"
         "L_eob_%=:\n\t"
         INF_CONSUME
@@ -127,17 +168,23 @@ __device__ __forceinline__ void rcx_inf_run(uint32_t& lo, uint32_t& hi, uint32_t
         "L_out_%=:\n\t"
         "v_mov_b32_e32 %[lo], v80\n\t" "v_mov_b32_e32 %[hi], v81\n\t" "v_mov_b32_e32 %[bc], v82\n\t" "v_mov_b32_e32 %[off], v83\n\t"
         "v_mov_b32_e32 %[cnt], v84\n\t" "v_mov_b32_e32 %[litv], v85\n\t" "v_mov_b32_e32 %[len], v90\n\t" "v_mov_b32_e32 %[dist], v91\n\t"
-        "v_mov_b32_e32 %[status], v92\n\t"
+        "v_mov_b32_e32 %[status], v92\n\t" "v_mov_b32_e32 %[ns], v93\n\t" "v_mov_b32_e32 %[runL], v94\n\t" "v_mov_b32_e32 %[runsrc], v95\n\t"
+        "v_mov_b32_e32 %[otot], v96\n\t"
         : [lo] "+v"(lo), [hi] "+v"(hi), [bc] "+v"(bc), [off] "+v"(off), [cnt] "+v"(cnt), [litv] "+v"(litv),
+          [ns] "+v"(ns), [runL] "+v"(runL), [runsrc] "+v"(runsrc), [otot] "+v"(otot),
           [len] "=&v"(len), [dist] "=&v"(dist), [status] "=&v"(status)
-        : [room] "v"(room), [lim] "v"(lim), [lane] "v"(lane), [cb] "v"(cb), [lutL] "v"(lutL), [lutD] "v"(lutD), [ltab] "v"(ltab), [dtab] "v"(dtab)
-        : "vcc", "memory", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92");
+        : [room] "v"(room), [lim] "v"(lim), [lane] "v"(lane), [litn0] "v"(litn0), [cb] "v"(cb), [lutL] "v"(lutL), [lutD] "v"(lutD),
+          [ltab] "v"(ltab), [dtab] "v"(dtab), [descb] "v"(descb)
+        : "vcc", "memory", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94",
+          "v95", "v96", "v97", "v98", "v99", "s90", "s91");
 #undef INF_REFILL
 #undef INF_CONSUME
+#undef INF_POST
 }
 #define RCX_LDSADDR(p) rcx_vgpr((uint32_t)(uintptr_t)(p))     // low half of a generic LDS pointer = the LDS byte address
-#define RCX_INF_RUN_CALL(lo, hi, bc, off, cnt, litv, len, dist, st, room, lim, lane, cb, lutL, lutD, ltab, dtab) \
-    rcx_inf_run(lo, hi, bc, off, cnt, litv, len, dist, st, room, lim, lane, RCX_LDSADDR(cb), RCX_LDSADDR(lutL), RCX_LDSADDR(lutD), RCX_LDSADDR(ltab), RCX_LDSADDR(dtab))
+#define RCX_INF_RUN_CALL(lo, hi, bc, off, cnt, litv, len, dist, st, ns, runL, runsrc, otot, room, lim, lane, litn0, cb, lutL, lutD, ltab, dtab, desc) \
+    rcx_inf_run(lo, hi, bc, off, cnt, litv, len, dist, st, ns, runL, runsrc, otot, room, lim, lane, litn0, RCX_LDSADDR(cb), RCX_LDSADDR(lutL),    \
+                RCX_LDSADDR(lutD), RCX_LDSADDR(ltab), RCX_LDSADDR(dtab), RCX_LDSADDR(desc))
 #endif
 
 template <int CB>
@@ -429,35 +476,30 @@ struct Inf3 : Lz4V5<CB, 1536, 1024> {
                 }
             } else {                                                   // P_SYMBOLS: Decoder::codes, flate.rs:262-341
                 for (;;) {
-                    // The fast path: runs of literals and matches with short codes are decoded on the vector ALU by
-                    // rcx_inf_run (literal j of a pass in lane j); everything else comes back as a status.
+                    // The fast path: symbols with short codes are decoded AND booked on the vector ALU by rcx_inf_run
+                    // (literal j of a pass in lane j, sequence descriptors written by the pass); the rest comes back as a status.
                     uint32_t fs = 5u, flen = carry_len, fdist = 0;
-                    if (carry_len) carry_len = 0;                      // resuming behind a flush with a decoded length
+                    if (carry_len) carry_len = 0;                      // resuming behind a flush / restage with a decoded length
                     else {
-                        const uint32_t a0 = (uint32_t)B::LCAP - runL, a1 = (uint32_t)LITCAP - litn;
-                        const uint32_t room = RCX_VGPR(a0 < a1 ? a0 : a1);                       // <= 32
+                        const uint32_t a1 = (uint32_t)LITCAP - litn;
+                        const uint32_t room = RCX_VGPR(a1 < 64u ? a1 : 64u);
                         uint32_t vlo = RCX_VGPR((uint32_t)bb), vhi = RCX_VGPR((uint32_t)(bb >> 32)), vbc = RCX_VGPR(bc);
                         uint32_t voff = RCX_VGPR((uint32_t)((int32_t)p - this->cbase)), vcnt = RCX_VGPR(0), litv = 0, vst = 0, vlen = 0, vdist = 0;
-                        RCX_INF_RUN_CALL(vlo, vhi, vbc, voff, vcnt, litv, vlen, vdist, vst, room, RCX_VGPR((uint32_t)(CB - 12)), RCX_VGPR(lane),
-                                         this->cbuf, lutL, lutD, ltab, ltab + 32);
+                        uint32_t vns = RCX_VGPR((uint32_t)ns), vrunL = RCX_VGPR(runL), vrunsrc = RCX_VGPR(runsrc), votot = RCX_VGPR(otot);
+                        RCX_INF_RUN_CALL(vlo, vhi, vbc, voff, vcnt, litv, vlen, vdist, vst, vns, vrunL, vrunsrc, votot, room,
+                                         RCX_VGPR((uint32_t)(CB - 12)), RCX_VGPR(lane), RCX_VGPR(litn), this->cbuf, lutL, lutD, ltab, ltab + 32, desc);
                         const uint32_t cnt = RCX_U(vcnt);
                         fs = RCX_U(vst); flen = RCX_U(vlen); fdist = RCX_U(vdist);
                         if (cnt) if (lane < cnt) litbuf[litn + lane] = (uint8_t)litv;
-                        litn = RCX_U(litn + cnt); runL = RCX_U(runL + cnt); otot = RCX_U(otot + cnt);
+                        litn = RCX_U(litn + cnt); ns = (int)RCX_U(vns); runL = RCX_U(vrunL); runsrc = RCX_U(vrunsrc); otot = RCX_U(votot);
                         bb = ((uint64_t)RCX_U(vhi) << 32) | RCX_U(vlo); bc = RCX_U(vbc); p = (uint32_t)(this->cbase + (int32_t)RCX_U(voff));
                     }
-                    if (fs == 1u) {                                    // a match, decoded
-                        if (fdist > otot || fdist > 32768u) { st = RCX_ST_FALLBACK; break; }   // :314
+                    if (fs == 4u) { st = RCX_ST_FALLBACK; break; }      // :314 distance beyond the output
+                    if (fs == 1u) {                                    // a match longer than 64 bytes: flush, then the wave-wide copy
                         otot = RCX_U(otot + flen);
-                        if (flen <= (uint32_t)B::MCAP) {
-                            post(runL, flen, fdist);
-                            if (ns >= 64) { want_flush = true; break; }
-                        } else {
-                            want_flush = true;
-                            pend_why = B::SOLO_; pend_L = 0; pend_M = flen; pend_off = fdist; pend_src = 0;
-                            break;
-                        }
-                        continue;
+                        want_flush = true;
+                        pend_why = B::SOLO_; pend_L = 0; pend_M = flen; pend_off = fdist; pend_src = 0;
+                        break;
                     }
                     if (fs == 2u) {                                    // :290 end of block (its bits are consumed: act on it first)
                         if (otot == before && !eof) flags |= RCX_W_EMPTY_BLOCK_MIDSTREAM;       // :474-476 quirk

@@ -243,23 +243,29 @@ static inline void ws_lds_store16(uint8_t* p, uint32_t v0, uint32_t v1, uint32_t
     for (uint32_t i = 0; i < nv && i < 16; i++) p[i] = (uint8_t)(v[i >> 2] >> (8 * (i & 3)));
 }
 
-// portable version of k_inflate3.hip's hand-written symbol pass (same contract; LDS "addresses" are host pointers' low bits
-// there, so the simulator passes real pointers through a side channel: see RCX_LDSADDR below)
+// portable version of k_inflate3.hip's hand-written symbol pass (same contract; the product passes LDS addresses, the
+// simulator real pointers)
 static inline void ws_inf_run(uint32_t& lo, uint32_t& hi, uint32_t& bc, uint32_t& off, uint32_t& cnt, uint32_t& litv, uint32_t& len,
-                              uint32_t& dist, uint32_t& status, uint32_t room, uint32_t lim, uint32_t lane, const uint8_t* cb,
-                              const uint16_t* lutL, const uint16_t* lutD, const uint32_t* ltab, const uint32_t* dtab)
+                              uint32_t& dist, uint32_t& status, uint32_t& ns, uint32_t& runL, uint32_t& runsrc, uint32_t& otot,
+                              uint32_t room, uint32_t lim, uint32_t lane, uint32_t litn0, const uint8_t* cb,
+                              const uint16_t* lutL, const uint16_t* lutD, const uint32_t* ltab, const uint32_t* dtab, uint32_t* desc)
 {
     uint64_t bb = ((uint64_t)hi << 32) | lo;
     auto refill = [&] { if (bc <= 32) { uint64_t w; memcpy(&w, cb + off, 8); bb |= w << bc; bc += 32; off += 4; } };
+    auto post = [&](uint32_t M, uint32_t D) {
+        if (lane == 0) { desc[2 * ns] = runsrc; desc[2 * ns + 1] = runL | (M << 8) | (D << 16); }
+        ns++; runL = 0; runsrc = litn0 + cnt;
+    };
     len = 0; dist = 0; status = 0;
     for (;;) {
-        if (off > lim || cnt >= room) break;
+        if (off > lim || cnt >= room || ns > 63) break;
         refill();
         uint32_t e = lutL[bb & 0x1ff];
         if (e <= 0x7fff) {
             const uint32_t l = e & 15; bb >>= l; bc -= l;
             if (lane == cnt) litv = e >> 4;
-            cnt++;
+            cnt++; runL++; otot++;
+            if (runL == 32) post(0, 0);
             continue;
         }
         uint32_t l = e & 15;
@@ -278,8 +284,11 @@ static inline void ws_inf_run(uint32_t& lo, uint32_t& hi, uint32_t& bc, uint32_t
         bb >>= l; bc -= l;
         t = dtab[d]; xb = t >> 16;
         dist = (t & 0xffff) + ((uint32_t)bb & ((1u << xb) - 1u)); bb >>= xb; bc -= xb;
-        status = 1;
-        break;
+        if (dist > otot || dist > 0x8000u) { status = 4; break; }
+        if (len > 64) { status = 1; break; }
+        post(len, dist);
+        otot += len;
+        len = 0; dist = 0;
     }
     lo = (uint32_t)bb; hi = (uint32_t)(bb >> 32);
 }
