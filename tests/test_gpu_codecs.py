@@ -105,3 +105,33 @@ def test_rle_ari_malformed(ctx, oracle):
         assert es == res.status[i], (i, es, res.status[i])
         if es == 0:
             assert eo == res.outputs[i] and eu == res.in_used[i]
+
+
+def test_inflate_large_and_ragged_streams(ctx):
+    """A few long streams (the wave-per-stream decoder's home ground): every level, fixed codes, stored blocks, 1 B .. 3 MiB,
+    several dynamic blocks per stream, long matches (runs) and far ones (dna), against Python's zlib."""
+    from rust_compress_amd import synth
+    rng = np.random.default_rng(11)
+    raws = []
+    for i, kind in enumerate(("text", "runs", "dna4", "rand", "words", "mix")):
+        raws.append(synth.gen(kind, int(rng.integers(1 << 20, 3 << 20)), 100 + i).tobytes())
+    raws += [b"", b"a", b"ab" * 70000, bytes(200000), synth.gen("text", 70001, 3).tobytes()]
+    zs, exp = [], []
+    for i, r in enumerate(raws):
+        for lvl in (0, 1, 4, 9):
+            zs.append(zlib.compress(r, lvl)); exp.append(r)
+        c = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+        zs.append(c.compress(r) + c.flush()); exp.append(r)
+        c = zlib.compressobj(9, zlib.DEFLATED, 15, 9, zlib.Z_DEFAULT_STRATEGY)            # flush points: empty stored blocks mid-stream
+        zs.append(c.compress(r[: len(r) // 2]) + c.flush(zlib.Z_FULL_FLUSH) + c.compress(r[len(r) // 2:]) + c.flush()); exp.append(r)
+    for variant in (0, 9):
+        ctx.set_variant(N.ZLIB_DECODE, variant)
+        res = ctx.zlib_decode(zs, [len(e) for e in exp]).check()
+        assert res.outputs == exp and [int(u) for u in res.in_used] == [len(z) for z in zs], variant
+    ctx.set_variant(N.ZLIB_DECODE, 0)
+    # short output slots: the status (and nothing else) must be "output buffer too small", as the lane-per-stream kernel reports it
+    res0 = ctx.zlib_decode(zs[:12], [max(0, len(e) - 1) for e in exp[:12]])
+    ctx.set_variant(N.ZLIB_DECODE, 9)
+    res9 = ctx.zlib_decode(zs[:12], [max(0, len(e) - 1) for e in exp[:12]])
+    ctx.set_variant(N.ZLIB_DECODE, 0)
+    assert [int(s) for s in res0.status] == [int(s) for s in res9.status]
