@@ -110,16 +110,17 @@ struct Lz4V4 {
         if (delta <= 0) return;
         const int32_t keep = ((int32_t)oend - nb + 15) & ~15;
         if (delta < LIN) {
-            rcx_u32x4 v[3];
+            constexpr int NK = (H + 32 + 1023) / 1024;         // keep <= H + 31: all reads, then all writes
+            rcx_u32x4 v[NK];
 #pragma unroll
-            for (int k = 0; k < 3; k++) {                      // keep <= H+16 <= 3 x 1024: all reads, then all writes
+            for (int k = 0; k < NK; k++) {
                 const int32_t j = 1024 * k + 16 * (int32_t)lane;
                 v[k] = rcx_u32x4{0, 0, 0, 0};
                 if (j < keep && j + delta + 16 <= LIN + 64) v[k] = *(const rcx_u32x4*)(wb_ + j + delta);
             }
             rcx_wave_sync();
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
+            for (int k = 0; k < NK; k++) {
                 const int32_t j = 1024 * k + 16 * (int32_t)lane;
                 if (j < keep && j + delta + 16 <= LIN + 64) *(rcx_u32x4*)(wb_ + j) = v[k];
             }

@@ -266,10 +266,10 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
     }
 };
 
-template <int CB>
+template <int CB, int TC = 2560, int HH = 2048>
 __global__ __launch_bounds__(128, 8) void k_lz4_decode_v5(rcx_kargs a)
 {
-    typedef Lz4V5<CB> S;
+    typedef Lz4V5<CB, TC, HH> S;
     __shared__ __align__(16) uint8_t s_cbuf[CB + 96];
     __shared__ __align__(16) uint8_t s_wbuf[S::WBUF5];
     __shared__ uint32_t s_epos[64];
