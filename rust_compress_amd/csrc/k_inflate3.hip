@@ -28,17 +28,23 @@
 // literals in a row close a run without a match.  It returns when something needs the caller:
 //   status 0  limits: staging (off > lim), literal register / buffer (cnt >= room) or descriptors (ns >= 64) ran out
 //          1  a match longer than 64 bytes: len, dist decoded, NOT booked (the wave-wide copy path takes it)
-//          2  end of block (consumed)        3  the next lit/len code is long or invalid: nothing consumed
+//          2  end of block (consumed)        3  the next bits are no lit/len code (or symbol 286/287): nothing consumed
 //          4  a distance beyond the output or 32 KiB (the caller falls back)
-//          5  length decoded into len, the distance code is long or invalid: nothing of the distance consumed
+//          5  length decoded into len, the next bits are no distance code (or symbol 30/31): nothing of it consumed
+// Codes longer than the lookup tables cover are decoded from the canonical limits (INF_CANON).
 // Bits: the 64-bit buffer is refilled 8 bytes at a time (only 32 counted; the rest are the same bits the next refill ORs
 // in again).  ltab/dtab: base | extra_bits << 16 per length / distance symbol.  Fixed registers v80-v99, s[90:91].
 #ifndef RCX_INF_RUN_CALL
 __device__ __forceinline__ void rcx_inf_run(uint32_t& lo, uint32_t& hi, uint32_t& bc, uint32_t& off, uint32_t& cnt, uint32_t& litv,
                                             uint32_t& len, uint32_t& dist, uint32_t& status, uint32_t& ns, uint32_t& runL, uint32_t& runsrc,
                                             uint32_t& otot, uint32_t room, uint32_t lim, uint32_t lane, uint32_t litn0,
-                                            uint32_t cb, uint32_t lutL, uint32_t lutD, uint32_t ltab, uint32_t dtab, uint32_t descb)
+                                            uint32_t cb, uint32_t lutL, uint32_t lutD, uint32_t ltab, uint32_t dtab, uint32_t descb,
+                                            uint32_t tabb, uint32_t symLb, uint32_t symDb)
 {
+    // registers: v80:81 bit buffer, v82 bits, v83 staged offset, v84 cnt, v85 litv, v86-v89 v97 temporaries, v90 len, v91 dist,
+    // v92 status, v93 ns, v94 cnt at the start of the open run (minus what the run held before the pass), v95 run source,
+    // v96 output bytes before this pass + matches booked in it (+ cnt = output so far), v79 cnt at which something happens
+    // (the run reaches 32 literals or the pass is out of room), v98:99 descriptor
 #define INF_REFILL(L)                                          \
         "v_cmp_gt_u32_e32 vcc, 33, v82\n\t"                    \
         "s_cbranch_vccz " L "\n\t"                             \
@@ -54,10 +60,11 @@ __device__ __forceinline__ void rcx_inf_run(uint32_t& lo, uint32_t& hi, uint32_t
 #define INF_CONSUME                                            \
         "v_lshrrev_b64 v[80:81], v86, v[80:81]\n\t"            \
         "v_sub_u32_e32 v82, v82, v86\n\t"
-    /* desc[ns] = {runsrc, runL | len << 8 | dist << 16} by lane 0; ns++, the next run starts at litn0 + cnt */
-#define INF_POST                                               \
+    /* desc[ns] = {runsrc, runL | len << 8 | dist << 16} by lane 0; ns++, the next run starts at litn0 + cnt; out when ns = 64 */
+#define INF_POST(OUT)                                          \
+        "v_sub_u32_e32 v97, v84, v94\n\t"                      \
         "v_mov_b32_e32 v98, v95\n\t"                           \
-        "v_lshl_or_b32 v99, v90, 8, v94\n\t"                   \
+        "v_lshl_or_b32 v99, v90, 8, v97\n\t"                   \
         "v_lshl_or_b32 v99, v91, 16, v99\n\t"                  \
         "v_lshl_add_u32 v97, v93, 3, %[descb]\n\t"             \
         "v_cmp_eq_u32_e32 vcc, 0, %[lane]\n\t"                 \
@@ -65,46 +72,77 @@ __device__ __forceinline__ void rcx_inf_run(uint32_t& lo, uint32_t& hi, uint32_t
         "ds_write_b64 v97, v[98:99]\n\t"                       \
         "s_mov_b64 exec, s[90:91]\n\t"                         \
         "v_add_u32_e32 v93, 1, v93\n\t"                        \
-        "v_mov_b32_e32 v94, 0\n\t"                             \
-        "v_add_u32_e32 v95, %[litn0], v84\n\t"
+        "v_mov_b32_e32 v94, v84\n\t"                           \
+        "v_add_u32_e32 v95, %[litn0], v84\n\t"                 \
+        "v_add_u32_e32 v79, 32, v94\n\t"                       \
+        "v_min_u32_e32 v79, v79, %[room]\n\t"                  \
+        "v_cmp_lt_u32_e32 vcc, 63, v93\n\t"                    \
+        "s_cbranch_vccnz " OUT "\n\t"
+    /* canonical decode of a code longer than the lookup table covers (HuffmanTree::decode, flate.rs:129-146): lim[l] / base[l] at
+       TAB / TAB+64, symbols in canonical order at SYM; in: v80; out: v87 symbol, v86 code length; FAIL: these bits are no code */
+#define INF_CANON(TAB, SYM, L0, TAG, FAIL)                     \
+        "v_bfrev_b32_e32 v88, v80\n\t"                         \
+        "v_lshrrev_b32_e32 v88, 17, v88\n\t"                   \
+        "v_mov_b32_e32 v86, " L0 "\n\t"                        \
+        "L_c" TAG "_%=:\n\t"                                   \
+        "v_lshl_add_u32 v97, v86, 2, " TAB "\n\t"              \
+        "ds_read_b32 v89, v97\n\t"                             \
+        "ds_read_b32 v97, v97 offset:64\n\t"                   \
+        "s_waitcnt lgkmcnt(0)\n\t"                             \
+        "v_cmp_lt_u32_e32 vcc, v88, v89\n\t"                   \
+        "s_cbranch_vccnz L_f" TAG "_%=\n\t"                    \
+        "v_add_u32_e32 v86, 1, v86\n\t"                        \
+        "v_cmp_gt_u32_e32 vcc, 16, v86\n\t"                    \
+        "s_cbranch_vccnz L_c" TAG "_%=\n\t"                    \
+        "s_branch " FAIL "\n\t"                                \
+        "L_f" TAG "_%=:\n\t"                                   \
+        "v_sub_u32_e32 v89, 15, v86\n\t"                       \
+        "v_lshrrev_b32_e32 v89, v89, v88\n\t"                  \
+        "v_add_u32_e32 v89, v89, v97\n\t"                      \
+        "v_lshl_add_u32 v89, v89, 1, " SYM "\n\t"              \
+        "ds_read_u16 v87, v89\n\t"                             \
+        "s_waitcnt lgkmcnt(0)\n\t"
     asm volatile(
         "v_mov_b32_e32 v80, %[lo]\n\t" "v_mov_b32_e32 v81, %[hi]\n\t" "v_mov_b32_e32 v82, %[bc]\n\t" "v_mov_b32_e32 v83, %[off]\n\t"
         "v_mov_b32_e32 v84, %[cnt]\n\t" "v_mov_b32_e32 v85, %[litv]\n\t" "v_mov_b32_e32 v90, 0\n\t" "v_mov_b32_e32 v91, 0\n\t"
-        "v_mov_b32_e32 v92, 0\n\t" "v_mov_b32_e32 v93, %[ns]\n\t" "v_mov_b32_e32 v94, %[runL]\n\t" "v_mov_b32_e32 v95, %[runsrc]\n\t"
+        "v_mov_b32_e32 v92, 0\n\t" "v_mov_b32_e32 v93, %[ns]\n\t" "v_sub_u32_e32 v94, %[cnt], %[runL]\n\t" "v_mov_b32_e32 v95, %[runsrc]\n\t"
         "v_mov_b32_e32 v96, %[otot]\n\t"
-        "L_top_%=:\n\t"
-        "v_cmp_lt_u32_e32 vcc, %[lim], v83\n\t"
-        "s_cbranch_vccnz L_out_%=\n\t"
-        "v_cmp_ge_u32_e32 vcc, v84, %[room]\n\t"
+        "v_add_u32_e32 v79, 32, v94\n\t"
+        "v_min_u32_e32 v79, v79, %[room]\n\t"
+        "v_cmp_ge_u32_e32 vcc, v84, %[room]\n\t"               /* no room at all */
         "s_cbranch_vccnz L_out_%=\n\t"
         "v_cmp_lt_u32_e32 vcc, 63, v93\n\t"
+        "s_cbranch_vccnz L_out_%=\n\t"
+        "L_top_%=:\n\t"
+        "v_cmp_lt_u32_e32 vcc, %[lim], v83\n\t"
         "s_cbranch_vccnz L_out_%=\n\t"
         INF_REFILL("L_h1_%=")
         "v_and_b32_e32 v86, 0x1ff, v80\n\t"
         "v_lshl_add_u32 v86, v86, 1, %[lutL]\n\t"
         "ds_read_u16 v88, v86\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
+        "v_and_b32_e32 v86, 15, v88\n\t"
         "v_cmp_lt_u32_e32 vcc, 0x7fff, v88\n\t"
         "s_cbranch_vccnz L_nonlit_%=\n\t"
-        "v_and_b32_e32 v86, 15, v88\n\t"
         INF_CONSUME
         "v_lshrrev_b32_e32 v87, 4, v88\n\t"
+        "L_lit_%=:\n\t"                                        /* a literal: v87, its bits are consumed */
         "v_cmp_eq_u32_e32 vcc, %[lane], v84\n\t"
         "v_cndmask_b32_e32 v85, v85, v87, vcc\n\t"
         "v_add_u32_e32 v84, 1, v84\n\t"
-        "v_add_u32_e32 v94, 1, v94\n\t"
-        "v_add_u32_e32 v96, 1, v96\n\t"
-        "v_cmp_ne_u32_e32 vcc, 32, v94\n\t"
+        "v_cmp_ne_u32_e32 vcc, v84, v79\n\t"
         "s_cbranch_vccnz L_top_%=\n\t"
+        "v_cmp_ge_u32_e32 vcc, v84, %[room]\n\t"               /* out of room (checked before the 32-literal rule: the caller books it) */
+        "s_cbranch_vccnz L_out_%=\n\t"
         "v_mov_b32_e32 v90, 0\n\t"                             /* 32 literals in a row: a run without a match */
         "v_mov_b32_e32 v91, 0\n\t"
-        INF_POST
+        INF_POST("L_out_%=")
         "s_branch L_top_%=\n\t"
         "L_nonlit_%=:\n\t"
-        "v_and_b32_e32 v86, 15, v88\n\t"
         "v_cmp_eq_u32_e32 vcc, 0, v86\n\t"
-        "s_cbranch_vccnz L_slow_%=\n\t"
+        "s_cbranch_vccnz L_llong_%=\n\t"
         "v_bfe_u32 v87, v88, 4, 11\n\t"
+        "L_nl2_%=:\n\t"                                        /* a symbol >= 256 in v87, code length v86, nothing consumed yet */
         "v_cmp_eq_u32_e32 vcc, 0x100, v87\n\t"
         "s_cbranch_vccnz L_eob_%=\n\t"
         "v_subrev_u32_e32 v87, 0x101, v87\n\t"
@@ -127,8 +165,9 @@ __device__ __forceinline__ void rcx_inf_run(uint32_t& lo, uint32_t& hi, uint32_t
         "s_waitcnt lgkmcnt(0)\n\t"
         "v_and_b32_e32 v86, 15, v88\n\t"
         "v_cmp_eq_u32_e32 vcc, 0, v86\n\t"
-        "s_cbranch_vccnz L_dslow_%=\n\t"
+        "s_cbranch_vccnz L_dlong_%=\n\t"
         "v_bfe_u32 v87, v88, 4, 11\n\t"
+        "L_d2_%=:\n\t"                                         /* a distance symbol in v87, code length v86, not consumed yet */
         "v_cmp_lt_u32_e32 vcc, 29, v87\n\t"
         "s_cbranch_vccnz L_dslow_%=\n\t"
         INF_CONSUME
@@ -141,15 +180,25 @@ __device__ __forceinline__ void rcx_inf_run(uint32_t& lo, uint32_t& hi, uint32_t
         "v_and_b32_e32 v87, v87, v80\n\t"
         "v_add_u32_e32 v91, v89, v87\n\t"
         INF_CONSUME
-        "v_cmp_gt_u32_e32 vcc, v91, v96\n\t"                   /* distance beyond the output so far */
+        "v_add_u32_e32 v97, v96, v84\n\t"                      /* output so far */
+        "v_cmp_gt_u32_e32 vcc, v91, v97\n\t"                   /* distance beyond it */
         "s_cbranch_vccnz L_bad_%=\n\t"
         "v_cmp_lt_u32_e32 vcc, 0x8000, v91\n\t"
         "s_cbranch_vccnz L_bad_%=\n\t"
         "v_cmp_lt_u32_e32 vcc, 64, v90\n\t"
         "s_cbranch_vccnz L_long_%=\n\t"
-        INF_POST
         "v_add_u32_e32 v96, v96, v90\n\t"
+        INF_POST("L_out_%=")
         "s_branch L_top_%=\n\t"
+        "L_llong_%=:\n\t"
+        INF_CANON("%[tabb]", "%[symLb]", "10", "l", "L_slow_%=")
+        "v_cmp_lt_u32_e32 vcc, 0xff, v87\n\t"
+        "s_cbranch_vccnz L_nl2_%=\n\t"
+        INF_CONSUME
+        "s_branch L_lit_%=\n\t"
+        "L_dlong_%=:\n\t"
+        INF_CANON("%[tabd]", "%[symDb]", "9", "d", "L_dslow_%=")
+        "s_branch L_d2_%=\n\t"
         "L_long_%=:\n\t"
         "v_mov_b32_e32 v92, 1\n\t"
         "s_branch L_out_%=\n\t"
@@ -167,24 +216,25 @@ __device__ __forceinline__ void rcx_inf_run(uint32_t& lo, uint32_t& hi, uint32_t
         "v_mov_b32_e32 v92, 5\n\t"
         "L_out_%=:\n\t"
         "v_mov_b32_e32 %[lo], v80\n\t" "v_mov_b32_e32 %[hi], v81\n\t" "v_mov_b32_e32 %[bc], v82\n\t" "v_mov_b32_e32 %[off], v83\n\t"
+        "v_sub_u32_e32 %[runL], v84, v94\n\t" "v_add_u32_e32 %[otot], v96, v84\n\t"
         "v_mov_b32_e32 %[cnt], v84\n\t" "v_mov_b32_e32 %[litv], v85\n\t" "v_mov_b32_e32 %[len], v90\n\t" "v_mov_b32_e32 %[dist], v91\n\t"
-        "v_mov_b32_e32 %[status], v92\n\t" "v_mov_b32_e32 %[ns], v93\n\t" "v_mov_b32_e32 %[runL], v94\n\t" "v_mov_b32_e32 %[runsrc], v95\n\t"
-        "v_mov_b32_e32 %[otot], v96\n\t"
+        "v_mov_b32_e32 %[status], v92\n\t" "v_mov_b32_e32 %[ns], v93\n\t" "v_mov_b32_e32 %[runsrc], v95\n\t"
         : [lo] "+v"(lo), [hi] "+v"(hi), [bc] "+v"(bc), [off] "+v"(off), [cnt] "+v"(cnt), [litv] "+v"(litv),
           [ns] "+v"(ns), [runL] "+v"(runL), [runsrc] "+v"(runsrc), [otot] "+v"(otot),
           [len] "=&v"(len), [dist] "=&v"(dist), [status] "=&v"(status)
         : [room] "v"(room), [lim] "v"(lim), [lane] "v"(lane), [litn0] "v"(litn0), [cb] "v"(cb), [lutL] "v"(lutL), [lutD] "v"(lutD),
-          [ltab] "v"(ltab), [dtab] "v"(dtab), [descb] "v"(descb)
-        : "vcc", "memory", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94",
+          [ltab] "v"(ltab), [dtab] "v"(dtab), [descb] "v"(descb), [tabb] "v"(tabb), [tabd] "v"(tabb + 128u), [symLb] "v"(symLb), [symDb] "v"(symDb)
+        : "vcc", "memory", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94",
           "v95", "v96", "v97", "v98", "v99", "s90", "s91");
 #undef INF_REFILL
 #undef INF_CONSUME
 #undef INF_POST
+#undef INF_CANON
 }
 #define RCX_LDSADDR(p) rcx_vgpr((uint32_t)(uintptr_t)(p))     // low half of a generic LDS pointer = the LDS byte address
-#define RCX_INF_RUN_CALL(lo, hi, bc, off, cnt, litv, len, dist, st, ns, runL, runsrc, otot, room, lim, lane, litn0, cb, lutL, lutD, ltab, dtab, desc) \
+#define RCX_INF_RUN_CALL(lo, hi, bc, off, cnt, litv, len, dist, st, ns, runL, runsrc, otot, room, lim, lane, litn0, cb, lutL, lutD, ltab, dtab, desc, tab, symL, symD) \
     rcx_inf_run(lo, hi, bc, off, cnt, litv, len, dist, st, ns, runL, runsrc, otot, room, lim, lane, litn0, RCX_LDSADDR(cb), RCX_LDSADDR(lutL),    \
-                RCX_LDSADDR(lutD), RCX_LDSADDR(ltab), RCX_LDSADDR(dtab), RCX_LDSADDR(desc))
+                RCX_LDSADDR(lutD), RCX_LDSADDR(ltab), RCX_LDSADDR(dtab), RCX_LDSADDR(desc), RCX_LDSADDR(tab), RCX_LDSADDR(symL), RCX_LDSADDR(symD))
 #endif
 
 template <int CB>
@@ -487,7 +537,8 @@ struct Inf3 : Lz4V5<CB, 1536, 1024> {
                         uint32_t voff = RCX_VGPR((uint32_t)((int32_t)p - this->cbase)), vcnt = RCX_VGPR(0), litv = 0, vst = 0, vlen = 0, vdist = 0;
                         uint32_t vns = RCX_VGPR((uint32_t)ns), vrunL = RCX_VGPR(runL), vrunsrc = RCX_VGPR(runsrc), votot = RCX_VGPR(otot);
                         RCX_INF_RUN_CALL(vlo, vhi, vbc, voff, vcnt, litv, vlen, vdist, vst, vns, vrunL, vrunsrc, votot, room,
-                                         RCX_VGPR((uint32_t)(CB - 12)), RCX_VGPR(lane), RCX_VGPR(litn), this->cbuf, lutL, lutD, ltab, ltab + 32, desc);
+                                         RCX_VGPR((uint32_t)(CB - 12)), RCX_VGPR(lane), RCX_VGPR(litn), this->cbuf, lutL, lutD, ltab, ltab + 32, desc,
+                                         tab, symL, symD);
                         const uint32_t cnt = RCX_U(vcnt);
                         fs = RCX_U(vst); flen = RCX_U(vlen); fdist = RCX_U(vdist);
                         if (cnt) if (lane < cnt) litbuf[litn + lane] = (uint8_t)litv;

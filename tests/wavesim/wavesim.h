@@ -248,7 +248,8 @@ static inline void ws_lds_store16(uint8_t* p, uint32_t v0, uint32_t v1, uint32_t
 static inline void ws_inf_run(uint32_t& lo, uint32_t& hi, uint32_t& bc, uint32_t& off, uint32_t& cnt, uint32_t& litv, uint32_t& len,
                               uint32_t& dist, uint32_t& status, uint32_t& ns, uint32_t& runL, uint32_t& runsrc, uint32_t& otot,
                               uint32_t room, uint32_t lim, uint32_t lane, uint32_t litn0, const uint8_t* cb,
-                              const uint16_t* lutL, const uint16_t* lutD, const uint32_t* ltab, const uint32_t* dtab, uint32_t* desc)
+                              const uint16_t* lutL, const uint16_t* lutD, const uint32_t* ltab, const uint32_t* dtab, uint32_t* desc,
+                              const uint32_t* tab, const uint16_t* symL, const uint16_t* symD)
 {
     uint64_t bb = ((uint64_t)hi << 32) | lo;
     auto refill = [&] { if (bc <= 32) { uint64_t w; memcpy(&w, cb + off, 8); bb |= w << bc; bc += 32; off += 4; } };
@@ -256,21 +257,26 @@ static inline void ws_inf_run(uint32_t& lo, uint32_t& hi, uint32_t& bc, uint32_t
         if (lane == 0) { desc[2 * ns] = runsrc; desc[2 * ns + 1] = runL | (M << 8) | (D << 16); }
         ns++; runL = 0; runsrc = litn0 + cnt;
     };
+    auto canon = [&](const uint32_t* limb, const uint16_t* sym, uint32_t l0, uint32_t& s_, uint32_t& l_) {   // limits at limb, bases 16 words on
+        uint32_t r = 0; for (int i = 0; i < 15; i++) r |= (((uint32_t)bb >> i) & 1u) << (14 - i);
+        for (uint32_t l = l0; l <= 15; l++) if (r < limb[l]) { s_ = sym[(r >> (15 - l)) + limb[16 + l]]; l_ = l; return true; }
+        return false;
+    };
     len = 0; dist = 0; status = 0;
+    if (cnt >= room || ns > 63) { lo = (uint32_t)bb; hi = (uint32_t)(bb >> 32); return; }
     for (;;) {
-        if (off > lim || cnt >= room || ns > 63) break;
+        if (off > lim) break;
         refill();
-        uint32_t e = lutL[bb & 0x1ff];
-        if (e <= 0x7fff) {
-            const uint32_t l = e & 15; bb >>= l; bc -= l;
-            if (lane == cnt) litv = e >> 4;
+        uint32_t e = lutL[bb & 0x1ff], l = e & 15, sym = (e >> 4) & 0x7ff;
+        if (e > 0x7fff && l == 0 && !canon(tab, symL, 10, sym, l)) { status = 3; break; }
+        if (sym < 256) {
+            bb >>= l; bc -= l;
+            if (lane == cnt) litv = sym;
             cnt++; runL++; otot++;
-            if (runL == 32) post(0, 0);
+            if (cnt >= room) break;
+            if (runL == 32) { post(0, 0); if (ns > 63) break; }
             continue;
         }
-        uint32_t l = e & 15;
-        if (l == 0) { status = 3; break; }
-        uint32_t sym = (e >> 4) & 0x7ff;
         if (sym == 256) { bb >>= l; bc -= l; status = 2; break; }
         const uint32_t nn = sym - 257;
         if (nn > 28) { status = 3; break; }
@@ -279,16 +285,18 @@ static inline void ws_inf_run(uint32_t& lo, uint32_t& hi, uint32_t& bc, uint32_t
         len = (t & 0xffff) + ((uint32_t)bb & ((1u << xb) - 1u)); bb >>= xb; bc -= xb;
         refill();
         e = lutD[bb & 0xff]; l = e & 15;
-        const uint32_t d = (e >> 4) & 0x7ff;
-        if (l == 0 || d > 29) { status = 5; break; }
+        uint32_t d = (e >> 4) & 0x7ff;
+        if (l == 0 && !canon(tab + 32, symD, 9, d, l)) { status = 5; break; }
+        if (d > 29) { status = 5; break; }
         bb >>= l; bc -= l;
         t = dtab[d]; xb = t >> 16;
         dist = (t & 0xffff) + ((uint32_t)bb & ((1u << xb) - 1u)); bb >>= xb; bc -= xb;
         if (dist > otot || dist > 0x8000u) { status = 4; break; }
         if (len > 64) { status = 1; break; }
-        post(len, dist);
         otot += len;
+        post(len, dist);
         len = 0; dist = 0;
+        if (ns > 63) break;
     }
     lo = (uint32_t)bb; hi = (uint32_t)(bb >> 32);
 }
