@@ -26,7 +26,7 @@
 // literals go to `litv` (literal j of the pass in lane j; the caller stores them at litbuf[litn0 + j]), a match of <= 64
 // bytes closes the open literal run as a sequence descriptor {run source, L | M << 8 | dist << 16} at desc[ns], 32
 // literals in a row close a run without a match.  It returns when something needs the caller:
-//   status 0  limits: staging (off > lim), literal register / buffer (cnt >= room) or descriptors (ns >= 64) ran out
+//   status 0  limits: staging (a refill with off > lim), literal register / buffer (cnt >= room) or descriptors (ns >= 64) ran out
 //          1  a match longer than 64 bytes: len, dist decoded, NOT booked (the wave-wide copy path takes it)
 //          2  end of block (consumed)        3  the next bits are no lit/len code (or symbol 286/287): nothing consumed
 //          4  a distance beyond the output or 32 KiB (the caller falls back)
@@ -45,9 +45,11 @@ __device__ __forceinline__ void rcx_inf_run(uint32_t& lo, uint32_t& hi, uint32_t
     // v92 status, v93 ns, v94 cnt at the start of the open run (minus what the run held before the pass), v95 run source,
     // v96 output bytes before this pass + matches booked in it (+ cnt = output so far), v79 cnt at which something happens
     // (the run reaches 32 literals or the pass is out of room), v98:99 descriptor
-#define INF_REFILL(L)                                          \
+#define INF_REFILL(L, DRY)                                     \
         "v_cmp_gt_u32_e32 vcc, 33, v82\n\t"                    \
         "s_cbranch_vccz " L "\n\t"                             \
+        "v_cmp_lt_u32_e32 vcc, %[lim], v83\n\t"                \
+        "s_cbranch_vccnz " DRY "\n\t"                          \
         "v_add_u32_e32 v86, %[cb], v83\n\t"                    \
         "ds_read2_b32 v[86:87], v86 offset1:1\n\t"             \
         "v_add_u32_e32 v83, 4, v83\n\t"                        \
@@ -114,9 +116,7 @@ __device__ __forceinline__ void rcx_inf_run(uint32_t& lo, uint32_t& hi, uint32_t
         "v_cmp_lt_u32_e32 vcc, 63, v93\n\t"
         "s_cbranch_vccnz L_out_%=\n\t"
         "L_top_%=:\n\t"
-        "v_cmp_lt_u32_e32 vcc, %[lim], v83\n\t"
-        "s_cbranch_vccnz L_out_%=\n\t"
-        INF_REFILL("L_h1_%=")
+        INF_REFILL("L_h1_%=", "L_out_%=")                      /* staged bytes ran out between symbols: status 0 */
         "v_and_b32_e32 v86, 0x1ff, v80\n\t"
         "v_lshl_add_u32 v86, v86, 1, %[lutL]\n\t"
         "ds_read_u16 v88, v86\n\t"
@@ -158,7 +158,7 @@ __device__ __forceinline__ void rcx_inf_run(uint32_t& lo, uint32_t& hi, uint32_t
         "v_and_b32_e32 v87, v87, v80\n\t"
         "v_add_u32_e32 v90, v89, v87\n\t"
         INF_CONSUME
-        INF_REFILL("L_h2_%=")
+        INF_REFILL("L_h2_%=", "L_dslow_%=")                    /* ... behind a decoded length: the caller restages and decodes the distance */
         "v_and_b32_e32 v86, 0xff, v80\n\t"
         "v_lshl_add_u32 v86, v86, 1, %[lutD]\n\t"
         "ds_read_u16 v88, v86\n\t"
@@ -537,7 +537,7 @@ struct Inf3 : Lz4V5<CB, 1536, 1024> {
                         uint32_t voff = RCX_VGPR((uint32_t)((int32_t)p - this->cbase)), vcnt = RCX_VGPR(0), litv = 0, vst = 0, vlen = 0, vdist = 0;
                         uint32_t vns = RCX_VGPR((uint32_t)ns), vrunL = RCX_VGPR(runL), vrunsrc = RCX_VGPR(runsrc), votot = RCX_VGPR(otot);
                         RCX_INF_RUN_CALL(vlo, vhi, vbc, voff, vcnt, litv, vlen, vdist, vst, vns, vrunL, vrunsrc, votot, room,
-                                         RCX_VGPR((uint32_t)(CB - 12)), RCX_VGPR(lane), RCX_VGPR(litn), this->cbuf, lutL, lutD, ltab, ltab + 32, desc,
+                                         RCX_VGPR((uint32_t)(CB - 8)), RCX_VGPR(lane), RCX_VGPR(litn), this->cbuf, lutL, lutD, ltab, ltab + 32, desc,
                                          tab, symL, symD);
                         const uint32_t cnt = RCX_U(vcnt);
                         fs = RCX_U(vst); flen = RCX_U(vlen); fdist = RCX_U(vdist);

@@ -252,7 +252,7 @@ static inline void ws_inf_run(uint32_t& lo, uint32_t& hi, uint32_t& bc, uint32_t
                               const uint32_t* tab, const uint16_t* symL, const uint16_t* symD)
 {
     uint64_t bb = ((uint64_t)hi << 32) | lo;
-    auto refill = [&] { if (bc <= 32) { uint64_t w; memcpy(&w, cb + off, 8); bb |= w << bc; bc += 32; off += 4; } };
+    auto refill = [&]() -> bool { if (bc <= 32) { if (off > lim) return false; uint64_t w; memcpy(&w, cb + off, 8); bb |= w << bc; bc += 32; off += 4; } return true; };
     auto post = [&](uint32_t M, uint32_t D) {
         if (lane == 0) { desc[2 * ns] = runsrc; desc[2 * ns + 1] = runL | (M << 8) | (D << 16); }
         ns++; runL = 0; runsrc = litn0 + cnt;
@@ -265,8 +265,7 @@ static inline void ws_inf_run(uint32_t& lo, uint32_t& hi, uint32_t& bc, uint32_t
     len = 0; dist = 0; status = 0;
     if (cnt >= room || ns > 63) { lo = (uint32_t)bb; hi = (uint32_t)(bb >> 32); return; }
     for (;;) {
-        if (off > lim) break;
-        refill();
+        if (!refill()) break;
         uint32_t e = lutL[bb & 0x1ff], l = e & 15, sym = (e >> 4) & 0x7ff;
         if (e > 0x7fff && l == 0 && !canon(tab, symL, 10, sym, l)) { status = 3; break; }
         if (sym < 256) {
@@ -283,7 +282,7 @@ static inline void ws_inf_run(uint32_t& lo, uint32_t& hi, uint32_t& bc, uint32_t
         bb >>= l; bc -= l;
         uint32_t t = ltab[nn], xb = t >> 16;
         len = (t & 0xffff) + ((uint32_t)bb & ((1u << xb) - 1u)); bb >>= xb; bc -= xb;
-        refill();
+        if (!refill()) { status = 5; break; }
         e = lutD[bb & 0xff]; l = e & 15;
         uint32_t d = (e >> 4) & 0x7ff;
         if (l == 0 && !canon(tab + 32, symD, 9, d, l)) { status = 5; break; }
