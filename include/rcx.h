@@ -205,7 +205,9 @@ enum rcx_codec {
     RCX_DC_ENCODE, RCX_DC_DECODE, RCX_ARI_BYTE_ENCODE, RCX_ARI_BYTE_DECODE,
     RCX_RLE_ENCODE, RCX_RLE_DECODE, RCX_CRC32, RCX_GZIP_DECODE, RCX_CODEC_COUNT
 };
-/* scratch bytes (HBM) the codec needs for nblocks blocks of <= max_block bytes */
+/* scratch bytes (HBM) the codec needs for nblocks blocks of <= max_block bytes.  Required for LZ4 encode, BWT and gzip
+ * decode; for RCX_INFLATE / RCX_ZLIB_DECODE it is what the default (wave-per-stream) decoder needs -- without it
+ * rcx_launch_dev falls back to the lane-per-stream kernel (same results, slower on small batches). */
 uint64_t rcx_scratch_bytes(int codec, uint32_t nblocks, uint64_t max_block);
 int rcx_launch_dev(rcx_ctx*, int codec, const rcx_dev_batch*, void* scratch, uint64_t scratch_bytes);
 /* kernel variant knob for A/B measurements (0 = default/best). */
