@@ -173,6 +173,16 @@ int rcx_ari_byte_encode_batch(rcx_ctx*, const rcx_batch*);
  * in_used[i] = bytes consumed so the next stream stays addressable */
 int rcx_ari_byte_decode_batch(rcx_ctx*, const rcx_batch*);
 uint64_t rcx_ari_byte_encode_bound(uint64_t in_len);
+/* The crate's other two models have no stream codec; these entry points drive them exactly as the reference's
+ * tests do.  reference: src/entropy/ari/bin.rs:17-103 bin::Model::new_flat(RANGE_DEFAULT_THRESHOLD >> 3, rate),
+ * 8 decisions per byte LSB first (src/entropy/ari/test.rs:22-50).  rate must be 1..31.  The coding has no end
+ * marker: the decoder produces exactly out_cap[i] bytes.  Encoded size <= rcx_ari_byte_encode_bound(n). */
+int rcx_ari_binary_encode_batch(rcx_ctx*, const rcx_batch*, uint32_t rate);
+int rcx_ari_binary_decode_batch(rcx_ctx*, const rcx_batch*, uint32_t rate);
+/* reference: table::SumProxy (table.rs:127-180, weights 2:1 >> 0, update 10/5) for the high nibble + bin::SumProxy
+ * (bin.rs:112-167, weights 1:1 >> 1, rates 3 and 5) for the low 4 bits, as src/entropy/ari/test.rs:91-148 */
+int rcx_ari_proxy_encode_batch(rcx_ctx*, const rcx_batch*);
+int rcx_ari_proxy_decode_batch(rcx_ctx*, const rcx_batch*);
 
 /* ---- RLE -------------------------------------------------------------------- */
 /* reference: src/rle.rs:82-122 (one-shot write + finish) */
@@ -203,7 +213,8 @@ enum rcx_codec {
     RCX_LZ4_DECODE = 0, RCX_LZ4_ENCODE, RCX_INFLATE, RCX_ZLIB_DECODE, RCX_ADLER32,
     RCX_BWT_FORWARD, RCX_BWT_INVERSE, RCX_MTF_ENCODE, RCX_MTF_DECODE,
     RCX_DC_ENCODE, RCX_DC_DECODE, RCX_ARI_BYTE_ENCODE, RCX_ARI_BYTE_DECODE,
-    RCX_RLE_ENCODE, RCX_RLE_DECODE, RCX_CRC32, RCX_GZIP_DECODE, RCX_CODEC_COUNT
+    RCX_RLE_ENCODE, RCX_RLE_DECODE, RCX_CRC32, RCX_GZIP_DECODE,
+    RCX_ARI_BINARY_ENCODE, RCX_ARI_BINARY_DECODE, RCX_ARI_PROXY_ENCODE, RCX_ARI_PROXY_DECODE, RCX_CODEC_COUNT
 };
 /* scratch bytes (HBM) the codec needs for nblocks blocks of <= max_block bytes.  Required for LZ4 encode, BWT and gzip
  * decode; for RCX_INFLATE / RCX_ZLIB_DECODE it is what the default (wave-per-stream) decoder needs -- without it
@@ -212,6 +223,8 @@ uint64_t rcx_scratch_bytes(int codec, uint32_t nblocks, uint64_t max_block);
 int rcx_launch_dev(rcx_ctx*, int codec, const rcx_dev_batch*, void* scratch, uint64_t scratch_bytes);
 /* kernel variant knob for A/B measurements (0 = default/best). */
 int rcx_ctx_set_variant(rcx_ctx*, int codec, int variant);
+/* codec parameter for rcx_launch_dev (the *_batch entry points take it as an argument): the rate of RCX_ARI_BINARY_* */
+int rcx_ctx_set_param(rcx_ctx*, int codec, uint32_t value);
 
 #ifdef __cplusplus
 }

@@ -68,7 +68,7 @@ class Context:
         self._chk(N.lib().rcx_ctx_set_stream(self._h, C.c_void_p(stream_ptr)))
 
     # ---------------- host-memory batches ----------------
-    def _run_host(self, fn_name, blobs, caps, extra_in=None, extra_out=False, n_out=None, needs_out=True):
+    def _run_host(self, fn_name, blobs, caps, extra_in=None, extra_out=False, n_out=None, needs_out=True, scalar=None):
         n = len(blobs)
         base, off, lens = B.pack(blobs)
         total, ooff, ocap = B.layout(caps if needs_out else [0] * n)
@@ -80,7 +80,9 @@ class Context:
         b = N.Batch(p(base), p(off), p(lens), p(out), p(ooff), p(ocap), p(out_len), p(in_used), p(status), n, N.MEM_HOST)
         fn = getattr(N.lib(), fn_name)
         aux = None
-        if extra_in is not None:
+        if scalar is not None:
+            self._chk(fn(self._h, C.byref(b), scalar))
+        elif extra_in is not None:
             aux = np.ascontiguousarray(extra_in, dtype=np.uint32)
             self._chk(fn(self._h, C.byref(b), C.c_void_p(p(aux))))
         elif n_out is not None:
@@ -140,6 +142,21 @@ class Context:
 
     def ari_byte_decode(self, blobs, caps):
         return self._run_host("rcx_ari_byte_decode_batch", blobs, caps)
+
+    def ari_binary_encode(self, blobs, rate):
+        """bin::Model, 8 decisions per byte (src/entropy/ari/test.rs:22-50)."""
+        return self._run_host("rcx_ari_binary_encode_batch", blobs, [int(N.lib().rcx_ari_byte_encode_bound(len(b))) for b in blobs], scalar=rate)
+
+    def ari_binary_decode(self, blobs, rate, nbytes):
+        """nbytes[i] = bytes to decode from stream i (the coding has no end marker)."""
+        return self._run_host("rcx_ari_binary_decode_batch", blobs, list(nbytes), scalar=rate)
+
+    def ari_proxy_encode(self, blobs):
+        """table::SumProxy + bin::SumProxy (src/entropy/ari/test.rs:91-148)."""
+        return self._run_host("rcx_ari_proxy_encode_batch", blobs, [int(N.lib().rcx_ari_byte_encode_bound(len(b))) for b in blobs])
+
+    def ari_proxy_decode(self, blobs, nbytes):
+        return self._run_host("rcx_ari_proxy_decode_batch", blobs, list(nbytes))
 
     def rle_encode(self, blobs):
         return self._run_host("rcx_rle_encode_batch", blobs, [int(N.lib().rcx_rle_encode_bound(len(b))) for b in blobs])

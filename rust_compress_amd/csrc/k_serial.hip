@@ -575,6 +575,150 @@ __global__ __launch_bounds__(64) void k_ari_byte(rcx_kargs a, int decode)
 }
 
 // -------------------------------------------------------------------------------------------------
+// The other two models of src/entropy/ari, driven the way the reference's own tests drive them (they have no stream
+// codec of their own): MODE 0 = bin::Model (bin.rs:17-103), 8 binary decisions per byte, LSB first (test.rs:22-50);
+// MODE 1 = table::SumProxy over two 16-entry tables for the high nibble + bin::SumProxy over two binary models for
+// the 4 low bits (table.rs:127-180, bin.rs:112-167, test.rs:91-148).  One lane per stream; the 2 x 16 frequencies of
+// MODE 1 sit in LDS, lane-strided.  Neither coding has an end marker: the decoder produces exactly out_cap[b] bytes.
+struct AriBin {                                                // bin::Model
+    uint32_t zero, total, rate;
+    __device__ __forceinline__ void init(uint32_t threshold, uint32_t r) { zero = threshold >> 1; total = threshold; rate = r; }   // new_flat :30-37
+    __device__ __forceinline__ void update(uint32_t bit)       // :60-82
+    {
+        if (bit) zero -= zero >> rate; else zero += (total - zero) >> rate;
+    }
+};
+struct AriTab16 {                                              // table::Model with 16 values, cut_shift 1
+    uint16_t* tab; unsigned t; uint32_t total;
+    __device__ __forceinline__ uint16_t& f(uint32_t e) { return tab[e * 64u + t]; }
+    __device__ __forceinline__ void init() { for (uint32_t e = 0; e < 16; e++) f(e) = 1; total = 16; }
+    __device__ __forceinline__ void load(uint32_t* x)
+    {
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = f((uint32_t)j);
+    }
+    __device__ __forceinline__ void update(uint32_t v, uint32_t add_log, uint32_t threshold)   // table.rs:69-91
+    {
+        const uint32_t add = (total >> add_log) + 1u;
+        f(v) = (uint16_t)(f(v) + (uint16_t)add);
+        total += add;
+        if (total >= threshold) {
+            total = 0;
+            for (uint32_t e = 0; e < 16; e++) { const uint32_t x = ((uint32_t)f(e) + 1u) >> 1; f(e) = (uint16_t)x; total += x; }
+        }
+    }
+};
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_ari_model(rcx_kargs a, int decode, uint32_t rate)
+{
+    __shared__ uint16_t s_t0[MODE ? 16 * 64 : 1];
+    __shared__ uint16_t s_t1[MODE ? 16 * 64 : 1];
+    const unsigned t = threadIdx.x;
+    const uint32_t b = blockIdx.x * 64 + t;
+    if (b >= a.nblocks) return;
+    const uint32_t threshold = (1u << 14) >> 3;               // RANGE_DEFAULT_THRESHOLD >> 3, test.rs:27,96
+    AriBin B0, B1;
+    AriTab16 T0, T1;
+    B0.init(threshold, MODE ? 3u : rate); B1.init(threshold, 5u);
+    T0.tab = s_t0; T1.tab = s_t1; T0.t = T1.t = t; T0.total = T1.total = 16;
+    if (MODE) { T0.init(); T1.init(); }
+    AriRange R; R.low = 0; R.hai = 0xffffffffu;
+    const uint8_t* in = a.in_base + a.in_off[b];
+    const uint64_t n = a.in_len[b];
+    uint8_t* out = a.out_base + a.out_off[b];
+    const uint64_t cap = a.out_cap[b];
+    uint64_t o = 0, used = 0;
+    int st = RCX_OK;
+    uint8_t tmp[4];
+    AriBytes src; src.start(in, n);
+    // the binary decision under the current model(s): (zero, total) of bin::Model or of the 1:1 >>1 SumProxy
+    auto bin_zero = [&]() -> uint32_t { return MODE ? (B0.zero + B1.zero) >> 1 : B0.zero; };
+    auto bin_total = [&]() -> uint32_t { return MODE ? (B0.total + B1.total) >> 1 : B0.total; };
+    auto bin_update = [&](uint32_t bit) { B0.update(bit); if (MODE) B1.update(bit); };
+    if (!decode) {
+        auto put = [&](uint32_t total, uint32_t lo, uint32_t hi) {
+            const unsigned k = R.process(total, lo, hi, tmp);
+            if (o + k > cap) { st = RCX_E_OUTPUT_TOO_SMALL; return; }
+            for (unsigned j = 0; j < k; j++) out[o + j] = tmp[j];
+            o += k;
+        };
+        for (uint64_t i = 0; i < n && !st; i++) {
+            const uint32_t v = src.next();
+            if (MODE) {                                        // high nibble under 2*t0 + 1*t1, table.rs:150-155
+                const uint32_t high = v >> 4;
+                uint32_t x0[16], x1[16];
+                T0.load(x0); T1.load(x1);
+                uint32_t lo = 0, fv = 0;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const uint32_t w = 2u * x0[j] + x1[j];
+                    lo += (uint32_t)j < high ? w : 0u; fv = (uint32_t)j == high ? w : fv;
+                }
+                put(2u * T0.total + T1.total, lo, lo + fv);
+                T0.update(high, 10, threshold); T1.update(high, 5, threshold);
+            }
+            for (int k = 0; k < (MODE ? 4 : 8) && !st; k++) {
+                const uint32_t bit = (v >> k) & 1u;
+                const uint32_t z = bin_zero(), tot = bin_total();
+                if (bit) put(tot, z, tot); else put(tot, 0, z);     // get_range, bin.rs:86-92
+                bin_update(bit);
+            }
+        }
+        if (!st) {                                             // Encoder::finish, mod.rs:230-237
+            if (o + 4 > cap) st = RCX_E_OUTPUT_TOO_SMALL;
+            else { out[o] = (uint8_t)(R.low >> 24); out[o + 1] = (uint8_t)(R.low >> 16); out[o + 2] = (uint8_t)(R.low >> 8); out[o + 3] = (uint8_t)R.low; o += 4; }
+        }
+        used = n;
+    } else {
+        uint32_t code = 0; unsigned pending = 4;
+        auto feed = [&]() {                                    // mod.rs:271-278; the tests' decode().unwrap() panics at the end of input
+            while (pending) {
+                if (src.p >= n) { st = RCX_E_MALFORMED; return; }
+                code = (code << 8) + src.next(); pending--;
+            }
+        };
+        for (; o < cap && !st; ) {
+            uint32_t v = 0;
+            if (MODE) {
+                feed(); if (st) break;
+                const uint32_t tot = 2u * T0.total + T1.total;
+                const uint32_t offset = (code - R.low) / ((R.hai - R.low) / tot);
+                if (offset >= tot) { st = RCX_E_MALFORMED; break; }     // table.rs:158 assert
+                uint32_t x0[16], x1[16];
+                T0.load(x0); T1.load(x1);
+                uint32_t c = 0, lo = 0, hi = 0, high = 0; bool found = false;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {                 // SumProxy::find_value, table.rs:157-173
+                    const uint32_t nc = c + 2u * x0[j] + x1[j];
+                    const bool hit = !found && nc > offset;
+                    if (hit) { lo = c; hi = nc; high = (uint32_t)j; }
+                    found = found || hit; c = nc;
+                }
+                if (!found) { st = RCX_E_MALFORMED; break; }
+                pending = R.process(tot, lo, hi, tmp);
+                T0.update(high, 10, threshold); T1.update(high, 5, threshold);
+                v = high << 4;
+            }
+            for (int k = 0; k < (MODE ? 4 : 8); k++) {
+                feed(); if (st) break;
+                const uint32_t z = bin_zero(), tot = bin_total();
+                const uint32_t offset = (code - R.low) / ((R.hai - R.low) / tot);
+                if (offset >= tot) { st = RCX_E_MALFORMED; break; }     // bin.rs:95 assert
+                const uint32_t bit = offset < z ? 0u : 1u;              // find_value, bin.rs:94-103
+                pending = bit ? R.process(tot, z, tot, tmp) : R.process(tot, 0, z, tmp);
+                bin_update(bit);
+                v += bit << k;
+            }
+            if (st) break;
+            out[o++] = (uint8_t)v;
+        }
+        used = src.p;
+    }
+    a.status[b] = st; a.out_len[b] = o; if (a.in_used) a.in_used[b] = used;
+}
+
+// -------------------------------------------------------------------------------------------------
 // Same coder, one WAVE per stream (the pipeline has a few thousand long streams, not 64 K short ones: with one lane
 // per stream that is 60 waves on the whole chip, each paying ~250 dependent instructions per symbol).  The 256 byte
 // frequencies live in registers, 4 per lane (entry e in lane e>>2), the EOF entry and every coder variable are
@@ -736,7 +880,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_ari_byte_wave(rcx_kargs a)
 }
 
 // -------------------------------------------------------------------------------------------------
-static void launch_serial(hipStream_t s, int codec, rcx_kargs& k, int v)
+static void launch_serial(hipStream_t s, int codec, rcx_kargs& k, int v, uint32_t param)
 {
     const uint32_t n = k.nblocks;
     switch (codec) {
@@ -755,6 +899,12 @@ static void launch_serial(hipStream_t s, int codec, rcx_kargs& k, int v)
         else hipLaunchKernelGGL(k_ari_byte, dim3((n + 63) / 64), dim3(64), 0, s, k, dec);
         break;
     }
+    case RCX_ARI_BINARY_ENCODE: case RCX_ARI_BINARY_DECODE:
+        hipLaunchKernelGGL((k_ari_model<0>), dim3((n + 63) / 64), dim3(64), 0, s, k, codec == RCX_ARI_BINARY_DECODE ? 1 : 0, param);
+        break;
+    case RCX_ARI_PROXY_ENCODE: case RCX_ARI_PROXY_DECODE:
+        hipLaunchKernelGGL((k_ari_model<1>), dim3((n + 63) / 64), dim3(64), 0, s, k, codec == RCX_ARI_PROXY_DECODE ? 1 : 0, 0u);
+        break;
     default: break;
     }
 }

@@ -42,6 +42,7 @@ struct rcx_ctx {
     hipStream_t own_stream = nullptr;
     std::string err;
     int variant[RCX_CODEC_COUNT] = {0};
+    uint32_t param[RCX_CODEC_COUNT] = {0};
     DevBuf d_in, d_out, d_desc, d_scratch;
     std::vector<uint8_t> h_desc;
 };
@@ -92,6 +93,13 @@ extern "C" int rcx_ctx_set_variant(rcx_ctx* c, int codec, int variant)
 {
     if (!c || codec < 0 || codec >= RCX_CODEC_COUNT) return RCX_RC_BAD_ARG;
     c->variant[codec] = variant;
+    return RCX_RC_OK;
+}
+
+extern "C" int rcx_ctx_set_param(rcx_ctx* c, int codec, uint32_t value)
+{
+    if (!c || codec < 0 || codec >= RCX_CODEC_COUNT) return RCX_RC_BAD_ARG;
+    c->param[codec] = value;
     return RCX_RC_OK;
 }
 
@@ -206,9 +214,13 @@ static int launch_codec(rcx_ctx* c, int codec, rcx_kargs& k)
         int rc = launch_bwt_inverse(s, k, v, c->err);
         if (rc) return rc;
         break; }
+    case RCX_ARI_BINARY_ENCODE: case RCX_ARI_BINARY_DECODE:
+        if (c->param[codec] < 1 || c->param[codec] > 31) { c->err = "ari binary: rate must be 1..31"; return RCX_RC_BAD_ARG; }
+        [[fallthrough]];
     case RCX_MTF_ENCODE: case RCX_MTF_DECODE: case RCX_DC_ENCODE: case RCX_DC_DECODE:
+    case RCX_ARI_PROXY_ENCODE: case RCX_ARI_PROXY_DECODE:
     case RCX_ARI_BYTE_ENCODE: case RCX_ARI_BYTE_DECODE: case RCX_RLE_ENCODE: case RCX_RLE_DECODE:
-        launch_serial(s, codec, k, v);
+        launch_serial(s, codec, k, v, c->param[codec]);
         break;
     default:
         c->err = "unknown codec";
@@ -324,5 +336,19 @@ extern "C" int rcx_dc_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run_
 extern "C" int rcx_dc_decode_batch(rcx_ctx* c, const rcx_batch* b, const uint64_t* n_out) { return run_batch(c, RCX_DC_DECODE, b, nullptr, nullptr, n_out, true); }
 extern "C" int rcx_ari_byte_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_ARI_BYTE_ENCODE, b, nullptr, nullptr, nullptr, true); }
 extern "C" int rcx_ari_byte_decode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_ARI_BYTE_DECODE, b, nullptr, nullptr, nullptr, true); }
+extern "C" int rcx_ari_binary_encode_batch(rcx_ctx* c, const rcx_batch* b, uint32_t rate)
+{
+    if (!c) return RCX_RC_BAD_ARG;
+    c->param[RCX_ARI_BINARY_ENCODE] = rate;
+    return run_batch(c, RCX_ARI_BINARY_ENCODE, b, nullptr, nullptr, nullptr, true);
+}
+extern "C" int rcx_ari_binary_decode_batch(rcx_ctx* c, const rcx_batch* b, uint32_t rate)
+{
+    if (!c) return RCX_RC_BAD_ARG;
+    c->param[RCX_ARI_BINARY_DECODE] = rate;
+    return run_batch(c, RCX_ARI_BINARY_DECODE, b, nullptr, nullptr, nullptr, true);
+}
+extern "C" int rcx_ari_proxy_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_ARI_PROXY_ENCODE, b, nullptr, nullptr, nullptr, true); }
+extern "C" int rcx_ari_proxy_decode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_ARI_PROXY_DECODE, b, nullptr, nullptr, nullptr, true); }
 extern "C" int rcx_rle_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_RLE_ENCODE, b, nullptr, nullptr, nullptr, true); }
 extern "C" int rcx_rle_decode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_RLE_DECODE, b, nullptr, nullptr, nullptr, true); }

@@ -89,6 +89,23 @@ def test_mtf_dc_ari_rle(ctx, oracle):
     assert ctx.dc_decode(e.outputs, lens).check().outputs == raws
 
 
+def test_ari_binary_and_proxy_models(ctx, oracle):
+    """bin::Model (every rate the reference's tests use, test.rs:52-89) and the SumProxy pair (test.rs:91-148)."""
+    raws = [r[:20000] for r in corpus.small_corpus()] + [bytes(range(256)) * 8]
+    lens = [len(r) for r in raws]
+    for rate in (1, 2, 3, 4, 5, 6, 7):
+        e = ctx.ari_binary_encode(raws, rate).check()
+        assert e.outputs == [oracle.ari_binary_encode(r, rate) for r in raws], rate
+        assert ctx.ari_binary_decode(e.outputs, rate, lens).check().outputs == raws
+    e = ctx.ari_proxy_encode(raws).check()
+    assert e.outputs == [oracle.ari_proxy_encode(r) for r in raws]
+    assert ctx.ari_proxy_decode(e.outputs, lens).check().outputs == raws
+    res = ctx.ari_proxy_decode([x[:-5] for x in e.outputs], [n + 4 for n in lens])       # runs off the end of the input
+    assert all(s == N.E_MALFORMED for s in res.status)
+    with pytest.raises(Exception):
+        ctx.ari_binary_encode(raws, 0)                                                    # rate out of range
+
+
 def test_rle_ari_malformed(ctx, oracle):
     rng = np.random.default_rng(2)
     arb = [bytes(rng.integers(0, 4, rng.integers(0, 200), dtype=np.uint8) * rng.integers(1, 100)) for _ in range(200)]

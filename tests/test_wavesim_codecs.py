@@ -61,6 +61,40 @@ def test_mtf_rle_ari_dc(oracle):
     assert not st.any() and dec == raws
 
 
+def _oracle_status(fn, *args):
+    try:
+        fn(*args)
+        return 0
+    except Exception as e:                       # oracle_py.OracleError
+        return e.status
+
+
+def test_ari_binary_and_proxy_models(oracle):
+    """bin::Model and the two SumProxy models, driven as src/entropy/ari/test.rs drives them."""
+    import simrun
+    raws = [r[:3000] for r in _raws(oracle)] + [bytes(range(256)) * 4, b"\xff" * 500]
+    lens = [len(r) for r in raws]
+    caps = [2 * n + 16 for n in lens]
+    for rate in (1, 3, 5, 9):
+        enc, _, _, st, _ = simrun.run(N.ARI_BINARY_ENCODE, rate, raws, caps)
+        assert not st.any() and enc == [oracle.ari_binary_encode(r, rate) for r in raws], rate
+        dec, _, _, st, _ = simrun.run(N.ARI_BINARY_DECODE, rate, enc, lens)
+        assert not st.any() and dec == raws, rate
+    enc, _, _, st, _ = simrun.run(N.ARI_PROXY_ENCODE, 0, raws, caps)
+    assert not st.any() and enc == [oracle.ari_proxy_encode(r) for r in raws]
+    dec, _, _, st, _ = simrun.run(N.ARI_PROXY_DECODE, 0, enc, lens)
+    assert not st.any() and dec == raws
+    # truncated streams / asking for more bytes than were coded: same status as the oracle
+    bad = [e[: max(0, len(e) - k)] for e in enc[:8] for k in (2, 6)] + [b"", bytes([255] * 30)]
+    want = [n + 3 for n in lens[:8] for _ in range(2)] + [1, 50]
+    _, _, _, st, _ = simrun.run(N.ARI_PROXY_DECODE, 0, bad, want)
+    assert list(st) == [_oracle_status(oracle.ari_proxy_decode, b_, w) for b_, w in zip(bad, want)]
+    _, _, _, st, _ = simrun.run(N.ARI_BINARY_DECODE, 5, bad, want)
+    assert list(st) == [_oracle_status(oracle.ari_binary_decode, b_, 5, w) for b_, w in zip(bad, want)]
+    _, _, _, st, _ = simrun.run(N.ARI_BINARY_ENCODE, 5, raws[:4], [3] * 4)     # short output slots
+    assert all(int(x) == N.E_OUTPUT_TOO_SMALL for x in st)
+
+
 def synth_dna(n):
     from rust_compress_amd import synth
     return synth.gen("dna4", n, 5).tobytes()
