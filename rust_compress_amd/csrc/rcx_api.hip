@@ -143,7 +143,7 @@ extern "C" uint64_t rcx_ari_byte_encode_bound(uint64_t n) { return 2 * n + 16; }
 extern "C" uint64_t rcx_rle_encode_bound(uint64_t n) { return n + n / 2 + 16; }
 
 // ---- scratch requirements ---------------------------------------------------------------------
-static const uint32_t LZ4E_CHUNK = 2048;        // LZ4 blocks encoded per launch (512 KiB table each)
+static const uint32_t LZ4E_CHUNK = 8192;        // LZ4 blocks encoded per launch (512 KiB table each): 32 waves per CU
 
 extern "C" uint64_t rcx_scratch_bytes(int codec, uint32_t nblocks, uint64_t max_block)
 {
@@ -189,7 +189,9 @@ static int launch_codec(rcx_ctx* c, int codec, rcx_kargs& k)
         for (uint32_t b0 = 0; b0 < n; b0 += LZ4E_CHUNK) {
             const uint32_t cnt = n - b0 < LZ4E_CHUNK ? n - b0 : LZ4E_CHUNK;
             HIPCHK(c, hipMemsetAsync(k.scratch, 0, (size_t)cnt * LZ4E_TABLE * 4ull, s));
-            hipLaunchKernelGGL(k_lz4_encode, dim3(cnt), dim3(64), 0, s, k, b0);
+            if (v == 1) hipLaunchKernelGGL(k_lz4_encode, dim3(cnt), dim3(64), 0, s, k, b0);          // serial probe chain (A/B)
+            else if (v == 2) hipLaunchKernelGGL(k_lz4_encode_w<64>, dim3(cnt), dim3(64), 0, s, k, b0);
+            else hipLaunchKernelGGL(k_lz4_encode_w<8>, dim3(cnt), dim3(64), 0, s, k, b0);
         }
         break; }
     case RCX_INFLATE:

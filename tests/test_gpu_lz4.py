@@ -22,9 +22,15 @@ def _raws(golden):
     return raws
 
 
-def test_encode_bit_exact_vs_oracle(ctx, oracle, golden):
+@pytest.mark.parametrize("variant", [0, 1, 2])     # windowed probe (8 lanes widening), serial probe chain, always 64 lanes
+def test_encode_bit_exact_vs_oracle(ctx, oracle, golden, variant):
     raws = _raws(golden)
-    res = ctx.lz4_encode_blocks(raws).check()
+    raws += [synth.gen(k, 300000, 11).tobytes() for k in ("rand", "mix", "words")]    # skip acceleration, back-tracking
+    ctx.set_variant(N.LZ4_ENCODE, variant)
+    try:
+        res = ctx.lz4_encode_blocks(raws).check()
+    finally:
+        ctx.set_variant(N.LZ4_ENCODE, 0)
     for r, e in zip(raws, res.outputs):
         assert e == oracle.lz4_encode_block(r)
     assert list(res.in_used) == [len(r) for r in raws]

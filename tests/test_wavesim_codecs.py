@@ -16,9 +16,13 @@ def _raws(oracle):
 def test_lz4_encode(oracle):
     import simrun
     raws = _raws(oracle)
-    outs, _, _, st, _ = simrun.run(N.LZ4_ENCODE, 0, raws, [oracle.lz4_compression_bound(len(r)) for r in raws],
-                                   scratch_bytes=len(raws) * (1 << 19))
-    assert not st.any() and outs == [oracle.lz4_encode_block(r) for r in raws]
+    from rust_compress_amd import synth
+    raws += [synth.gen(k, 70000, 3).tobytes() for k in ("text", "rand", "runs", "dna4")]   # skip acceleration, back-tracking
+    exp = [oracle.lz4_encode_block(r) for r in raws]
+    for variant in (0, 2, 1):                    # windowed probe (8 lanes widening / always 64), serial probe chain
+        outs, _, _, st, _ = simrun.run(N.LZ4_ENCODE, variant, raws, [oracle.lz4_compression_bound(len(r)) for r in raws],
+                                       scratch_bytes=len(raws) * (1 << 19))
+        assert not st.any() and outs == exp, variant
 
 
 def test_mtf_rle_ari_dc(oracle):

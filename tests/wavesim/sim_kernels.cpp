@@ -35,7 +35,9 @@ extern "C" int sim_launch(int codec, int variant, const rcx_kargs* a)
         else ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_decode_v4<1024, 1>(k); });
         return 0;
     case RCX_LZ4_ENCODE:
-        ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_encode(k, 0); });
+        if (variant == 1) ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_encode(k, 0); });
+        else if (variant == 2) ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_encode_w<64>(k, 0); });
+        else ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_encode_w<8>(k, 0); });
         return 0;
     case RCX_MTF_ENCODE: case RCX_MTF_DECODE: case RCX_DC_ENCODE: case RCX_DC_DECODE:
     case RCX_ARI_BYTE_ENCODE: case RCX_ARI_BYTE_DECODE: case RCX_RLE_ENCODE: case RCX_RLE_DECODE:
