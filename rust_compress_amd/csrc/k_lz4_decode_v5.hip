@@ -18,7 +18,7 @@
 // write tail" need no more than compiler ordering.  64 VGPRs (launch bound) keep 8 waves per SIMD = 16 blocks per CU.
 #include "rcx_dev.h"
 
-template <int CB, int TC = 2560, int HH = 2048>
+template <int CB, int TC = 2560, int HH = 2048, bool PROF5 = false>
 struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
     typedef Lz4V4<CB, false, TC, HH> B;
     static constexpr int NSLOT = 3;
@@ -27,6 +27,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
     static constexpr int STAGE5 = B::LIN + 64;         // 64 lanes x 32 bytes of old-match staging (bytes 32.. of a longer
     static constexpr int WBUF5 = STAGE5 + 64 * 32;     // gathered match go straight to their place): 16 blocks per CU fit
     Ring* ring;
+    uint64_t pw[4] = {0, 0, 0, 0};                 // PROF5: cycles waiting on the ring, cycles working, batches, -
 
     // ------------------------------------------------------------------------------------------ parser wave
     __device__ void run_parser()
@@ -56,12 +57,14 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
                 w0 = src; w1 = L | (M << 8) | (off << 16);
             }
             // a free slot
+            uint64_t tp0 = PROF5 ? (uint64_t)__builtin_readcyclecounter() : 0;
             for (;;) {
                 const uint32_t t = RCX_U(ring->tail);
                 if (RCX_U(ring->abort_)) return;
                 if (head - t < (uint32_t)NSLOT) break;
                 __builtin_amdgcn_s_sleep(16);                        // ~1K cycles: an executor batch takes ~20K
             }
+            if (PROF5) { pw[0] += (uint64_t)__builtin_readcyclecounter() - tp0; pw[2] += 1; }
             rcx_wave_sync();
             Slot* sl = &ring->slot[head % NSLOT];
             *(uint64_t*)sl->desc[lane] = (uint64_t)w0 | ((uint64_t)w1 << 32);
@@ -241,7 +244,9 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
         int st = RCX_OK;
         uint32_t tail = 0;
         for (;;) {
+            uint64_t te0 = PROF5 ? (uint64_t)__builtin_readcyclecounter() : 0;
             while (RCX_U(ring->head) == tail) __builtin_amdgcn_s_sleep(4);
+            if (PROF5) { pw[0] += (uint64_t)__builtin_readcyclecounter() - te0; pw[2] += 1; }
             rcx_wave_sync();
             const Slot* sl = &ring->slot[tail % NSLOT];
             typename B::Batch bt;
@@ -266,10 +271,11 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
     }
 };
 
-template <int CB, int TC = 2560, int HH = 2048>
+template <int CB, int TC = 2560, int HH = 2048, bool PROF5 = false>
 __global__ __launch_bounds__(128, 8) void k_lz4_decode_v5(rcx_kargs a)
 {
-    typedef Lz4V5<CB, TC, HH> S;
+    typedef Lz4V5<CB, TC, HH, PROF5> S;
+    const uint64_t tk0 = PROF5 ? (uint64_t)__builtin_readcyclecounter() : 0;
     __shared__ __align__(16) uint8_t s_cbuf[CB + 96];
     __shared__ __align__(16) uint8_t s_wbuf[S::WBUF5];
     __shared__ uint32_t s_epos[64];
@@ -289,9 +295,20 @@ __global__ __launch_bounds__(128, 8) void k_lz4_decode_v5(rcx_kargs a)
     s.wb_ = s_wbuf;
     s.epos = s_epos;
     s.ring = &s_ring;
-    if (role == 0) { s.run_parser(); return; }
+    if (role == 0) {
+        s.run_parser();
+        if (PROF5 && a.scratch && (threadIdx.x & 63u) == 0) {          // [0..3] parser: ring-full wait, total, posts
+            uint64_t* q = (uint64_t*)a.scratch + (size_t)b * 8;
+            q[0] = s.pw[0]; q[1] = (uint64_t)__builtin_readcyclecounter() - tk0; q[2] = s.pw[2];
+        }
+        return;
+    }
     int32_t st; uint32_t olen;
     s.run_executor(&st, &olen);
+    if (PROF5 && a.scratch && (threadIdx.x & 63u) == 0) {              // [4..7] executor: ring-empty wait, total, batches
+        uint64_t* q = (uint64_t*)a.scratch + (size_t)b * 8 + 4;
+        q[0] = s.pw[0]; q[1] = (uint64_t)__builtin_readcyclecounter() - tk0; q[2] = s.pw[2];
+    }
     if ((threadIdx.x & 63u) == 0) {
         a.status[b] = st;
         a.out_len[b] = olen;
