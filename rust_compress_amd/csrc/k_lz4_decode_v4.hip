@@ -371,10 +371,12 @@ struct Lz4V4 {
                 }
             }
             LZ4P_ADD(4);
-            const int32_t sbase = isfar ? STAGE + MCAP * (int32_t)lane : (int32_t)(mdst - S) - lbase;
+            int32_t sbase = isfar ? STAGE + MCAP * (int32_t)lane : (int32_t)(mdst - S) - lbase;
             // A chunk of 16 bytes only needs its source to be 16 bytes behind: matches with off >= 16 ride the
-            // plain path even when they overlap themselves; off < 16 reads a periodic source 8 bytes at a time.
-            const bool ovl = M && !isfar && off < 16u && off < M;
+            // plain path even when they overlap themselves; off < 16 reads a periodic source 8 bytes at a time
+            // until 16 bytes stand, then copies from off * ceil(16 / off) >= 16 bytes behind (same period) on the plain path.
+            bool ovl = M && !isfar && off < 16u && off < M;
+            const bool anyovl = __ballot(ovl) != 0;
             bool pending = M != 0;
             uint32_t prog = 0, r = 0;
             for (;;) {
@@ -403,6 +405,10 @@ struct Lz4V4 {
                 rcx_wave_sync();
                 prog += nv;
                 pending = pending && prog < M;
+                if (anyovl && ovl && prog >= 16u) {                      // off * ceil(16 / off) bytes behind: same period, no overlap
+                    ovl = false;
+                    sbase = li_m - (int32_t)(off * (((uint32_t)(0x11111111223357F0ull >> (4u * (off & 15u))) & 15u) + 1u));
+                }
             }
         }
         LZ4P_ADD(5);

@@ -17,6 +17,7 @@
 // LDS operations of one wave are performed in issue order, so "write data, then write head" / "read data, then
 // write tail" need no more than compiler ordering.  64 VGPRs (launch bound) keep 8 waves per SIMD = 16 blocks per CU.
 #include "rcx_dev.h"
+#include <type_traits>
 
 template <int CB, int TC = 2560, int HH = 2048, bool PROF5 = false>
 struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
@@ -197,39 +198,52 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
         }
         rcx_wave_sync();
 
-        // ---- window matches: copy rounds (16 bytes per ready lane), see Lz4V4::emit
+        // ---- window matches: copy rounds (16 bytes per ready lane), see Lz4V4::emit.  A short-period match (off < 16, off < M)
+        // reads its periodic source 8 bytes a pass; once 16 bytes stand it copies from off * ceil(16 / off) >= 16 bytes
+        // behind (same period, no overlap) on the plain path.  Batches without such a match (nearly all of a text) run the
+        // loop instantiated without that switch: its `sbase` / `ovl` stay loop invariant.
         {
-            const int32_t sbase = far16 ? STAGE5 + 32 * (int32_t)lane : (int32_t)(mdst - S) - lbase;
-            const bool ovl = M && !isfar && off < 16u && off < M;
+            const int32_t sbase0 = far16 ? STAGE5 + 32 * (int32_t)lane : (int32_t)(mdst - S) - lbase;
+            const bool ovl0 = M && !isfar && off < 16u && off < M;
             const uint32_t Mc = far16 ? (M < 32u ? M : 32u) : M;     // staged gathers ride the rounds for their first 32 bytes
-            bool pending = M != 0 && !farb;
-            uint32_t prog = 0, r = 0;
-            for (;;) {
-                const unsigned long long pm = __ballot(pending);
-                if (!pm) break;
-                const bool ready = pending && (pm & dep) == 0;
-                const bool rn = ready && !ovl;
-                uint32_t v0, v1, v2 = 0, v3 = 0, nv;
-                if (__ballot(rn)) {
-                    const int32_t rb = rn ? sbase + (int32_t)prog : 0;
-                    const uint64_t x0 = *(const rcx_u64_u*)(wb_ + rb), x1 = *(const rcx_u64_u*)(wb_ + rb + 8);
-                    v0 = (uint32_t)x0; v1 = (uint32_t)(x0 >> 32); v2 = (uint32_t)x1; v3 = (uint32_t)(x1 >> 32);
-                    nv = rn ? (Mc - prog < 16u ? Mc - prog : 16u) : 0u;
-                } else {
-                    const bool ro = ready && ovl;
-                    uint32_t b[8];
+            auto rounds = [&](auto conv) __attribute__((always_inline)) {
+                constexpr bool CONV = decltype(conv)::value;
+                int32_t sbase = sbase0;
+                bool ovl = ovl0;
+                bool pending = M != 0 && !farb;
+                uint32_t prog = 0, r = 0;
+                for (;;) {
+                    const unsigned long long pm = __ballot(pending);
+                    if (!pm) break;
+                    const bool ready = pending && (pm & dep) == 0;
+                    const bool rn = ready && !ovl;
+                    uint32_t v0, v1, v2 = 0, v3 = 0, nv;
+                    if (__ballot(rn)) {
+                        const int32_t rb = rn ? sbase + (int32_t)prog : 0;
+                        const uint64_t x0 = *(const rcx_u64_u*)(wb_ + rb), x1 = *(const rcx_u64_u*)(wb_ + rb + 8);
+                        v0 = (uint32_t)x0; v1 = (uint32_t)(x0 >> 32); v2 = (uint32_t)x1; v3 = (uint32_t)(x1 >> 32);
+                        nv = rn ? (Mc - prog < 16u ? Mc - prog : 16u) : 0u;
+                    } else {
+                        const bool ro = ready && ovl;
+                        uint32_t b[8];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) { b[u] = wb_[ro ? sbase + (int32_t)r : 0]; r = !ro ? r : (r + 1 == off) ? 0u : r + 1; }
-                    v0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-                    v1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
-                    nv = ro ? (M - prog < 8u ? M - prog : 8u) : 0u;
+                        for (int u = 0; u < 8; u++) { b[u] = wb_[ro ? sbase + (int32_t)r : 0]; r = !ro ? r : (r + 1 == off) ? 0u : r + 1; }
+                        v0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+                        v1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+                        nv = ro ? (M - prog < 8u ? M - prog : 8u) : 0u;
+                    }
+                    rcx_wave_sync();
+                    RCX_LDS_STORE16(wb_ + li_m + (int32_t)prog, v0, v1, v2, v3, nv);
+                    rcx_wave_sync();
+                    prog += nv;
+                    pending = pending && prog < Mc;
+                    if (CONV && ovl && prog >= 16u) {
+                        ovl = false;
+                        sbase = li_m - (int32_t)(off * (((uint32_t)(0x11111111223357F0ull >> (4u * (off & 15u))) & 15u) + 1u));
+                    }
                 }
-                rcx_wave_sync();
-                RCX_LDS_STORE16(wb_ + li_m + (int32_t)prog, v0, v1, v2, v3, nv);
-                rcx_wave_sync();
-                prog += nv;
-                pending = pending && prog < Mc;
-            }
+            };
+            if (__ballot(ovl0 && M > 16u)) rounds(std::true_type{}); else rounds(std::false_type{});
         }
         this->oend = RCX_U(oend0 + T);
         this->flush(this->oend, false);
