@@ -183,6 +183,14 @@ int rcx_ari_binary_decode_batch(rcx_ctx*, const rcx_batch*, uint32_t rate);
  * (bin.rs:112-167, weights 1:1 >> 1, rates 3 and 5) for the low 4 bits, as src/entropy/ari/test.rs:91-148 */
 int rcx_ari_proxy_encode_batch(rcx_ctx*, const rcx_batch*);
 int rcx_ari_proxy_decode_batch(rcx_ctx*, const rcx_batch*);
+/* reference: apm::Bit passed through an apm::Gate, update(rate 10, bias 0), 8 decisions per byte LSB first, as
+ * src/entropy/ari/test.rs:150-182 (apm.rs:36-198).  The f32 ln / exp of Bit::to_wide / from_wide are evaluated on the
+ * host with libm's logf / expf (what Rust's f32::ln / exp call) into a 4096-entry stretch table and the 17 initial
+ * gate bins; the device code is integer only.  A status of RCX_E_MALFORMED on ENCODE means the reference panics on
+ * that input (a skewed enough bit history drives the gate index out of its 17 bins, apm.rs:162-166).  The decoder
+ * produces exactly out_cap[i] bytes. */
+int rcx_ari_apm_encode_batch(rcx_ctx*, const rcx_batch*);
+int rcx_ari_apm_decode_batch(rcx_ctx*, const rcx_batch*);
 
 /* ---- RLE -------------------------------------------------------------------- */
 /* reference: src/rle.rs:82-122 (one-shot write + finish) */
@@ -214,7 +222,8 @@ enum rcx_codec {
     RCX_BWT_FORWARD, RCX_BWT_INVERSE, RCX_MTF_ENCODE, RCX_MTF_DECODE,
     RCX_DC_ENCODE, RCX_DC_DECODE, RCX_ARI_BYTE_ENCODE, RCX_ARI_BYTE_DECODE,
     RCX_RLE_ENCODE, RCX_RLE_DECODE, RCX_CRC32, RCX_GZIP_DECODE,
-    RCX_ARI_BINARY_ENCODE, RCX_ARI_BINARY_DECODE, RCX_ARI_PROXY_ENCODE, RCX_ARI_PROXY_DECODE, RCX_CODEC_COUNT
+    RCX_ARI_BINARY_ENCODE, RCX_ARI_BINARY_DECODE, RCX_ARI_PROXY_ENCODE, RCX_ARI_PROXY_DECODE,
+    RCX_ARI_APM_ENCODE, RCX_ARI_APM_DECODE, RCX_CODEC_COUNT
 };
 /* scratch bytes (HBM) the codec needs for nblocks blocks of <= max_block bytes.  Required for LZ4 encode, BWT and gzip
  * decode; for RCX_INFLATE / RCX_ZLIB_DECODE it is what the default (wave-per-stream) decoder needs -- without it

@@ -268,3 +268,98 @@ int o_ari_proxy_decode(const uint8_t* in, size_t n, uint8_t* out, size_t nbytes)
     }
     return RCX_OK;
 }
+
+/* ---- apm::Bit / apm::Gate, apm.rs:36-198, driven as test.rs:150-182 (roundtrip_apm) ----
+ * f32 ln/exp: Rust's f32::ln / f32::exp are the platform libm's logf / expf, the functions called here (apm.rs:56-58,
+ * 72-74); the reference cannot be run in this image, so these bits are pinned to glibc's libm, not to a Rust run. */
+#include <math.h>
+#define APM_FLAT_TOTAL 4096
+#define APM_WIDE_OFFSET 2048
+#define APM_BINS 17
+static int apm_to_wide(uint32_t fp, int* wp)                             /* Bit::to_wide :53-59 */
+{
+    float p = (float)fp / (float)APM_FLAT_TOTAL;
+    float d = logf(p / (1.0f - p));
+    float w = d * (float)APM_WIDE_OFFSET;
+    if (!(w > -32769.0f && w < 32768.0f)) return 0;                      /* to_i16().unwrap() */
+    *wp = (int)(int16_t)w;
+    return 1;
+}
+static uint32_t apm_from_wide(int wp)                                    /* Bit::from_wide :69-75 */
+{
+    float d = (float)wp / (float)APM_WIDE_OFFSET;
+    float p = 1.0f / (1.0f + expf(-d));
+    return (uint32_t)(uint16_t)(p * (float)APM_FLAT_TOTAL);
+}
+void o_apm_tables(int16_t* stretch, uint16_t* gate)                      /* stretch[fp] (0x8000 = to_i16 fails), Gate::new :144-154 */
+{
+    for (uint32_t fp = 0; fp < APM_FLAT_TOTAL; fp++) { int w; stretch[fp] = apm_to_wide(fp, &w) ? (int16_t)w : (int16_t)0x8000; }
+    for (int i = 0; i < APM_BINS; i++) {
+        float rp = (float)i / 8.0f - 1.0f;
+        gate[i] = (uint16_t)apm_from_wide((int)(int16_t)(rp * (float)APM_WIDE_OFFSET));
+    }
+}
+typedef struct { uint32_t bit; uint16_t map[APM_BINS]; int16_t stretch[APM_FLAT_TOTAL]; } apm_t;
+static void apm_new(apm_t* a) { a->bit = APM_FLAT_TOTAL >> 1; o_apm_tables(a->stretch, a->map); }
+static void apm_upd(uint16_t* fp, int value)                             /* Bit::update(value, 10, 0) :78-101 */
+{
+    if (!value) *fp = (uint16_t)(*fp + (uint16_t)((APM_FLAT_TOTAL - (int)*fp) >> 10));
+    else *fp = (uint16_t)(*fp - (uint16_t)(((int)*fp) >> 10));
+}
+/* gate.pass(&bit) :157-173: 0 if the reference would panic (to_i16 fails, or the bin index leaves the map) */
+static int apm_pass(const apm_t* a, uint32_t* fp_new, int* index)
+{
+    int16_t wp = a->stretch[a->bit & 4095];
+    if (wp == (int16_t)0x8000) return 0;
+    int idx = ((int)wp + APM_WIDE_OFFSET) >> 8;
+    if (idx < 0 || idx + 1 >= APM_BINS) return 0;
+    uint32_t weight = (uint32_t)(uint16_t)wp & 255u;
+    uint32_t sum = (uint32_t)a->map[idx] * (256u - weight) + (uint32_t)a->map[idx + 1] * weight;
+    *fp_new = (uint32_t)(uint16_t)(sum >> 8);
+    *index = idx;
+    return 1;
+}
+static void apm_update(apm_t* a, int value, int idx)
+{
+    uint16_t b = (uint16_t)a->bit; apm_upd(&b, value); a->bit = b;
+    apm_upd(&a->map[idx], value); apm_upd(&a->map[idx + 1], value);
+}
+int o_ari_apm_encode(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len)
+{
+    aenc_t e; aenc_new(&e, out, cap);
+    apm_t a; apm_new(&a);
+    *out_len = 0;
+    for (size_t i = 0; i < n; i++)
+        for (int k = 0; k < 8; k++) {
+            int bit = (in[i] >> k) & 1, idx; uint32_t fp;
+            if (!apm_pass(&a, &fp, &idx)) return RCX_E_MALFORMED;        /* the reference panics here */
+            if (bit) aenc_encode(&e, APM_FLAT_TOTAL, fp, APM_FLAT_TOTAL); else aenc_encode(&e, APM_FLAT_TOTAL, 0, fp);
+            apm_update(&a, bit, idx);
+        }
+    aenc_finish(&e);
+    *out_len = e.o;
+    return e.overflow ? RCX_E_OUTPUT_TOO_SMALL : RCX_OK;
+}
+int o_ari_apm_decode(const uint8_t* in, size_t n, uint8_t* out, size_t nbytes)
+{
+    adec_t d; adec_new(&d, in, n);
+    apm_t a; apm_new(&a);
+    uint8_t tmp[4];
+    for (size_t i = 0; i < nbytes; i++) {
+        uint8_t v = 0;
+        for (int k = 0; k < 8; k++) {
+            int idx; uint32_t fp;
+            if (!apm_pass(&a, &fp, &idx)) return RCX_E_MALFORMED;
+            if (!adec_feed(&d)) return RCX_E_MALFORMED;
+            uint32_t offset = range_query(&d.range, APM_FLAT_TOTAL, d.code);
+            if (offset >= APM_FLAT_TOTAL) return RCX_E_MALFORMED;       /* apm.rs:116 assert */
+            int bit = !(offset < fp);
+            if (bit) d.pending = range_process(&d.range, APM_FLAT_TOTAL, fp, APM_FLAT_TOTAL, tmp);
+            else d.pending = range_process(&d.range, APM_FLAT_TOTAL, 0, fp, tmp);
+            apm_update(&a, bit, idx);
+            v = (uint8_t)(v + (bit << k));
+        }
+        out[i] = v;
+    }
+    return RCX_OK;
+}

@@ -74,6 +74,10 @@ int      o_ari_binary_decode(const uint8_t* in, size_t n, uint32_t rate, uint8_t
 /* test.rs:91-148 proxy coder (table SumProxy for the high nibble, binary SumProxy for the low bits) */
 int      o_ari_proxy_encode(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len);
 int      o_ari_proxy_decode(const uint8_t* in, size_t n, uint8_t* out, size_t nbytes);
+/* apm::Bit + apm::Gate as src/entropy/ari/test.rs:150-182 drives them (f32 ln/exp through this host's libm) */
+int      o_ari_apm_encode(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len);
+int      o_ari_apm_decode(const uint8_t* in, size_t n, uint8_t* out, size_t nbytes);
+void     o_apm_tables(int16_t* stretch, uint16_t* gate);
 
 /* ---- rle.rs ---- */
 int      o_rle_encode(const uint8_t* in, size_t n, uint8_t* out, size_t cap, size_t* out_len);

@@ -245,6 +245,25 @@ def ari_binary_decode(data, rate, nbytes):
     return out[:nbytes].tobytes()
 
 
+def ari_apm_encode(data, raise_on_error=True):
+    return _call_bytes(lib().o_ari_apm_encode, data, 2 * len(data) + 16, raise_on_error=raise_on_error)
+
+
+def ari_apm_decode(data, nbytes):
+    a = _buf(data)
+    out = np.empty(max(nbytes, 1), dtype=np.uint8)
+    st = lib().o_ari_apm_decode(_ptr(a), C.c_size_t(a.size), _ptr(out), C.c_size_t(nbytes))
+    if st:
+        raise OracleError(st)
+    return out[:nbytes].tobytes()
+
+
+def apm_tables():
+    stretch = np.zeros(4096, dtype=np.int16); gate = np.zeros(17, dtype=np.uint16)
+    lib().o_apm_tables(stretch.ctypes.data_as(C.c_void_p), gate.ctypes.data_as(C.c_void_p))
+    return stretch, gate
+
+
 def ari_proxy_encode(data):
     return _call_bytes(lib().o_ari_proxy_encode, data, 2 * len(data) + 16)
 

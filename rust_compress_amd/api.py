@@ -158,6 +158,13 @@ class Context:
     def ari_proxy_decode(self, blobs, nbytes):
         return self._run_host("rcx_ari_proxy_decode_batch", blobs, list(nbytes))
 
+    def ari_apm_encode(self, blobs):
+        """apm::Bit through apm::Gate (src/entropy/ari/test.rs:150-182); status E_MALFORMED = the reference panics on this input."""
+        return self._run_host("rcx_ari_apm_encode_batch", blobs, [int(N.lib().rcx_ari_byte_encode_bound(len(b))) for b in blobs])
+
+    def ari_apm_decode(self, blobs, nbytes):
+        return self._run_host("rcx_ari_apm_decode_batch", blobs, list(nbytes))
+
     def rle_encode(self, blobs):
         return self._run_host("rcx_rle_encode_batch", blobs, [int(N.lib().rcx_rle_encode_bound(len(b))) for b in blobs])
 

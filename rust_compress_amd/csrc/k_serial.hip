@@ -578,8 +578,12 @@ __global__ __launch_bounds__(64) void k_ari_byte(rcx_kargs a, int decode)
 // The other two models of src/entropy/ari, driven the way the reference's own tests drive them (they have no stream
 // codec of their own): MODE 0 = bin::Model (bin.rs:17-103), 8 binary decisions per byte, LSB first (test.rs:22-50);
 // MODE 1 = table::SumProxy over two 16-entry tables for the high nibble + bin::SumProxy over two binary models for
-// the 4 low bits (table.rs:127-180, bin.rs:112-167, test.rs:91-148).  One lane per stream; the 2 x 16 frequencies of
-// MODE 1 sit in LDS, lane-strided.  Neither coding has an end marker: the decoder produces exactly out_cap[b] bytes.
+// the 4 low bits (table.rs:127-180, bin.rs:112-167, test.rs:91-148); MODE 2 = apm::Bit passed through an apm::Gate, 8
+// decisions per byte (apm.rs:36-198, test.rs:150-182): `scratch` holds the stretch table (Bit::to_wide for every flat
+// probability, 4096 x i16, 0x8000 where the reference's to_i16().unwrap() panics) and the 17 initial gate bins, both
+// computed on the host with libm's logf / expf exactly as the reference computes them; everything on the device is
+// integer.  One lane per stream; the 2 x 16 frequencies of MODE 1 / the 17 gate bins of MODE 2 sit in LDS, lane-strided.
+// No coding here has an end marker: the decoder produces exactly out_cap[b] bytes.
 struct AriBin {                                                // bin::Model
     uint32_t zero, total, rate;
     __device__ __forceinline__ void init(uint32_t threshold, uint32_t r) { zero = threshold >> 1; total = threshold; rate = r; }   // new_flat :30-37
@@ -612,8 +616,8 @@ struct AriTab16 {                                              // table::Model w
 template <int MODE>
 __global__ __launch_bounds__(64) void k_ari_model(rcx_kargs a, int decode, uint32_t rate)
 {
-    __shared__ uint16_t s_t0[MODE ? 16 * 64 : 1];
-    __shared__ uint16_t s_t1[MODE ? 16 * 64 : 1];
+    __shared__ uint16_t s_t0[MODE == 1 ? 16 * 64 : MODE == 2 ? 17 * 64 : 1];
+    __shared__ uint16_t s_t1[MODE == 1 ? 16 * 64 : 1];
     const unsigned t = threadIdx.x;
     const uint32_t b = blockIdx.x * 64 + t;
     if (b >= a.nblocks) return;
@@ -622,7 +626,11 @@ __global__ __launch_bounds__(64) void k_ari_model(rcx_kargs a, int decode, uint3
     AriTab16 T0, T1;
     B0.init(threshold, MODE ? 3u : rate); B1.init(threshold, 5u);
     T0.tab = s_t0; T1.tab = s_t1; T0.t = T1.t = t; T0.total = T1.total = 16;
-    if (MODE) { T0.init(); T1.init(); }
+    if (MODE == 1) { T0.init(); T1.init(); }
+    // MODE 2 state: the Bit's flat probability, the gate bins (LDS), this decision's bin index
+    const int16_t* stretch = (const int16_t*)a.scratch;
+    uint32_t apm_fp = 2048u; int apm_idx = 0;
+    if (MODE == 2) for (uint32_t e = 0; e < 17; e++) s_t0[e * 64u + t] = ((const uint16_t*)a.scratch)[4096 + e];
     AriRange R; R.low = 0; R.hai = 0xffffffffu;
     const uint8_t* in = a.in_base + a.in_off[b];
     const uint64_t n = a.in_len[b];
@@ -633,9 +641,30 @@ __global__ __launch_bounds__(64) void k_ari_model(rcx_kargs a, int decode, uint3
     uint8_t tmp[4];
     AriBytes src; src.start(in, n);
     // the binary decision under the current model(s): (zero, total) of bin::Model or of the 1:1 >>1 SumProxy
-    auto bin_zero = [&]() -> uint32_t { return MODE ? (B0.zero + B1.zero) >> 1 : B0.zero; };
-    auto bin_total = [&]() -> uint32_t { return MODE ? (B0.total + B1.total) >> 1 : B0.total; };
-    auto bin_update = [&](uint32_t bit) { B0.update(bit); if (MODE) B1.update(bit); };
+    auto apm_upd = [&](uint32_t fp, uint32_t bit) -> uint32_t {          // Bit::update(value, 10, 0), apm.rs:78-101 (u16 state)
+        return (bit ? fp - (fp >> 10) : fp + ((4096u - fp) >> 10)) & 0xffffu;
+    };
+    auto bin_zero = [&]() -> uint32_t {
+        if (MODE == 2) {                                       // gate.pass(&bit), apm.rs:157-173
+            const int wp = (int)stretch[apm_fp & 4095u];
+            const int idx = (wp + 2048) >> 8;
+            if (wp == -32768 || idx < 0 || idx > 15) { st = RCX_E_MALFORMED; return 0u; }   // the reference panics (unwrap / bounds)
+            apm_idx = idx;
+            const uint32_t w = (uint32_t)wp & 255u;
+            return (((uint32_t)s_t0[(uint32_t)idx * 64u + t] * (256u - w) + (uint32_t)s_t0[((uint32_t)idx + 1u) * 64u + t] * w) >> 8) & 0xffffu;
+        }
+        return MODE ? (B0.zero + B1.zero) >> 1 : B0.zero;
+    };
+    auto bin_total = [&]() -> uint32_t { return MODE == 2 ? 4096u : MODE ? (B0.total + B1.total) >> 1 : B0.total; };
+    auto bin_update = [&](uint32_t bit) {
+        if (MODE == 2) {
+            apm_fp = apm_upd(apm_fp, bit);
+            uint16_t& g0 = s_t0[(uint32_t)apm_idx * 64u + t]; uint16_t& g1 = s_t0[((uint32_t)apm_idx + 1u) * 64u + t];
+            g0 = (uint16_t)apm_upd(g0, bit); g1 = (uint16_t)apm_upd(g1, bit);
+            return;
+        }
+        B0.update(bit); if (MODE) B1.update(bit);
+    };
     if (!decode) {
         auto put = [&](uint32_t total, uint32_t lo, uint32_t hi) {
             const unsigned k = R.process(total, lo, hi, tmp);
@@ -645,7 +674,7 @@ __global__ __launch_bounds__(64) void k_ari_model(rcx_kargs a, int decode, uint3
         };
         for (uint64_t i = 0; i < n && !st; i++) {
             const uint32_t v = src.next();
-            if (MODE) {                                        // high nibble under 2*t0 + 1*t1, table.rs:150-155
+            if (MODE == 1) {                                   // high nibble under 2*t0 + 1*t1, table.rs:150-155
                 const uint32_t high = v >> 4;
                 uint32_t x0[16], x1[16];
                 T0.load(x0); T1.load(x1);
@@ -658,10 +687,11 @@ __global__ __launch_bounds__(64) void k_ari_model(rcx_kargs a, int decode, uint3
                 put(2u * T0.total + T1.total, lo, lo + fv);
                 T0.update(high, 10, threshold); T1.update(high, 5, threshold);
             }
-            for (int k = 0; k < (MODE ? 4 : 8) && !st; k++) {
+            for (int k = 0; k < (MODE == 1 ? 4 : 8) && !st; k++) {
                 const uint32_t bit = (v >> k) & 1u;
                 const uint32_t z = bin_zero(), tot = bin_total();
-                if (bit) put(tot, z, tot); else put(tot, 0, z);     // get_range, bin.rs:86-92
+                if (st) break;
+                if (bit) put(tot, z, tot); else put(tot, 0, z);     // get_range, bin.rs:86-92 / apm.rs:104-111
                 bin_update(bit);
             }
         }
@@ -680,7 +710,7 @@ __global__ __launch_bounds__(64) void k_ari_model(rcx_kargs a, int decode, uint3
         };
         for (; o < cap && !st; ) {
             uint32_t v = 0;
-            if (MODE) {
+            if (MODE == 1) {
                 feed(); if (st) break;
                 const uint32_t tot = 2u * T0.total + T1.total;
                 const uint32_t offset = (code - R.low) / ((R.hai - R.low) / tot);
@@ -700,9 +730,10 @@ __global__ __launch_bounds__(64) void k_ari_model(rcx_kargs a, int decode, uint3
                 T0.update(high, 10, threshold); T1.update(high, 5, threshold);
                 v = high << 4;
             }
-            for (int k = 0; k < (MODE ? 4 : 8); k++) {
-                feed(); if (st) break;
+            for (int k = 0; k < (MODE == 1 ? 4 : 8); k++) {
                 const uint32_t z = bin_zero(), tot = bin_total();
+                if (st) break;
+                feed(); if (st) break;
                 const uint32_t offset = (code - R.low) / ((R.hai - R.low) / tot);
                 if (offset >= tot) { st = RCX_E_MALFORMED; break; }     // bin.rs:95 assert
                 const uint32_t bit = offset < z ? 0u : 1u;              // find_value, bin.rs:94-103
@@ -904,6 +935,9 @@ static void launch_serial(hipStream_t s, int codec, rcx_kargs& k, int v, uint32_
         break;
     case RCX_ARI_PROXY_ENCODE: case RCX_ARI_PROXY_DECODE:
         hipLaunchKernelGGL((k_ari_model<1>), dim3((n + 63) / 64), dim3(64), 0, s, k, codec == RCX_ARI_PROXY_DECODE ? 1 : 0, 0u);
+        break;
+    case RCX_ARI_APM_ENCODE: case RCX_ARI_APM_DECODE:          // k.scratch = stretch table + gate bins (rcx_api.hip)
+        hipLaunchKernelGGL((k_ari_model<2>), dim3((n + 63) / 64), dim3(64), 0, s, k, codec == RCX_ARI_APM_DECODE ? 1 : 0, 0u);
         break;
     default: break;
     }

@@ -2,6 +2,7 @@
 // HBM staging for host-memory batches, kernel dispatch on the ctx stream.  There is no CPU code path:
 // every entry point needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -44,6 +45,7 @@ struct rcx_ctx {
     int variant[RCX_CODEC_COUNT] = {0};
     uint32_t param[RCX_CODEC_COUNT] = {0};
     DevBuf d_in, d_out, d_desc, d_scratch;
+    DevBuf d_apm;                        // apm stretch table + gate bins (filled on first use)
     std::vector<uint8_t> h_desc;
 };
 
@@ -77,7 +79,7 @@ extern "C" void rcx_ctx_destroy(rcx_ctx* c)
 {
     if (!c) return;
     (void)hipStreamSynchronize(c->stream);
-    c->d_in.release(); c->d_out.release(); c->d_desc.release(); c->d_scratch.release();
+    c->d_in.release(); c->d_out.release(); c->d_desc.release(); c->d_scratch.release(); c->d_apm.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -217,6 +219,26 @@ static int launch_codec(rcx_ctx* c, int codec, rcx_kargs& k)
         int rc = launch_bwt_inverse(s, k, v, c->err);
         if (rc) return rc;
         break; }
+    case RCX_ARI_APM_ENCODE: case RCX_ARI_APM_DECODE: {
+        if (!c->d_apm.p) {                                       // apm.rs:53-59, 69-75, 144-154 through this host's libm
+            std::vector<uint16_t> h(4096 + 32, 0);
+            for (uint32_t fp = 0; fp < 4096; fp++) {
+                const float p = (float)fp / 4096.0f;
+                const float w = logf(p / (1.0f - p)) * 2048.0f;
+                h[fp] = (w > -32769.0f && w < 32768.0f) ? (uint16_t)(int16_t)w : (uint16_t)0x8000;
+            }
+            for (int i = 0; i < 17; i++) {
+                const float rp = (float)i / 8.0f - 1.0f;
+                const int16_t wp = (int16_t)(rp * 2048.0f);
+                const float pr = 1.0f / (1.0f + expf(-((float)wp / 2048.0f)));
+                h[4096 + i] = (uint16_t)(pr * 4096.0f);
+            }
+            HIPCHK(c, c->d_apm.reserve(h.size() * 2));
+            HIPCHK(c, hipMemcpy(c->d_apm.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        }
+        k.scratch = c->d_apm.p; k.scratch_bytes = (4096 + 32) * 2;
+        launch_serial(s, codec, k, v, 0);
+        break; }
     case RCX_ARI_BINARY_ENCODE: case RCX_ARI_BINARY_DECODE:
         if (c->param[codec] < 1 || c->param[codec] > 31) { c->err = "ari binary: rate must be 1..31"; return RCX_RC_BAD_ARG; }
         [[fallthrough]];
@@ -353,5 +375,7 @@ extern "C" int rcx_ari_binary_decode_batch(rcx_ctx* c, const rcx_batch* b, uint3
 }
 extern "C" int rcx_ari_proxy_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_ARI_PROXY_ENCODE, b, nullptr, nullptr, nullptr, true); }
 extern "C" int rcx_ari_proxy_decode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_ARI_PROXY_DECODE, b, nullptr, nullptr, nullptr, true); }
+extern "C" int rcx_ari_apm_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_ARI_APM_ENCODE, b, nullptr, nullptr, nullptr, true); }
+extern "C" int rcx_ari_apm_decode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_ARI_APM_DECODE, b, nullptr, nullptr, nullptr, true); }
 extern "C" int rcx_rle_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_RLE_ENCODE, b, nullptr, nullptr, nullptr, true); }
 extern "C" int rcx_rle_decode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_RLE_DECODE, b, nullptr, nullptr, nullptr, true); }

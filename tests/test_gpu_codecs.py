@@ -104,6 +104,15 @@ def test_ari_binary_and_proxy_models(ctx, oracle):
     assert all(s == N.E_MALFORMED for s in res.status)
     with pytest.raises(Exception):
         ctx.ari_binary_encode(raws, 0)                                                    # rate out of range
+    # apm::Bit + apm::Gate (test.rs:150-182); all-equal bits drive the gate index out of range: the reference panics
+    apm_in = [r for r in raws if len(r)] + [b"", bytes(300), b"\xff" * 300]
+    exp = [oracle.ari_apm_encode(r, raise_on_error=False) for r in apm_in]
+    e = ctx.ari_apm_encode(apm_in)
+    assert [int(x) for x in e.status] == [s for _, s in exp] and N.E_MALFORMED in list(e.status)
+    good = [i for i, (_, s) in enumerate(exp) if s == 0]
+    assert len(good) > 5 and all(e.outputs[i] == exp[i][0] for i in good)
+    d = ctx.ari_apm_decode([e.outputs[i] for i in good], [len(apm_in[i]) for i in good]).check()
+    assert d.outputs == [apm_in[i] for i in good]
 
 
 def test_rle_ari_malformed(ctx, oracle):

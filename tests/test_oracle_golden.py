@@ -128,6 +128,8 @@ def test_roundtrip_properties(oracle, golden):
             assert o.ari_binary_decode(e, rate, len(d[:2000])) == d[:2000]
         e = o.ari_proxy_encode(d[:2000])
         assert o.ari_proxy_decode(e, len(d[:2000])) == d[:2000]
+        e, st = o.ari_apm_encode(d[:2000], raise_on_error=False)          # test.rs:150-182 (status 3: the reference panics)
+        assert st in (0, 3) and (st or o.ari_apm_decode(e, len(d[:2000])) == d[:2000])
     assert o.bwt_decode(*o.bwt_encode(b"abracadabra"), minimal=True) == b"abracadabra"   # bwt/mod.rs:549-551
     assert o.bwt_decode(*o.bwt_encode(b"test"), minimal=True) != b"test"                 # A.4: decode_minimal is wrong here
 

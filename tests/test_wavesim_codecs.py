@@ -95,6 +95,20 @@ def test_ari_binary_and_proxy_models(oracle):
     assert list(st) == [_oracle_status(oracle.ari_proxy_decode, b_, w) for b_, w in zip(bad, want)]
     _, _, _, st, _ = simrun.run(N.ARI_BINARY_DECODE, 5, bad, want)
     assert list(st) == [_oracle_status(oracle.ari_binary_decode, b_, 5, w) for b_, w in zip(bad, want)]
+    # apm::Bit + apm::Gate: the stretch / gate tables come from the host (libm); a skewed history makes the reference panic
+    stretch, gate = oracle.apm_tables()
+    tabs = stretch.tobytes() + gate.tobytes()
+    apm_in = [r for r in raws if len(r)] + [b"", bytes(300), b"\xff" * 300]
+    exp = [oracle.ari_apm_encode(r, raise_on_error=False) for r in apm_in]
+    assert any(s for _, s in exp) and any(s == 0 and len(o) > 10 for o, s in exp)
+    enc, _, _, st, _ = simrun.run(N.ARI_APM_ENCODE, 0, apm_in, [2 * len(r) + 16 for r in apm_in], scratch_init=tabs)
+    assert [int(x) for x in st] == [s for _, s in exp]
+    good = [i for i, (_, s) in enumerate(exp) if s == 0]
+    assert all(enc[i] == exp[i][0] for i in good)
+    dec, _, _, st, _ = simrun.run(N.ARI_APM_DECODE, 0, [enc[i] for i in good], [len(apm_in[i]) for i in good], scratch_init=tabs)
+    assert not st.any() and dec == [apm_in[i] for i in good]
+    _, _, _, st, _ = simrun.run(N.ARI_APM_DECODE, 0, [enc[i][:-6] for i in good[:6]], [len(apm_in[i]) + 2 for i in good[:6]], scratch_init=tabs)
+    assert list(st) == [_oracle_status(oracle.ari_apm_decode, enc[i][:-6], len(apm_in[i]) + 2) for i in good[:6]]
     _, _, _, st, _ = simrun.run(N.ARI_BINARY_ENCODE, 5, raws[:4], [3] * 4)     # short output slots
     assert all(int(x) == N.E_OUTPUT_TOO_SMALL for x in st)
 

@@ -42,6 +42,7 @@ extern "C" int sim_launch(int codec, int variant, const rcx_kargs* a)
     case RCX_MTF_ENCODE: case RCX_MTF_DECODE: case RCX_DC_ENCODE: case RCX_DC_DECODE:
     case RCX_ARI_BYTE_ENCODE: case RCX_ARI_BYTE_DECODE: case RCX_RLE_ENCODE: case RCX_RLE_DECODE:
     case RCX_ARI_BINARY_ENCODE: case RCX_ARI_BINARY_DECODE: case RCX_ARI_PROXY_ENCODE: case RCX_ARI_PROXY_DECODE:
+    case RCX_ARI_APM_ENCODE: case RCX_ARI_APM_DECODE:            // scratch = stretch table + gate bins, from the caller
         launch_serial(0, codec, k, variant, (uint32_t)variant);      // the binary model's rate rides in `variant` here
         return 0;
     case RCX_INFLATE: launch_inflate(0, k, false, variant); return 0;

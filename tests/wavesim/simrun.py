@@ -31,7 +31,7 @@ def lib():
     return _lib
 
 
-def run(codec, variant, blobs, caps, aux=None, n_out=None, in_misalign=0, out_misalign=0, scratch_bytes=0):
+def run(codec, variant, blobs, caps, aux=None, n_out=None, in_misalign=0, out_misalign=0, scratch_bytes=0, scratch_init=None):
     """-> (outputs list[bytes], out_len, in_used, status, aux)"""
     n = len(blobs)
     base, off, lens = B.pack(blobs)
@@ -45,6 +45,8 @@ def run(codec, variant, blobs, caps, aux=None, n_out=None, in_misalign=0, out_mi
     if aux is None:
         aux = np.zeros(max(n, 1), np.uint32)
     scratch = np.zeros(max(scratch_bytes, 8), np.uint8)
+    if scratch_init is not None:
+        scratch = np.frombuffer(bytes(scratch_init) + bytes(64), dtype=np.uint8).copy()
     p = lambda a: a.ctypes.data
     k = KArgs(p(base), p(off), p(lens), p(out), p(ooff), p(ocap), p(out_len), p(in_used), p(status), p(aux),
               p(n_out) if n_out is not None else None, p(scratch), scratch.size, n)
