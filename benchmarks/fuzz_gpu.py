@@ -10,13 +10,9 @@ import rust_compress_amd as R
 from rust_compress_amd import _native as N, synth, batch as B
 import oracle_py as O
 
-COUNT = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-rng = np.random.default_rng(SEED)
-ctx = R.Context(0)
 
 
-def sources():
+def sources(rng):
     out = []
     for kind in ("text", "words", "runs", "dna4", "mix", "rand"):
         for sz in (0, 1, 13, 200, 3000, 20000, 70000):
@@ -25,7 +21,7 @@ def sources():
     return out
 
 
-def mutate(valid, count):
+def mutate(rng, valid, count):
     blobs, caps = [], []
     for it in range(count):
         b = bytearray(valid[int(rng.integers(len(valid)))])
@@ -59,8 +55,9 @@ def oracle_batch(codec, blobs, caps):
     return out, ooff, out_len, in_used, status
 
 
-def check(name, codec, gpu_fn, blobs, caps, variants, cmp_used, cmp_partial):
+def check(ctx, name, codec, gpu_fn, blobs, caps, variants, cmp_used, cmp_partial):
     out, ooff, olen, used, st = oracle_batch(codec, blobs, caps)
+    total = 0
     for v in variants:
         ctx.set_variant(codec, v)
         res = gpu_fn(blobs, caps)
@@ -80,25 +77,37 @@ def check(name, codec, gpu_fn, blobs, caps, variants, cmp_used, cmp_partial):
                     open(os.path.join(ROOT, "gpurun_out", "fuzz_%s_v%d_%d.bin" % (name, v, i)), "wb").write(blobs[i])
         print("%-12s variant %2d: %6d streams, %5d ok status, %d mismatches" % (name, v, len(blobs), int((st == 0).sum()), bad), flush=True)
         ctx.set_variant(codec, 0)
+        total += bad
+    return total
 
 
-os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-src = sources()
-lz4 = [O.lz4_encode_block(s) for s in src]
-blobs, caps = mutate(lz4, COUNT)
-check("lz4", N.LZ4_DECODE, ctx.lz4_decode_blocks, blobs, caps, (0, 11), False, False)
-zs = [zlib.compress(s, int(rng.integers(0, 10))) for s in src]
-c = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
-zs.append(c.compress(src[10]) + c.flush())
-blobs, caps = mutate(zs, COUNT // 2)
-check("zlib", N.ZLIB_DECODE, ctx.zlib_decode, blobs, caps, (0, 9), True, False)
-raw = [z[2:-4] for z in zs]
-blobs, caps = mutate(raw, COUNT // 2)
-check("inflate", N.INFLATE, ctx.inflate, blobs, caps, (0, 9), True, True)
-rle = [O.rle_encode(s) for s in src]
-blobs, caps = mutate(rle, COUNT // 4)
-check("rle", N.RLE_DECODE, ctx.rle_decode, blobs, caps, (0,), False, False)
-ari = [O.ari_byte_encode(s) for s in src if len(s) <= 20000]
-blobs, caps = mutate(ari, COUNT // 8)
-check("ari", N.ARI_BYTE_DECODE, ctx.ari_byte_decode, blobs, caps, (1, 2), True, False)
-print("done")
+
+def main(count=20000, seed=1, ctx=None):
+    rng = np.random.default_rng(seed)
+    ctx = ctx or R.Context(0)
+    bad = 0
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    src = sources(rng)
+    lz4 = [O.lz4_encode_block(s) for s in src]
+    blobs, caps = mutate(rng, lz4, count)
+    bad += check(ctx, "lz4", N.LZ4_DECODE, ctx.lz4_decode_blocks, blobs, caps, (0, 11), False, False)
+    zs = [zlib.compress(s, int(rng.integers(0, 10))) for s in src]
+    c = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+    zs.append(c.compress(src[10]) + c.flush())
+    blobs, caps = mutate(rng, zs, count // 2)
+    bad += check(ctx, "zlib", N.ZLIB_DECODE, ctx.zlib_decode, blobs, caps, (0, 9), True, False)
+    raw = [z[2:-4] for z in zs]
+    blobs, caps = mutate(rng, raw, count // 2)
+    bad += check(ctx, "inflate", N.INFLATE, ctx.inflate, blobs, caps, (0, 9), True, True)
+    rle = [O.rle_encode(s) for s in src]
+    blobs, caps = mutate(rng, rle, count // 4)
+    bad += check(ctx, "rle", N.RLE_DECODE, ctx.rle_decode, blobs, caps, (0,), False, False)
+    ari = [O.ari_byte_encode(s) for s in src if len(s) <= 20000]
+    blobs, caps = mutate(rng, ari, count // 8)
+    bad += check(ctx, "ari", N.ARI_BYTE_DECODE, ctx.ari_byte_decode, blobs, caps, (1, 2), True, False)
+    print("done")
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 20000, int(sys.argv[2]) if len(sys.argv) > 2 else 1) else 0)
