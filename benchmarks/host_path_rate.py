@@ -17,8 +17,16 @@ ctx = R.Context(0)
 nb = 4096
 dec, raw, cb, ob = bench.make_workload(R, ctx, torch, dev, "text", nb, 0x4C5A3401)
 u64 = lambda t: np.ascontiguousarray(t.cpu().numpy().astype(np.uint64))
-in_base = np.ascontiguousarray(dec.in_base.cpu().numpy())
-in_off, in_len, out_off, out_cap = u64(dec.in_off), u64(dec.in_len), u64(dec.out_off), u64(dec.out_cap)
+slots = np.ascontiguousarray(dec.in_base.cpu().numpy())
+so, in_len, out_off, out_cap = u64(dec.in_off), u64(dec.in_len), u64(dec.out_off), u64(dec.out_cap)
+# the encoder wrote one block per compression_bound-sized slot; a caller hands over packed blocks (as an LZ4 frame holds them)
+in_off = np.zeros(nb, np.uint64)
+pos = 0
+for i in range(nb):
+    in_off[i] = pos; pos += (int(in_len[i]) + 15) & ~15
+in_base = np.zeros(pos + 64, np.uint8)
+for i in range(nb):
+    in_base[int(in_off[i]): int(in_off[i]) + int(in_len[i])] = slots[int(so[i]): int(so[i]) + int(in_len[i])]
 for pinned in (False, True):
     if pinned:
         inb = torch.from_numpy(in_base).pin_memory(); outb = torch.empty(nb * bench.BLOCK + 64, dtype=torch.uint8).pin_memory()
