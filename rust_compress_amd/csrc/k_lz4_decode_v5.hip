@@ -17,6 +17,9 @@
 // LDS operations of one wave are performed in issue order, so "write data, then write head" / "read data, then
 // write tail" need no more than compiler ordering.  64 VGPRs (launch bound) keep 8 waves per SIMD = 16 blocks per CU.
 #include "rcx_dev.h"
+#ifndef RCX_EXEC_PRIO
+#define RCX_EXEC_PRIO 2
+#endif
 #include <type_traits>
 
 template <int CB, int TC = 2560, int HH = 2048, bool PROF5 = false>
@@ -318,6 +321,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_decode_v5(rcx_kargs a)
         return;
     }
     int32_t st; uint32_t olen;
+    __builtin_amdgcn_s_setprio(RCX_EXEC_PRIO);
     s.run_executor(&st, &olen);
     if (PROF5 && a.scratch && (threadIdx.x & 63u) == 0) {              // [4..7] executor: ring-empty wait, total, batches
         uint64_t* q = (uint64_t*)a.scratch + (size_t)b * 8 + 4;
