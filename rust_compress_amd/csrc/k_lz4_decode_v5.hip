@@ -79,6 +79,10 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
             rcx_wave_sync();
             head++;
             if (lane == 0) ring->head = head;
+            // Issue priorities (s_setprio): the executor runs at 2; the parser outranks it (3) while the ring has a free slot --
+            // a batch it delivers sooner is a batch the executor never waits for -- and drops to 0 once the ring is full (it
+            // would only collect a batch it cannot post).  Measured: 300 -> 330 GiB/s on G-text, 245 -> 269 on G-words.
+            if (head - RCX_U(ring->tail) < (uint32_t)NSLOT) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
             if (bt.why == B::END_ || bt.why == B::ERR_) return;
             if (bt.why == B::STAGE_) { this->stage(cur); continue; }
             if (bt.why == B::SOLO_ || bt.why == B::WIDE_) cur = bt.gnext;
