@@ -227,8 +227,12 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
                     uint32_t v0, v1, v2 = 0, v3 = 0, nv;
                     if (__ballot(rn)) {
                         const int32_t rb = rn ? sbase + (int32_t)prog : 0;
-                        const uint64_t x0 = *(const rcx_u64_u*)(wb_ + rb), x1 = *(const rcx_u64_u*)(wb_ + rb + 8);
-                        v0 = (uint32_t)x0; v1 = (uint32_t)(x0 >> 32); v2 = (uint32_t)x1; v3 = (uint32_t)(x1 >> 32);
+                        // 16 bytes at any address as five ALIGNED dwords + v_alignbyte: an unaligned ds_read_b64 holds the
+                        // CU's LDS pipe ~24 cycles (SQ_LDS_UNALIGNED_STALL was 19 % of the kernel's cycles), an aligned pair ~4
+                        const uint32_t* q = (const uint32_t*)(wb_ + (rb & ~3));
+                        const uint32_t sh = (uint32_t)rb & 3u;
+                        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+                        v0 = RCX_ALIGNBYTE(d1, d0, sh); v1 = RCX_ALIGNBYTE(d2, d1, sh); v2 = RCX_ALIGNBYTE(d3, d2, sh); v3 = RCX_ALIGNBYTE(d4, d3, sh);
                         nv = rn ? (Mc - prog < 16u ? Mc - prog : 16u) : 0u;
                     } else {
                         const bool ro = ready && ovl;
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_decode_v5(rcx_kargs a)
     typedef Lz4V5<CB, TC, HH, PROF5> S;
     const uint64_t tk0 = PROF5 ? (uint64_t)__builtin_readcyclecounter() : 0;
     __shared__ __align__(16) uint8_t s_cbuf[CB + 96];
-    __shared__ __align__(16) uint8_t s_wbuf[S::WBUF5];
+    __shared__ __align__(16) uint8_t s_wbuf[S::WBUF5 + 16];     // + 16: the last staging slot is read one dword past its end
     __shared__ uint32_t s_epos[64];
     __shared__ __align__(16) typename S::Ring s_ring;
     const uint32_t b = blockIdx.x;
