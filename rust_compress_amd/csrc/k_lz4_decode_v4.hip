@@ -56,11 +56,21 @@ struct Lz4V4 {
     uint32_t oend, gflush, rlo, omis;
     unsigned lane;
 
-    // 4 bytes at any LDS address as two aligned dword reads + v_alignbyte (an unaligned ds_read costs ~24 cycles)
-    static __device__ __forceinline__ uint32_t lds_load4u(const uint8_t* p)
+    // 4 / 16 bytes at any offset of a 16-byte aligned LDS buffer as aligned dword reads + v_alignbyte (an unaligned ds_read
+    // holds the LDS pipe ~24 cycles).  The address is formed as base + (idx & ~3), never through an integer, so that the
+    // loads stay ds_read (a pointer rebuilt from an integer is a flat pointer: flat_load).  The buffer must be readable one
+    // dword past the bytes asked for.
+    static __device__ __forceinline__ uint32_t lds_load4u(const uint8_t* base, int32_t idx)
     {
-        const uint32_t* q = (const uint32_t*)((uintptr_t)p & ~(uintptr_t)3);
-        return RCX_ALIGNBYTE(q[1], q[0], (uint32_t)(uintptr_t)p & 3u);
+        const uint32_t* q = (const uint32_t*)(base + (idx & ~3));
+        return RCX_ALIGNBYTE(q[1], q[0], (uint32_t)idx & 3u);
+    }
+    static __device__ __forceinline__ void lds_load16u(const uint8_t* base, int32_t idx, uint32_t& v0, uint32_t& v1, uint32_t& v2, uint32_t& v3)
+    {
+        const uint32_t* q = (const uint32_t*)(base + (idx & ~3));
+        const uint32_t sh = (uint32_t)idx & 3u;
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+        v0 = RCX_ALIGNBYTE(d1, d0, sh); v1 = RCX_ALIGNBYTE(d2, d1, sh); v2 = RCX_ALIGNBYTE(d3, d2, sh); v3 = RCX_ALIGNBYTE(d4, d3, sh);
     }
     __device__ __forceinline__ int32_t lbase_for(uint32_t pos) const
     {
@@ -265,7 +275,7 @@ struct Lz4V4 {
             else {
                 const uint32_t t = cbuf[(int32_t)e - cbase];
                 L = t >> 4; M = (t & 15u) + 4u; src = e + 1;
-                const uint32_t w = lds_load4u(cbuf + ((int32_t)(src + L) - cbase));   // offset lo, hi, extension byte
+                const uint32_t w = lds_load4u(cbuf, (int32_t)(src + L) - cbase);   // offset lo, hi, extension byte
                 off = w & 0xffffu;
                 if (M == 19u) M += (w >> 16) & 0xffu;                    // one match-length extension byte (< 255, lz4.rs:112-122)
             }
@@ -321,9 +331,10 @@ struct Lz4V4 {
             for (uint32_t i0 = 0; __ballot(i0 < L); i0 += 16) {
                 const bool on = i0 < L;
                 const int32_t rb = on ? sb + (int32_t)i0 : 0;
-                const uint64_t x0 = *(const rcx_u64_u*)(cbuf + rb), x1 = *(const rcx_u64_u*)(cbuf + rb + 8);
+                uint32_t x0, x1, x2, x3;
+                lds_load16u(cbuf, rb, x0, x1, x2, x3);
                 const uint32_t nv = on ? (L - i0 < 16u ? L - i0 : 16u) : 0u;
-                RCX_LDS_STORE16(wb_ + li_o + (int32_t)i0, (uint32_t)x0, (uint32_t)(x0 >> 32), (uint32_t)x1, (uint32_t)(x1 >> 32), nv);
+                RCX_LDS_STORE16(wb_ + li_o + (int32_t)i0, x0, x1, x2, x3, nv);
             }
         }
         if (anyfar) {                                                // gathered bytes -> the lane's staging slot
@@ -388,8 +399,7 @@ struct Lz4V4 {
                 uint32_t v0, v1, v2 = 0, v3 = 0, nv;
                 if (__ballot(rn)) {
                     const int32_t rb = rn ? sbase + (int32_t)prog : 0;
-                    const uint64_t x0 = *(const rcx_u64_u*)(wb_ + rb), x1 = *(const rcx_u64_u*)(wb_ + rb + 8);
-                    v0 = (uint32_t)x0; v1 = (uint32_t)(x0 >> 32); v2 = (uint32_t)x1; v3 = (uint32_t)(x1 >> 32);
+                    lds_load16u(wb_, rb, v0, v1, v2, v3);
                     nv = rn ? (M - prog < 16u ? M - prog : 16u) : 0u;
                 } else {                                   // self-overlapping short-period matches, batched up
                     const bool ro = ready && ovl;

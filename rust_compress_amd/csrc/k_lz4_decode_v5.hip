@@ -17,6 +17,9 @@
 // LDS operations of one wave are performed in issue order, so "write data, then write head" / "read data, then
 // write tail" need no more than compiler ordering.  64 VGPRs (launch bound) keep 8 waves per SIMD = 16 blocks per CU.
 #include "rcx_dev.h"
+#ifndef RCX_LDS_AS
+#define RCX_LDS_AS __attribute__((address_space(3)))
+#endif
 #ifndef RCX_EXEC_PRIO
 #define RCX_EXEC_PRIO 2
 #endif
@@ -30,7 +33,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
     struct Ring { Slot slot[NSLOT]; volatile uint32_t head, tail, abort_, pad; };
     static constexpr int STAGE5 = B::LIN + 64;         // 64 lanes x 32 bytes of old-match staging (bytes 32.. of a longer
     static constexpr int WBUF5 = STAGE5 + 64 * 32;     // gathered match go straight to their place): 16 blocks per CU fit
-    Ring* ring;
+    RCX_LDS_AS Ring* ring;                         // address space 3: the volatile head / tail accesses must be ds_read / ds_write, not flat
     uint64_t pw[4] = {0, 0, 0, 0};                 // PROF5: cycles waiting on the ring, cycles working, batches, -
 
     // ------------------------------------------------------------------------------------------ parser wave
@@ -54,7 +57,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
                 else {
                     const uint32_t t = this->cbuf[(int32_t)e - this->cbase];
                     L = t >> 4; M = (t & 15u) + 4u; src = e + 1;
-                    const uint32_t w = B::lds_load4u(this->cbuf + ((int32_t)(src + L) - this->cbase));
+                    const uint32_t w = B::lds_load4u(this->cbuf, (int32_t)(src + L) - this->cbase);
                     off = w & 0xffffu;
                     if (M == 19u) M += (w >> 16) & 0xffu;
                 }
@@ -70,8 +73,8 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
             }
             if (PROF5) { pw[0] += (uint64_t)__builtin_readcyclecounter() - tp0; pw[2] += 1; }
             rcx_wave_sync();
-            Slot* sl = &ring->slot[head % NSLOT];
-            *(uint64_t*)sl->desc[lane] = (uint64_t)w0 | ((uint64_t)w1 << 32);
+            RCX_LDS_AS Slot* sl = &ring->slot[head % NSLOT];
+            *(RCX_LDS_AS uint64_t*)sl->desc[lane] = (uint64_t)w0 | ((uint64_t)w1 << 32);
             if (lane == 0) {
                 sl->hdr[0] = (uint32_t)bt.ns; sl->hdr[1] = (uint32_t)bt.why; sl->hdr[2] = (uint32_t)bt.perr;
                 sl->hdr[3] = bt.gL; sl->hdr[4] = bt.gM; sl->hdr[5] = bt.goff; sl->hdr[6] = bt.gsrc;
@@ -141,12 +144,13 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
         const bool litb = L && !lit16;                               // within 32 bytes of the block's end: byte loads
         if (LITLDS) {
             if (__ballot(lit16)) {
-                const uint8_t* q = litbuf + (lit16 ? src : 0u);
-                const uint64_t x0 = *(const rcx_u64_u*)q, x1 = *(const rcx_u64_u*)(q + 8);
-                g0 = rcx_u32x4{(uint32_t)x0, (uint32_t)(x0 >> 32), (uint32_t)x1, (uint32_t)(x1 >> 32)};
+                const int32_t qi = lit16 ? (int32_t)src : 0;
+                uint32_t x0, x1, x2, x3;
+                B::lds_load16u(litbuf, qi, x0, x1, x2, x3);
+                g0 = rcx_u32x4{x0, x1, x2, x3};
                 if (__ballot(lit16 && L > 16)) {
-                    const uint64_t y0 = *(const rcx_u64_u*)(q + 16), y1 = *(const rcx_u64_u*)(q + 24);
-                    g1 = rcx_u32x4{(uint32_t)y0, (uint32_t)(y0 >> 32), (uint32_t)y1, (uint32_t)(y1 >> 32)};
+                    B::lds_load16u(litbuf, qi + 16, x0, x1, x2, x3);
+                    g1 = rcx_u32x4{x0, x1, x2, x3};
                 }
             }
         } else if (lit16) { g0 = *(const rcx_u32x4_u*)(in + src); if (L > 16) g1 = *(const rcx_u32x4_u*)(in + src + 16); }
@@ -227,12 +231,9 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
                     uint32_t v0, v1, v2 = 0, v3 = 0, nv;
                     if (__ballot(rn)) {
                         const int32_t rb = rn ? sbase + (int32_t)prog : 0;
-                        // 16 bytes at any address as five ALIGNED dwords + v_alignbyte: an unaligned ds_read_b64 holds the
-                        // CU's LDS pipe ~24 cycles (SQ_LDS_UNALIGNED_STALL was 19 % of the kernel's cycles), an aligned pair ~4
-                        const uint32_t* q = (const uint32_t*)(wb_ + (rb & ~3));
-                        const uint32_t sh = (uint32_t)rb & 3u;
-                        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
-                        v0 = RCX_ALIGNBYTE(d1, d0, sh); v1 = RCX_ALIGNBYTE(d2, d1, sh); v2 = RCX_ALIGNBYTE(d3, d2, sh); v3 = RCX_ALIGNBYTE(d4, d3, sh);
+                        // five ALIGNED dwords + v_alignbyte: an unaligned ds_read_b64 holds the CU's LDS pipe ~24 cycles
+                        // (SQ_LDS_UNALIGNED_STALL was 19 % of the kernel's cycles), an aligned pair ~4
+                        B::lds_load16u(wb_, rb, v0, v1, v2, v3);
                         nv = rn ? (Mc - prog < 16u ? Mc - prog : 16u) : 0u;
                     } else {
                         const bool ro = ready && ovl;
@@ -273,12 +274,12 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
             while (RCX_U(ring->head) == tail) __builtin_amdgcn_s_sleep(4);
             if (PROF5) { pw[0] += (uint64_t)__builtin_readcyclecounter() - te0; pw[2] += 1; }
             rcx_wave_sync();
-            const Slot* sl = &ring->slot[tail % NSLOT];
+            const RCX_LDS_AS Slot* sl = &ring->slot[tail % NSLOT];
             typename B::Batch bt;
             bt.ns = (int)RCX_U(sl->hdr[0]); bt.why = (int)RCX_U(sl->hdr[1]); bt.perr = (int)RCX_U(sl->hdr[2]);
             bt.gL = RCX_U(sl->hdr[3]); bt.gM = RCX_U(sl->hdr[4]); bt.goff = RCX_U(sl->hdr[5]); bt.gsrc = RCX_U(sl->hdr[6]);
             bt.gnext = 0;
-            const uint64_t d = *(const uint64_t*)sl->desc[lane];
+            const uint64_t d = *(const RCX_LDS_AS uint64_t*)sl->desc[lane];
             const uint32_t w0 = (uint32_t)d, w1 = (uint32_t)(d >> 32);
             rcx_wave_sync();
             tail++;
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_decode_v5(rcx_kargs a)
     s.cbuf = s_cbuf;
     s.wb_ = s_wbuf;
     s.epos = s_epos;
-    s.ring = &s_ring;
+    s.ring = (RCX_LDS_AS typename S::Ring*)&s_ring;
     if (role == 0) {
         s.run_parser();
         if (PROF5 && a.scratch && (threadIdx.x & 63u) == 0) {          // [0..3] parser: ring-full wait, total, posts
