@@ -625,7 +625,7 @@ __global__ __launch_bounds__(64) void k_inflate3(rcx_kargs a, int zlib)
 {
     typedef Inf3<CB> S;
     __shared__ __align__(16) uint8_t s_cbuf[CB + 96];
-    __shared__ __align__(16) uint8_t s_wbuf[S::WBUF5];
+    __shared__ __align__(16) uint8_t s_wbuf[S::WBUF5 + 16];     // + 16: lds_load16u reads one dword past the last staging slot
     __shared__ __align__(16) uint16_t s_lutL[512];
     __shared__ __align__(16) uint16_t s_lutD[S::DLUTN];
     __shared__ uint16_t s_symL[288];

@@ -617,7 +617,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_lz4_decode_v4(rcx_kargs a)
 {
     typedef Lz4V4<CB, PROF> S;
     __shared__ __align__(16) uint8_t s_cbuf[WAVES][CB + 96];
-    __shared__ __align__(16) uint8_t s_wbuf[WAVES][S::WBUF];
+    __shared__ __align__(16) uint8_t s_wbuf[WAVES][S::WBUF + 16];   // + 16: lds_load16u reads one dword past the last staging slot
     __shared__ uint32_t s_epos[WAVES][64];
     const unsigned w = threadIdx.x >> 6;
     const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + w));

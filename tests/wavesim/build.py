@@ -14,7 +14,8 @@ def build(force=False, sanitize=False):
     deps += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
-    cmd = ["g++", "-std=c++17", "-O1", "-g"] + (["-DRCX_SIM_TRACE"] if os.environ.get("RCX_SIM_TRACE") else []) + [ "-fPIC", "-shared", "-x", "c++", "-include", os.path.join(HERE, "wavesim.h"),
+    cmd = ["g++", "-std=c++17", "-O1", "-g"] + (["-DRCX_SIM_TRACE"] if os.environ.get("RCX_SIM_TRACE") else []) + \
+          (["-fsanitize=address", "-fno-omit-frame-pointer"] if (sanitize or os.environ.get("RCX_SIM_ASAN")) else []) + [ "-fPIC", "-shared", "-x", "c++", "-include", os.path.join(HERE, "wavesim.h"),
            "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-unused-variable", "-Wno-attributes",
            "-o", OUT] + srcs
     subprocess.check_call(cmd)
