@@ -52,6 +52,15 @@ struct BwtfPairMax {
         BwtfPair r; r.s = a.s > b.s ? a.s : b.s; r.g = a.g > b.g ? a.g : b.g; return r;
     }
 };
+struct BwtfFlagOf {                                           // the same pair, computed on the fly as the scan's input
+    const uint64_t* keys; uint32_t so;
+    __device__ BwtfPair operator()(uint32_t j) const
+    {
+        const uint64_t k = keys[j], kp = j ? keys[j - 1] : ~k;
+        BwtfPair p; p.s = (j && (k >> so) == (kp >> so)) ? 0u : j; p.g = (j && k == kp) ? 0u : j;
+        return p;
+    }
+};
 __global__ void k_bwtf_flags(const uint64_t* keys, BwtfPair* pair, uint32_t n, uint32_t so)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -163,7 +172,8 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
         {
             rocprim::double_buffer<uint64_t> dk(keysA, keysB); rocprim::double_buffer<uint32_t> dv(valsA, valsB);
             (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, dk, dv, N, 0, 64, s);
-            (void)rocprim::inclusive_scan(nullptr, scan_tmp, pair, pair, N, BwtfPairMax(), s);
+            (void)rocprim::inclusive_scan(nullptr, scan_tmp, rocprim::make_transform_iterator(rocprim::make_counting_iterator(0u), BwtfFlagOf{keysA, 36}),
+                                          pair, N, BwtfPairMax(), s);
             (void)rocprim::exclusive_scan(nullptr, scan2_tmp, keep, pos, 0u, N, rocprim::plus<uint32_t>(), s);
         }
         size_t tmp_bytes = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
@@ -182,9 +192,9 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
             const uint32_t gn = (n + 255) / 256;
             size_t tb = tmp_bytes;
             if (rocprim::radix_sort_pairs(tmp, tb, dk, dv, n, 0, end_bit, s) != hipSuccess) { err = "bwt forward: radix sort failed"; return RCX_RC_HIP_ERROR; }
-            hipLaunchKernelGGL(k_bwtf_flags, dim3(gn), dim3(256), 0, s, dk.current(), pair, n, so);
-            tb = tmp_bytes;
-            if (rocprim::inclusive_scan(tmp, tb, pair, pair, n, BwtfPairMax(), s) != hipSuccess) { err = "bwt forward: scan failed"; return RCX_RC_HIP_ERROR; }
+            tb = tmp_bytes;                                      // group flags computed inside the scan's loads (no flag array round trip)
+            if (rocprim::inclusive_scan(tmp, tb, rocprim::make_transform_iterator(rocprim::make_counting_iterator(0u), BwtfFlagOf{dk.current(), so}),
+                                        pair, n, BwtfPairMax(), s) != hipSuccess) { err = "bwt forward: scan failed"; return RCX_RC_HIP_ERROR; }
             hipLaunchKernelGGL(k_bwtf_rank, dim3(gn), dim3(256), 0, s, dk.current(), dv.current(), pair, bstart, rank, sa, keep, n, sb, br, round == 0 ? 1 : 0);
             tb = tmp_bytes;
             if (rocprim::exclusive_scan(tmp, tb, keep, pos, 0u, n, rocprim::plus<uint32_t>(), s) != hipSuccess) { err = "bwt forward: scan failed"; return RCX_RC_HIP_ERROR; }
