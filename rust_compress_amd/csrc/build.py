@@ -17,6 +17,7 @@ def build(force=False, verbose=False):
            "-Wno-unused-result", "-Wl,-rpath,/opt/rocm/lib", "-o", OUT, os.path.join(HERE, "rcx_api.hip")]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    cmd[1:1] = os.environ.get("RCX_EXTRA_FLAGS", "").split()        # A/B experiments with compiler options
     subprocess.check_call(cmd)
     return OUT
 
