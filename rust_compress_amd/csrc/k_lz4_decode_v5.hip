@@ -21,7 +21,16 @@
 #define RCX_LDS_AS __attribute__((address_space(3)))
 #endif
 #ifndef RCX_EXEC_PRIO
-#define RCX_EXEC_PRIO 2
+#define RCX_EXEC_PRIO 1
+#endif
+#ifndef RCX_PARSER_PRIO
+#define RCX_PARSER_PRIO 2
+#endif
+#ifndef RCX_FLUSH_PRIO
+#define RCX_FLUSH_PRIO 2
+#endif
+#ifndef RCX_ROUND_PRIO
+#define RCX_ROUND_PRIO 3
 #endif
 #include <type_traits>
 
@@ -82,10 +91,11 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
             rcx_wave_sync();
             head++;
             if (lane == 0) ring->head = head;
-            // Issue priorities (s_setprio): the executor runs at 2; the parser outranks it (3) while the ring has a free slot --
-            // a batch it delivers sooner is a batch the executor never waits for -- and drops to 0 once the ring is full (it
-            // would only collect a batch it cannot post).  Measured: 300 -> 330 GiB/s on G-text, 245 -> 269 on G-words.
-            if (head - RCX_U(ring->tail) < (uint32_t)NSLOT) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+            // Issue priorities (s_setprio), found by measurement: an executor in its dependency analysis and copy rounds (chains
+            // of LDS round trips) runs at 3, in its drain at 2, elsewhere at 1; the parser runs at 2 while the ring has a free
+            // slot -- a batch delivered sooner is a batch the executor never waits for -- and at 0 once the ring is full (it
+            // would only collect a batch it cannot post).  No priorities: 300 GiB/s on G-text; these: 364 (with the LDS fixes).
+            if (head - RCX_U(ring->tail) < (uint32_t)NSLOT) __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO); else __builtin_amdgcn_s_setprio(0);
             if (bt.why == B::END_ || bt.why == B::ERR_) return;
             if (bt.why == B::STAGE_) { this->stage(cur); continue; }
             if (bt.why == B::SOLO_ || bt.why == B::WIDE_) cur = bt.gnext;
@@ -164,6 +174,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
             if (M > 48) f3 = *(const rcx_u32x4_u*)(out + slo + 48);
         }
 
+        if (!LITLDS) __builtin_amdgcn_s_setprio(RCX_ROUND_PRIO);
         // ---- producer lanes of [slo, shi) inside this batch, chains redirected (see Lz4V4::emit) while the loads fly
         unsigned long long dep = 0;
         bool inb = M && !isfar && shi > oend0;
@@ -256,9 +267,11 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
                 }
             };
             if (__ballot(ovl0 && M > 16u)) rounds(std::true_type{}); else rounds(std::false_type{});
+            if (!LITLDS) __builtin_amdgcn_s_setprio(RCX_FLUSH_PRIO);
         }
         this->oend = RCX_U(oend0 + T);
         this->flush(this->oend, false);
+        if (!LITLDS && RCX_FLUSH_PRIO != RCX_EXEC_PRIO) __builtin_amdgcn_s_setprio(RCX_EXEC_PRIO);
         return 0;
     }
 
