@@ -26,6 +26,9 @@
 #ifndef RCX_PARSER_PRIO
 #define RCX_PARSER_PRIO 2
 #endif
+#ifndef RCX_INF_ROUNDS_PRIO
+#define RCX_INF_ROUNDS_PRIO 1
+#endif
 #ifndef RCX_FLUSH_PRIO
 #define RCX_FLUSH_PRIO 2
 #endif
@@ -174,7 +177,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
             if (M > 48) f3 = *(const rcx_u32x4_u*)(out + slo + 48);
         }
 
-        if (!LITLDS) __builtin_amdgcn_s_setprio(RCX_ROUND_PRIO);
+        if (RCX_INF_ROUNDS_PRIO || !LITLDS) __builtin_amdgcn_s_setprio(RCX_ROUND_PRIO);
         // ---- producer lanes of [slo, shi) inside this batch, chains redirected (see Lz4V4::emit) while the loads fly
         unsigned long long dep = 0;
         bool inb = M && !isfar && shi > oend0;
@@ -267,7 +270,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
                 }
             };
             if (__ballot(ovl0 && M > 16u)) rounds(std::true_type{}); else rounds(std::false_type{});
-            if (!LITLDS) __builtin_amdgcn_s_setprio(RCX_FLUSH_PRIO);
+            if (!LITLDS) __builtin_amdgcn_s_setprio(RCX_FLUSH_PRIO); else if (RCX_INF_ROUNDS_PRIO) __builtin_amdgcn_s_setprio(0);
         }
         this->oend = RCX_U(oend0 + T);
         this->flush(this->oend, false);
