@@ -15,7 +15,7 @@ dev = torch.device("cuda", 0)
 ctx = R.Context(0)
 lens = [min(BS, total - i) for i in range(0, total, BS)]
 raw = torch.from_numpy(synth.gen_blocks("text", (total + BS - 1) // BS, BS, 0xE9)[:total]).to(dev)
-pipe = P.BwtDcAri(ctx, dev)
+pipe = P.BwtDcAri(ctx, dev, int(os.environ.get("PARTS", P.PARTS)))
 orig = ctx.launch_dev
 names = {N.BWT_FORWARD: "bwt_forward", N.DC_ENCODE: "dc_encode", N.ARI_BYTE_ENCODE: "ari_encode", N.ARI_BYTE_DECODE: "ari_decode",
          N.BWT_INVERSE: "bwt_inverse"}
@@ -29,11 +29,11 @@ ctx.launch_dev = timed
 for rep in range(2):
     acc.clear()
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    comp, coff, clen, stg = pipe.encode(raw, lens, keep_stages=(rep == 1))
+    comp, coff, clen, praw, stg = pipe.encode(raw, lens, keep_stages=(rep == 1))
     torch.cuda.synchronize(); te = time.perf_counter() - t0
     if stg: print("range coder input: %.0f bytes per block (record = 4 x (3 + 256 + k) bytes)" % float(stg["rec_len"].float().mean()))
     t0 = time.perf_counter()
-    out = pipe.decode(comp, coff, clen, lens)
+    out = pipe.decode(comp, coff, clen, praw, lens)
     torch.cuda.synchronize(); td = time.perf_counter() - t0
 assert torch.equal(out, raw)
 print("bytes %d blocks %d  encode %.3f s  decode %.3f s  ratio %.2f" % (total, len(lens), te, td, total / clen.sum()))

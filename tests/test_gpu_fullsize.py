@@ -91,8 +91,8 @@ def test_config5_pipeline_roundtrip_and_stage_parity(ctx, oracle):
     lens = [BLOCK] * 96 + [182784]
     pipe = P.BwtDcAri(ctx, dev)
     raw = torch.from_numpy(data).to(dev)
-    comp, coff, clen, st = pipe.encode(raw, lens, keep_stages=True)
-    back = pipe.decode(comp, coff, clen, lens)
+    comp, coff, clen, praw, st = pipe.encode(raw, lens, keep_stages=True)
+    back = pipe.decode(comp, coff, clen, praw, lens)
     assert torch.equal(back, raw)
     assert clen.sum() < 0.45 * data.size                               # it does compress text
     Lall = st["bwt"].out_base.cpu().numpy()
@@ -106,7 +106,11 @@ def test_config5_pipeline_roundtrip_and_stage_parity(ctx, oracle):
         record = struct.pack("<III", lens[i], eo, len(words) - 256) + words.tobytes()
         o = int(st["rec_off"][i])
         assert rec[o:o + len(record)].tobytes() == record
-        assert compn[int(coff[i]):int(coff[i]) + int(clen[i])].tobytes() == oracle.ari_byte_encode(record)
+        assert int(praw[i].sum()) == len(record)
+        cut = 0
+        for s_ in range(praw.shape[1]):                                  # every piece of the record is its own Ari stream
+            piece = record[cut:cut + int(praw[i, s_])]; cut += int(praw[i, s_])
+            assert compn[int(coff[i, s_]):int(coff[i, s_]) + int(clen[i, s_])].tobytes() == oracle.ari_byte_encode(piece)
     blob = P.encode_stream(ctx, data[: 3 * BLOCK + 17].tobytes())
     assert P.decode_stream(ctx, blob) == data[: 3 * BLOCK + 17].tobytes()
     ctx.set_stream(0)
