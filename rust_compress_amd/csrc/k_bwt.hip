@@ -28,16 +28,32 @@ struct BwtfArgs {
     uint32_t nblocks;
 };
 
-__global__ void k_bwtf_init(BwtfArgs a, uint64_t* keys, uint32_t* vals, uint32_t maxn)
+__global__ void k_bwtf_hist(BwtfArgs a, uint32_t* hist)      // symbol counts of the whole batch (alphabet compaction)
 {
+    __shared__ uint32_t s_h[256];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t b = blockIdx.y;
+    const uint32_t n = (uint32_t)a.in_len[b];
+    const uint8_t* T = a.in_base + a.in_off[b];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) atomicAdd(&s_h[T[i]], 1u);
+    __syncthreads();
+    if (s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+}
+// first key of suffix i: block | `nsym` symbols of `bits` bits each, a symbol = 1 + rank of the byte among the bytes that
+// occur in the batch (order preserving), 0 = past the end (the reference's implicit sentinel order)
+__global__ void k_bwtf_init(BwtfArgs a, uint64_t* keys, uint32_t* vals, const uint8_t* map, uint32_t nsym, uint32_t bits, uint32_t plus1)
+{
+    __shared__ uint32_t s_map[256];
+    s_map[threadIdx.x] = (uint32_t)map[threadIdx.x] + plus1;      // plus1: the map is the identity and a symbol is byte + 1
+    __syncthreads();
     const uint32_t b = blockIdx.y;
     const uint32_t n = (uint32_t)a.in_len[b];
     const uint8_t* T = a.in_base + a.in_off[b];
     const uint32_t g0 = a.bstart[b];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         uint64_t k = b;
-#pragma unroll
-        for (int c = 0; c < 4; c++) k = (k << 9) | (i + c < n ? (uint64_t)T[i + c] + 1u : 0u);   // 0 = past the end
+        for (uint32_t c = 0; c < nsym; c++) k = (k << bits) | (i + c < n ? (uint64_t)s_map[T[i + c]] : 0u);
         keys[g0 + i] = k;
         vals[g0 + i] = g0 + i;
     }
@@ -158,6 +174,7 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
     const uint32_t N = (uint32_t)N64;
     const uint32_t bblk = bits_for(nb), br = bits_for(maxn + 1);
     if (bblk + 2 * br > 64 || bblk + 36 > 64) { err = "bwt forward: block too large for 64-bit keys"; return RCX_RC_BAD_ARG; }
+    uint32_t nsym = 4, sbits = 9; bool plain_bytes = true;
     if (N) {
         // carve scratch
         uint8_t* p = (uint8_t*)k.scratch;
@@ -168,11 +185,12 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
         BwtfPair* pair = (BwtfPair*)carve(8ull * N);
         uint32_t* keep = (uint32_t*)carve(4ull * N);  uint32_t* pos = (uint32_t*)carve(4ull * N);
         uint32_t* bstart = (uint32_t*)carve(4ull * (nb + 1)); uint32_t* counter = (uint32_t*)carve(256);
+        uint32_t* hist = (uint32_t*)carve(1024); uint8_t* symmap = (uint8_t*)carve(256);
         size_t sort_tmp = 0, scan_tmp = 0, scan2_tmp = 0;
         {
             rocprim::double_buffer<uint64_t> dk(keysA, keysB); rocprim::double_buffer<uint32_t> dv(valsA, valsB);
             (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, dk, dv, N, 0, 64, s);
-            (void)rocprim::inclusive_scan(nullptr, scan_tmp, rocprim::make_transform_iterator(rocprim::make_counting_iterator(0u), BwtfFlagOf{keysA, 36}),
+            (void)rocprim::inclusive_scan(nullptr, scan_tmp, rocprim::make_transform_iterator(rocprim::make_counting_iterator(0u), BwtfFlagOf{keysA, 36u}),
                                           pair, N, BwtfPairMax(), s);
             (void)rocprim::exclusive_scan(nullptr, scan2_tmp, keep, pos, 0u, N, rocprim::plus<uint32_t>(), s);
         }
@@ -183,11 +201,35 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
         if (hipMemcpyAsync(bstart, h_bstart.data(), 4ull * (nb + 1), hipMemcpyHostToDevice, s) != hipSuccess) { err = "bwt forward: H2D"; return RCX_RC_HIP_ERROR; }
         BwtfArgs fa{k.in_base, k.in_off, k.in_len, bstart, nb};
         const uint32_t gx = (uint32_t)((maxn + 255) / 256 < 1024 ? (maxn + 255) / 256 : 1024);
-        hipLaunchKernelGGL(k_bwtf_init, dim3(gx ? gx : 1, nb), dim3(256), 0, s, fa, keysA, valsA, (uint32_t)maxn);
+        // Alphabet compaction: the bytes that occur get dense, order-preserving codes, so that more symbols fit the first
+        // key when the alphabet is small and skewed (text: 7 of 7 bits instead of 4 of 9; DNA: 16).  High-entropy data is
+        // resolved by 4 bytes anyway and keeps the shorter key (fewer radix passes).
+        {
+            uint32_t h_hist[256];
+            if (hipMemsetAsync(hist, 0, 1024, s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
+            hipLaunchKernelGGL(k_bwtf_hist, dim3(gx ? gx : 1, nb), dim3(256), 0, s, fa, hist);
+            if (hipMemcpyAsync(h_hist, hist, 1024, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+                err = "bwt forward: histogram"; return RCX_RC_HIP_ERROR; }
+            uint8_t h_map[256]; uint32_t sigma = 0; double H0 = 0;
+            for (int v = 0; v < 256; v++) h_map[v] = h_hist[v] ? (uint8_t)(++sigma > 255 ? 255 : sigma) : 0;
+            if (sigma == 256) for (int v = 0; v < 256; v++) h_map[v] = (uint8_t)v;          // codes 1..256 do not fit a byte: keep byte + 1 below
+            for (int v = 0; v < 256; v++) if (h_hist[v]) { const double pr = (double)h_hist[v] / (double)N; H0 -= pr * log2(pr); }
+            if (sigma < 256 && H0 < 6.0) {
+                sbits = bits_for(sigma);
+                nsym = (64 - bblk - 1) / sbits; if (nsym > 16) nsym = 16; if (nsym < 4) nsym = 4;
+                while (nsym > 4 && nsym * sbits + bblk > 60) nsym--;                      // at most 8 radix passes in round 0
+            } else {
+                for (int v = 0; v < 256; v++) h_map[v] = (uint8_t)v;                         // plain bytes: symbol = byte + 1 (9 bits) via the +1 below
+            }
+            plain_bytes = !(sigma < 256 && H0 < 6.0);
+            if (hipMemcpyAsync(symmap, h_map, 256, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+                err = "bwt forward: symbol map"; return RCX_RC_HIP_ERROR; }
+        }
+        hipLaunchKernelGGL(k_bwtf_init, dim3(gx ? gx : 1, nb), dim3(256), 0, s, fa, keysA, valsA, symmap, nsym, sbits, plain_bytes ? 1u : 0u);
         rocprim::double_buffer<uint64_t> dk(keysA, keysB); rocprim::double_buffer<uint32_t> dv(valsA, valsB);
         // Round 0 sorts every suffix by its first 4 bytes; each later round sorts only the suffixes whose group
         // is still larger than one (Larsson-Sadakane style discarding) by (group rank, rank of suffix + h).
-        uint32_t sb = 36, so = 36, end_bit = 36 + bblk, h = 4, n = N;
+        uint32_t sb = nsym * sbits, so = nsym * sbits, end_bit = nsym * sbits + bblk, h = nsym, n = N;
         for (int round = 0; round < 40 && n; round++) {
             const uint32_t gn = (n + 255) / 256;
             size_t tb = tmp_bytes;
@@ -204,6 +246,7 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
             uint32_t left = 0;
             (void)hipMemcpyAsync(&left, counter, 4, hipMemcpyDeviceToHost, s);
             if (hipStreamSynchronize(s) != hipSuccess) { err = "bwt forward: sync failed"; return RCX_RC_HIP_ERROR; }
+            if (getenv("RCX_BWT_TRACE")) fprintf(stderr, "bwt forward round %d: h=%u elements %u -> survivors %u\n", round, h, n, left);
             dk.swap(); dv.swap();
             n = left; sb = 2 * br; so = br; end_bit = 2 * br + bblk; h *= 2;
         }
