@@ -88,14 +88,14 @@ __global__ void k_bwtf_flags(const uint64_t* keys, BwtfPair* pair, uint32_t n, u
 // new rank of element j = rank of its old group + (start of its new group - start of its old group); a new group
 // of one element is final: its suffix goes to SA[new rank] and leaves U.
 __global__ void k_bwtf_rank(const uint64_t* keys, const uint32_t* vals, const BwtfPair* pair, const uint32_t* bstart,
-                            uint32_t* rank, uint32_t* sa, uint32_t* keep, uint32_t n, uint32_t sb, uint32_t br, int round0)
+                            uint32_t* rank, uint32_t* sa, uint32_t* keep, uint32_t n, uint32_t sb, uint32_t br, uint32_t br1, int round0)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const uint64_t k = keys[j];
     const BwtfPair p = pair[j];
     const uint32_t b = (uint32_t)(k >> sb);
-    const uint32_t base = round0 ? bstart[b] : bstart[b] + (uint32_t)((k >> br) & ((1ull << br) - 1ull)) - 1u;
+    const uint32_t base = round0 ? bstart[b] : bstart[b] + (uint32_t)((k >> br) & ((1ull << br1) - 1ull));
     const uint32_t nr = base + (p.g - p.s);
     const uint32_t g = vals[j];
     rank[g] = nr;
@@ -103,20 +103,20 @@ __global__ void k_bwtf_rank(const uint64_t* keys, const uint32_t* vals, const Bw
     if (single) sa[nr] = g;
     keep[j] = single ? 0u : 1u;
 }
-// compact the survivors and give them their next key: block | new local rank + 1 | local rank + 1 of suffix + h (0 = past the end)
+// compact the survivors and give them their next key: block | new local rank | local rank + 1 of suffix + h (0 = past the end)
 __global__ void k_bwtf_next(const uint64_t* keys, const uint32_t* vals, const uint32_t* keep, const uint32_t* pos,
                             const uint32_t* rank, const uint32_t* bstart, uint64_t* keys_out, uint32_t* vals_out,
-                            uint32_t n, uint32_t sb, uint32_t br, uint32_t h)
+                            uint32_t n, uint32_t sb, uint32_t br, uint32_t br1, uint32_t h)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n || !keep[j]) return;
     const uint32_t b = (uint32_t)(keys[j] >> sb);
     const uint32_t g = vals[j];
     const uint32_t g0 = bstart[b], e = bstart[b + 1];
-    const uint64_t r1 = rank[g] - g0 + 1u;
+    const uint64_t r1 = rank[g] - g0;                             // local rank, br1 bits (no sentinel needed here)
     const uint64_t r2 = (g + h < e) ? rank[g + h] - g0 + 1u : 0u;
     const uint32_t o = pos[j];
-    keys_out[o] = ((uint64_t)b << (2 * br)) | (r1 << br) | r2;
+    keys_out[o] = ((uint64_t)b << (br1 + br)) | (r1 << br) | r2;
     vals_out[o] = g;
 }
 __global__ void k_bwtf_count(const uint32_t* keep, const uint32_t* pos, uint32_t n, uint32_t* out)
@@ -172,8 +172,9 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
     h_bstart[nb] = (uint32_t)N64;
     if (N64 >= 0xffffffffull) { err = "bwt forward: batch larger than 4 Gi suffixes"; return RCX_RC_BAD_ARG; }
     const uint32_t N = (uint32_t)N64;
-    const uint32_t bblk = bits_for(nb), br = bits_for(maxn + 1);
-    if (bblk + 2 * br > 64 || bblk + 36 > 64) { err = "bwt forward: block too large for 64-bit keys"; return RCX_RC_BAD_ARG; }
+    // key fields: block index (0 .. nb-1), local rank (0 .. maxn-1), local rank + 1 with 0 = past the end (0 .. maxn)
+    const uint32_t bblk = bits_for(nb ? nb - 1 : 0), br = bits_for(maxn), br1 = bits_for(maxn ? maxn - 1 : 0);
+    if (bblk + br1 + br > 64 || bblk + 36 > 64) { err = "bwt forward: block too large for 64-bit keys"; return RCX_RC_BAD_ARG; }
     uint32_t nsym = 4, sbits = 9; bool plain_bytes = true;
     if (N) {
         // carve scratch
@@ -237,18 +238,18 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
             tb = tmp_bytes;                                      // group flags computed inside the scan's loads (no flag array round trip)
             if (rocprim::inclusive_scan(tmp, tb, rocprim::make_transform_iterator(rocprim::make_counting_iterator(0u), BwtfFlagOf{dk.current(), so}),
                                         pair, n, BwtfPairMax(), s) != hipSuccess) { err = "bwt forward: scan failed"; return RCX_RC_HIP_ERROR; }
-            hipLaunchKernelGGL(k_bwtf_rank, dim3(gn), dim3(256), 0, s, dk.current(), dv.current(), pair, bstart, rank, sa, keep, n, sb, br, round == 0 ? 1 : 0);
+            hipLaunchKernelGGL(k_bwtf_rank, dim3(gn), dim3(256), 0, s, dk.current(), dv.current(), pair, bstart, rank, sa, keep, n, sb, br, br1, round == 0 ? 1 : 0);
             tb = tmp_bytes;
             if (rocprim::exclusive_scan(tmp, tb, keep, pos, 0u, n, rocprim::plus<uint32_t>(), s) != hipSuccess) { err = "bwt forward: scan failed"; return RCX_RC_HIP_ERROR; }
             hipLaunchKernelGGL(k_bwtf_count, dim3(1), dim3(64), 0, s, keep, pos, n, counter);
             hipLaunchKernelGGL(k_bwtf_next, dim3(gn), dim3(256), 0, s, dk.current(), dv.current(), keep, pos, rank, bstart,
-                               dk.alternate(), dv.alternate(), n, sb, br, h);
+                               dk.alternate(), dv.alternate(), n, sb, br, br1, h);
             uint32_t left = 0;
             (void)hipMemcpyAsync(&left, counter, 4, hipMemcpyDeviceToHost, s);
             if (hipStreamSynchronize(s) != hipSuccess) { err = "bwt forward: sync failed"; return RCX_RC_HIP_ERROR; }
             if (getenv("RCX_BWT_TRACE")) fprintf(stderr, "bwt forward round %d: h=%u elements %u -> survivors %u\n", round, h, n, left);
             dk.swap(); dv.swap();
-            n = left; sb = 2 * br; so = br; end_bit = 2 * br + bblk; h *= 2;
+            n = left; sb = br1 + br; so = br; end_bit = br1 + br + bblk; h *= 2;
         }
         if (n) { err = "bwt forward: did not converge"; return RCX_RC_HIP_ERROR; }
         hipLaunchKernelGGL(k_bwtf_emit, dim3(gx ? gx : 1, nb), dim3(256), 0, s, fa, sa, k.out_base, k.out_off, k.out_cap, k.aux);
