@@ -200,6 +200,18 @@ class DeviceBatch:
                             out_off.data_ptr(), out_cap.data_ptr(), self.out_len.data_ptr(), self.in_used.data_ptr(),
                             self.status.data_ptr(), self.aux.data_ptr(), n)
 
+    def sub(self, lo, hi):
+        """Blocks [lo, hi) of this batch as a batch of its own: the same tensors, sliced (results land in this batch's arrays)."""
+        v = object.__new__(DeviceBatch)
+        v.n = hi - lo
+        v.in_base, v.out_base = self.in_base, self.out_base
+        for name in ("in_off", "in_len", "out_off", "out_cap", "out_len", "in_used", "status", "aux"):
+            setattr(v, name, getattr(self, name)[lo:hi])
+        v.c = N.DevBatch(v.in_base.data_ptr(), v.in_off.data_ptr(), v.in_len.data_ptr(), v.out_base.data_ptr(),
+                         v.out_off.data_ptr(), v.out_cap.data_ptr(), v.out_len.data_ptr(), v.in_used.data_ptr(),
+                         v.status.data_ptr(), v.aux.data_ptr(), v.n)
+        return v
+
     @staticmethod
     def from_host(blobs_base, off, lens, out_total, out_off, out_cap, device):
         import torch

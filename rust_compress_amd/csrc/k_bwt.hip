@@ -152,9 +152,13 @@ __global__ void k_bwtf_finish(rcx_kargs a)
 
 static inline uint32_t bits_for(uint64_t v) { uint32_t b = 1; while ((1ull << b) <= v && b < 63) b++; return b; }
 
+// Blocks per suffix-sort pass: with <= 1024 the block index takes 10 key bits, which keeps the refinement rounds of 256 KiB
+// blocks at 6 radix passes (47 key bits) and the scratch at 13 GB; larger batches are sorted 1024 blocks at a time.
+#define BWTF_CHUNK 1024u
+
 static uint64_t bwt_forward_scratch_bytes(uint32_t nblocks, uint64_t max_block)
 {
-    const uint64_t N = (uint64_t)nblocks * max_block;
+    const uint64_t N = (uint64_t)(nblocks < BWTF_CHUNK ? nblocks : BWTF_CHUNK) * max_block;
     // keys 2x8N, vals 2x4N, rank 4N, SA 4N, group pairs 8N, keep 4N, positions 4N, bstart, counters, sort/scan temp
     return 48 * N + N / 16 + (uint64_t)(nblocks + 2) * 4 + (64ull << 20);
 }
@@ -162,6 +166,19 @@ static uint64_t bwt_forward_scratch_bytes(uint32_t nblocks, uint64_t max_block)
 static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::string& err)
 {
     (void)variant;
+    if (k.nblocks > BWTF_CHUNK) {
+        for (uint32_t lo = 0; lo < k.nblocks; lo += BWTF_CHUNK) {
+            rcx_kargs kk = k;
+            kk.in_off += lo; kk.in_len += lo; kk.out_off += lo; kk.out_cap += lo; kk.out_len += lo; kk.status += lo;
+            if (kk.in_used) kk.in_used += lo;
+            if (kk.aux) kk.aux += lo;
+            if (kk.n_out) kk.n_out += lo;
+            kk.nblocks = k.nblocks - lo < BWTF_CHUNK ? k.nblocks - lo : BWTF_CHUNK;
+            const int rc = launch_bwt_forward(s, kk, variant, err);
+            if (rc) return rc;
+        }
+        return RCX_RC_OK;
+    }
     const uint32_t nb = k.nblocks;
     std::vector<uint64_t> h_len(nb);
     if (hipMemcpyAsync(h_len.data(), k.in_len, nb * 8ull, hipMemcpyDeviceToHost, s) != hipSuccess ||

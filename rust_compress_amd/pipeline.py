@@ -37,8 +37,8 @@ class BwtDcAri:
         return self.torch.as_tensor(np.asarray(a, dtype=np.int64), device=self.dev)
 
     def _scratch(self, codec, nb, maxn):
-        """One scratch buffer per pipeline object, grown on demand: the suffix sort wants 48 B per input byte, and a
-        fresh 48 GB hipMalloc per call costs about a second."""
+        """One scratch buffer per pipeline object, grown on demand: the suffix sort wants 48 B per input byte of the (at
+        most 1024) blocks it sorts at a time, 13 GB for 256 KiB blocks, and a fresh hipMalloc of that size per call is slow."""
         need = self.ctx.scratch_bytes(codec, nb, maxn) + 256
         if getattr(self, "_sc", None) is None or self._sc.numel() < need:
             self._sc = None
@@ -56,7 +56,7 @@ class BwtDcAri:
         # 1. BWT
         bw = DeviceBatch(raw, self._i64(off), self._i64(lens), torch.empty(int(lens.sum()) + 64, dtype=torch.uint8, device=self.dev),
                          self._i64(off), self._i64(lens))
-        sc = self._scratch(N.BWT_FORWARD, nb, maxn)
+        sc = self._scratch(N.BWT_FORWARD, nb, maxn)          # the library sorts 1024 blocks at a time (13 GB of scratch)
         self.ctx.launch_dev(N.BWT_FORWARD, bw, sc)
         # 2. DC into the record slot, 12 bytes in (n, origin, k go in front)
         slot = (4 * (HDR_WORDS + 256 + maxn) + 63) // 64 * 64
