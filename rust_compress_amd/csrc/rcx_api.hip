@@ -182,9 +182,11 @@ static int launch_codec(rcx_ctx* c, int codec, rcx_kargs& k)
         else if (v == 8) hipLaunchKernelGGL((k_lz4_decode_v4<1024, 4>), dim3((n + 3) / 4), dim3(256), 0, s, k);
         else if (v == 12) hipLaunchKernelGGL((k_lz4_decode_v5<1024, 1536, 3072>), dim3(n), dim3(128), 0, s, k);   // A/B: longer history, smaller batch cap
         else if (v == 13) hipLaunchKernelGGL((k_lz4_decode_v5<1024, 2048, 2560>), dim3(n), dim3(128), 0, s, k);
+        else if (v == 16) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 2048, 1536>), dim3(n), dim3(128), 0, s, k);
         else if (v == 14) hipLaunchKernelGGL((k_lz4_decode_v5<1024, 2560, 2048, true>), dim3(n), dim3(128), 0, s, k);   // ring wait timers -> scratch
-        else if (v == 10 || v == 0)
-            hipLaunchKernelGGL((k_lz4_decode_v5<1024>), dim3(n), dim3(128), 0, s, k);   // parser + executor waves
+        else if (v == 10) hipLaunchKernelGGL((k_lz4_decode_v5<1024>), dim3(n), dim3(128), 0, s, k);   // 1 KiB of staged input, batch cap 2560
+        else if (v == 0 || v == 15)
+            hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1536, 2048>), dim3(n), dim3(128), 0, s, k);   // parser + executor waves (default)
         else hipLaunchKernelGGL((k_lz4_decode_v4<1024, 1>), dim3(n), dim3(64), 0, s, k); // v == 11
         break;
     case RCX_LZ4_ENCODE: {

@@ -31,7 +31,8 @@ extern "C" int sim_launch(int codec, int variant, const rcx_kargs* a)
         else if (variant == 6) ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_decode_v3<2048, 2048, 64, 64, 1>(k); });
         else if (variant == 7) ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_decode_v4<2048, 1>(k); });
         else if (variant == 8) ws::launch(dim3((k.nblocks + 3) / 4), dim3(256), [&] { k_lz4_decode_v4<1024, 4>(k); });
-        else if (variant == 10 || variant == 0) ws::launch(dim3(k.nblocks), dim3(128), [&] { k_lz4_decode_v5<1024>(k); });
+        else if (variant == 10) ws::launch(dim3(k.nblocks), dim3(128), [&] { k_lz4_decode_v5<1024>(k); });
+        else if (variant == 0) ws::launch(dim3(k.nblocks), dim3(128), [&] { k_lz4_decode_v5<2048, 1536, 2048>(k); });
         else ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_decode_v4<1024, 1>(k); });
         return 0;
     case RCX_LZ4_ENCODE:
