@@ -71,6 +71,26 @@ def test_bwt_forward_and_inverse(ctx, oracle):
     assert bad.status[0] == 3
 
 
+def test_bwt_forward_key_layouts(ctx, oracle):
+    """The first sort key adapts to the batch (alphabet compaction, symbols per key) and big batches are sorted 1024 blocks
+    at a time: every layout must give the reference's (L, origin)."""
+    from rust_compress_amd import synth
+    rng = np.random.default_rng(5)
+    def check(raws):
+        fw = ctx.bwt_forward(raws).check()
+        for r, L, og in zip(raws, fw.outputs, fw.aux):
+            eL, eo = oracle.bwt_encode(r)
+            assert L == eL and (not r or og == eo)
+    check([synth.gen("dna4", 50000, 1).tobytes(), b"ab" * 9000, bytes(5000), b"abracadabra" * 700])      # 1-4 symbols: 16+ per key
+    check([synth.gen("text", 60000, 2).tobytes(), synth.gen("words", 30000, 3).tobytes()])                # ~6 bits: 8 per key
+    skew = bytes(rng.choice(256, 40000, p=np.r_[[0.7], np.full(255, 0.3 / 255)]).astype(np.uint8))
+    check([skew + bytes(range(256))])                                                                     # all 256 bytes occur, low entropy: plain bytes
+    check([bytes(rng.integers(0, 255, 40000, dtype=np.uint8))])                                           # 255 symbols, high entropy: plain bytes
+    check([bytes(rng.choice(200, 30000, p=np.r_[[0.5], np.full(199, 0.5 / 199)]).astype(np.uint8))])      # 200 symbols, 8-bit codes
+    small = [synth.gen(("text", "runs", "dna4", "rand")[i % 4], int(rng.integers(1, 400)), 100 + i).tobytes() for i in range(2500)]
+    check(small)                                                                                          # > 1024 blocks: three passes
+
+
 def test_mtf_dc_ari_rle(ctx, oracle):
     raws = _raws(oracle)
     lens = [len(r) for r in raws]

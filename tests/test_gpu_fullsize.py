@@ -113,4 +113,8 @@ def test_config5_pipeline_roundtrip_and_stage_parity(ctx, oracle):
             assert compn[int(coff[i, s_]):int(coff[i, s_]) + int(clen[i, s_])].tobytes() == oracle.ari_byte_encode(piece)
     blob = P.encode_stream(ctx, data[: 3 * BLOCK + 17].tobytes())
     assert P.decode_stream(ctx, blob) == data[: 3 * BLOCK + 17].tobytes()
+    for parts in (1, 2, 8):                                            # the container records how many pieces a block record has
+        blob = P.encode_stream(ctx, data[: BLOCK + 5].tobytes(), parts=parts)
+        assert P.decode_stream(ctx, blob) == data[: BLOCK + 5].tobytes()
+    assert P.decode_stream(ctx, P.encode_stream(ctx, b"")) == b"" and P.decode_stream(ctx, P.encode_stream(ctx, b"x")) == b"x"
     ctx.set_stream(0)
