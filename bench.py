@@ -195,7 +195,20 @@ def main():
                                                     "hbm_frac": round((cb + ob) / (km * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ok": bool(ok)}
                 del d2, r2
             res["extras"] = extras
-        print(json.dumps(res), flush=True)
+        line = json.dumps(res)
+    else:
+        line = None
+    # RCCL writes its version banner to stdout through C stdio, which is flushed at exit -- after anything Python prints.
+    # Every rank pushes it out first; rank 0 prints the JSON line after a barrier, as the last line of the job's stdout.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if dist is not None:
+        dist.barrier()
+    if line is not None:
+        print(line, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
