@@ -28,17 +28,44 @@ struct BwtfArgs {
     uint32_t nblocks;
 };
 
-__global__ void k_bwtf_hist(BwtfArgs a, uint32_t* hist)      // symbol counts of the whole batch (alphabet compaction)
+// Alphabet of the whole batch: hist[0..255] = symbol counts of a 1/64 SAMPLE (only the order-0 entropy estimate uses them),
+// hist[256..263] = EXACT 256-bit presence set of every byte of every block (the symbol map must cover all of them).
+// Presence is kept in 8 registers per lane (LDS atomics on a skewed text serialise: the first version took 13 ms).
+__global__ __launch_bounds__(256) void k_bwtf_hist(BwtfArgs a, uint32_t* hist)
 {
     __shared__ uint32_t s_h[256];
+    __shared__ uint32_t s_p[8];
     s_h[threadIdx.x] = 0;
+    if (threadIdx.x < 8) s_p[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t b = blockIdx.y;
     const uint32_t n = (uint32_t)a.in_len[b];
     const uint8_t* T = a.in_base + a.in_off[b];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) atomicAdd(&s_h[T[i]], 1u);
+    uint32_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto mark = [&](uint32_t v) {
+        const uint32_t bit = 1u << (v & 31u), w = v >> 5;
+#pragma unroll
+        for (int k = 0; k < 8; k++) m[k] |= (w == (uint32_t)k) ? bit : 0u;
+    };
+    const uint32_t nch = n >> 4;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nch; c += gridDim.x * blockDim.x) {
+        const rcx_u32x4 x = *(const rcx_u32x4_u*)(T + 16ull * c);
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) mark((x[d] >> (8 * e)) & 0xffu);
+        if ((c & 63u) == 0)
+#pragma unroll
+            for (int d = 0; d < 4; d++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) atomicAdd(&s_h[(x[d] >> (8 * e)) & 0xffu], 1u);
+    }
+    if (blockIdx.x == 0) for (uint32_t i = (nch << 4) + threadIdx.x; i < n; i += blockDim.x) { mark(T[i]); atomicAdd(&s_h[T[i]], 1u); }
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (m[k]) atomicOr(&s_p[k], m[k]);
     __syncthreads();
     if (s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+    if (threadIdx.x < 8 && s_p[threadIdx.x]) atomicOr(&hist[256 + threadIdx.x], s_p[threadIdx.x]);
 }
 // first key of suffix i: block | `nsym` symbols of `bits` bits each, a symbol = 1 + rank of the byte among the bytes that
 // occur in the batch (order preserving), 0 = past the end (the reference's implicit sentinel order)
@@ -203,7 +230,7 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
         BwtfPair* pair = (BwtfPair*)carve(8ull * N);
         uint32_t* keep = (uint32_t*)carve(4ull * N);  uint32_t* pos = (uint32_t*)carve(4ull * N);
         uint32_t* bstart = (uint32_t*)carve(4ull * (nb + 1)); uint32_t* counter = (uint32_t*)carve(256);
-        uint32_t* hist = (uint32_t*)carve(1024); uint8_t* symmap = (uint8_t*)carve(256);
+        uint32_t* hist = (uint32_t*)carve(1056); uint8_t* symmap = (uint8_t*)carve(256);
         size_t sort_tmp = 0, scan_tmp = 0, scan2_tmp = 0;
         {
             rocprim::double_buffer<uint64_t> dk(keysA, keysB); rocprim::double_buffer<uint32_t> dv(valsA, valsB);
@@ -223,15 +250,18 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
         // key when the alphabet is small and skewed (text: 7 of 7 bits instead of 4 of 9; DNA: 16).  High-entropy data is
         // resolved by 4 bytes anyway and keeps the shorter key (fewer radix passes).
         {
-            uint32_t h_hist[256];
-            if (hipMemsetAsync(hist, 0, 1024, s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
+            uint32_t h_hist[264];
+            if (hipMemsetAsync(hist, 0, 1056, s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
             hipLaunchKernelGGL(k_bwtf_hist, dim3(gx ? gx : 1, nb), dim3(256), 0, s, fa, hist);
-            if (hipMemcpyAsync(h_hist, hist, 1024, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            if (hipMemcpyAsync(h_hist, hist, 1056, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
                 err = "bwt forward: histogram"; return RCX_RC_HIP_ERROR; }
             uint8_t h_map[256]; uint32_t sigma = 0; double H0 = 0;
-            for (int v = 0; v < 256; v++) h_map[v] = h_hist[v] ? (uint8_t)(++sigma > 255 ? 255 : sigma) : 0;
+            auto present = [&](int v) { return (h_hist[256 + (v >> 5)] >> (v & 31)) & 1u; };
+            uint64_t sampled = 0;
+            for (int v = 0; v < 256; v++) { h_map[v] = present(v) ? (uint8_t)(++sigma > 255 ? 255 : sigma) : 0; sampled += h_hist[v]; }
             if (sigma == 256) for (int v = 0; v < 256; v++) h_map[v] = (uint8_t)v;          // codes 1..256 do not fit a byte: keep byte + 1 below
-            for (int v = 0; v < 256; v++) if (h_hist[v]) { const double pr = (double)h_hist[v] / (double)N; H0 -= pr * log2(pr); }
+            for (int v = 0; v < 256; v++) if (h_hist[v]) { const double pr = (double)h_hist[v] / (double)sampled; H0 -= pr * log2(pr); }
+            if (!sampled) H0 = 8.0;
             if (sigma < 256 && H0 < 6.0) {
                 sbits = bits_for(sigma);
                 nsym = (64 - bblk - 1) / sbits; if (nsym > 16) nsym = 16; if (nsym < 4) nsym = 4;
