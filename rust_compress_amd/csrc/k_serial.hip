@@ -35,18 +35,47 @@ __device__ __forceinline__ void mtf_front(uint8_t* lst, uint32_t rank, uint32_t 
     if (lane == 0) lst[0] = (uint8_t)sym;
     rcx_wave_sync();
 }
-// length of the run of bytes equal to `sym` starting at in[i] (i < n), found 64 bytes per step
-__device__ __forceinline__ uint32_t run_length(const uint8_t* in, uint32_t i, uint32_t n, uint32_t sym, unsigned lane)
-{
-    uint32_t j = i;
-    for (;;) {
-        const uint32_t p = j + lane;
-        const bool differ = (p >= n) || (in[p] != sym);
-        const unsigned long long m = __ballot(differ);
-        if (m) return j + (uint32_t)(__ffsll(m) - 1) - i;
-        j += 64;
+// Sequential input of one stream held 64 elements at a time across the lanes (lane j: element base + j), the following 64
+// requested one window early: a serial loop that did `x = in[i]` paid a full global-memory round trip (~700 ns) per step
+// (34 ms for one 256 KiB block of BWT output, whatever the batch size); readlane from the window costs a few cycles.
+template <typename T>
+struct SeqWin {
+    const T* in; uint32_t n, base; uint32_t cur, nxt; unsigned lane;
+    __device__ __forceinline__ void start(const T* in_, uint32_t n_, unsigned lane_)
+    {
+        in = in_; n = n_; lane = lane_; base = 0;
+        cur = lane < n ? (uint32_t)in[lane] : 0u;
+        nxt = 64u + lane < n ? (uint32_t)in[64u + lane] : 0u;
     }
-}
+    __device__ __forceinline__ void seek(uint32_t i)           // make element i (uniform, >= base) addressable
+    {
+        if (i < base + 64u) return;
+        if (i < base + 128u) { base += 64u; cur = nxt; }
+        else { base = i & ~63u; cur = base + lane < n ? (uint32_t)in[base + lane] : 0u; }
+        const uint32_t q = base + 64u + lane;
+        nxt = q < n ? (uint32_t)in[q] : 0u;
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t i)        // i uniform, i < n
+    {
+        seek(i);
+        return (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(i - base));
+    }
+    // length of the run of elements equal to `sym` starting at i (element i is known to equal sym)
+    __device__ __forceinline__ uint32_t run(uint32_t i, uint32_t sym)
+    {
+        seek(i);
+        const uint32_t p = base + lane;
+        const unsigned long long m = __ballot(p >= i && (p >= n || cur != sym));
+        if (m) return base + (uint32_t)(__ffsll(m) - 1) - i;
+        uint32_t j = base + 64u;                               // the run leaves the window: 64 elements per step from memory
+        for (;;) {
+            const uint32_t q = j + lane;
+            const unsigned long long m2 = __ballot(q >= n || (uint32_t)in[q] != sym);
+            if (m2) return j + (uint32_t)(__ffsll(m2) - 1) - i;
+            j += 64u;
+        }
+    }
+};
 
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_mtf(rcx_kargs a, int decode)
@@ -66,12 +95,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_mtf(rcx_kargs a, int decode)
     for (int k = 0; k < 4; k++) lst[lane + 64 * k] = (uint8_t)(lane + 64 * k);
     rcx_wave_sync();
     uint32_t i = 0;
+    SeqWin<uint8_t> win; win.start(in, n, lane);
     while (i < n) {
-        const uint32_t x = __builtin_amdgcn_readfirstlane((uint32_t)in[i]);
+        const uint32_t x = win.get(i);
         if (!decode) {
             const uint32_t head = __builtin_amdgcn_readfirstlane((uint32_t)lst[0]);
             if (x == head) {                                  // rank 0: the whole run encodes to zeros
-                const uint32_t rl = run_length(in, i, n, x, lane);
+                const uint32_t rl = win.run(i, x);
                 for (uint32_t t = lane; t < rl; t += 64) out[i + t] = 0;
                 i += rl;
             } else {
@@ -82,7 +112,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mtf(rcx_kargs a, int decode)
             }
         } else {
             if (x == 0) {                                     // rank 0 repeats the front symbol
-                const uint32_t rl = run_length(in, i, n, 0, lane);
+                const uint32_t rl = win.run(i, 0);
                 const uint8_t head = lst[0];
                 for (uint32_t t = lane; t < rl; t += 64) out[i + t] = head;
                 i += rl;
@@ -123,8 +153,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a)
     for (int k = 0; k < 4; k++) { lst[lane + 64 * k] = 0; last[lane + 64 * k] = n; words[lane + 64 * k] = n; }   // :114-115, MTF::new()
     rcx_wave_sync();
     uint32_t num_unique = 0, i = 0;
+    SeqWin<uint8_t> win; win.start(in, n, lane);
     while (i < n) {                                           // :117-138
-        const uint32_t sym = __builtin_amdgcn_readfirstlane((uint32_t)in[i]);
+        const uint32_t sym = win.get(i);
         const uint32_t base = __builtin_amdgcn_readfirstlane(last[sym]);
         if (base == n) {                                      // first occurrence, :121-128
             if (lane == 0) { lst[num_unique] = (uint8_t)sym; words[sym] = i; last[sym] = i; dist[i] = n; }
@@ -134,7 +165,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a)
             num_unique++;
             i += 1;
         } else if (base == i - 1) {                           // inside a run: rank 0, nothing is emitted
-            const uint32_t rl = run_length(in, i, n, sym, lane);
+            const uint32_t rl = win.run(i, sym);
             for (uint32_t t = lane; t < rl; t += 64) dist[i + t] = n;
             if (lane == 0) last[sym] = i + rl - 1;
             rcx_wave_sync();
@@ -211,6 +242,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_decode(rcx_kargs a)
             for (uint32_t t = lane; t < n; t += 64) out[t] = sym;
             i = n;
         }
+        SeqWin<uint32_t> wwin; wwin.start(words, nwords, lane);
         while (i < n) {                                        // :199-229
             const uint32_t sym = __builtin_amdgcn_readfirstlane((uint32_t)lst[0]);
             const uint32_t stop = __builtin_amdgcn_readfirstlane(next[lst[1]]);
@@ -219,7 +251,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_decode(rcx_kargs a)
             if (stop > i) i = stop;
             di++;                                              // decode_simple closure :243-249
             if (di > nwords) { st = RCX_E_EOF; break; }
-            const uint32_t d = __builtin_amdgcn_readfirstlane(words[di - 1]);
+            const uint32_t d = wwin.get(di - 1);
             const uint64_t future64 = (uint64_t)stop + d;
             if (future64 > n) { st = RCX_E_MALFORMED; break; } /* :213 assert */
             const uint32_t future = (uint32_t)future64;
