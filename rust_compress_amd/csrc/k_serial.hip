@@ -35,6 +35,46 @@ __device__ __forceinline__ void mtf_front(uint8_t* lst, uint32_t rank, uint32_t 
     if (lane == 0) lst[0] = (uint8_t)sym;
     rcx_wave_sync();
 }
+// The same list held in registers: lane l keeps entries 4l .. 4l+3 in the bytes of one dword.  find needs no memory access
+// and move-to-front is one DPP wave shift plus a few selects -- the LDS version paid three dependent LDS round trips and
+// two wave syncs per symbol, which is what a serial MTF / DC step is made of.
+struct MtfRegs {
+    uint32_t w; unsigned lane;
+    __device__ __forceinline__ void identity(unsigned lane_) { lane = lane_; const uint32_t b = 4u * lane; w = b | ((b + 1u) << 8) | ((b + 2u) << 16) | ((b + 3u) << 24); }
+    __device__ __forceinline__ void zero(unsigned lane_) { lane = lane_; w = 0; }
+    __device__ __forceinline__ uint32_t at(uint32_t pos) const          // pos uniform
+    {
+        return ((uint32_t)__builtin_amdgcn_readlane((int)w, (int)(pos >> 2)) >> (8u * (pos & 3u))) & 0xffu;
+    }
+    __device__ __forceinline__ void set(uint32_t pos, uint32_t sym)     // pos uniform
+    {
+        const uint32_t sh = 8u * (pos & 3u);
+        w = lane == (pos >> 2) ? (w & ~(0xffu << sh)) | (sym << sh) : w;
+    }
+    __device__ __forceinline__ uint32_t find(uint32_t sym) const        // symbols are unique in a well-formed list
+    {
+        uint32_t hit = 4;
+        if (((w >> 24) & 0xff) == sym) hit = 3;
+        if (((w >> 16) & 0xff) == sym) hit = 2;
+        if (((w >> 8) & 0xff) == sym) hit = 1;
+        if ((w & 0xff) == sym) hit = 0;
+        const unsigned long long m = __ballot(hit < 4);
+        const int first = __ffsll(m) - 1;
+        return 4u * (uint32_t)first + (uint32_t)__builtin_amdgcn_readlane((int)hit, first);
+    }
+    // entries 1..rank = old entries 0..rank-1, entry 0 = sym   (rotate right by one, mtf.rs:68-78 / :85-89)
+    __device__ __forceinline__ void front(uint32_t rank, uint32_t sym)
+    {
+        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x138, 0xf, 0xf, false);   // wave_shr:1: lane l-1's dword
+        const uint32_t sh = (w << 8) | (prev >> 24);
+        const uint32_t p0 = 4u * lane;
+        uint32_t nw = w;
+        if (p0 + 3u <= rank) nw = sh;
+        else if (p0 <= rank) { const uint32_t mask = (1u << (8u * (rank - p0 + 1u))) - 1u; nw = (sh & mask) | (w & ~mask); }
+        w = lane == 0 ? (nw & ~0xffu) | sym : nw;
+    }
+};
+
 // Sequential input of one stream held 64 elements at a time across the lanes (lane j: element base + j), the following 64
 // requested one window early: a serial loop that did `x = in[i]` paid a full global-memory round trip (~700 ns) per step
 // (34 ms for one 256 KiB block of BWT output, whatever the batch size); readlane from the window costs a few cycles.
@@ -80,11 +120,9 @@ struct SeqWin {
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_mtf(rcx_kargs a, int decode)
 {
-    __shared__ __align__(16) uint8_t s_lst[WAVES][256];
     const unsigned w = threadIdx.x >> 6, lane = rcx_lane();
     const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + w));   // wave-uniform: keeps descriptors in SGPRs
     if (b >= a.nblocks) return;
-    uint8_t* lst = s_lst[w];
     const uint8_t* in = a.in_base + a.in_off[b];
     const uint32_t n = (uint32_t)a.in_len[b];
     uint8_t* out = a.out_base + a.out_off[b];
@@ -92,34 +130,33 @@ __global__ __launch_bounds__(64 * WAVES) void k_mtf(rcx_kargs a, int decode)
         if (lane == 0) { a.status[b] = RCX_E_OUTPUT_TOO_SMALL; a.out_len[b] = 0; if (a.in_used) a.in_used[b] = 0; }
         return;
     }
-    for (int k = 0; k < 4; k++) lst[lane + 64 * k] = (uint8_t)(lane + 64 * k);
-    rcx_wave_sync();
+    MtfRegs L; L.identity(lane);                              // mtf.rs:103-104, :141-142
     uint32_t i = 0;
     SeqWin<uint8_t> win; win.start(in, n, lane);
     while (i < n) {
         const uint32_t x = win.get(i);
         if (!decode) {
-            const uint32_t head = __builtin_amdgcn_readfirstlane((uint32_t)lst[0]);
+            const uint32_t head = L.at(0);
             if (x == head) {                                  // rank 0: the whole run encodes to zeros
                 const uint32_t rl = win.run(i, x);
                 for (uint32_t t = lane; t < rl; t += 64) out[i + t] = 0;
                 i += rl;
             } else {
-                const uint32_t rank = mtf_find(lst, x, lane);
+                const uint32_t rank = L.find(x);
                 if (lane == 0) out[i] = (uint8_t)rank;
-                mtf_front(lst, rank, x, lane);
+                L.front(rank, x);
                 i += 1;
             }
         } else {
             if (x == 0) {                                     // rank 0 repeats the front symbol
                 const uint32_t rl = win.run(i, 0);
-                const uint8_t head = lst[0];
+                const uint8_t head = (uint8_t)L.at(0);
                 for (uint32_t t = lane; t < rl; t += 64) out[i + t] = head;
                 i += rl;
             } else {
-                const uint32_t sym = __builtin_amdgcn_readfirstlane((uint32_t)lst[x]);
+                const uint32_t sym = L.at(x);
                 if (lane == 0) out[i] = (uint8_t)sym;
-                mtf_front(lst, x, sym, lane);
+                L.front(x, sym);
                 i += 1;
             }
         }
@@ -134,12 +171,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_mtf(rcx_kargs a, int decode)
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a)
 {
-    __shared__ __align__(16) uint8_t s_lst[WAVES][256];
     __shared__ uint32_t s_last[WAVES][256];
     const unsigned w = threadIdx.x >> 6, lane = rcx_lane();
     const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + w));   // wave-uniform: keeps descriptors in SGPRs
     if (b >= a.nblocks) return;
-    uint8_t* lst = s_lst[w];
     uint32_t* last = s_last[w];
     const uint8_t* in = a.in_base + a.in_off[b];
     const uint32_t n = (uint32_t)a.in_len[b];
@@ -150,7 +185,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a)
         return;
     }
     uint32_t* dist = words + 256;
-    for (int k = 0; k < 4; k++) { lst[lane + 64 * k] = 0; last[lane + 64 * k] = n; words[lane + 64 * k] = n; }   // :114-115, MTF::new()
+    for (int k = 0; k < 4; k++) { last[lane + 64 * k] = n; words[lane + 64 * k] = n; }   // :114-115
+    MtfRegs L; L.zero(lane);                                  // MTF::new()
     rcx_wave_sync();
     uint32_t num_unique = 0, i = 0;
     SeqWin<uint8_t> win; win.start(in, n, lane);
@@ -158,10 +194,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a)
         const uint32_t sym = win.get(i);
         const uint32_t base = __builtin_amdgcn_readfirstlane(last[sym]);
         if (base == n) {                                      // first occurrence, :121-128
-            if (lane == 0) { lst[num_unique] = (uint8_t)sym; words[sym] = i; last[sym] = i; dist[i] = n; }
+            if (lane == 0) { words[sym] = i; last[sym] = i; dist[i] = n; }
             rcx_wave_sync();
-            const uint32_t rank = mtf_find(lst, sym, lane);   // mtf.encode(sym)
-            if (rank) mtf_front(lst, rank, sym, lane);
+            L.set(num_unique, sym);
+            // mtf.encode(sym): the symbols ahead of it are unique and differ from it (first occurrence), zero-filled slots
+            // behind it may equal it -- the first hit is the one to take, and that is what find returns
+            const uint32_t rank = L.find(sym);
+            if (rank) L.front(rank, sym);
             num_unique++;
             i += 1;
         } else if (base == i - 1) {                           // inside a run: rank 0, nothing is emitted
@@ -171,17 +210,21 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a)
             rcx_wave_sync();
             i += rl;
         } else {                                              // :129-136
-            const uint32_t rank = mtf_find(lst, sym, lane);
+            const uint32_t rank = L.find(sym);
             if (lane == 0) { dist[i] = n; last[sym] = i; if (rank) dist[base] = i - base - rank - 1; }
-            if (rank) mtf_front(lst, rank, sym, lane); else rcx_wave_sync();
+            rcx_wave_sync();
+            if (rank) L.front(rank, sym);
             i += 1;
         }
     }
     rcx_wave_sync();
-    for (uint32_t rank = lane; rank < num_unique; rank += 64) {      // sweep, :139-144
-        const uint32_t sym = lst[rank];
-        const uint32_t base = last[sym];
-        dist[base] = n - base - rank - 1;
+    for (uint32_t k2 = 0; k2 < 4; k2++) {                      // sweep, :139-144 (lane l holds ranks 4l .. 4l+3)
+        const uint32_t rank = 4u * lane + k2;
+        if (rank < num_unique) {
+            const uint32_t sym = (L.w >> (8u * k2)) & 0xffu;
+            const uint32_t base = last[sym];
+            dist[base] = n - base - rank - 1;
+        }
     }
     rcx_wave_sync();
     // compact the non-filler distances in position order (EncodeIterator :88-104): ballot + prefix popcount
