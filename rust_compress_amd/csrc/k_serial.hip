@@ -73,6 +73,21 @@ struct MtfRegs {
         else if (p0 <= rank) { const uint32_t mask = (1u << (8u * (rank - p0 + 1u))) - 1u; nw = (sh & mask) | (w & ~mask); }
         w = lane == 0 ? (nw & ~0xffu) | sym : nw;
     }
+    // entries 0..rank-2 = old entries 1..rank-1, entry rank-1 = sym   (the DC decoder's move, dc.rs:219-227; rank >= 1)
+    __device__ __forceinline__ void back(uint32_t rank, uint32_t sym)
+    {
+        const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x130, 0xf, 0xf, false);    // wave_shl:1: lane l+1's dword
+        const uint32_t sh = (w >> 8) | (nxt << 24);
+        const uint32_t p0 = 4u * lane;
+        uint32_t nw = w;
+        if (rank >= 2u) {
+            const uint32_t lastq = rank - 2u;                  // last position that takes its right neighbour
+            if (p0 + 3u <= lastq) nw = sh;
+            else if (p0 <= lastq) { const uint32_t mask = (1u << (8u * (lastq - p0 + 1u))) - 1u; nw = (sh & mask) | (w & ~mask); }
+        }
+        const uint32_t pos = rank - 1u, bsh = 8u * (pos & 3u);
+        w = lane == (pos >> 2) ? (nw & ~(0xffu << bsh)) | (sym << bsh) : nw;
+    }
 };
 
 // Sequential input of one stream held 64 elements at a time across the lanes (lane j: element base + j), the following 64
@@ -244,7 +259,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a)
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_dc_decode(rcx_kargs a)
 {
-    __shared__ __align__(16) uint8_t s_lst[WAVES][256];
+    __shared__ __align__(16) uint8_t s_lst[WAVES][256];    // only to order the alphabet once; the loop keeps the list in registers
     __shared__ uint32_t s_next[WAVES][256];
     const unsigned w = threadIdx.x >> 6, lane = rcx_lane();
     const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + w));   // wave-uniform: keeps descriptors in SGPRs
@@ -280,6 +295,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_decode(rcx_kargs a)
         for (int k = 0; k < 4; k++) cnt += (next[lane + 64 * k] < n) ? 1u : 0u;
         A = rcx_wave_sum(cnt);
         rcx_wave_sync();
+        MtfRegs L; L.lane = lane; L.w = *(const uint32_t*)(lst + 4 * lane);
         if (A <= 1) {                                          // :180-187 redundant alphabet: no distance is read
             const uint8_t sym = lst[0];
             for (uint32_t t = lane; t < n; t += 64) out[t] = sym;
@@ -287,8 +303,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_decode(rcx_kargs a)
         }
         SeqWin<uint32_t> wwin; wwin.start(words, nwords, lane);
         while (i < n) {                                        // :199-229
-            const uint32_t sym = __builtin_amdgcn_readfirstlane((uint32_t)lst[0]);
-            const uint32_t stop = __builtin_amdgcn_readfirstlane(next[lst[1]]);
+            const uint32_t sym = L.at(0);
+            const uint32_t stop = __builtin_amdgcn_readfirstlane(next[L.at(1)]);
             if (stop > n) { st = RCX_E_MALFORMED; break; }     // output[i] index panic
             for (uint32_t t = i + lane; t < stop; t += 64) out[t] = (uint8_t)sym;
             if (stop > i) i = stop;
@@ -299,21 +315,20 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_decode(rcx_kargs a)
             if (future64 > n) { st = RCX_E_MALFORMED; break; } /* :213 assert */
             const uint32_t future = (uint32_t)future64;
             // :214-218 first rank r >= 1 with !(future + r > next[lst[r]]), else A
-            uint32_t rank = A;
-            for (uint32_t r0 = 1; r0 < A; r0 += 64) {
-                const uint32_t r = r0 + lane;
-                const bool stopper = r < A && !(future + r > next[lst[r]]);
-                const unsigned long long m = __ballot(stopper);
-                if (m) { rank = r0 + (uint32_t)(__ffsll(m) - 1); break; }
+            uint32_t rank = A;                                  // lane l tests its own ranks 4l .. 4l+3 (ranks grow with the lane)
+            {
+                uint32_t cand = 0xffffffffu;
+#pragma unroll
+                for (int k = 3; k >= 0; k--) {
+                    const uint32_t r = 4u * lane + (uint32_t)k;
+                    const uint32_t sy = (L.w >> (8 * k)) & 0xffu;
+                    if (r >= 1u && r < A && !(future + r > next[sy])) cand = r;
+                }
+                const unsigned long long m = __ballot(cand != 0xffffffffu);
+                if (m) rank = (uint32_t)__builtin_amdgcn_readlane((int)cand, __ffsll(m) - 1);
             }
-            // lst[0..rank-2] = lst[1..rank-1]; lst[rank-1] = sym
-            uint8_t v[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) { const uint32_t q = lane + 64u * k; v[k] = (q + 1 < rank) ? lst[q + 1] : (uint8_t)0; }
-            rcx_wave_sync();
-#pragma unroll
-            for (int k = 0; k < 4; k++) { const uint32_t q = lane + 64u * k; if (q + 1 < rank) lst[q] = v[k]; }
-            if (lane == 0) { lst[rank - 1] = (uint8_t)sym; next[sym] = future + rank - 1; }   // :225-227
+            L.back(rank, sym);                                  // lst[0..rank-2] = lst[1..rank-1]; lst[rank-1] = sym
+            if (lane == 0) next[sym] = future + rank - 1;       // :225-227
             rcx_wave_sync();
         }
         if (!st && A > 1) {                                    // :230 assert over all 256 entries

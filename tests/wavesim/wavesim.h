@@ -138,7 +138,7 @@ template <class T> inline T readfirstlane(T x)
     for (int i = 0; i < 64; i++) if (v[i]) return from_u64<T>(o[i]);
     return x;
 }
-// __builtin_amdgcn_update_dpp for the controls the kernels use (row_shr/row_shl/row_bcast15/31/wave_shr1)
+// __builtin_amdgcn_update_dpp for the controls the kernels use (row_shr/row_shl/row_bcast15/31/wave_shr1/wave_shl1)
 inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
 {
     uint64_t o[64]; bool v[64];
@@ -151,6 +151,7 @@ inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, b
     else if (ctrl == 0x142) { if (row >= 1) s = row * 16 - 1; }
     else if (ctrl == 0x143) { if (row >= 2) s = 31; }
     else if (ctrl == 0x138) { if (l >= 1) s = l - 1; }
+    else if (ctrl == 0x130) { if (l < 63) s = l + 1; }
     else { fprintf(stderr, "wavesim: unsupported dpp ctrl 0x%x\n", ctrl); abort(); }
     if (s < 0 || !v[s]) return bound_ctrl ? 0 : old;
     return from_u64<int>(o[s]);
