@@ -16,6 +16,8 @@ ctx = R.Context(0)
 lens = [min(BS, total - i) for i in range(0, total, BS)]
 raw = torch.from_numpy(synth.gen_blocks("text", (total + BS - 1) // BS, BS, 0xE9)[:total]).to(dev)
 pipe = P.BwtDcAri(ctx, dev, int(os.environ.get("PARTS", P.PARTS)))
+if os.environ.get("ARI_VARIANT"):
+    ctx.set_variant(N.ARI_BYTE_ENCODE, int(os.environ["ARI_VARIANT"])); ctx.set_variant(N.ARI_BYTE_DECODE, int(os.environ["ARI_VARIANT"]))
 orig = ctx.launch_dev
 names = {N.BWT_FORWARD: "bwt_forward", N.DC_ENCODE: "dc_encode", N.ARI_BYTE_ENCODE: "ari_encode", N.ARI_BYTE_DECODE: "ari_decode",
          N.BWT_INVERSE: "bwt_inverse"}

@@ -1012,9 +1012,12 @@ static void launch_serial(hipStream_t s, int codec, rcx_kargs& k, int v, uint32_
     case RCX_RLE_ENCODE: hipLaunchKernelGGL((k_rle_encode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k); break;
     case RCX_RLE_DECODE: hipLaunchKernelGGL((k_rle_decode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k); break;
     case RCX_ARI_BYTE_ENCODE: case RCX_ARI_BYTE_DECODE: {
-        // one wave per stream until there are enough streams to fill the chip with one LANE per stream (variant 1 / 2 pin it)
+        // one wave per stream while the waves fit one residency round, one LANE per stream beyond (variant 1 / 2 pin it)
         const int dec = codec == RCX_ARI_BYTE_DECODE ? 1 : 0;
-        const bool per_wave = v == 2 ? true : v == 1 ? false : n < 32768u;
+        // measured (config 5): a wave-per-stream step is ~0.9 us at 15 waves per CU, a lane-per-stream step ~1.7 us but for 64
+        // streams at once and nearly independent of the stream count: once the waves no longer fit one residency round
+        // (8192), lanes win (15 260 streams of 49 K symbols: 82 against 127 ms)
+        const bool per_wave = v == 2 ? true : v == 1 ? false : n < 12288u;
         if (per_wave && dec) hipLaunchKernelGGL((k_ari_byte_wave<4, true>), dim3((n + 3) / 4), dim3(256), 0, s, k);
         else if (per_wave) hipLaunchKernelGGL((k_ari_byte_wave<4, false>), dim3((n + 3) / 4), dim3(256), 0, s, k);
         else hipLaunchKernelGGL(k_ari_byte, dim3((n + 63) / 64), dim3(64), 0, s, k, dec);

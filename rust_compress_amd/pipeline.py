@@ -8,9 +8,9 @@ container; parity is per stage:
     Ari bytes                        == ari::ByteEncoder over the block record below
 Block record (little-endian u32 words):  n, origin, k, init[256], dist[k].  The record is cut into PARTS contiguous
 pieces (word aligned, equal length to within a word) and every piece is range coded on its own: the adaptive coder is a
-serial chain per stream (~1200 cycles per symbol), so the kernel's rate is the number of streams in flight, and 3815
-blocks are 15 waves per CU.  Measured per 10^9 bytes (decode / encode of the coder, ratio): 1 piece 175 / 122 ms, 4.80;
-2 pieces 148 / 95, 4.79; 4 pieces (default) 127 / 81, 4.78; 8 pieces 121 / 76, 4.75.
+serial chain per stream, so the kernel's time is the length of a stream, not the amount of data.  Measured per 10^9 bytes
+(decode / encode of the coder, compression ratio): 1 piece 175 / 122 ms, 4.80; 4 pieces 82 / 63, 4.78; 16 pieces (default)
+21 / 16, 4.70; 32 pieces 20 / 15, 4.60 (from 15 000 streams on the library runs one LANE per stream).
 Stream container:  b"RCXQ" u32 block_size u32 nblocks u32 parts, then per block u32 n and parts x (u32 raw_len,
 u32 comp_len), then the payloads.  Blocks are independent in every stage, so a stream shards across GPUs by block
 ranges (dist.partition).
@@ -24,7 +24,7 @@ from .api import DeviceBatch
 
 MAGIC = b"RCXQ"
 HDR_WORDS = 3
-PARTS = 4
+PARTS = 16
 
 
 class BwtDcAri:
