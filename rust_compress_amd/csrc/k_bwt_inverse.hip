@@ -35,6 +35,7 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
     uint8_t* out = a.out_base + a.out_off[b];
     const uint32_t origin = a.aux ? a.aux[b] : 0u;
     uint32_t* table = (uint32_t*)((uint8_t*)a.scratch + (size_t)slot * table_stride);
+    const bool packed = n < 0xffffffu;                        // index + 1 fits 24 bits: the entry also holds the byte
     if (n == 0 || a.out_cap[b] < n || origin >= n) {
         if (tid == 0) {
             a.status[b] = n == 0 ? RCX_OK : (origin >= n ? RCX_E_MALFORMED : RCX_E_OUTPUT_TOO_SMALL);   // mod.rs:230 index panic
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
     __syncthreads();
     // the origin element itself was counted in its wave's slice: take it out of that slice's budget
     if (tid == 0) {
-        table[s_base[osym]] = 0;                                  // table[place(L[origin])] = 0
+        table[s_base[osym]] = packed ? (osym << 24) : 0u;         // table[place(L[origin])] = 0 (+ the byte there, see below)
         const uint32_t ow = origin / per;
         for (int ww = (int)ow + 1; ww < BWTI_WAVES; ww++) s_cnt[ww][osym] -= 1u;
     }
@@ -87,7 +88,9 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
         if (valid) basec = s_cnt[w][c];
         rcx_wave_sync();
         if (valid) {
-            table[basec + before] = i + 1u;
+            // the entry carries the byte the walker will emit from there (L[i]) in its top 8 bits when the block is shorter
+            // than 2^24: the chase then costs ONE random load per step instead of two (the kernel is bound by random accesses)
+            table[basec + before] = packed ? (i + 1u) | (c << 24) : i + 1u;
             if (before == 0) s_cnt[w][c] = basec + (uint32_t)__popcll(peers);   // group leader advances the counter
         }
         rcx_wave_sync();
@@ -120,7 +123,10 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
 #pragma unroll
                 for (int q = 0; q < 4; q++) v[q] = live[q] ? table[cur[q]] : 0u;          // 4 jump-table loads in flight
 #pragma unroll
-                for (int q = 0; q < 4; q++) { c2[q] = v[q] ? v[q] - 1u : origin; ch[q] = live[q] ? L[c2[q]] : (uint8_t)0; }
+                for (int q = 0; q < 4; q++) {
+                    if (packed) { ch[q] = (uint8_t)(v[q] >> 24); v[q] &= 0xffffffu; c2[q] = v[q] ? v[q] - 1u : origin; }
+                    else { c2[q] = v[q] ? v[q] - 1u : origin; ch[q] = live[q] ? L[c2[q]] : (uint8_t)0; }
+                }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     if (!live[q]) continue;
