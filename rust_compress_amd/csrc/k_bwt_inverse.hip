@@ -12,14 +12,22 @@
 #define BWTI_MAXMARK 4096        /* marked nodes per block (<= 4 per thread) */
 #define BWTI_CHUNK 1024u         /* blocks per launch: bounds the jump-table scratch */
 
+// per in-flight block: the 4n-byte jump table + BWTI_CAPX n bytes where the walkers park what they emit on the first chase
+#define BWTI_CAPX 16u
+static uint64_t bwti_table_bytes(uint64_t max_block) { return (max_block * 4 + 255) & ~255ull; }
+static uint64_t bwti_slot_bytes(uint64_t max_block)
+{
+    const uint64_t stride = (max_block + BWTI_MAXMARK - 1) / BWTI_MAXMARK;
+    return bwti_table_bytes(max_block) + (((uint64_t)BWTI_CAPX * (stride ? stride : 1) * (BWTI_MAXMARK + 1) + 255) & ~255ull);
+}
 static uint64_t bwt_inverse_scratch_bytes(uint32_t nblocks, uint64_t max_block)
 {
     const uint64_t nb = nblocks < BWTI_CHUNK ? nblocks : BWTI_CHUNK;
-    return nb * ((max_block * 4 + 255) & ~255ull) + 256;
+    return nb * bwti_slot_bytes(max_block) + 256;
 }
 
 // One workgroup (16 waves) per block.
-__global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint32_t block0, uint64_t table_stride)
+__global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint32_t block0, uint64_t table_stride, uint64_t table_bytes)
 {
     __shared__ uint32_t s_cnt[BWTI_WAVES][256];       // per-wave symbol counters -> running slots
     __shared__ uint32_t s_next[BWTI_MAXMARK + 1];     // marked node -> next marked node id (or NONE)
@@ -35,6 +43,7 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
     uint8_t* out = a.out_base + a.out_off[b];
     const uint32_t origin = a.aux ? a.aux[b] : 0u;
     uint32_t* table = (uint32_t*)((uint8_t*)a.scratch + (size_t)slot * table_stride);
+    uint8_t* park = (uint8_t*)table + table_bytes;            // walker m parks its first-chase bytes at park[m * cap ..]
     const bool packed = n < 0xffffffu;                        // index + 1 fits 24 bits: the entry also holds the byte
     if (n == 0 || a.out_cap[b] < n || origin >= n) {
         if (tid == 0) {
@@ -104,6 +113,9 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
     const bool origin_marked = (origin % stride) == 0;
     const uint32_t M = M0 + (origin_marked ? 0u : 1u);
     const uint32_t NONE = 0xffffffffu;
+    // First chase: a walker also parks the bytes it emits (up to `cap`, 16 times the mean chain length); once the marked
+    // nodes are ranked, a parked chain is COPIED to its place -- only a chain longer than `cap` is chased a second time.
+    const uint32_t cap = BWTI_CAPX * stride;
     // each thread owns marked nodes tid, tid+1024, ... (<= 4 + 1), chased 4 at a time
     for (int pass = 0; pass < 2; pass++) {
         for (uint32_t m0 = tid; m0 < M; m0 += 4 * BWTI_THREADS) {
@@ -116,6 +128,15 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
                 cnt[q] = 0;
                 wr[q] = (pass == 1 && live[q]) ? s_base[m] : NONE;
                 if (pass == 1 && wr[q] == NONE) live[q] = false;          // not reachable from origin
+                if (pass == 1 && live[q] && s_len[m] <= cap) {             // parked on the first chase: copy, no second chase
+                    const uint8_t* src = park + (size_t)m * cap;
+                    const uint32_t len = s_len[m];
+                    uint32_t t = 0;
+                    for (; t + 16 <= len && wr[q] + t + 16 <= n; t += 16)          // park slots are 16-byte aligned, `out` need not be
+                        *(rcx_u32x4_u*)(out + wr[q] + t) = *(const rcx_u32x4*)(src + t);
+                    for (; t < len; t++) if (wr[q] + t < n) out[wr[q] + t] = src[t];
+                    live[q] = false;
+                }
             }
             for (;;) {
                 if (!(live[0] || live[1] || live[2] || live[3])) break;
@@ -140,6 +161,7 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
                         cur[q] = c2[q];
                     }
                     if (pass == 1) { if (wr[q] + cnt[q] < n) out[wr[q] + cnt[q]] = ch[q]; }
+                    else if (cnt[q] < cap) park[(size_t)(m0 + q * BWTI_THREADS) * cap + cnt[q]] = ch[q];
                     cnt[q]++;
                     if (stop) {
                         live[q] = false;
@@ -178,12 +200,12 @@ static int launch_bwt_inverse(hipStream_t s, rcx_kargs& k, int variant, std::str
     uint64_t maxn = 0;
     for (uint32_t b = 0; b < nb; b++) if (h_len[b] > maxn) maxn = h_len[b];
     if (maxn >= 0xfffffff0ull) { err = "bwt inverse: block too large"; return RCX_RC_BAD_ARG; }
-    const uint64_t stride = (maxn * 4 + 255) & ~255ull;
+    const uint64_t stride = bwti_slot_bytes(maxn), tbytes = bwti_table_bytes(maxn);
     const uint32_t chunk = nb < BWTI_CHUNK ? nb : BWTI_CHUNK;
     if ((uint64_t)chunk * stride > k.scratch_bytes) { err = "bwt inverse: scratch too small"; return RCX_RC_BAD_ARG; }
     for (uint32_t b0 = 0; b0 < nb; b0 += BWTI_CHUNK) {
         const uint32_t cnt = nb - b0 < BWTI_CHUNK ? nb - b0 : BWTI_CHUNK;
-        hipLaunchKernelGGL(k_bwt_inverse, dim3(cnt), dim3(BWTI_THREADS), 0, s, k, b0, stride);
+        hipLaunchKernelGGL(k_bwt_inverse, dim3(cnt), dim3(BWTI_THREADS), 0, s, k, b0, stride, tbytes);
     }
     return RCX_RC_OK;
 }
