@@ -314,7 +314,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
 };
 
 template <int CB, int TC = 2560, int HH = 2048, bool PROF5 = false>
-__global__ __launch_bounds__(128, 8) void k_lz4_decode_v5(rcx_kargs a)
+__global__ __launch_bounds__(128, 8) void k_lz4_decode_v5(rcx_kargs a, int only_status = 0)
 {
     typedef Lz4V5<CB, TC, HH, PROF5> S;
     const uint64_t tk0 = PROF5 ? (uint64_t)__builtin_readcyclecounter() : 0;
@@ -324,6 +324,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_decode_v5(rcx_kargs a)
     __shared__ __align__(16) typename S::Ring s_ring;
     const uint32_t b = blockIdx.x;
     if (b >= a.nblocks) return;
+    if (only_status && a.status[b] != only_status) return;       // second pass over the blocks another kernel handed back
     if (threadIdx.x == 0) { s_ring.head = 0; s_ring.tail = 0; s_ring.abort_ = 0; }
     __syncthreads();
     const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

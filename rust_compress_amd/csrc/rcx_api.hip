@@ -13,6 +13,7 @@
 #include "k_lz4_decode.hip"
 #include "k_lz4_decode_v4.hip"
 #include "k_lz4_decode_v5.hip"
+#include "k_lz4_decode_v6.hip"
 #include "k_lz4_encode.hip"
 #include "k_inflate.hip"
 #include "k_inflate2.hip"
@@ -180,13 +181,19 @@ static int launch_codec(rcx_ctx* c, int codec, rcx_kargs& k)
         else if (v == 7) hipLaunchKernelGGL((k_lz4_decode_v4<2048, 1>), dim3(n), dim3(64), 0, s, k);
         else if (v == 9) hipLaunchKernelGGL((k_lz4_decode_v4<1024, 1, true>), dim3(n), dim3(64), 0, s, k);   // phase timers -> scratch
         else if (v == 8) hipLaunchKernelGGL((k_lz4_decode_v4<1024, 4>), dim3((n + 3) / 4), dim3(256), 0, s, k);
-        else if (v == 12) hipLaunchKernelGGL((k_lz4_decode_v5<1024, 1536, 3072>), dim3(n), dim3(128), 0, s, k);   // A/B: longer history, smaller batch cap
-        else if (v == 13) hipLaunchKernelGGL((k_lz4_decode_v5<1024, 2048, 2560>), dim3(n), dim3(128), 0, s, k);
-        else if (v == 16) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 2048, 1536>), dim3(n), dim3(128), 0, s, k);
-        else if (v == 14) hipLaunchKernelGGL((k_lz4_decode_v5<1024, 2560, 2048, true>), dim3(n), dim3(128), 0, s, k);   // ring wait timers -> scratch
-        else if (v == 10) hipLaunchKernelGGL((k_lz4_decode_v5<1024>), dim3(n), dim3(128), 0, s, k);   // 1 KiB of staged input, batch cap 2560
+        else if (v == 12) hipLaunchKernelGGL((k_lz4_decode_v5<1024, 1536, 3072>), dim3(n), dim3(128), 0, s, k, 0);   // A/B: longer history, smaller batch cap
+        else if (v == 13) hipLaunchKernelGGL((k_lz4_decode_v5<1024, 2048, 2560>), dim3(n), dim3(128), 0, s, k, 0);
+        else if (v == 16) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 2048, 1536>), dim3(n), dim3(128), 0, s, k, 0);
+        else if (v == 14) hipLaunchKernelGGL((k_lz4_decode_v5<1024, 2560, 2048, true>), dim3(n), dim3(128), 0, s, k, 0);   // ring wait timers -> scratch
+        else if (v == 10) hipLaunchKernelGGL((k_lz4_decode_v5<1024>), dim3(n), dim3(128), 0, s, k, 0);   // 1 KiB of staged input, batch cap 2560
+        else if (v == 17) {
+            // workgroup per block, history in LDS; the blocks it hands back (RCX_ST_BAIL6) are re-run by the exact two-wave kernel
+            hipLaunchKernelGGL((k_lz4_decode_v6<8>), dim3(n), dim3(512), 0, s, k);
+            hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1536, 2048>), dim3(n), dim3(128), 0, s, k, (int)RCX_ST_BAIL6);
+        }
+        else if (v == 19) hipLaunchKernelGGL((k_lz4_decode_v6<8, true>), dim3(n), dim3(512), 0, s, k);      // phase timers -> scratch, no second pass
         else if (v == 0 || v == 15)
-            hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1536, 2048>), dim3(n), dim3(128), 0, s, k);   // parser + executor waves (default)
+            hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1536, 2048>), dim3(n), dim3(128), 0, s, k, 0);   // parser + executor waves (default)
         else hipLaunchKernelGGL((k_lz4_decode_v4<1024, 1>), dim3(n), dim3(64), 0, s, k); // v == 11
         break;
     case RCX_LZ4_ENCODE: {

@@ -3,6 +3,7 @@
 #include "../../rust_compress_amd/csrc/k_lz4_decode.hip"
 #include "../../rust_compress_amd/csrc/k_lz4_decode_v4.hip"
 #include "../../rust_compress_amd/csrc/k_lz4_decode_v5.hip"
+#include "../../rust_compress_amd/csrc/k_lz4_decode_v6.hip"
 #include "../../rust_compress_amd/csrc/k_lz4_encode.hip"
 #define hipStream_t int
 #define hipLaunchKernelGGL(kern, grid, block, shm, stream, ...) ws::launch(grid, block, [&] { kern(__VA_ARGS__); })
@@ -32,7 +33,12 @@ extern "C" int sim_launch(int codec, int variant, const rcx_kargs* a)
         else if (variant == 7) ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_decode_v4<2048, 1>(k); });
         else if (variant == 8) ws::launch(dim3((k.nblocks + 3) / 4), dim3(256), [&] { k_lz4_decode_v4<1024, 4>(k); });
         else if (variant == 10) ws::launch(dim3(k.nblocks), dim3(128), [&] { k_lz4_decode_v5<1024>(k); });
-        else if (variant == 0) ws::launch(dim3(k.nblocks), dim3(128), [&] { k_lz4_decode_v5<2048, 1536, 2048>(k); });
+        else if (variant == 17) {
+            ws::launch(dim3(k.nblocks), dim3(512), [&] { k_lz4_decode_v6<8>(k); });
+            ws::launch(dim3(k.nblocks), dim3(128), [&] { k_lz4_decode_v5<2048, 1536, 2048>(k, (int)RCX_ST_BAIL6); });
+        }
+        else if (variant == 18) ws::launch(dim3(k.nblocks), dim3(512), [&] { k_lz4_decode_v6<8>(k); });      // no second pass: which blocks bail
+        else if (variant == 0 || variant == 15) ws::launch(dim3(k.nblocks), dim3(128), [&] { k_lz4_decode_v5<2048, 1536, 2048>(k); });
         else ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_decode_v4<1024, 1>(k); });
         return 0;
     case RCX_LZ4_ENCODE:
