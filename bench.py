@@ -185,7 +185,7 @@ def main():
             extras = {}
             for kind in ("text", "words", "runs", "rand", "mix"):
                 d2, r2, cb, ob = make_workload(R, ctx, torch, dev, kind, args.nblocks, 0x77 + len(kind))
-                for v in (0, 1, 6, 10, 11):
+                for v in N.LZ4_DECODE_VARIANTS:
                     ctx.set_variant(N.LZ4_DECODE, v)
                     ctx.launch_dev(N.LZ4_DECODE, d2)
                     torch.cuda.synchronize()

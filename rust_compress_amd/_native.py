@@ -7,7 +7,13 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librcx.so")
+# RCX_AB=1 loads the A/B build (csrc/librcx_ab.so, -DRCX_AB_VARIANTS: earlier kernel generations, profiling
+# instantiations, experiments) that benchmarks/ compares against; the product is librcx.so.
+AB = bool(os.environ.get("RCX_AB"))
+LIB_PATH = os.path.join(_HERE, "csrc", "librcx_ab.so" if AB else "librcx.so")
+# kernel variants each build accepts (rcx_ctx_set_variant): default + one fallback per codec in the shipped library
+LZ4_DECODE_VARIANTS = (0, 11, 1, 2, 3, 4, 5, 6, 7, 8, 10, 17) if AB else (0, 11)
+INFLATE_VARIANTS = (0, 9, 10, 1) if AB else (0, 9, 10)
 
 # enum rcx_codec
 (LZ4_DECODE, LZ4_ENCODE, INFLATE, ZLIB_DECODE, ADLER32, BWT_FORWARD, BWT_INVERSE, MTF_ENCODE, MTF_DECODE,

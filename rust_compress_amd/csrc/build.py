@@ -1,26 +1,54 @@
-"""Builds librcx.so (the C-ABI + gfx950 kernels) in-tree with hipcc.  Cross-compiles without a GPU."""
+"""Builds librcx.so (the C-ABI + gfx950 kernels) in-tree with hipcc.  Cross-compiles without a GPU.
+
+The library is five translation units (rcx_api + one per codec family) compiled in parallel and linked once;
+objects are cached under csrc/build/ and rebuilt when a source they include is newer.
+`ab=True` (or RCX_AB=1 in the environment) builds librcx_ab.so with -DRCX_AB_VARIANTS: the earlier kernel
+generations, profiling instantiations and experiments that benchmarks/ compares against.  The shipped librcx.so
+holds the default kernel and one fallback per codec only."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-OUT = os.path.join(HERE, "librcx.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+TUS = ["rcx_api", "tu_lz4", "tu_inflate", "tu_bwt", "tu_serial"]
 
 
-def build(force=False, verbose=False):
-    srcs = [os.path.join(HERE, f) for f in sorted(os.listdir(HERE)) if f.endswith((".hip", ".h"))]
-    srcs.append(os.path.join(HERE, "..", "..", "include", "rcx.h"))
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in srcs):
-        return OUT
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-fno-gpu-rdc",
-           "-Wno-unused-result", "-Wl,-rpath,/opt/rocm/lib", "-o", OUT, os.path.join(HERE, "rcx_api.hip")]
+def _out(ab):
+    return os.path.join(HERE, "librcx_ab.so" if ab else "librcx.so")
+
+
+def build(force=False, verbose=False, ab=None):
+    if ab is None:
+        ab = bool(os.environ.get("RCX_AB"))
+    out = _out(ab)
+    deps = [os.path.join(HERE, f) for f in sorted(os.listdir(HERE)) if f.endswith((".hip", ".h"))]
+    deps.append(os.path.join(HERE, "..", "..", "include", "rcx.h"))
+    newest = max(os.path.getmtime(d) for d in deps)
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
+        return out
+    objdir = os.path.join(HERE, "build", "ab" if ab else "ship")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
+    if ab:
+        flags.append("-DRCX_AB_VARIANTS")
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    cmd[1:1] = os.environ.get("RCX_EXTRA_FLAGS", "").split()        # A/B experiments with compiler options
-    subprocess.check_call(cmd)
-    return OUT
+        flags.append("-Rpass-analysis=kernel-resource-usage")
+    flags += os.environ.get("RCX_EXTRA_FLAGS", "").split()        # A/B experiments with compiler options
+
+    def compile_tu(tu):
+        obj = os.path.join(objdir, tu + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
+            return obj
+        subprocess.check_call([HIPCC] + flags + ["-c", os.path.join(HERE, tu + ".hip"), "-o", obj])
+        return obj
+
+    with ThreadPoolExecutor(len(TUS)) as ex:
+        objs = list(ex.map(compile_tu, TUS))
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-Wl,-rpath,/opt/rocm/lib", "-o", out] + objs)
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose="-v" in sys.argv))
+    print(build(force=True, verbose="-v" in sys.argv, ab="--ab" in sys.argv or None))

@@ -17,6 +17,7 @@
 #define FL_MAXD 30
 #define FL_HISTORY 32768u
 
+#ifdef RCX_AB_VARIANTS            /* the first inflate kernel (one lane per stream, per-lane tables in LDS): A/B builds only */
 struct FlTabs {              // per-lane views into the interleaved LDS tables
     uint16_t* lcount; uint16_t* lsym; uint16_t* dcount; uint16_t* dsym; uint8_t* lens; unsigned t;   // lens: per-lane private array (header parsing only)
     __device__ __forceinline__ uint16_t& LC(unsigned i) { return lcount[i * 64 + t]; }
@@ -299,6 +300,8 @@ __global__ __launch_bounds__(64) void k_inflate(rcx_kargs a, int zlib)
 
 // adler::State32 over whole blocks, one wave per block: lane l sums a contiguous slice, slices are
 // combined with the closed form  a = 1 + sum(x_i),  b = n + sum((n - i) * x_i)   (mod 65521).
+#endif  // RCX_AB_VARIANTS
+
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_adler32(rcx_kargs a)
 {
@@ -358,11 +361,13 @@ static void launch_inflate2(hipStream_t s, rcx_kargs& k, int flags, int v)
     const uint32_t n = k.nblocks;
     int spw = v == 2 ? 64 : v == 3 ? 32 : v == 4 ? 16 : v == 5 ? 8 : (n >= 32u * 2048u ? 32 : n >= 16u * 2048u ? 16 : 8);
     const int z = flags;
-    if (v == 6) hipLaunchKernelGGL((k_inflate2<16, 4, 4>), dim3((n + 15) / 16), dim3(16), 0, s, k, z);
-    else if (v == 7) hipLaunchKernelGGL((k_inflate2<32, 5, 3>), dim3((n + 31) / 32), dim3(32), 0, s, k, z);
-    else if (v == 8) hipLaunchKernelGGL((k_inflate2<16, 4, 3>), dim3((n + 15) / 16), dim3(16), 0, s, k, z);
-    else if (spw == 64) hipLaunchKernelGGL((k_inflate2<64, 6, 1>), dim3((n + 63) / 64), dim3(64), 0, s, k, z);
-    else if (spw == 32) hipLaunchKernelGGL((k_inflate2<32, 5, 1>), dim3((n + 31) / 32), dim3(32), 0, s, k, z);
+#ifdef RCX_AB_VARIANTS
+    if (v == 6) { hipLaunchKernelGGL((k_inflate2<16, 4, 4>), dim3((n + 15) / 16), dim3(16), 0, s, k, z); return; }
+    if (v == 7) { hipLaunchKernelGGL((k_inflate2<32, 5, 3>), dim3((n + 31) / 32), dim3(32), 0, s, k, z); return; }
+    if (v == 8) { hipLaunchKernelGGL((k_inflate2<16, 4, 3>), dim3((n + 15) / 16), dim3(16), 0, s, k, z); return; }
+    if (spw == 64) { hipLaunchKernelGGL((k_inflate2<64, 6, 1>), dim3((n + 63) / 64), dim3(64), 0, s, k, z); return; }
+#endif
+    if (spw >= 32) hipLaunchKernelGGL((k_inflate2<32, 5, 1>), dim3((n + 31) / 32), dim3(32), 0, s, k, z);
     else if (spw == 16) hipLaunchKernelGGL((k_inflate2<16, 4, 1>), dim3((n + 15) / 16), dim3(16), 0, s, k, z);
     else hipLaunchKernelGGL((k_inflate2<8, 3, 1>), dim3((n + 7) / 8), dim3(8), 0, s, k, z);
 }
@@ -377,7 +382,9 @@ static uint64_t inflate_scratch_bytes(uint32_t nblocks) { return 12ull * nblocks
 static void launch_inflate(hipStream_t s, rcx_kargs& k, bool zlib, int v)
 {
     const uint32_t n = k.nblocks;
+#ifdef RCX_AB_VARIANTS
     if (v == 1) { hipLaunchKernelGGL(k_inflate, dim3((n + 63) / 64), dim3(64), 0, s, k, zlib ? 1 : 0); return; }   // first version (A/B)
+#endif
     // one wave per stream (16 waves per CU) against one lane per stream: 65536 streams of 16 KiB 28 vs 34 ms, 4096 streams
     // 2.2 vs 20.7 ms (benchmarks/inflate_spw_sweep.py); variant 10 forces it, 9 forces k_inflate2
     const bool wave_per_stream = v == 10 || (v == 0 && n < INF3_MAX_STREAMS);

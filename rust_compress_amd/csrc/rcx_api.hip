@@ -9,20 +9,7 @@
 #include <string>
 #include <vector>
 
-#include "rcx_dev.h"
-#include "k_lz4_decode.hip"
-#include "k_lz4_decode_v4.hip"
-#include "k_lz4_decode_v5.hip"
-#include "k_lz4_decode_v6.hip"
-#include "k_lz4_encode.hip"
-#include "k_inflate.hip"
-#include "k_inflate2.hip"
-#include "k_inflate3.hip"
-#include "k_bwt.hip"
-#include "k_bwt_inverse.hip"
-#include "k_serial.hip"
-#include "k_crc32.hip"
-#include "k_gzip.hip"
+#include "rcx_tu.h"
 
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
@@ -146,24 +133,19 @@ extern "C" uint64_t rcx_ari_byte_encode_bound(uint64_t n) { return 2 * n + 16; }
 extern "C" uint64_t rcx_rle_encode_bound(uint64_t n) { return n + n / 2 + 16; }
 
 // ---- scratch requirements ---------------------------------------------------------------------
-static const uint32_t LZ4E_CHUNK = 8192;        // LZ4 blocks encoded per launch (512 KiB table each): 32 waves per CU
-
 extern "C" uint64_t rcx_scratch_bytes(int codec, uint32_t nblocks, uint64_t max_block)
 {
     switch (codec) {
-    case RCX_LZ4_ENCODE: return (uint64_t)(nblocks < LZ4E_CHUNK ? nblocks : LZ4E_CHUNK) * LZ4E_TABLE * 4ull;
-    case RCX_BWT_FORWARD: return bwt_forward_scratch_bytes(nblocks, max_block);
-    case RCX_BWT_INVERSE: return bwt_inverse_scratch_bytes(nblocks, max_block);
-    case RCX_INFLATE: case RCX_ZLIB_DECODE: return inflate_scratch_bytes(nblocks);
-    case RCX_GZIP_DECODE: return gzip_scratch_bytes(nblocks) + inflate_scratch_bytes(nblocks);
+    case RCX_LZ4_ENCODE: return rcx_tu_lz4_encode_scratch(nblocks);
+    case RCX_BWT_FORWARD: return rcx_tu_bwt_forward_scratch(nblocks, max_block);
+    case RCX_BWT_INVERSE: return rcx_tu_bwt_inverse_scratch(nblocks, max_block);
+    case RCX_INFLATE: case RCX_ZLIB_DECODE: return rcx_tu_inflate_scratch(nblocks);
+    case RCX_GZIP_DECODE: return rcx_tu_gzip_scratch(nblocks) + rcx_tu_inflate_scratch(nblocks) + 512;   // + the carve's alignment slack
     default: return 0;
     }
 }
 
-// ---- kernel dispatch ----------------------------------------------------------------------------
-// LZ4 decode, default variant: the two-wave kernel (parser || executor).  It is 1.2-1.4x faster than the
-// single-wave kernel below ~12 blocks per CU (latency bound) and still 5-7 % faster at 16 and more blocks per CU
-// (measured: benchmarks/lz4_occupancy_sweep.py); variant 11 selects the single-wave kernel.
+// ---- kernel dispatch (the kernels and their launch code live in the tu_*.hip translation units) ------------------
 static int launch_codec(rcx_ctx* c, int codec, rcx_kargs& k)
 {
     hipStream_t s = c->stream;
@@ -171,61 +153,34 @@ static int launch_codec(rcx_ctx* c, int codec, rcx_kargs& k)
     if (n == 0) return RCX_RC_OK;
     const int v = c->variant[codec];
     switch (codec) {
-    case RCX_LZ4_DECODE:
-        if (v == 1) hipLaunchKernelGGL(k_lz4_decode_v1, dim3(n), dim3(64), 0, s, k);
-        else if (v == 2) hipLaunchKernelGGL((k_lz4_decode_v3<2048, 2048, 64, 64, 4>), dim3((n + 3) / 4), dim3(256), 0, s, k);
-        else if (v == 3) hipLaunchKernelGGL((k_lz4_decode_v3<4096, 2048, 64, 64, 1>), dim3(n), dim3(64), 0, s, k);
-        else if (v == 4) hipLaunchKernelGGL((k_lz4_decode_v3<2048, 2048, 32, 32, 1>), dim3(n), dim3(64), 0, s, k);
-        else if (v == 5) hipLaunchKernelGGL((k_lz4_decode_v2<4096, 2048, 64, 64, 1>), dim3(n), dim3(64), 0, s, k);
-        else if (v == 6) hipLaunchKernelGGL((k_lz4_decode_v3<2048, 2048, 64, 64, 1>), dim3(n), dim3(64), 0, s, k);
-        else if (v == 7) hipLaunchKernelGGL((k_lz4_decode_v4<2048, 1>), dim3(n), dim3(64), 0, s, k);
-        else if (v == 9) hipLaunchKernelGGL((k_lz4_decode_v4<1024, 1, true>), dim3(n), dim3(64), 0, s, k);   // phase timers -> scratch
-        else if (v == 8) hipLaunchKernelGGL((k_lz4_decode_v4<1024, 4>), dim3((n + 3) / 4), dim3(256), 0, s, k);
-        else if (v == 12) hipLaunchKernelGGL((k_lz4_decode_v5<1024, 1536, 3072>), dim3(n), dim3(128), 0, s, k, 0);   // A/B: longer history, smaller batch cap
-        else if (v == 13) hipLaunchKernelGGL((k_lz4_decode_v5<1024, 2048, 2560>), dim3(n), dim3(128), 0, s, k, 0);
-        else if (v == 16) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 2048, 1536>), dim3(n), dim3(128), 0, s, k, 0);
-        else if (v == 14) hipLaunchKernelGGL((k_lz4_decode_v5<1024, 2560, 2048, true>), dim3(n), dim3(128), 0, s, k, 0);   // ring wait timers -> scratch
-        else if (v == 10) hipLaunchKernelGGL((k_lz4_decode_v5<1024>), dim3(n), dim3(128), 0, s, k, 0);   // 1 KiB of staged input, batch cap 2560
-        else if (v == 17) {
-            // workgroup per block, history in LDS; the blocks it hands back (RCX_ST_BAIL6) are re-run by the exact two-wave kernel
-            hipLaunchKernelGGL((k_lz4_decode_v6<8>), dim3(n), dim3(512), 0, s, k);
-            hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1536, 2048>), dim3(n), dim3(128), 0, s, k, (int)RCX_ST_BAIL6);
-        }
-        else if (v == 19) hipLaunchKernelGGL((k_lz4_decode_v6<8, true>), dim3(n), dim3(512), 0, s, k);      // phase timers -> scratch, no second pass
-        else if (v == 0 || v == 15)
-            hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1536, 2048>), dim3(n), dim3(128), 0, s, k, 0);   // parser + executor waves (default)
-        else hipLaunchKernelGGL((k_lz4_decode_v4<1024, 1>), dim3(n), dim3(64), 0, s, k); // v == 11
-        break;
+    case RCX_LZ4_DECODE: {
+        int rc = rcx_tu_lz4_decode(s, k, v, c->err);
+        if (rc) return rc;
+        break; }
     case RCX_LZ4_ENCODE: {
-        if (k.scratch_bytes < rcx_scratch_bytes(codec, n, 0)) { c->err = "lz4 encode: scratch too small"; return RCX_RC_BAD_ARG; }
-        for (uint32_t b0 = 0; b0 < n; b0 += LZ4E_CHUNK) {
-            const uint32_t cnt = n - b0 < LZ4E_CHUNK ? n - b0 : LZ4E_CHUNK;
-            HIPCHK(c, hipMemsetAsync(k.scratch, 0, (size_t)cnt * LZ4E_TABLE * 4ull, s));
-            if (v == 1) hipLaunchKernelGGL(k_lz4_encode, dim3(cnt), dim3(64), 0, s, k, b0);          // serial probe chain (A/B)
-            else if (v == 2) hipLaunchKernelGGL(k_lz4_encode_w<64>, dim3(cnt), dim3(64), 0, s, k, b0);
-            else hipLaunchKernelGGL(k_lz4_encode_w<8>, dim3(cnt), dim3(64), 0, s, k, b0);
-        }
+        int rc = rcx_tu_lz4_encode(s, k, v, c->err);
+        if (rc) return rc;
         break; }
     case RCX_INFLATE:
     case RCX_ZLIB_DECODE:
-        launch_inflate(s, k, codec == RCX_ZLIB_DECODE, v);
+        rcx_tu_inflate(s, k, codec == RCX_ZLIB_DECODE, v);
         break;
     case RCX_ADLER32:
-        launch_adler32(s, k);
+        rcx_tu_adler32(s, k);
         break;
     case RCX_CRC32:
-        launch_crc32(s, k);
+        rcx_tu_crc32(s, k);
         break;
     case RCX_GZIP_DECODE:
-        if (k.scratch_bytes < gzip_scratch_bytes(n)) { c->err = "gzip decode: scratch too small"; return RCX_RC_BAD_ARG; }
-        launch_gzip_decode(s, k, v);
+        if (k.scratch_bytes < rcx_tu_gzip_scratch(n)) { c->err = "gzip decode: scratch too small"; return RCX_RC_BAD_ARG; }
+        rcx_tu_gzip_decode(s, k, v);
         break;
     case RCX_BWT_FORWARD: {
-        int rc = launch_bwt_forward(s, k, v, c->err);
+        int rc = rcx_tu_bwt_forward(s, k, v, c->err);
         if (rc) return rc;
         break; }
     case RCX_BWT_INVERSE: {
-        int rc = launch_bwt_inverse(s, k, v, c->err);
+        int rc = rcx_tu_bwt_inverse(s, k, v, c->err);
         if (rc) return rc;
         break; }
     case RCX_ARI_APM_ENCODE: case RCX_ARI_APM_DECODE: {
@@ -246,7 +201,7 @@ static int launch_codec(rcx_ctx* c, int codec, rcx_kargs& k)
             HIPCHK(c, hipMemcpy(c->d_apm.p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
         }
         k.scratch = c->d_apm.p; k.scratch_bytes = (4096 + 32) * 2;
-        launch_serial(s, codec, k, v, 0);
+        rcx_tu_serial(s, codec, k, v, 0);
         break; }
     case RCX_ARI_BINARY_ENCODE: case RCX_ARI_BINARY_DECODE:
         if (c->param[codec] < 1 || c->param[codec] > 31) { c->err = "ari binary: rate must be 1..31"; return RCX_RC_BAD_ARG; }
@@ -254,7 +209,7 @@ static int launch_codec(rcx_ctx* c, int codec, rcx_kargs& k)
     case RCX_MTF_ENCODE: case RCX_MTF_DECODE: case RCX_DC_ENCODE: case RCX_DC_DECODE:
     case RCX_ARI_PROXY_ENCODE: case RCX_ARI_PROXY_DECODE:
     case RCX_ARI_BYTE_ENCODE: case RCX_ARI_BYTE_DECODE: case RCX_RLE_ENCODE: case RCX_RLE_DECODE:
-        launch_serial(s, codec, k, v, c->param[codec]);
+        rcx_tu_serial(s, codec, k, v, c->param[codec]);
         break;
     default:
         c->err = "unknown codec";

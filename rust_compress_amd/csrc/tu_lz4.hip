@@ -1,0 +1,65 @@
+// tu_lz4.hip -- LZ4 block decode / encode kernels + their launch code (one translation unit).
+// Shipped variants of the decoder: 0 = two waves per block (parser || executor, k_lz4_decode_v5), 11 = one wave per block
+// (k_lz4_decode_v4, the fallback).  Everything else -- the earlier kernel generations, profiling instantiations and the
+// workgroup-per-block experiment (k_lz4_decode_v6) -- is compiled only with -DRCX_AB_VARIANTS (benchmarks/, A/B history).
+#include "rcx_tu.h"
+#ifdef RCX_AB_VARIANTS
+#include "k_lz4_decode.hip"
+#endif
+#include "k_lz4_decode_v4.hip"
+#include "k_lz4_decode_v5.hip"
+#ifdef RCX_AB_VARIANTS
+#include "k_lz4_decode_v6.hip"
+#endif
+#include "k_lz4_encode.hip"
+
+static const uint32_t LZ4E_CHUNK = 8192;        // LZ4 blocks encoded per launch (512 KiB table each): 32 waves per CU
+
+uint64_t rcx_tu_lz4_encode_scratch(uint32_t nblocks) { return (uint64_t)(nblocks < LZ4E_CHUNK ? nblocks : LZ4E_CHUNK) * LZ4E_TABLE * 4ull; }
+
+// Default: the two-wave kernel (parser || executor).  It is 1.2-1.4x faster than the single-wave kernel below ~12 blocks
+// per CU (latency bound) and still 5-7 % faster at 16 and more blocks per CU (benchmarks/lz4_occupancy_sweep.py).
+int rcx_tu_lz4_decode(hipStream_t s, rcx_kargs& k, int v, std::string& err)
+{
+    const uint32_t n = k.nblocks;
+    if (v == 0 || v == 15) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1536, 2048>), dim3(n), dim3(128), 0, s, k, 0);
+    else if (v == 11) hipLaunchKernelGGL((k_lz4_decode_v4<1024, 1>), dim3(n), dim3(64), 0, s, k);
+#ifdef RCX_AB_VARIANTS
+    else if (v == 1) hipLaunchKernelGGL(k_lz4_decode_v1, dim3(n), dim3(64), 0, s, k);
+    else if (v == 2) hipLaunchKernelGGL((k_lz4_decode_v3<2048, 2048, 64, 64, 4>), dim3((n + 3) / 4), dim3(256), 0, s, k);
+    else if (v == 3) hipLaunchKernelGGL((k_lz4_decode_v3<4096, 2048, 64, 64, 1>), dim3(n), dim3(64), 0, s, k);
+    else if (v == 4) hipLaunchKernelGGL((k_lz4_decode_v3<2048, 2048, 32, 32, 1>), dim3(n), dim3(64), 0, s, k);
+    else if (v == 5) hipLaunchKernelGGL((k_lz4_decode_v2<4096, 2048, 64, 64, 1>), dim3(n), dim3(64), 0, s, k);
+    else if (v == 6) hipLaunchKernelGGL((k_lz4_decode_v3<2048, 2048, 64, 64, 1>), dim3(n), dim3(64), 0, s, k);
+    else if (v == 7) hipLaunchKernelGGL((k_lz4_decode_v4<2048, 1>), dim3(n), dim3(64), 0, s, k);
+    else if (v == 9) hipLaunchKernelGGL((k_lz4_decode_v4<1024, 1, true>), dim3(n), dim3(64), 0, s, k);   // phase timers -> scratch
+    else if (v == 8) hipLaunchKernelGGL((k_lz4_decode_v4<1024, 4>), dim3((n + 3) / 4), dim3(256), 0, s, k);
+    else if (v == 12) hipLaunchKernelGGL((k_lz4_decode_v5<1024, 1536, 3072>), dim3(n), dim3(128), 0, s, k, 0);   // longer history, smaller batch cap
+    else if (v == 13) hipLaunchKernelGGL((k_lz4_decode_v5<1024, 2048, 2560>), dim3(n), dim3(128), 0, s, k, 0);
+    else if (v == 16) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 2048, 1536>), dim3(n), dim3(128), 0, s, k, 0);
+    else if (v == 14) hipLaunchKernelGGL((k_lz4_decode_v5<1024, 2560, 2048, true>), dim3(n), dim3(128), 0, s, k, 0);   // ring wait timers -> scratch
+    else if (v == 10) hipLaunchKernelGGL((k_lz4_decode_v5<1024>), dim3(n), dim3(128), 0, s, k, 0);   // 1 KiB of staged input, batch cap 2560
+    else if (v == 17) {
+        // workgroup per block, history in LDS; the blocks it hands back (RCX_ST_BAIL6) are re-run by the exact two-wave kernel
+        hipLaunchKernelGGL((k_lz4_decode_v6<8>), dim3(n), dim3(512), 0, s, k);
+        hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1536, 2048>), dim3(n), dim3(128), 0, s, k, (int)RCX_ST_BAIL6);
+    }
+    else if (v == 19) hipLaunchKernelGGL((k_lz4_decode_v6<8, true>), dim3(n), dim3(512), 0, s, k);      // phase timers -> scratch, no second pass
+#endif
+    else { err = "lz4 decode: unknown kernel variant (A/B variants need a -DRCX_AB_VARIANTS build)"; return RCX_RC_BAD_ARG; }
+    return RCX_RC_OK;
+}
+
+int rcx_tu_lz4_encode(hipStream_t s, rcx_kargs& k, int v, std::string& err)
+{
+    const uint32_t n = k.nblocks;
+    if (k.scratch_bytes < rcx_tu_lz4_encode_scratch(n)) { err = "lz4 encode: scratch too small"; return RCX_RC_BAD_ARG; }
+    for (uint32_t b0 = 0; b0 < n; b0 += LZ4E_CHUNK) {
+        const uint32_t cnt = n - b0 < LZ4E_CHUNK ? n - b0 : LZ4E_CHUNK;
+        if (hipMemsetAsync(k.scratch, 0, (size_t)cnt * LZ4E_TABLE * 4ull, s) != hipSuccess) { err = "lz4 encode: hipMemsetAsync failed"; return RCX_RC_HIP_ERROR; }
+        if (v == 1) hipLaunchKernelGGL(k_lz4_encode, dim3(cnt), dim3(64), 0, s, k, b0);          // serial probe chain
+        else if (v == 2) hipLaunchKernelGGL(k_lz4_encode_w<64>, dim3(cnt), dim3(64), 0, s, k, b0);
+        else hipLaunchKernelGGL(k_lz4_encode_w<8>, dim3(cnt), dim3(64), 0, s, k, b0);
+    }
+    return RCX_RC_OK;
+}

@@ -1,0 +1,5 @@
+// tu_serial.hip -- MTF, DC, RLE and the range coders (one stream per wave or lane) + their launch code (one translation unit).
+#include "rcx_tu.h"
+#include "k_serial.hip"
+
+void rcx_tu_serial(hipStream_t s, int codec, rcx_kargs& k, int variant, uint32_t param) { launch_serial(s, codec, k, variant, param); }

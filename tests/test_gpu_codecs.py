@@ -27,7 +27,7 @@ def test_inflate_zlib_fixtures_and_python_zlib(ctx, oracle, golden):
         zs.append(c.compress(r) + c.flush()); exp.append(r)
     for i in range(10):
         zs.append(golden("test.z.%d" % i)); exp.append(txt)                 # zlib.rs:151-164
-    for variant in (0, 9, 10, 1):              # auto (wave per stream + exact fallback here), lane per stream, wave per stream, v1
+    for variant in N.INFLATE_VARIANTS:          # auto (wave per stream + exact fallback here), lane per stream, wave per stream, v1
         ctx.set_variant(N.ZLIB_DECODE, variant)
         res = ctx.zlib_decode(zs, [len(e) for e in exp]).check()
         assert res.outputs == exp and list(res.in_used) == [len(z) for z in zs], variant

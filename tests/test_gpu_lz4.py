@@ -36,7 +36,7 @@ def test_encode_bit_exact_vs_oracle(ctx, oracle, golden, variant):
     assert list(res.in_used) == [len(r) for r in raws]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11])
+@pytest.mark.parametrize("variant", N.LZ4_DECODE_VARIANTS)
 def test_decode_bit_exact_vs_oracle(ctx, oracle, golden, variant):
     ctx.set_variant(N.LZ4_DECODE, variant)
     raws = _raws(golden)
@@ -52,7 +52,7 @@ def test_decode_bit_exact_vs_oracle(ctx, oracle, golden, variant):
     ctx.set_variant(N.LZ4_DECODE, 0)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 5, 10, 11])
+@pytest.mark.parametrize("variant", N.LZ4_DECODE_VARIANTS[:6])
 def test_decode_malformed_statuses(ctx, oracle, variant):
     ctx.set_variant(N.LZ4_DECODE, variant)
     rng = np.random.default_rng(5)
@@ -103,7 +103,7 @@ def test_full_size_roundtrip_device_resident(ctx, oracle, kind):
     torch.cuda.synchronize()
     assert int(enc.status.abs().max()) == 0
     clen = enc.out_len[:nb].clone()
-    for variant in (0, 1, 3, 5, 6, 8):
+    for variant in N.LZ4_DECODE_VARIANTS[:6]:
         ctx.set_variant(N.LZ4_DECODE, variant)
         dec = R.DeviceBatch(enc.out_base, enc.out_off, clen, torch.zeros(nb * BLOCK + 64, dtype=torch.uint8, device=dev),
                             i64(ar * BLOCK), i64(np.full(nb, BLOCK)))

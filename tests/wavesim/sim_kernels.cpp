@@ -1,5 +1,6 @@
 // sim_kernels.cpp -- runs the UNMODIFIED .hip kernel sources on the wave64 simulator (TEST INFRASTRUCTURE).
 // Built by tests/wavesim/build.py with:  g++ -include wavesim.h sim_kernels.cpp wavesim.cpp
+#define RCX_AB_VARIANTS 1              /* the simulator runs every kernel generation */
 #include "../../rust_compress_amd/csrc/k_lz4_decode.hip"
 #include "../../rust_compress_amd/csrc/k_lz4_decode_v4.hip"
 #include "../../rust_compress_amd/csrc/k_lz4_decode_v5.hip"
