@@ -6,12 +6,28 @@ A "step" is one decode pass over the whole batch with inputs (compressed blocks 
 resident in HBM.  For N>1 every rank owns its own 4096 blocks (weak scaling, no data-path collective:
 blocks are independent -- SURVEY.md 8e).  One JSON line is printed by rank 0.
 
-Inputs are synthetic (rust_compress_amd.synth) and are compressed on the GPU by the product's own
-bit-exact LZ4 encoder; the oracle is used only for the cpu_baseline leg (and its parity check).
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches itself under
+`torch.distributed.run` with one rank per GPU; launched by the driver under torch.distributed.run it reads
+RANK / LOCAL_RANK / WORLD_SIZE as given.  Besides the kernel-only headline value the line carries
+  * `end_to_end`: the same job when the compressed blocks live on rank 0 -- root scatter of the compressed ranges,
+    decode, root gather of the decoded ranges (RCCL grouped send/recv, rust_compress_amd/dist.py), timed per phase;
+  * `other_configs` (N=1): BASELINE configs 3, 4, 5 from the same process (benchmarks/bench_configs.py);
+  * `hbm_ceiling_measured`: a device-to-device copy, next to the 8 TB/s spec peak the roofline uses;
+  * `cpu_baseline` (N=1): the oracle on the host cores.
+Inputs are synthetic (rust_compress_amd.synth) and are compressed on the GPU by the product's own bit-exact LZ4 encoder;
+the oracle is used only for the cpu_baseline leg (and its parity check).
+
+`--dry-gloo` (CPU test of the launcher / rank / scatter / gather logic only): gloo backend, CPU tensors, a tiny workload,
+and the block codec taken from the module named by RCX_BENCH_DRY_CODEC (the test suite supplies it; this file never
+imports the oracle outside cpu_baseline).
 """
 import argparse
+import hashlib
+import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,6 +39,123 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 BLOCK = 65536
 NBLOCKS = 4096
+HEADLINE_KERNEL_SOURCES = ["k_lz4_decode_v4.hip", "k_lz4_decode_v5.hip", "rcx_dev.h"]
+
+
+def kernel_source_hash():
+    """sha256 over the sources of the headline kernel: a PMC traffic figure is only quoted for the code it was measured on."""
+    h = hashlib.sha256()
+    for f in HEADLINE_KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "rust_compress_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+# ------------------------------------------------------------------------------------------------ engines
+class GpuEngine:
+    """The product: HIP kernels through the C-ABI, tensors in HBM."""
+    name = "gpu"
+
+    def __init__(self, args, local_rank):
+        import torch
+        import rust_compress_amd as R
+        from rust_compress_amd import _native as N
+        self.torch, self.R, self.N = torch, R, N
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        self.ctx = R.Context(torch.cuda.current_device())
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.ctx.set_variant(N.LZ4_DECODE, args.variant)
+        self.backend = "nccl"
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def make_workload(self, kind, nblocks, seed):
+        dec, raw, cb, ob = make_workload(self.R, self.ctx, self.torch, self.dev, kind, nblocks, seed)
+        return {"dec": dec, "raw": raw, "comp_bytes": cb, "out_bytes": ob, "nblocks": nblocks}
+
+    def check(self, wl):
+        torch, dec, nb = self.torch, wl["dec"], wl["nblocks"]
+        self.ctx.launch_dev(self.N.LZ4_DECODE, dec)
+        torch.cuda.synchronize()
+        assert int(dec.status.abs().max()) == 0, "decode status != OK"
+        assert bool((dec.out_len[:nb] == BLOCK).all())
+        assert torch.equal(dec.out_base[: nb * BLOCK], wl["raw"][: nb * BLOCK]), "GPU decode != source"
+
+    def decode(self, wl):
+        self.ctx.launch_dev(self.N.LZ4_DECODE, wl["dec"])
+
+    def events(self, n):
+        return [self.torch.cuda.Event(enable_timing=True) for _ in range(n)]
+
+    def compressed(self, wl):
+        dec = wl["dec"]
+        return dec.in_base, dec.in_off.cpu().numpy(), dec.in_len.cpu().numpy()
+
+    def decode_packed(self, local, loff, llen, nblk):
+        """decode blocks that arrived packed (end-to-end leg) -> (out tensor, offsets, lengths as numpy)"""
+        torch, R = self.torch, self.R
+        i64 = lambda a: torch.tensor(np.asarray(a, dtype=np.int64), dtype=torch.int64, device=self.dev)
+        ar = np.arange(nblk, dtype=np.int64)
+        if getattr(self, "_e2e_out", None) is None or self._e2e_out.numel() < nblk * BLOCK + 64:
+            self._e2e_out = torch.zeros(nblk * BLOCK + 64, dtype=torch.uint8, device=self.dev)
+        padded = local if local.numel() % 16 == 0 and local.numel() else torch.cat([local, torch.zeros(64, dtype=torch.uint8, device=self.dev)])
+        db = R.DeviceBatch(padded, i64(loff), i64(llen), self._e2e_out, i64(ar * BLOCK), i64(np.full(nblk, BLOCK)))
+        self.ctx.launch_dev(self.N.LZ4_DECODE, db)
+        torch.cuda.synchronize()
+        assert nblk == 0 or int(db.status[:nblk].abs().max()) == 0
+        return self._e2e_out, ar * BLOCK, db.out_len[:nblk].cpu().numpy()
+
+    def close(self):
+        self.ctx.close()
+
+
+class DryEngine:
+    """CPU stand-in for the test of the multi-rank plumbing (--dry-gloo): the codec comes from RCX_BENCH_DRY_CODEC."""
+    name = "dry"
+
+    def __init__(self, args, local_rank):
+        import torch
+        self.torch = torch
+        self.dev = torch.device("cpu")
+        self.backend = "gloo"
+        self.codec = importlib.import_module(os.environ["RCX_BENCH_DRY_CODEC"])
+
+    def sync(self):
+        pass
+
+    def make_workload(self, kind, nblocks, seed):
+        from rust_compress_amd import batch as B
+        blobs, raws = self.codec.make_blocks(kind, nblocks, BLOCK, seed)
+        base, off, lens = B.pack(blobs)
+        return {"blobs": blobs, "raws": raws, "base": self.torch.from_numpy(base), "off": off, "lens": lens,
+                "comp_bytes": int(sum(map(len, blobs))), "out_bytes": int(sum(map(len, raws))), "nblocks": nblocks, "out": None}
+
+    def check(self, wl):
+        assert [self.codec.decode(b, BLOCK) for b in wl["blobs"]] == wl["raws"]
+
+    def decode(self, wl):
+        wl["out"] = [self.codec.decode(b, BLOCK) for b in wl["blobs"]]
+
+    def events(self, n):
+        class Ev:
+            def record(s): s.t = time.perf_counter()
+            def elapsed_time(s, o): return (o.t - s.t) * 1e3
+        return [Ev() for _ in range(n)]
+
+    def compressed(self, wl):
+        return wl["base"], wl["off"], wl["lens"]
+
+    def decode_packed(self, local, loff, llen, nblk):
+        buf = local.numpy()
+        outs = [self.codec.decode(buf[int(o):int(o) + int(l)].tobytes(), BLOCK) for o, l in zip(loff, llen)]
+        lens = np.array([len(o) for o in outs], dtype=np.int64)
+        out = self.torch.from_numpy(np.frombuffer(b"".join(outs) + b"\0", dtype=np.uint8).copy())
+        return out, np.concatenate([[0], np.cumsum(lens)[:-1]]) if nblk else np.zeros(0, np.int64), lens
+
+    def close(self):
+        pass
 
 
 def make_workload(R, ctx, torch, dev, kind, nblocks, seed):
@@ -49,23 +182,25 @@ def make_workload(R, ctx, torch, dev, kind, nblocks, seed):
     return dec, raw, int(comp_len.sum()), nblocks * BLOCK
 
 
-def time_steps(ctx, torch, dec, steps, warmup, codec, dist=None):
+def time_steps(eng, wl, steps, warmup, dist):
+    """W untimed steps, then exactly K steps between barrier + device sync on both sides; per-step device time from events
+    recorded on the stream the kernels are launched on."""
     for _ in range(warmup):
-        ctx.launch_dev(codec, dec)
-    torch.cuda.synchronize()
+        eng.decode(wl)
+    eng.sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    eng.sync()
+    evs = eng.events(steps + 1)
     t0 = time.perf_counter()
     evs[0].record()
     for i in range(steps):
-        ctx.launch_dev(codec, dec)
+        eng.decode(wl)
         evs[i + 1].record()
-    torch.cuda.synchronize()
+    eng.sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    eng.sync()
     wall = time.perf_counter() - t0
     kern_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
     return wall, float(np.mean(kern_ms)), float(np.median(kern_ms))
@@ -99,6 +234,94 @@ def cpu_baseline(dec, raw, torch, nblocks, budget_s=10.0):
                                                                  float(out_len1.sum()) / secs1 / 2**30, ok)}
 
 
+# ------------------------------------------------------------------------------------------------ end-to-end leg
+def end_to_end(eng, wl, dist, rank, world, reps=3):
+    """Root holds every rank's compressed blocks; timed: scatter (compressed) -> decode -> gather (decoded)."""
+    import rust_compress_amd.dist as D
+    torch = eng.torch
+    base, off, lens = eng.compressed(wl)
+    nb = wl["nblocks"]
+    # untimed set-up: collect every rank's compressed blocks on the root, packed
+    packed, clens = D.gather_blocks(base, off, lens, np.arange(world + 1, dtype=np.int64) * nb, root=0)
+    raw_sum = torch.zeros(1, dtype=torch.float64, device=eng.dev)
+    if eng.name == "gpu":
+        raw_sum[0] = wl["raw"][: nb * BLOCK].to(torch.float64).sum()
+    else:
+        raw_sum[0] = float(sum(sum(r) for r in wl["raws"]))
+    dist.all_reduce(raw_sum, op=dist.ReduceOp.SUM)
+    roff = bounds = None
+    if rank == 0:
+        roff = np.concatenate([[0], np.cumsum(clens)[:-1]])
+        bounds = D.partition(np.full(world * nb, BLOCK), world)
+    best = None
+    for rep in range(reps + 1):
+        times = []
+        eng.sync(); dist.barrier(); t0 = time.perf_counter()
+        local, loff, llen, bnd = D.scatter_blocks(packed, roff, clens, bounds, root=0, device=eng.dev)
+        eng.sync(); dist.barrier(); t1 = time.perf_counter()
+        nblk = int(bnd[rank + 1] - bnd[rank])
+        out, ooff, olen = eng.decode_packed(local, loff, llen, nblk)
+        eng.sync(); dist.barrier(); t2 = time.perf_counter()
+        got, glens = D.gather_blocks(out, ooff, olen, bnd, root=0)
+        eng.sync(); dist.barrier(); t3 = time.perf_counter()
+        times = [t1 - t0, t2 - t1, t3 - t2]
+        if rep and (best is None or sum(times) < sum(best)):      # the first pass pays allocations and RCCL channel set-up
+            best = times
+    tt = torch.tensor(best, dtype=torch.float64, device=eng.dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    res = None
+    if rank == 0:
+        ok = bool(int(glens.sum()) == world * nb * BLOCK and abs(float(got.to(torch.float64).sum()) - float(raw_sum[0])) < 0.5)
+        sc, de, ga = [float(x) for x in tt.tolist()]
+        res = {"scatter_ms": round(sc * 1e3, 3), "decode_ms": round(de * 1e3, 3), "gather_ms": round(ga * 1e3, 3),
+               "value": round(float(glens.sum()) / (sc + de + ga) / 2**30, 3), "unit": "GiB/s decoded, root scatter + decode + root gather",
+               "bytes_scattered": int(clens.sum()) - int(clens[:nb].sum()), "bytes_gathered": int(glens.sum()) - nb * BLOCK,
+               "verified": ok, "transport": "%s grouped isend/irecv (batch_isend_irecv), %d ranks" % (eng.backend, world)}
+    return res
+
+
+def rccl_self_sendrecv(eng, dist, rank, nbytes=64 << 20):
+    """One grouped send+recv of a device tensor to this rank itself: exercises the RCCL point-to-point path with device
+    tensors even on a one-GPU box (world 1 has no peer to talk to)."""
+    torch = eng.torch
+    try:
+        a = torch.arange(nbytes // 8, dtype=torch.int64, device=eng.dev)
+        b = torch.zeros_like(a)
+        for rep in range(3):
+            eng.sync(); t0 = time.perf_counter()
+            for r in dist.batch_isend_irecv([dist.P2POp(dist.isend, a, rank), dist.P2POp(dist.irecv, b, rank)]):
+                r.wait()
+            eng.sync(); t = time.perf_counter() - t0
+        return {"bytes": nbytes, "GB/s": round(nbytes / t / 1e9, 2), "ok": bool(torch.equal(a, b))}
+    except Exception as e:                                     # pragma: no cover (backend dependent)
+        return {"error": str(e)[:200]}
+
+
+def hbm_ceiling(torch, dev, nbytes=1 << 30, reps=10):
+    a = torch.empty(nbytes, dtype=torch.uint8, device=dev).fill_(1)
+    b = torch.empty_like(a)
+    b.copy_(a); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record(); torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / reps
+    return {"GB/s": round(2 * nbytes / t / 1e9, 1), "what": "device-to-device copy of 1 GiB (read + write bytes / time)", "spec_peak_GB/s": HBM_PEAK_GBS}
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def self_spawn(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start one rank per GPU and pass their output through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,54 +331,72 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (A/B)")
     ap.add_argument("--nblocks", type=int, default=NBLOCKS)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the scatter / decode / gather leg")
+    ap.add_argument("--no-others", action="store_true", help="skip BASELINE configs 3-5 and the HBM ceiling")
+    ap.add_argument("--others-scale", type=float, default=1.0, help="fraction of the full size of configs 3-5")
     ap.add_argument("--extras", action="store_true", help="also time the other distributions / variants")
+    ap.add_argument("--dry-gloo", action="store_true", help="CPU test of the multi-rank plumbing (see the module docstring)")
     args = ap.parse_args()
 
-    import torch
-    import rust_compress_amd as R
-    from rust_compress_amd import _native as N
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    eng = (DryEngine if args.dry_gloo else GpuEngine)(args, local_rank)
+    torch = eng.torch
     dist = None
-    if world > 1 or os.environ.get("RCX_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL path on one GPU
+    want_dist = world > 1 or not args.no_e2e or os.environ.get("RCX_BENCH_FORCE_DIST")
+    if want_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", torch.cuda.current_device())
-    ctx = R.Context(torch.cuda.current_device())
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    ctx.set_variant(N.LZ4_DECODE, args.variant)
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        try:
+            if eng.backend == "nccl":
+                dist.init_process_group("nccl", device_id=eng.dev)
+            else:
+                dist.init_process_group("gloo")
+        except Exception as e:
+            if world > 1:
+                raise
+            print("bench.py: process group unavailable (%s): end_to_end skipped" % str(e)[:120], file=sys.stderr)
+            dist = None
 
-    dec, raw, comp_bytes, out_bytes = make_workload(R, ctx, torch, dev, args.kind, args.nblocks, 0x4C5A3401 + 7919 * rank)
-    # parity (untimed): decoded bytes == the synthetic source on this rank
-    ctx.launch_dev(N.LZ4_DECODE, dec)
-    torch.cuda.synchronize()
-    assert int(dec.status.abs().max()) == 0, "decode status != OK"
-    assert bool((dec.out_len[: args.nblocks] == BLOCK).all())
-    assert torch.equal(dec.out_base[: args.nblocks * BLOCK], raw[: args.nblocks * BLOCK]), "GPU decode != source"
+    wl = eng.make_workload(args.kind, args.nblocks, 0x4C5A3401 + 7919 * rank)
+    eng.check(wl)                                               # parity (untimed): decoded bytes == the synthetic source on this rank
+    comp_bytes, out_bytes = wl["comp_bytes"], wl["out_bytes"]
 
-    wall, kern_ms, kern_med = time_steps(ctx, torch, dec, args.steps, args.warmup, N.LZ4_DECODE, dist)
-    t = torch.tensor([wall], dtype=torch.float64, device=dev)
-    tot = torch.tensor([float(out_bytes), float(comp_bytes)], dtype=torch.float64, device=dev)
+    wall, kern_ms, kern_med = time_steps(eng, wl, args.steps, args.warmup, dist)
+    t = torch.tensor([wall], dtype=torch.float64, device=eng.dev)
+    tot = torch.tensor([float(out_bytes), float(comp_bytes)], dtype=torch.float64, device=eng.dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     wall = float(t.item())
     total_out = float(tot[0].item())
 
+    e2e = selfp2p = None
+    if dist is not None and not args.no_e2e:
+        e2e = end_to_end(eng, wl, dist, rank, world)
+        if eng.backend == "nccl":
+            selfp2p = rccl_self_sendrecv(eng, dist, rank)
+
     if rank == 0:
         alg_bytes = comp_bytes + out_bytes                     # per launch on this rank
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = traffic_src = None
         pmc = os.path.join(ROOT, "profiles", "pmc_lz4_decode.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and not args.dry_gloo:           # only a figure measured on exactly these kernel sources is quoted
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                j = json.load(open(pmc))
+                if j.get("kernel_source_hash") == kernel_source_hash() and args.variant == 0 and args.kind == "text":
+                    traffic = j.get("hbm_bytes_per_launch")
+                    traffic_src = {"file": "profiles/pmc_lz4_decode.json", "kernel_source_hash": j.get("kernel_source_hash"), "date": j.get("date")}
             except Exception:
                 traffic = None
         res = {
@@ -175,25 +416,47 @@ def main():
                        "distribution": "G-%s" % args.kind, "lz4_ratio": round(out_bytes / comp_bytes, 3),
                        "kernel_variant": args.variant, "parallelism": "blocks sharded, %d per rank, no collective" % args.nblocks},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": round(kern_ms, 4),
                          "kernel_ms_median": round(kern_med, 4)},
+            "end_to_end": e2e,
         }
-        if world == 1 and not args.no_cpu:
-            res["cpu_baseline"] = cpu_baseline(dec, raw, torch, args.nblocks)
-        if args.extras and world == 1:
+        if selfp2p is not None:
+            res["rccl_self_sendrecv"] = selfp2p
+        if args.dry_gloo:
+            res["data"] = "synthetic (dry run on CPU: plumbing test, not a measurement)"
+        if world == 1 and not args.no_cpu and not args.dry_gloo:
+            res["cpu_baseline"] = cpu_baseline(wl["dec"], wl["raw"], torch, args.nblocks)
+        if world == 1 and not args.no_others and not args.dry_gloo:
+            sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
+            import bench_configs as BC
+            res["hbm_ceiling_measured"] = hbm_ceiling(torch, eng.dev)
+            del wl
+            others = []
+            for fn in (lambda: [BC.config3(eng.ctx, torch, eng.dev, args.others_scale, cpu=not args.no_cpu)],
+                       lambda: BC.config4(eng.ctx, torch, eng.dev, args.others_scale),
+                       lambda: [BC.config5(eng.ctx, torch, eng.dev, args.others_scale, reps=3)]):
+                try:
+                    others += fn()
+                except Exception as e:                          # a failing side config must not lose the headline line
+                    others.append({"error": "%s: %s" % (type(e).__name__, str(e)[:200])})
+                torch.cuda.empty_cache()
+            res["other_configs"] = others
+        if args.extras and world == 1 and not args.dry_gloo:
+            N = eng.N
             extras = {}
             for kind in ("text", "words", "runs", "rand", "mix"):
-                d2, r2, cb, ob = make_workload(R, ctx, torch, dev, kind, args.nblocks, 0x77 + len(kind))
+                w2 = eng.make_workload(kind, args.nblocks, 0x77 + len(kind))
                 for v in N.LZ4_DECODE_VARIANTS:
-                    ctx.set_variant(N.LZ4_DECODE, v)
-                    ctx.launch_dev(N.LZ4_DECODE, d2)
-                    torch.cuda.synchronize()
-                    ok = torch.equal(d2.out_base[: args.nblocks * BLOCK], r2[: args.nblocks * BLOCK]) and int(d2.status.abs().max()) == 0
-                    w, km, _ = time_steps(ctx, torch, d2, 5, 1, N.LZ4_DECODE)
-                    extras["%s/v%d" % (kind, v)] = {"GiB/s": round(ob / (km * 1e-3) / 2**30, 2), "ratio": round(ob / cb, 2),
-                                                    "hbm_frac": round((cb + ob) / (km * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ok": bool(ok)}
-                del d2, r2
+                    eng.ctx.set_variant(N.LZ4_DECODE, v)
+                    eng.decode(w2); eng.sync()
+                    d2 = w2["dec"]
+                    ok = torch.equal(d2.out_base[: args.nblocks * BLOCK], w2["raw"][: args.nblocks * BLOCK]) and int(d2.status.abs().max()) == 0
+                    _, km, _ = time_steps(eng, w2, 5, 1, None)
+                    extras["%s/v%d" % (kind, v)] = {"GiB/s": round(w2["out_bytes"] / (km * 1e-3) / 2**30, 2), "ratio": round(w2["out_bytes"] / w2["comp_bytes"], 2),
+                                                    "hbm_frac": round((w2["comp_bytes"] + w2["out_bytes"]) / (km * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ok": bool(ok)}
+                del w2
+            eng.ctx.set_variant(N.LZ4_DECODE, args.variant)
             res["extras"] = extras
         line = json.dumps(res)
     else:
@@ -212,7 +475,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    eng.close()
 
 
 if __name__ == "__main__":

@@ -10,7 +10,7 @@ for set in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_U
            "SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_CYCLES SQ_BUSY_CYCLES"; do
     i=$((i+1))
     rm -rf /tmp/pl_$i
-    rocprofv3 --pmc $set -d /tmp/pl_$i -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu --kind $KIND --variant $VAR > /tmp/pl_$i.log 2>&1
+    rocprofv3 --pmc $set -d /tmp/pl_$i -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu --no-e2e --no-others --kind $KIND --variant $VAR > /tmp/pl_$i.log 2>&1
     db=$(find /tmp/pl_$i -name "*.db" | head -1)
     python $REPO/benchmarks/pmcq.py $db lz4_decode 2>&1 | cut -c1-20,40- || tail -5 /tmp/pl_$i.log
 done

@@ -13,7 +13,7 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_IFETCH"; do
     i=$((i+1))
     rm -rf /tmp/pmc_$i
-    rocprofv3 --pmc $set -d /tmp/pmc_$i -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu --kind $KIND > /tmp/pmc_$i.log 2>&1
+    rocprofv3 --pmc $set -d /tmp/pmc_$i -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu --no-e2e --no-others --kind $KIND > /tmp/pmc_$i.log 2>&1
     db=$(find /tmp/pmc_$i -name "*.db" | head -1)
     python $REPO/benchmarks/pmcq.py $db lz4_decode > $REPO/gpurun_out/pmc_$i.txt 2>&1 || tail -5 /tmp/pmc_$i.log > $REPO/gpurun_out/pmc_$i.txt
 done

@@ -3,8 +3,10 @@
 Blocks never talk to each other, so the compute needs no collective: rank g gets the contiguous range of
 block indices [b_g, b_{g+1}) balanced by output bytes.  A collective appears only when the caller's data
 lives on ONE rank: `scatter_blocks` / `gather_blocks` move variable-length byte ranges root -> peers and
-peers -> root with grouped point-to-point transfers (RCCL over xGMI on GPUs: the root drives all seven
-links at once, which a ring collective would not; gloo on CPU in the tests).
+peers -> root as ONE group of point-to-point operations per direction (`torch.distributed.batch_isend_irecv`:
+on the nccl backend that is a single ncclGroupStart/End around world-1 ncclSend/ncclRecv, i.e. the root talks
+to all peers over their own xGMI links concurrently; on gloo, used by the CPU tests, the same calls are plain
+isend/irecv).  Descriptors travel as int64 tensors, never pickled.
 One process per GPU, `torch.distributed` initialised by the caller.
 """
 import numpy as np
@@ -27,74 +29,104 @@ def partition(weights, world):
     return np.maximum.accumulate(np.minimum(bounds, n))
 
 
-def _sizes_for(bounds, off, lens):
+def _spans(bounds, off, lens):
     """byte span [lo, hi) of each rank's block range in the packed buffer"""
-    spans = []
+    spans = np.zeros((len(bounds) - 1, 2), dtype=np.int64)
     for g in range(len(bounds) - 1):
         a, b = int(bounds[g]), int(bounds[g + 1])
-        if a == b:
-            spans.append((0, 0))
-        else:
-            spans.append((int(off[a]), int(off[b - 1] + lens[b - 1])))
+        if b > a:
+            spans[g] = (int(off[a]), int(off[b - 1]) + int(lens[b - 1]))
     return spans
 
 
+def _group(ops):
+    import torch.distributed as dist
+    if ops:
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+
+
 def scatter_blocks(base, off, lens, bounds, root=0, device=None):
-    """Root holds (base uint8 tensor, off, lens numpy); every rank returns (local_base tensor, local_off, local_len).
-    Descriptors travel with broadcast_object_list (tiny); payload bytes with grouped isend/irecv."""
+    """Root holds (base uint8 tensor, off, lens numpy, bounds); every rank returns
+    (local_base tensor, local_off uint64, local_len uint64, bounds).
+    Two grouped exchanges: the descriptors (a fixed-size header broadcast, then one int64 tensor per peer), the payload bytes."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
-    meta = [None]
+    dev = torch.device(device) if device is not None else (base.device if base is not None else torch.device("cpu"))
+    hdr = torch.zeros(3 * world + 1, dtype=torch.int64, device=dev)          # bounds[world+1] | span lo, hi per rank
     if rank == root:
-        spans = _sizes_for(bounds, off, lens)
-        meta = [(np.asarray(bounds), np.asarray(off), np.asarray(lens), spans)]
-    dist.broadcast_object_list(meta, src=root)
-    bounds, off, lens, spans = meta[0]
-    lo, hi = spans[rank]
+        bounds = np.asarray(bounds, dtype=np.int64)
+        off = np.asarray(off, dtype=np.int64)
+        lens = np.asarray(lens, dtype=np.int64)
+        spans = _spans(bounds, off, lens)
+        hdr = torch.from_numpy(np.concatenate([bounds, spans.reshape(-1)])).to(dev)
+    dist.broadcast(hdr, src=root)
+    h = hdr.cpu().numpy()
+    bounds, spans = h[: world + 1], h[world + 1:].reshape(world, 2)
     a, b = int(bounds[rank]), int(bounds[rank + 1])
-    dev = device if device is not None else (base.device if base is not None else "cpu")
+    lo, hi = int(spans[rank][0]), int(spans[rank][1])
+    desc = torch.empty(2 * (b - a), dtype=torch.int64, device=dev)           # local offsets | lengths of my blocks
+    local = torch.empty(hi - lo, dtype=torch.uint8, device=dev)
+    ops = []
     if rank == root:
-        local = base[lo:hi].clone()
-        reqs = []
+        keep = []                                                            # tensors a pending isend reads
         for g in range(world):
-            if g == root or spans[g][1] == spans[g][0]:
+            ga, gb = int(bounds[g]), int(bounds[g + 1])
+            d = torch.from_numpy(np.concatenate([off[ga:gb] - int(spans[g][0]), lens[ga:gb]])).to(dev)
+            if g == root:
+                desc = d
+                local = base[lo:hi].clone()
                 continue
-            reqs.append(dist.isend(base[spans[g][0]:spans[g][1]].contiguous(), dst=g))
-        for r in reqs:
-            r.wait()
+            keep.append(d)
+            if gb > ga:
+                ops.append(dist.P2POp(dist.isend, d, g))
+            if spans[g][1] > spans[g][0]:
+                ops.append(dist.P2POp(dist.isend, base[int(spans[g][0]):int(spans[g][1])], g))
     else:
-        local = torch.empty(hi - lo, dtype=torch.uint8, device=dev)
+        if b > a:
+            ops.append(dist.P2POp(dist.irecv, desc, root))
         if hi > lo:
-            dist.recv(local, src=root)
-    return local, (np.asarray(off[a:b]) - lo).astype(np.uint64), np.asarray(lens[a:b]).astype(np.uint64)
+            ops.append(dist.P2POp(dist.irecv, local, root))
+    _group(ops)
+    d = desc.cpu().numpy()
+    return local, d[: b - a].astype(np.uint64), d[b - a:].astype(np.uint64), bounds
 
 
 def gather_blocks(local_out, local_off, local_len, bounds, root=0):
-    """Inverse of scatter for the outputs: root returns (list of per-block bytes-like tensors in global order)."""
+    """Inverse of scatter for the outputs.  Root returns (packed uint8 tensor of every block's bytes in global order,
+    int64 numpy lengths per block); the other ranks return (None, None).  Two grouped exchanges: lengths, then bytes."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
-    # compact local outputs (offsets may have gaps)
-    parts = [local_out[int(o):int(o) + int(l)] for o, l in zip(local_off, local_len)]
-    packed = torch.cat(parts) if parts else torch.empty(0, dtype=torch.uint8, device=local_out.device)
-    lens_all = [None] * world
-    dist.all_gather_object(lens_all, [int(l) for l in local_len])
-    if rank == root:
-        out = []
-        for g in range(world):
-            tot = sum(lens_all[g])
-            if g == root:
-                buf = packed
-            else:
-                buf = torch.empty(tot, dtype=torch.uint8, device=local_out.device)
-                if tot:
-                    dist.recv(buf, src=g)
-            p = 0
-            for l in lens_all[g]:
-                out.append(buf[p:p + l])
-                p += l
-        return out
-    if packed.numel():
-        dist.send(packed, dst=root)
-    return None
+    dev = local_out.device
+    bounds = np.asarray(bounds, dtype=np.int64)
+    local_off = np.asarray(local_off, dtype=np.int64)
+    local_len = np.asarray(local_len, dtype=np.int64)
+    # compact the local outputs when the slots have gaps
+    n_local = len(local_len)
+    dense = n_local == 0 or bool(np.array_equal(local_off, np.concatenate([[local_off[0]], local_off[0] + np.cumsum(local_len)[:-1]])))
+    if n_local == 0:
+        packed = torch.empty(0, dtype=torch.uint8, device=dev)
+    elif dense:
+        packed = local_out[int(local_off[0]): int(local_off[0]) + int(local_len.sum())]
+    else:
+        packed = torch.cat([local_out[int(o):int(o) + int(l)] for o, l in zip(local_off, local_len)])
+    mylens = torch.from_numpy(local_len).to(dev)
+    if rank != root:
+        if n_local:
+            _group([dist.P2POp(dist.isend, mylens, root)])
+        if packed.numel():
+            _group([dist.P2POp(dist.isend, packed.contiguous(), root)])
+        return None, None
+    counts = np.diff(bounds)
+    lens_all = torch.empty(int(bounds[-1]), dtype=torch.int64, device=dev)
+    lens_all[int(bounds[root]): int(bounds[root + 1])] = mylens
+    _group([dist.P2POp(dist.irecv, lens_all[int(bounds[g]): int(bounds[g + 1])], g) for g in range(world) if g != root and counts[g]])
+    lens_np = lens_all.cpu().numpy()
+    tot = np.array([int(lens_np[int(bounds[g]): int(bounds[g + 1])].sum()) for g in range(world)], dtype=np.int64)
+    starts = np.concatenate([[0], np.cumsum(tot)])
+    out = torch.empty(int(starts[-1]), dtype=torch.uint8, device=dev)
+    out[int(starts[root]): int(starts[root + 1])] = packed
+    _group([dist.P2POp(dist.irecv, out[int(starts[g]): int(starts[g + 1])], g) for g in range(world) if g != root and tot[g]])
+    return out, lens_np

@@ -28,11 +28,9 @@ def main():
         base = torch.from_numpy(bnp)
         bounds = D.partition([len(r) for r in raws], world)
         assert bounds[0] == 0 and bounds[-1] == nblocks and all(np.diff(bounds) >= 0)
-    lbase, loff, llen = D.scatter_blocks(base, off, lens, bounds, root=0, device="cpu")
-    meta = [bounds]
-    dist.broadcast_object_list(meta, src=0)
-    bounds = meta[0]
+    lbase, loff, llen, bounds = D.scatter_blocks(base, off, lens, bounds, root=0, device="cpu")
     a, b = int(bounds[rank]), int(bounds[rank + 1])
+    assert len(loff) == b - a and len(llen) == b - a
     caps = [len(r) for r in raws[a:b]]
     total, ooff, ocap = B.layout(caps)
     out = np.zeros(total, dtype=np.uint8)
@@ -41,7 +39,13 @@ def main():
         assert not status.any() and list(out_len) == caps
     else:
         out_len = np.zeros(0, dtype=np.uint64)
-    got = D.gather_blocks(torch.from_numpy(out), ooff, out_len, bounds, root=0)
+    packed, lens_all = D.gather_blocks(torch.from_numpy(out), ooff, out_len, bounds, root=0)
+    got = None
+    if rank == 0:
+        ends = np.cumsum(lens_all)
+        got = [packed[int(e - l): int(e)] for e, l in zip(ends, lens_all)]
+    else:
+        assert packed is None
     if rank == 0:
         assert len(got) == nblocks
         for g, r in zip(got, raws):
