@@ -3,9 +3,13 @@
 //
 // Why a third kernel: k_inflate2 spends one LANE per stream, so a wave executes the union of 32-64 lanes' paths through
 // one big loop body (rocprof: ~1000 instructions per loop iteration, 29 GiB/s).  Here the wave follows ONE stream:
-//   * symbols are decoded by wave-uniform (scalar) code from a 9-bit lookup table in LDS (code <= 9 bits: one LDS read;
-//     longer codes: canonical limits, as in k_inflate2), literals go to an LDS literal buffer, matches become
-//     {literal run, match length, distance} sequences -- exactly what an LZ4 block is made of;
+//   * symbols are decoded a WINDOW at a time (Inf3::pass): lane j of the wave decodes the symbol that WOULD start at bit
+//     position j of the next 64 -- one bit fetch and two table reads (9-bit lit/len table whose entries carry a length's
+//     base and extra-bit count, 8-bit distance table) for the whole window -- and a scalar walk then hops from symbol to
+//     symbol with v_readlane, booking literals and {literal run, match length, distance} sequences in registers (lane-index compare + select):
+//     no LDS round trip and ~10-20 scalar instructions per symbol (the first version paid two to four dependent LDS reads
+//     and ~45 vector instructions per symbol in a hand-written serial loop).  Codes longer than the tables, distances
+//     beyond the output and the like drop to a general one-symbol path (canonical limits, as in k_inflate2);
 //   * up to 64 sequences are then emitted by Lz4V5::emit5 (prefix sum of output positions, 16-byte HBM gathers for
 //     matches older than the LDS window, redirection of chained matches, exec-narrowing byte stores, coalesced drain):
 //     the code that decodes LZ4 at 300 GiB/s; matches longer than 64 bytes and stored blocks take its wave-wide paths.
@@ -20,221 +24,130 @@
 
 #define RCX_ST_FALLBACK 0x7ff00001           /* internal, never leaves the library */
 
-// One pass of the symbol decoder on the vector ALU (hand-written: hipcc's version of the same loop costs ~17 scalar-unit
-// instructions per literal and ~120 per match, and the CU's single scalar unit is what bounds this kernel).  All
-// operands are wave-uniform values held in VGPRs.  The pass decodes symbols with short codes and BOOKS them itself:
-// literals go to `litv` (literal j of the pass in lane j; the caller stores them at litbuf[litn0 + j]), a match of <= 64
-// bytes closes the open literal run as a sequence descriptor {run source, L | M << 8 | dist << 16} at desc[ns], 32
-// literals in a row close a run without a match.  It returns when something needs the caller:
-//   status 0  limits: staging (a refill with off > lim), literal register / buffer (cnt >= room) or descriptors (ns >= 64) ran out
-//          1  a match longer than 64 bytes: len, dist decoded, NOT booked (the wave-wide copy path takes it)
-//          2  end of block (consumed)        3  the next bits are no lit/len code (or symbol 286/287): nothing consumed
-//          4  a distance beyond the output or 32 KiB (the caller falls back)
-//          5  length decoded into len, the next bits are no distance code (or symbol 30/31): nothing of it consumed
-// Codes longer than the lookup tables cover are decoded from the canonical limits (INF_CANON).
-// Bits: the 64-bit buffer is refilled 8 bytes at a time (only 32 counted; the rest are the same bits the next refill ORs
-// in again).  ltab/dtab: base | extra_bits << 16 per length / distance symbol.  Fixed registers v80-v99, s[90:91].
-#ifndef RCX_INF_RUN_CALL
-__device__ __forceinline__ void rcx_inf_run(uint32_t& lo, uint32_t& hi, uint32_t& bc, uint32_t& off, uint32_t& cnt, uint32_t& litv,
-                                            uint32_t& len, uint32_t& dist, uint32_t& status, uint32_t& ns, uint32_t& runL, uint32_t& runsrc,
-                                            uint32_t& otot, uint32_t room, uint32_t lim, uint32_t lane, uint32_t litn0,
-                                            uint32_t cb, uint32_t lutL, uint32_t lutD, uint32_t ltab, uint32_t dtab, uint32_t descb,
-                                            uint32_t tabb, uint32_t symLb, uint32_t symDb)
+// The walk over one pre-decoded window (see Inf3::pass).  pkL / pkD: lane j holds the lit/len symbol / the distance symbol that
+// would start at bit j (pkL: bits | isLength << 8 | decodable << 9 | kind << 10 | value << 16; pkD: distance | bits << 16 | ok << 24).
+// Starting at window position `pos`, books symbols -- literal j of the pass into lane j of litv, descriptor j into lane j of
+// (dw0, dw1) -- and returns why it stopped:
+//   0 the window is used up (pos = where the next one starts)   1 a match longer than 64 bytes (flen, fdist; consumed, not booked)
+//   2 end of block (consumed)   3 the symbol at pos needs the general path   4 a distance beyond the output or 32 KiB
+//   5 the literal register / buffer (cnt reached room) or the 64 descriptors ran out
+// Hand-written: everything here is wave-uniform, i.e. work for the CU's ONE scalar unit, which all 16 waves share at about one
+// instruction per cycle.  hipcc's version of this loop spends ~80 scalar instructions per symbol (copies between the loop's many
+// exits) and the kernel ran at 34 ms for BASELINE config 3; this one spends 15 per literal and ~30 per match.
+// The wave simulator supplies a portable version through this hook.
+#ifndef RCX_INF_WALK
+__device__ __forceinline__ uint32_t rcx_inf_walk(uint32_t pkL, uint32_t pkD, uint32_t& pos, uint32_t& cnt, uint32_t& ns, uint32_t& runL,
+                                                 uint32_t& otot, uint32_t& runsrc, uint32_t litn, uint32_t room, uint32_t& litv, uint32_t& dw0,
+                                                 uint32_t& dw1, uint32_t& flen, uint32_t& fdist)
 {
-    // registers: v80:81 bit buffer, v82 bits, v83 staged offset, v84 cnt, v85 litv, v86-v89 v97 temporaries, v90 len, v91 dist,
-    // v92 status, v93 ns, v94 cnt at the start of the open run (minus what the run held before the pass), v95 run source,
-    // v96 output bytes before this pass + matches booked in it (+ cnt = output so far), v79 cnt at which something happens
-    // (the run reaches 32 literals or the pass is out of room), v98:99 descriptor
-#define INF_REFILL(L, DRY)                                     \
-        "v_cmp_gt_u32_e32 vcc, 33, v82\n\t"                    \
-        "s_cbranch_vccz " L "\n\t"                             \
-        "v_cmp_lt_u32_e32 vcc, %[lim], v83\n\t"                \
-        "s_cbranch_vccnz " DRY "\n\t"                          \
-        "v_add_u32_e32 v86, %[cb], v83\n\t"                    \
-        "ds_read2_b32 v[86:87], v86 offset1:1\n\t"             \
-        "v_add_u32_e32 v83, 4, v83\n\t"                        \
-        "s_waitcnt lgkmcnt(0)\n\t"                             \
-        "v_lshlrev_b64 v[86:87], v82, v[86:87]\n\t"            \
-        "v_or_b32_e32 v80, v80, v86\n\t"                       \
-        "v_or_b32_e32 v81, v81, v87\n\t"                       \
-        "v_add_u32_e32 v82, 32, v82\n\t"                       \
-        L ":\n\t"
-#define INF_CONSUME                                            \
-        "v_lshrrev_b64 v[80:81], v86, v[80:81]\n\t"            \
-        "v_sub_u32_e32 v82, v82, v86\n\t"
-    /* desc[ns] = {runsrc, runL | len << 8 | dist << 16} by lane 0; ns++, the next run starts at litn0 + cnt; out when ns = 64 */
-#define INF_POST(OUT)                                          \
-        "v_sub_u32_e32 v97, v84, v94\n\t"                      \
-        "v_mov_b32_e32 v98, v95\n\t"                           \
-        "v_lshl_or_b32 v99, v90, 8, v97\n\t"                   \
-        "v_lshl_or_b32 v99, v91, 16, v99\n\t"                  \
-        "v_lshl_add_u32 v97, v93, 3, %[descb]\n\t"             \
-        "v_cmp_eq_u32_e32 vcc, 0, %[lane]\n\t"                 \
-        "s_and_saveexec_b64 s[90:91], vcc\n\t"                 \
-        "ds_write_b64 v97, v[98:99]\n\t"                       \
-        "s_mov_b64 exec, s[90:91]\n\t"                         \
-        "v_add_u32_e32 v93, 1, v93\n\t"                        \
-        "v_mov_b32_e32 v94, v84\n\t"                           \
-        "v_add_u32_e32 v95, %[litn0], v84\n\t"                 \
-        "v_add_u32_e32 v79, 32, v94\n\t"                       \
-        "v_min_u32_e32 v79, v79, %[room]\n\t"                  \
-        "v_cmp_lt_u32_e32 vcc, 63, v93\n\t"                    \
-        "s_cbranch_vccnz " OUT "\n\t"
-    /* canonical decode of a code longer than the lookup table covers (HuffmanTree::decode, flate.rs:129-146): lim[l] / base[l] at
-       TAB / TAB+64, symbols in canonical order at SYM; in: v80; out: v87 symbol, v86 code length; FAIL: these bits are no code */
-#define INF_CANON(TAB, SYM, L0, TAG, FAIL)                     \
-        "v_bfrev_b32_e32 v88, v80\n\t"                         \
-        "v_lshrrev_b32_e32 v88, 17, v88\n\t"                   \
-        "v_mov_b32_e32 v86, " L0 "\n\t"                        \
-        "L_c" TAG "_%=:\n\t"                                   \
-        "v_lshl_add_u32 v97, v86, 2, " TAB "\n\t"              \
-        "ds_read_b32 v89, v97\n\t"                             \
-        "ds_read_b32 v97, v97 offset:64\n\t"                   \
-        "s_waitcnt lgkmcnt(0)\n\t"                             \
-        "v_cmp_lt_u32_e32 vcc, v88, v89\n\t"                   \
-        "s_cbranch_vccnz L_f" TAG "_%=\n\t"                    \
-        "v_add_u32_e32 v86, 1, v86\n\t"                        \
-        "v_cmp_gt_u32_e32 vcc, 16, v86\n\t"                    \
-        "s_cbranch_vccnz L_c" TAG "_%=\n\t"                    \
-        "s_branch " FAIL "\n\t"                                \
-        "L_f" TAG "_%=:\n\t"                                   \
-        "v_sub_u32_e32 v89, 15, v86\n\t"                       \
-        "v_lshrrev_b32_e32 v89, v89, v88\n\t"                  \
-        "v_add_u32_e32 v89, v89, v97\n\t"                      \
-        "v_lshl_add_u32 v89, v89, 1, " SYM "\n\t"              \
-        "ds_read_u16 v87, v89\n\t"                             \
-        "s_waitcnt lgkmcnt(0)\n\t"
+    uint32_t code, e, d, a, b, lim, rb;          // rb: cnt at the start of the open literal run; lim: cnt at which something happens
     asm volatile(
-        "v_mov_b32_e32 v80, %[lo]\n\t" "v_mov_b32_e32 v81, %[hi]\n\t" "v_mov_b32_e32 v82, %[bc]\n\t" "v_mov_b32_e32 v83, %[off]\n\t"
-        "v_mov_b32_e32 v84, %[cnt]\n\t" "v_mov_b32_e32 v85, %[litv]\n\t" "v_mov_b32_e32 v90, 0\n\t" "v_mov_b32_e32 v91, 0\n\t"
-        "v_mov_b32_e32 v92, 0\n\t" "v_mov_b32_e32 v93, %[ns]\n\t" "v_sub_u32_e32 v94, %[cnt], %[runL]\n\t" "v_mov_b32_e32 v95, %[runsrc]\n\t"
-        "v_mov_b32_e32 v96, %[otot]\n\t"
-        "v_add_u32_e32 v79, 32, v94\n\t"
-        "v_min_u32_e32 v79, v79, %[room]\n\t"
-        "v_cmp_ge_u32_e32 vcc, v84, %[room]\n\t"               /* no room at all */
-        "s_cbranch_vccnz L_out_%=\n\t"
-        "v_cmp_lt_u32_e32 vcc, 63, v93\n\t"
-        "s_cbranch_vccnz L_out_%=\n\t"
+        "s_mov_b32 %[code], 0\n\t"
+        "s_mov_b32 %[flen], 0\n\t"
+        "s_mov_b32 %[fdist], 0\n\t"
+        "s_sub_u32 %[rb], %[cnt], %[runL]\n\t"
+        "s_sub_u32 %[otot], %[otot], %[cnt]\n\t"               /* otot - cnt only changes at matches */
+        "s_add_u32 %[lim], %[rb], 32\n\t"
+        "s_min_u32 %[lim], %[lim], %[room]\n\t"
         "L_top_%=:\n\t"
-        INF_REFILL("L_h1_%=", "L_out_%=")                      /* staged bytes ran out between symbols: status 0 */
-        "v_and_b32_e32 v86, 0x1ff, v80\n\t"
-        "v_lshl_add_u32 v86, v86, 1, %[lutL]\n\t"
-        "ds_read_u16 v88, v86\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_and_b32_e32 v86, 15, v88\n\t"
-        "v_cmp_lt_u32_e32 vcc, 0x7fff, v88\n\t"
-        "s_cbranch_vccnz L_nonlit_%=\n\t"
-        INF_CONSUME
-        "v_lshrrev_b32_e32 v87, 4, v88\n\t"
-        "L_lit_%=:\n\t"                                        /* a literal: v87, its bits are consumed */
-        "v_cmp_eq_u32_e32 vcc, %[lane], v84\n\t"
-        "v_cndmask_b32_e32 v85, v85, v87, vcc\n\t"
-        "v_add_u32_e32 v84, 1, v84\n\t"
-        "v_cmp_ne_u32_e32 vcc, v84, v79\n\t"
-        "s_cbranch_vccnz L_top_%=\n\t"
-        "v_cmp_ge_u32_e32 vcc, v84, %[room]\n\t"               /* out of room (checked before the 32-literal rule: the caller books it) */
-        "s_cbranch_vccnz L_out_%=\n\t"
-        "v_mov_b32_e32 v90, 0\n\t"                             /* 32 literals in a row: a run without a match */
-        "v_mov_b32_e32 v91, 0\n\t"
-        INF_POST("L_out_%=")
-        "s_branch L_top_%=\n\t"
-        "L_nonlit_%=:\n\t"
-        "v_cmp_eq_u32_e32 vcc, 0, v86\n\t"
-        "s_cbranch_vccnz L_llong_%=\n\t"
-        "v_bfe_u32 v87, v88, 4, 11\n\t"
-        "L_nl2_%=:\n\t"                                        /* a symbol >= 256 in v87, code length v86, nothing consumed yet */
-        "v_cmp_eq_u32_e32 vcc, 0x100, v87\n\t"
-        "s_cbranch_vccnz L_eob_%=\n\t"
-        "v_subrev_u32_e32 v87, 0x101, v87\n\t"
-        "v_cmp_lt_u32_e32 vcc, 28, v87\n\t"
-        "s_cbranch_vccnz L_slow_%=\n\t"
-        INF_CONSUME
-        "v_lshl_add_u32 v87, v87, 2, %[ltab]\n\t"
-        "ds_read_b32 v89, v87\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_lshrrev_b32_e32 v86, 16, v89\n\t"
-        "v_and_b32_e32 v89, 0xffff, v89\n\t"
-        "v_bfm_b32 v87, v86, 0\n\t"
-        "v_and_b32_e32 v87, v87, v80\n\t"
-        "v_add_u32_e32 v90, v89, v87\n\t"
-        INF_CONSUME
-        INF_REFILL("L_h2_%=", "L_dslow_%=")                    /* ... behind a decoded length: the caller restages and decodes the distance */
-        "v_and_b32_e32 v86, 0xff, v80\n\t"
-        "v_lshl_add_u32 v86, v86, 1, %[lutD]\n\t"
-        "ds_read_u16 v88, v86\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_and_b32_e32 v86, 15, v88\n\t"
-        "v_cmp_eq_u32_e32 vcc, 0, v86\n\t"
-        "s_cbranch_vccnz L_dlong_%=\n\t"
-        "v_bfe_u32 v87, v88, 4, 11\n\t"
-        "L_d2_%=:\n\t"                                         /* a distance symbol in v87, code length v86, not consumed yet */
-        "v_cmp_lt_u32_e32 vcc, 29, v87\n\t"
-        "s_cbranch_vccnz L_dslow_%=\n\t"
-        INF_CONSUME
-        "v_lshl_add_u32 v87, v87, 2, %[dtab]\n\t"
-        "ds_read_b32 v89, v87\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_lshrrev_b32_e32 v86, 16, v89\n\t"
-        "v_and_b32_e32 v89, 0xffff, v89\n\t"
-        "v_bfm_b32 v87, v86, 0\n\t"
-        "v_and_b32_e32 v87, v87, v80\n\t"
-        "v_add_u32_e32 v91, v89, v87\n\t"
-        INF_CONSUME
-        "v_add_u32_e32 v97, v96, v84\n\t"                      /* output so far */
-        "v_cmp_gt_u32_e32 vcc, v91, v97\n\t"                   /* distance beyond it */
-        "s_cbranch_vccnz L_bad_%=\n\t"
-        "v_cmp_lt_u32_e32 vcc, 0x8000, v91\n\t"
-        "s_cbranch_vccnz L_bad_%=\n\t"
-        "v_cmp_lt_u32_e32 vcc, 64, v90\n\t"
-        "s_cbranch_vccnz L_long_%=\n\t"
-        "v_add_u32_e32 v96, v96, v90\n\t"
-        INF_POST("L_out_%=")
-        "s_branch L_top_%=\n\t"
-        "L_llong_%=:\n\t"
-        INF_CANON("%[tabb]", "%[symLb]", "10", "l", "L_slow_%=")
-        "v_cmp_lt_u32_e32 vcc, 0xff, v87\n\t"
-        "s_cbranch_vccnz L_nl2_%=\n\t"
-        INF_CONSUME
-        "s_branch L_lit_%=\n\t"
-        "L_dlong_%=:\n\t"
-        INF_CANON("%[tabd]", "%[symDb]", "9", "d", "L_dslow_%=")
-        "s_branch L_d2_%=\n\t"
+        "s_cmp_gt_u32 %[pos], 63\n\t"
+        "s_cbranch_scc1 L_out_%=\n\t"
+        "v_readlane_b32 %[e], %[pkL], %[pos]\n\t"
+        "s_bitcmp1_b32 %[e], 9\n\t"
+        "s_cbranch_scc0 L_spec_%=\n\t"
+        "s_and_b32 %[a], %[e], 15\n\t"
+        "s_bitcmp1_b32 %[e], 8\n\t"
+        "s_cbranch_scc1 L_len_%=\n\t"
+        /* a literal */
+        "s_lshr_b32 %[b], %[e], 16\n\t"
+        "s_mov_b32 m0, %[cnt]\n\t"
+        "v_writelane_b32 %[litv], %[b], m0\n\t"
+        "s_add_u32 %[cnt], %[cnt], 1\n\t"
+        "s_add_u32 %[pos], %[pos], %[a]\n\t"
+        "s_cmp_lt_u32 %[cnt], %[lim]\n\t"
+        "s_cbranch_scc1 L_top_%=\n\t"
+        "s_cmp_lt_u32 %[cnt], %[room]\n\t"                     /* the literal register / buffer is full: leave */
+        "s_cbranch_scc0 L_lim_%=\n\t"
+        "s_sub_u32 %[b], %[cnt], %[rb]\n\t"                    /* 32 literals in a row: a run without a match */
+        "s_mov_b32 m0, %[ns]\n\t"
+        "v_writelane_b32 %[dw0], %[runsrc], m0\n\t"
+        "v_writelane_b32 %[dw1], %[b], m0\n\t"
+        "s_add_u32 %[ns], %[ns], 1\n\t"
+        "s_mov_b32 %[rb], %[cnt]\n\t"
+        "s_add_u32 %[runsrc], %[litn], %[cnt]\n\t"
+        "s_add_u32 %[lim], %[rb], 32\n\t"
+        "s_min_u32 %[lim], %[lim], %[room]\n\t"
+        "s_cmp_lt_u32 %[ns], 64\n\t"
+        "s_cbranch_scc1 L_top_%=\n\t"
+        "L_lim_%=:\n\t"
+        "s_mov_b32 %[code], 5\n\t"
+        "s_branch L_out_%=\n\t"
+        /* a length: its distance symbol was decoded by the lane where it starts */
+        "L_len_%=:\n\t"
+        "s_add_u32 %[a], %[pos], %[a]\n\t"
+        "s_cmp_gt_u32 %[a], 63\n\t"
+        "s_cbranch_scc1 L_out_%=\n\t"                          /* ... in the next window */
+        "v_readlane_b32 %[d], %[pkD], %[a]\n\t"
+        "s_bitcmp1_b32 %[d], 24\n\t"
+        "s_cbranch_scc0 L_slow_%=\n\t"
+        "s_and_b32 %[b], %[d], 0xffff\n\t"
+        "s_add_u32 %[code], %[otot], %[cnt]\n\t"               /* output so far */
+        "s_min_u32 %[code], %[code], 0x8000\n\t"
+        "s_cmp_gt_u32 %[b], %[code]\n\t"
+        "s_mov_b32 %[code], 0\n\t"
+        "s_cbranch_scc1 L_bad_%=\n\t"
+        "s_bfe_u32 %[d], %[d], 0x80010\n\t"
+        "s_add_u32 %[pos], %[a], %[d]\n\t"
+        "s_lshr_b32 %[e], %[e], 16\n\t"
+        "s_cmp_gt_u32 %[e], 64\n\t"
+        "s_cbranch_scc1 L_long_%=\n\t"
+        "s_add_u32 %[otot], %[otot], %[e]\n\t"
+        "s_sub_u32 %[d], %[cnt], %[rb]\n\t"                    /* the open run's length */
+        "s_lshl_b32 %[e], %[e], 8\n\t"
+        "s_or_b32 %[d], %[d], %[e]\n\t"
+        "s_lshl_b32 %[e], %[b], 16\n\t"
+        "s_or_b32 %[d], %[d], %[e]\n\t"
+        "s_mov_b32 m0, %[ns]\n\t"
+        "v_writelane_b32 %[dw0], %[runsrc], m0\n\t"
+        "v_writelane_b32 %[dw1], %[d], m0\n\t"
+        "s_add_u32 %[ns], %[ns], 1\n\t"
+        "s_mov_b32 %[rb], %[cnt]\n\t"
+        "s_add_u32 %[runsrc], %[litn], %[cnt]\n\t"
+        "s_add_u32 %[lim], %[rb], 32\n\t"
+        "s_min_u32 %[lim], %[lim], %[room]\n\t"
+        "s_cmp_lt_u32 %[ns], 64\n\t"
+        "s_cbranch_scc1 L_top_%=\n\t"
+        "s_mov_b32 %[code], 5\n\t"
+        "s_branch L_out_%=\n\t"
         "L_long_%=:\n\t"
-        "v_mov_b32_e32 v92, 1\n\t"
+        "s_mov_b32 %[flen], %[e]\n\t"
+        "s_mov_b32 %[fdist], %[b]\n\t"
+        "s_mov_b32 %[code], 1\n\t"
         "s_branch L_out_%=\n\t"
         "L_bad_%=:\n\t"
-        "v_mov_b32_e32 v92, 4\n\t"
+        "s_mov_b32 %[code], 4\n\t"
         "s_branch L_out_%=\n\t"
-        "L_eob_%=:\n\t"
-        INF_CONSUME
-        "v_mov_b32_e32 v92, 2\n\t"
+        "L_spec_%=:\n\t"
+        "s_bfe_u32 %[a], %[e], 0x3000a\n\t"
+        "s_cmp_eq_u32 %[a], 1\n\t"
+        "s_cbranch_scc0 L_slow_%=\n\t"
+        "s_and_b32 %[a], %[e], 15\n\t"                         /* end of block */
+        "s_add_u32 %[pos], %[pos], %[a]\n\t"
+        "s_mov_b32 %[code], 2\n\t"
         "s_branch L_out_%=\n\t"
         "L_slow_%=:\n\t"
-        "v_mov_b32_e32 v92, 3\n\t"
-        "s_branch L_out_%=\n\t"
-        "L_dslow_%=:\n\t"
-        "v_mov_b32_e32 v92, 5\n\t"
+        "s_mov_b32 %[code], 3\n\t"
         "L_out_%=:\n\t"
-        "v_mov_b32_e32 %[lo], v80\n\t" "v_mov_b32_e32 %[hi], v81\n\t" "v_mov_b32_e32 %[bc], v82\n\t" "v_mov_b32_e32 %[off], v83\n\t"
-        "v_sub_u32_e32 %[runL], v84, v94\n\t" "v_add_u32_e32 %[otot], v96, v84\n\t"
-        "v_mov_b32_e32 %[cnt], v84\n\t" "v_mov_b32_e32 %[litv], v85\n\t" "v_mov_b32_e32 %[len], v90\n\t" "v_mov_b32_e32 %[dist], v91\n\t"
-        "v_mov_b32_e32 %[status], v92\n\t" "v_mov_b32_e32 %[ns], v93\n\t" "v_mov_b32_e32 %[runsrc], v95\n\t"
-        : [lo] "+v"(lo), [hi] "+v"(hi), [bc] "+v"(bc), [off] "+v"(off), [cnt] "+v"(cnt), [litv] "+v"(litv),
-          [ns] "+v"(ns), [runL] "+v"(runL), [runsrc] "+v"(runsrc), [otot] "+v"(otot),
-          [len] "=&v"(len), [dist] "=&v"(dist), [status] "=&v"(status)
-        : [room] "v"(room), [lim] "v"(lim), [lane] "v"(lane), [litn0] "v"(litn0), [cb] "v"(cb), [lutL] "v"(lutL), [lutD] "v"(lutD),
-          [ltab] "v"(ltab), [dtab] "v"(dtab), [descb] "v"(descb), [tabb] "v"(tabb), [tabd] "v"(tabb + 128u), [symLb] "v"(symLb), [symDb] "v"(symDb)
-        : "vcc", "memory", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94",
-          "v95", "v96", "v97", "v98", "v99", "s90", "s91");
-#undef INF_REFILL
-#undef INF_CONSUME
-#undef INF_POST
-#undef INF_CANON
+        "s_sub_u32 %[runL], %[cnt], %[rb]\n\t"
+        "s_add_u32 %[otot], %[otot], %[cnt]\n\t"
+        : [code] "=&s"(code), [e] "=&s"(e), [d] "=&s"(d), [a] "=&s"(a), [b] "=&s"(b), [lim] "=&s"(lim), [rb] "=&s"(rb),
+          [pos] "+s"(pos), [cnt] "+s"(cnt), [ns] "+s"(ns), [runL] "+s"(runL), [otot] "+s"(otot), [runsrc] "+s"(runsrc),
+          [litv] "+v"(litv), [dw0] "+v"(dw0), [dw1] "+v"(dw1), [flen] "=&s"(flen), [fdist] "=&s"(fdist)
+        : [pkL] "v"(pkL), [pkD] "v"(pkD), [litn] "s"(litn), [room] "s"(room)
+        : "scc", "m0");
+    return code;
 }
-#define RCX_LDSADDR(p) rcx_vgpr((uint32_t)(uintptr_t)(p))     // low half of a generic LDS pointer = the LDS byte address
-#define RCX_INF_RUN_CALL(lo, hi, bc, off, cnt, litv, len, dist, st, ns, runL, runsrc, otot, room, lim, lane, litn0, cb, lutL, lutD, ltab, dtab, desc, tab, symL, symD) \
-    rcx_inf_run(lo, hi, bc, off, cnt, litv, len, dist, st, ns, runL, runsrc, otot, room, lim, lane, litn0, RCX_LDSADDR(cb), RCX_LDSADDR(lutL),    \
-                RCX_LDSADDR(lutD), RCX_LDSADDR(ltab), RCX_LDSADDR(dtab), RCX_LDSADDR(desc), RCX_LDSADDR(tab), RCX_LDSADDR(symL), RCX_LDSADDR(symD))
+#define RCX_INF_WALK rcx_inf_walk
 #endif
 
 template <int CB>
@@ -250,7 +163,6 @@ struct Inf3 : Lz4V5<CB, 1536, 1024> {
     uint8_t* lens;                            // [0, 320): lit/len + distance code lengths, [320, 352): code-length code
     uint32_t* tab;                            // [0..16) lim L, [16..32) base L, [32..48) lim D, [48..64) base D, [64..80) histogram
     uint8_t* litbuf; uint32_t* desc;
-    uint32_t* ltab;                           // [0..29) length symbols, [32..62) distance symbols: base | extra_bits << 16
     // bit reader and batch state (wave uniform)
     uint64_t bb; uint32_t bc, p;
     uint32_t otot; int ns; uint32_t litn, runL, runsrc;
@@ -281,13 +193,17 @@ struct Inf3 : Lz4V5<CB, 1536, 1024> {
     // HuffmanTree::construct (flate.rs:83-120) for nsym code lengths at L: 9-bit lookup table (entry = sym << 4 | len,
     // bit 15 set for everything that is not a literal; 0x8000 = no code of <= 9 bits starts like this), symbols in canonical order, limits/bases for the longer codes.
     // Returns 0, 1 (over-subscribed) or 2 (no code at all).
-    __device__ __forceinline__ int build(const uint8_t* L, uint32_t nsym, uint16_t* lut, uint32_t lutbits, uint16_t* symtab, uint32_t* lim, uint32_t* base)
+    // `fused` (the lit/len table): entries are what Inf3::pass wants in one read --
+    //   literal       0x0000 | value << 4 | code bits
+    //   length        0x8000 | (base - 3) << 7 | extra bit count << 4 | code bits + extra bits      (EXTRALENS / EXTRABITS, flate.rs:265-273)
+    //   end of block  0x1000 | code bits;   no code of <= 9 bits starts like this: 0x2000;   symbols 286 / 287: 0x3000 | code bits
+    __device__ __forceinline__ int build(const uint8_t* L, uint32_t nsym, uint16_t* lut, uint32_t lutbits, uint16_t* symtab, uint32_t* lim, uint32_t* base, bool fused)
     {
         const uint32_t lutn = 1u << lutbits;
         const unsigned lane = this->lane;
         uint32_t* hist = tab + 64;
         if (lane < 16) hist[lane] = 0;
-        for (uint32_t j = lane; j < lutn / 2; j += 64) ((uint32_t*)lut)[j] = 0x80008000u;   // "no short code" (bit 15, length 0)
+        for (uint32_t j = lane; j < lutn / 2; j += 64) ((uint32_t*)lut)[j] = fused ? 0x20002000u : 0x80008000u;   // "no short code"
         rcx_wave_sync();
         for (uint32_t c0 = 0; c0 < nsym; c0 += 64) {
             const uint32_t s = c0 + lane;
@@ -325,7 +241,13 @@ struct Inf3 : Lz4V5<CB, 1536, 1024> {
                 if (l <= lutbits) {
                     const uint32_t cd = pos - base[l];                          // first[l] + rank
                     const uint32_t r = __brev(cd) >> (32u - l);
-                    const uint16_t e = (uint16_t)((s << 4) | l | (s >= 256u ? 0x8000u : 0u));
+                    uint32_t e32 = (s << 4) | l | (s >= 256u ? 0x8000u : 0u);
+                    if (fused && s >= 256u) {
+                        const uint32_t nn = s - 257u, lb = nn < 8u ? 0u : (nn == 28u ? 0u : (nn - 4u) >> 2);
+                        const uint32_t lbase = nn < 8u ? 3u + nn : (nn == 28u ? 258u : 3u + ((4u + (nn & 3u)) << lb));
+                        e32 = s == 256u ? (0x1000u | l) : s > 285u ? (0x3000u | l) : (0x8000u | ((lbase - 3u) << 7) | (lb << 4) | (l + lb));
+                    }
+                    const uint16_t e = (uint16_t)e32;
                     for (uint32_t k = r; k < lutn; k += 1u << l) lut[k] = e;
                 }
             }
@@ -360,6 +282,105 @@ struct Inf3 : Lz4V5<CB, 1536, 1024> {
         runL = 0; runsrc = litn;
     }
 
+    // One lit/len symbol on the general path (any code length).  kind 0: literal `val`; 1: end of block; 2: length `val`
+    // (its extra bits consumed).  false: no code, or symbol 286 / 287 (the caller falls back).  The caller keeps >= 33 bits.
+    __device__ __forceinline__ bool decode_ll(uint32_t& kind, uint32_t& val)
+    {
+        const uint32_t e = RCX_U(lutL[(uint32_t)bb & (uint32_t)(LUTN - 1)]);
+        if (e & 0x8000u) {
+            const uint32_t tot = e & 15u, xb = (e >> 4) & 7u;
+            kind = 2; val = ((e >> 7) & 0xffu) + 3u + (((uint32_t)bb >> (tot - xb)) & ((1u << xb) - 1u));
+            bb >>= tot; bc -= tot;
+            return true;
+        }
+        const uint32_t sp = e >> 12;
+        if (sp == 0u) { kind = 0; val = e >> 4; bb >>= (e & 15u); bc -= (e & 15u); return true; }
+        if (sp == 1u) { kind = 1; val = 0; bb >>= (e & 15u); bc -= (e & 15u); return true; }
+        if (sp == 3u) return false;
+        const uint32_t rev = __brev((uint32_t)bb) >> 17;
+        uint32_t sym = 0;
+        bool ok = false;
+#pragma unroll 1
+        for (uint32_t l = LUTBITS + 1; l <= 15 && !ok; l++) {
+            if (rev < RCX_U(tab[l])) {
+                sym = RCX_U(symL[(rev >> (15u - l)) + RCX_U(tab[16 + l])]);
+                bb >>= l; bc -= l;
+                ok = true;
+            }
+        }
+        if (!ok) return false;
+        if (sym < 256u) { kind = 0; val = sym; return true; }
+        if (sym == 256u) { kind = 1; val = 0; return true; }
+        const uint32_t nn = sym - 257u;
+        if (nn >= 29u) return false;                                   // :294-297 (errors and the off-by-one)
+        const uint32_t lb = nn < 8 ? 0u : (nn == 28 ? 0u : (nn - 4u) >> 2);         // EXTRALENS/EXTRABITS, :265-273
+        const uint32_t lbase = nn < 8 ? 3u + nn : (nn == 28 ? 258u : 3u + ((4u + (nn & 3u)) << lb));
+        kind = 2; val = lbase + bits(lb);
+        return true;
+    }
+
+    // register-resident twin of post(): descriptor `ns` goes to lane ns of (dw0, dw1)
+    __device__ __forceinline__ void post_reg(uint32_t& dw0, uint32_t& dw1, uint32_t L, uint32_t M, uint32_t dist, uint32_t cnt)
+    {
+        if ((int)this->lane == ns) { dw0 = runsrc; dw1 = L | (M << 8) | (dist << 16); }      // v_cmp + 2 v_cndmask
+        ns = (int)RCX_U(ns + 1);
+        runL = 0; runsrc = RCX_U(litn + cnt);
+    }
+
+    // The symbol pass (Decoder::codes, flate.rs:262-341, for symbols with table-length codes).  Decodes and BOOKS symbols
+    // until something needs the caller:
+    //   0  limits: the staged bytes, the literal buffer (or 64 literals in this pass) or the 64 descriptors ran out
+    //   1  a match longer than 64 bytes: flen, fdist decoded and consumed, NOT booked (the wave-wide copy path takes it)
+    //   2  end of block (consumed)
+    //   3  the next symbol needs the general path (a code longer than the tables, symbols 286/287/30/31): nothing of it consumed
+    //   4  a distance beyond the output or 32 KiB (the caller falls back)
+    __device__ __forceinline__ uint32_t pass(uint32_t& flen, uint32_t& fdist)
+    {
+        const unsigned lane = this->lane;
+        uint32_t bp = RCX_U(8u * (uint32_t)((int32_t)p - this->cbase) - bc);       // the next unread bit, relative to cbuf[0]
+        const uint32_t a1 = (uint32_t)LITCAP - litn;
+        const uint32_t room = a1 < 64u ? a1 : 64u;
+        const int ns0 = ns;
+        uint32_t cnt = 0, litv = 0, dw0 = 0, dw1 = 0, status = 0;
+        flen = 0; fdist = 0;
+        if (room && ns < 64)
+            for (;;) {
+                if ((bp >> 3) + 16u > (uint32_t)CB) break;                             // restage
+                // ---- every lane: the symbol that would start at bit bp + lane
+                const uint32_t bl = bp + lane, ba = (bl >> 3) & ~3u;
+                const uint32_t wlo = *(const uint32_t*)(this->cbuf + ba), whi = *(const uint32_t*)(this->cbuf + ba + 4);
+                const uint32_t sh = (uint32_t)((((uint64_t)whi << 32) | wlo) >> (bl & 31u));
+                const uint32_t eL = lutL[sh & (uint32_t)(LUTN - 1)], eD = lutD[sh & (uint32_t)(DLUTN - 1)];
+                const uint32_t isLen = eL >> 15, sp = isLen ? 0u : (eL >> 12) & 7u;
+                const uint32_t tot = eL & 15u, xb = (eL >> 4) & 7u;
+                const uint32_t lenv = ((eL >> 7) & 0xffu) + 3u + ((sh >> (tot - xb)) & ((1u << xb) - 1u));
+                const uint32_t pkL = tot | (isLen << 8) | ((sp == 0u ? 1u : 0u) << 9) | (sp << 10) | ((isLen ? lenv : (eL >> 4) & 0xffu) << 16);
+                const uint32_t nbD = eD & 15u, dsy = (eD >> 4) & 0x7ffu;
+                const uint32_t xbD = dsy < 4u ? 0u : (dsy >> 1) - 1u;                 // EXTRADIST / EXTRADBITS (flate.rs:275-284), closed form
+                const uint32_t dbase = dsy < 4u ? dsy + 1u : ((2u + (dsy & 1u)) << (xbD & 15u)) + 1u;
+                const uint32_t okD = (nbD != 0u && dsy < 30u) ? 1u : 0u;
+                const uint32_t distv = dbase + ((sh >> nbD) & ((1u << (xbD & 15u)) - 1u));
+                const uint32_t pkD = (distv & 0xffffu) | ((nbD + xbD) << 16) | (okD << 24);
+                // ---- the walk: wave-uniform, from symbol to symbol
+                uint32_t pos = 0, ucnt = RCX_U(cnt), uns = RCX_U((uint32_t)ns), urunL = RCX_U(runL), uotot = RCX_U(otot), ursrc = RCX_U(runsrc);
+                const uint32_t why = RCX_INF_WALK(pkL, pkD, pos, ucnt, uns, urunL, uotot, ursrc, RCX_U(litn), RCX_U(room), litv, dw0, dw1, flen, fdist);
+                cnt = ucnt; ns = (int)uns; runL = urunL; otot = uotot; runsrc = ursrc;
+                const bool leave = why != 0u;
+                if (why == 5u) status = 0; else if (why) status = why;
+                bp = RCX_U(bp + pos);
+                if (leave) break;
+            }
+        if (cnt) if (lane < cnt) litbuf[litn + lane] = (uint8_t)litv;
+        if (ns > ns0) if ((int)lane >= ns0 && (int)lane < ns) { desc[2 * lane] = dw0; desc[2 * lane + 1] = dw1; }
+        litn = RCX_U(litn + cnt);
+        // the bit reader resumes at bit bp
+        const uint32_t pa = (bp >> 3) & ~3u, drop = bp - 8u * pa;
+        p = (uint32_t)(this->cbase + (int32_t)pa); bb = 0; bc = 0;
+        refill();
+        bb >>= drop; bc -= drop;
+        return status;
+    }
+
     // Decoder::block to BFINAL (flate.rs:195-206) after an optional zlib header (zlib.rs:55-86): the engine loop
     __device__ void run(int zlib, int32_t* st_out, uint32_t* len_out, uint32_t* used_out, uint32_t* flags_out)
     {
@@ -367,15 +388,6 @@ struct Inf3 : Lz4V5<CB, 1536, 1024> {
         const unsigned lane = this->lane;
         this->init_window();
         otot = 0; ns = 0; litn = 0; runL = 0; runsrc = 0; bb = 0; bc = 0; p = 0;
-        if (lane < 29) {                                               // EXTRALENS/EXTRABITS (:265-273), closed form
-            const uint32_t nn = lane, lb = nn < 8 ? 0u : (nn == 28 ? 0u : (nn - 4u) >> 2);
-            ltab[lane] = (nn < 8 ? 3u + nn : (nn == 28 ? 258u : 3u + ((4u + (nn & 3u)) << lb))) | (lb << 16);
-        }
-        if (lane < 30) {                                               // EXTRADIST/EXTRADBITS (:275-284)
-            const uint32_t d = lane, db = d < 4 ? 0u : (d - 2u) >> 1;
-            ltab[32 + lane] = (d < 4 ? 1u + d : 1u + ((2u + (d & 1u)) << db)) | (db << 16);
-        }
-        rcx_wave_sync();
         uint32_t* const limL = tab; uint32_t* const baseL = tab + 16; uint32_t* const limD = tab + 32; uint32_t* const baseD = tab + 48;
         int st = 0;
         uint32_t flags = 0;
@@ -385,7 +397,7 @@ struct Inf3 : Lz4V5<CB, 1536, 1024> {
         uint32_t stage_at = 0;
         uint32_t pend_why = 0, pend_L = 0, pend_M = 0, pend_off = 0, pend_src = 0, after_pos = 0;
         bool eof = false, stored_hdr = false;
-        uint32_t before = 0, hlit = 0, hdist = 0, ci = 0, bjob = 0, carry_len = 0;
+        uint32_t before = 0, hlit = 0, hdist = 0, ci = 0, bjob = 0;
         if (zlib) {
             if (this->n < 2) st = RCX_ST_FALLBACK;
             else {
@@ -430,7 +442,7 @@ struct Inf3 : Lz4V5<CB, 1536, 1024> {
                     refill();
                     bb >>= 8 * mis; bc -= 8 * mis;
                     realign = false;
-                } else this->stage(p);
+                } else this->stage(p - ((bc + 7u) >> 3));              // from the byte of the next unread bit: pass() reads the bits from the buffer
             }
             if (!staged(16)) { want_stage = true; continue; }          // every step below reads at most 12 bytes
             refill();
@@ -489,7 +501,7 @@ struct Inf3 : Lz4V5<CB, 1536, 1024> {
                     const bool isD = bjob == 0 || j == 1;
                     const uint8_t* Lp = bjob == 0 ? lens + 320 : (j == 0 ? lens : lens + hlit);
                     const uint32_t nsym = bjob == 0 ? 19u : (j == 0 ? hlit : hdist);
-                    const int r = build(Lp, nsym, isD ? lutD : lutL, isD ? (uint32_t)DBITS : (uint32_t)LUTBITS, isD ? symD : symL, isD ? limD : limL, isD ? baseD : baseL);
+                    const int r = build(Lp, nsym, isD ? lutD : lutL, isD ? (uint32_t)DBITS : (uint32_t)LUTBITS, isD ? symD : symL, isD ? limD : limL, isD ? baseD : baseL, !isD);
                     // no distance code at all is fine (:447-448, a block of literals only: its table stays empty);
                     // over-subscribed codes and an empty lit/len or code-length code go to the exact kernel
                     if (r == 1 || (r == 2 && !(bjob == 1 && j == 1))) st = RCX_ST_FALLBACK;
@@ -526,25 +538,9 @@ struct Inf3 : Lz4V5<CB, 1536, 1024> {
                 }
             } else {                                                   // P_SYMBOLS: Decoder::codes, flate.rs:262-341
                 for (;;) {
-                    // The fast path: symbols with short codes are decoded AND booked on the vector ALU by rcx_inf_run
-                    // (literal j of a pass in lane j, sequence descriptors written by the pass); the rest comes back as a status.
-                    uint32_t fs = 5u, flen = carry_len, fdist = 0;
-                    if (carry_len) carry_len = 0;                      // resuming behind a flush / restage with a decoded length
-                    else {
-                        const uint32_t a1 = (uint32_t)LITCAP - litn;
-                        const uint32_t room = RCX_VGPR(a1 < 64u ? a1 : 64u);
-                        uint32_t vlo = RCX_VGPR((uint32_t)bb), vhi = RCX_VGPR((uint32_t)(bb >> 32)), vbc = RCX_VGPR(bc);
-                        uint32_t voff = RCX_VGPR((uint32_t)((int32_t)p - this->cbase)), vcnt = RCX_VGPR(0), litv = 0, vst = 0, vlen = 0, vdist = 0;
-                        uint32_t vns = RCX_VGPR((uint32_t)ns), vrunL = RCX_VGPR(runL), vrunsrc = RCX_VGPR(runsrc), votot = RCX_VGPR(otot);
-                        RCX_INF_RUN_CALL(vlo, vhi, vbc, voff, vcnt, litv, vlen, vdist, vst, vns, vrunL, vrunsrc, votot, room,
-                                         RCX_VGPR((uint32_t)(CB - 8)), RCX_VGPR(lane), RCX_VGPR(litn), this->cbuf, lutL, lutD, ltab, ltab + 32, desc,
-                                         tab, symL, symD);
-                        const uint32_t cnt = RCX_U(vcnt);
-                        fs = RCX_U(vst); flen = RCX_U(vlen); fdist = RCX_U(vdist);
-                        if (cnt) if (lane < cnt) litbuf[litn + lane] = (uint8_t)litv;
-                        litn = RCX_U(litn + cnt); ns = (int)RCX_U(vns); runL = RCX_U(vrunL); runsrc = RCX_U(vrunsrc); otot = RCX_U(votot);
-                        bb = ((uint64_t)RCX_U(vhi) << 32) | RCX_U(vlo); bc = RCX_U(vbc); p = (uint32_t)(this->cbase + (int32_t)RCX_U(voff));
-                    }
+                    // The fast path: symbols with table-length codes are decoded AND booked by pass(); the rest comes back as a status.
+                    uint32_t flen = 0, fdist = 0;
+                    const uint32_t fs = pass(flen, fdist);
                     if (fs == 4u) { st = RCX_ST_FALLBACK; break; }      // :314 distance beyond the output
                     if (fs == 1u) {                                    // a match longer than 64 bytes: flush, then the wave-wide copy
                         otot = RCX_U(otot + flen);
@@ -557,32 +553,27 @@ struct Inf3 : Lz4V5<CB, 1536, 1024> {
                         phase = eof ? P_DONE : P_BLOCK;
                         break;
                     }
-                    if (runL == (uint32_t)B::LCAP) post(runL, 0, 0);
-                    if (fs == 5u && ns >= 64) { carry_len = flen; want_flush = true; break; }   // the decoded length survives the flush
-                    if (fs != 5u && (litn >= (uint32_t)LITCAP || ns >= 64)) { want_flush = true; break; }
+                    if (runL == (uint32_t)B::LCAP) post(runL, 0, 0);     // the pass left (literal register full) on the literal that filled the run
+                    if (litn >= (uint32_t)LITCAP || ns >= 64) { want_flush = true; break; }
                     if (fs == 0u) { if (!staged(16)) { want_stage = true; break; } continue; }   // room or staging ran out
-                    // fs == 3: a long (or no) lit/len code next; fs == 5: flen is decoded, the distance code is long (or none)
-                    if (!staged(16)) { if (fs == 5u) carry_len = flen; want_stage = true; break; }   // the decoded length survives the restage
+                    // fs == 3: one symbol on the general path
+                    if (!staged(16)) { want_stage = true; break; }
                     refill();                                          // >= 33 bits: a code (15) + extra (5) and more
-                    uint32_t sym = 257;
-                    if (fs != 5u && !decode(lutL, LUTBITS, symL, limL, baseL, sym)) { st = RCX_ST_FALLBACK; break; }
-                    if (sym < 256) {                                   // :289
-                        if (lane == 0) litbuf[litn] = (uint8_t)sym;
+                    uint32_t kind = 0, val = 0;
+                    if (!decode_ll(kind, val)) { st = RCX_ST_FALLBACK; break; }
+                    if (kind == 0u) {                                  // :289
+                        if (lane == 0) litbuf[litn] = (uint8_t)val;
                         litn = RCX_U(litn + 1); runL = RCX_U(runL + 1); otot = RCX_U(otot + 1);
                         if (runL == (uint32_t)B::LCAP) post(runL, 0, 0);
                         if (litn >= (uint32_t)LITCAP || ns >= 64) { want_flush = true; break; }
                         continue;
                     }
-                    if (sym == 256) {                                  // :290
+                    if (kind == 1u) {                                  // :290
                         if (otot == before && !eof) flags |= RCX_W_EMPTY_BLOCK_MIDSTREAM;       // :474-476 quirk
                         phase = eof ? P_DONE : P_BLOCK;
                         break;
                     }
-                    const uint32_t nn = sym - 257;
-                    if (nn >= 29) { st = RCX_ST_FALLBACK; break; }     // :294-297 (errors and the off-by-one)
-                    const uint32_t lb = nn < 8 ? 0u : (nn == 28 ? 0u : (nn - 4u) >> 2);         // EXTRALENS/EXTRABITS, :265-273
-                    const uint32_t lbase = nn < 8 ? 3u + nn : (nn == 28 ? 258u : 3u + ((4u + (nn & 3u)) << lb));
-                    const uint32_t len = fs == 5u ? flen : lbase + bits(lb);
+                    const uint32_t len = val;
                     refill();                                          // >= 33 bits: a code (15) + extra (13)
                     uint32_t d = 0;
                     if (!decode(lutD, DBITS, symD, limD, baseD, d) || d >= 30) { st = RCX_ST_FALLBACK; break; }
@@ -634,7 +625,6 @@ __global__ __launch_bounds__(64) void k_inflate3(rcx_kargs a, int zlib)
     __shared__ uint32_t s_tab[80];
     __shared__ __align__(16) uint8_t s_lit[S::LITCAP + 64];
     __shared__ __align__(16) uint32_t s_desc[128];
-    __shared__ uint32_t s_ltab[64];
     const uint32_t b = blockIdx.x;
     if (b >= a.nblocks) return;
     S s;
@@ -644,7 +634,7 @@ __global__ __launch_bounds__(64) void k_inflate3(rcx_kargs a, int zlib)
     s.out = a.out_base + a.out_off[b];
     s.cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;
     s.cbuf = s_cbuf; s.wb_ = s_wbuf; s.epos = nullptr; s.ring = nullptr;
-    s.lutL = s_lutL; s.lutD = s_lutD; s.symL = s_symL; s.symD = s_symD; s.lens = s_lens; s.tab = s_tab; s.litbuf = s_lit; s.desc = s_desc; s.ltab = s_ltab;
+    s.lutL = s_lutL; s.lutD = s_lutD; s.symL = s_symL; s.symD = s_symD; s.lens = s_lens; s.tab = s_tab; s.litbuf = s_lit; s.desc = s_desc;
     int32_t st; uint32_t olen, used, flags;
     s.run(zlib, &st, &olen, &used, &flags);
     if ((threadIdx.x & 63u) == 0) {

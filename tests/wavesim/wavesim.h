@@ -245,64 +245,46 @@ static inline void ws_lds_store16(uint8_t* p, uint32_t v0, uint32_t v1, uint32_t
     for (uint32_t i = 0; i < nv && i < 16; i++) p[i] = (uint8_t)(v[i >> 2] >> (8 * (i & 3)));
 }
 
-// portable version of k_inflate3.hip's hand-written symbol pass (same contract; the product passes LDS addresses, the
-// simulator real pointers)
-static inline void ws_inf_run(uint32_t& lo, uint32_t& hi, uint32_t& bc, uint32_t& off, uint32_t& cnt, uint32_t& litv, uint32_t& len,
-                              uint32_t& dist, uint32_t& status, uint32_t& ns, uint32_t& runL, uint32_t& runsrc, uint32_t& otot,
-                              uint32_t room, uint32_t lim, uint32_t lane, uint32_t litn0, const uint8_t* cb,
-                              const uint16_t* lutL, const uint16_t* lutD, const uint32_t* ltab, const uint32_t* dtab, uint32_t* desc,
-                              const uint32_t* tab, const uint16_t* symL, const uint16_t* symD)
+// portable version of k_inflate3.hip's hand-written window walk (same contract: see rcx_inf_walk there)
+static inline uint32_t ws_inf_walk(uint32_t pkL, uint32_t pkD, uint32_t& pos, uint32_t& cnt, uint32_t& ns, uint32_t& runL, uint32_t& otot,
+                                   uint32_t& runsrc, uint32_t litn, uint32_t room, uint32_t& litv, uint32_t& dw0, uint32_t& dw1,
+                                   uint32_t& flen, uint32_t& fdist)
 {
-    uint64_t bb = ((uint64_t)hi << 32) | lo;
-    auto refill = [&]() -> bool { if (bc <= 32) { if (off > lim) return false; uint64_t w; memcpy(&w, cb + off, 8); bb |= w << bc; bc += 32; off += 4; } return true; };
-    auto post = [&](uint32_t M, uint32_t D) {
-        if (lane == 0) { desc[2 * ns] = runsrc; desc[2 * ns + 1] = runL | (M << 8) | (D << 16); }
-        ns++; runL = 0; runsrc = litn0 + cnt;
+    const uint32_t lane = ws::cur->tid & 63;
+    flen = 0; fdist = 0;
+    auto post = [&](uint32_t L, uint32_t M, uint32_t dist) {
+        if (lane == ns) { dw0 = runsrc; dw1 = L | (M << 8) | (dist << 16); }
+        ns++; runL = 0; runsrc = litn + cnt;
     };
-    auto canon = [&](const uint32_t* limb, const uint16_t* sym, uint32_t l0, uint32_t& s_, uint32_t& l_) {   // limits at limb, bases 16 words on
-        uint32_t r = 0; for (int i = 0; i < 15; i++) r |= (((uint32_t)bb >> i) & 1u) << (14 - i);
-        for (uint32_t l = l0; l <= 15; l++) if (r < limb[l]) { s_ = sym[(r >> (15 - l)) + limb[16 + l]]; l_ = l; return true; }
-        return false;
-    };
-    len = 0; dist = 0; status = 0;
-    if (cnt >= room || ns > 63) { lo = (uint32_t)bb; hi = (uint32_t)(bb >> 32); return; }
     for (;;) {
-        if (!refill()) break;
-        uint32_t e = lutL[bb & 0x1ff], l = e & 15, sym = (e >> 4) & 0x7ff;
-        if (e > 0x7fff && l == 0 && !canon(tab, symL, 10, sym, l)) { status = 3; break; }
-        if (sym < 256) {
-            bb >>= l; bc -= l;
-            if (lane == cnt) litv = sym;
-            cnt++; runL++; otot++;
-            if (cnt >= room) break;
-            if (runL == 32) { post(0, 0); if (ns > 63) break; }
-            continue;
+        if (pos > 63) return 0;
+        const uint32_t e = (uint32_t)ws::shfl((int)pkL, (int)pos);
+        if (!(e & 0x200u)) {
+            if (((e >> 10) & 7u) == 1u) { pos += e & 15u; return 2; }
+            return 3;
         }
-        if (sym == 256) { bb >>= l; bc -= l; status = 2; break; }
-        const uint32_t nn = sym - 257;
-        if (nn > 28) { status = 3; break; }
-        bb >>= l; bc -= l;
-        uint32_t t = ltab[nn], xb = t >> 16;
-        len = (t & 0xffff) + ((uint32_t)bb & ((1u << xb) - 1u)); bb >>= xb; bc -= xb;
-        if (!refill()) { status = 5; break; }
-        e = lutD[bb & 0xff]; l = e & 15;
-        uint32_t d = (e >> 4) & 0x7ff;
-        if (l == 0 && !canon(tab + 32, symD, 9, d, l)) { status = 5; break; }
-        if (d > 29) { status = 5; break; }
-        bb >>= l; bc -= l;
-        t = dtab[d]; xb = t >> 16;
-        dist = (t & 0xffff) + ((uint32_t)bb & ((1u << xb) - 1u)); bb >>= xb; bc -= xb;
-        if (dist > otot || dist > 0x8000u) { status = 4; break; }
-        if (len > 64) { status = 1; break; }
-        otot += len;
-        post(len, dist);
-        len = 0; dist = 0;
-        if (ns > 63) break;
+        if (!(e & 0x100u)) {
+            if (lane == cnt) litv = e >> 16;
+            cnt++; runL++; otot++; pos += e & 15u;
+            if (cnt >= room) return 5;
+            if (runL == 32) { post(32, 0, 0); if (ns >= 64) return 5; }
+        } else {
+            const uint32_t p2 = pos + (e & 15u);
+            if (p2 > 63) return 0;
+            const uint32_t d = (uint32_t)ws::shfl((int)pkD, (int)p2);
+            if (!(d & (1u << 24))) return 3;
+            const uint32_t len = e >> 16, dist = d & 0xffffu;
+            if (dist > otot || dist > 32768u) return 4;
+            pos = p2 + ((d >> 16) & 0xffu);
+            if (len > 64) { flen = len; fdist = dist; return 1; }
+            otot += len;
+            post(runL, len, dist);
+            if (ns >= 64) return 5;
+        }
     }
-    lo = (uint32_t)bb; hi = (uint32_t)(bb >> 32);
 }
 #define RCX_LDS_STORE16 ws_lds_store16
-#define RCX_INF_RUN_CALL ws_inf_run
+#define RCX_INF_WALK ws_inf_walk
 #define RCX_VGPR(x) ((uint32_t)(x))
 #define RCX_ALIGNBYTE(hi, lo, sh) ((uint32_t)(((((uint64_t)(hi)) << 32) | (uint32_t)(lo)) >> (8 * ((sh) & 3u))))
 #define RCX_INV_BALLOT(m) ((((m) >> (threadIdx.x & 63u)) & 1ull) != 0)
