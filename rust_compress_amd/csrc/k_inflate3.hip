@@ -24,42 +24,41 @@
 
 #define RCX_ST_FALLBACK 0x7ff00001           /* internal, never leaves the library */
 
-// The walk over one pre-decoded window (see Inf3::pass).  pkL / pkD: lane j holds the lit/len symbol / the distance symbol that
-// would start at bit j (pkL: bits | isLength << 8 | decodable << 9 | kind << 10 | value << 16; pkD: distance | bits << 16 | ok << 24).
+// The walk over one pre-decoded window (see Inf3::pass).  Lane j of pk1 / pk2 describes the symbol that would start at bit j:
+//   pk1: bits it takes (a length: including its distance symbol) | isLength << 7 | decodable << 8 | kind << 9 | literal << 16
+//   pk2: a length: length << 8 | distance << 16 (the descriptor word less the literal run)
+// `decodable` already says that the whole symbol lies inside the window (so the walk cannot run off it), that its codes were in
+// the tables and that a match is at most 64 bytes long; `kind` says what else a lane is: 0 the window ends here, 1 end of block,
+// 2 the general path must decode this symbol.
 // Starting at window position `pos`, books symbols -- literal j of the pass into lane j of litv, descriptor j into lane j of
 // (dw0, dw1) -- and returns why it stopped:
-//   0 the window is used up (pos = where the next one starts)   1 a match longer than 64 bytes (flen, fdist; consumed, not booked)
-//   2 end of block (consumed)   3 the symbol at pos needs the general path   4 a distance beyond the output or 32 KiB
-//   5 the literal register / buffer (cnt reached room) or the 64 descriptors ran out
+//   0 the window is used up (pos = where the next one starts)   2 end of block (consumed)   3 the symbol at pos needs the general path
+//   4 a distance beyond the output   5 the literal register / buffer (cnt reached room) or the 64 descriptors ran out
 // Hand-written: everything here is wave-uniform, i.e. work for the CU's ONE scalar unit, which all 16 waves share at about one
 // instruction per cycle.  hipcc's version of this loop spends ~80 scalar instructions per symbol (copies between the loop's many
-// exits) and the kernel ran at 34 ms for BASELINE config 3; this one spends 15 per literal and ~30 per match.
+// exits) and the kernel ran at 34 ms for BASELINE config 3; this one spends 6 + 3 branches per literal and 17 + 3 per match.
 // The wave simulator supplies a portable version through this hook.
 #ifndef RCX_INF_WALK
-__device__ __forceinline__ uint32_t rcx_inf_walk(uint32_t pkL, uint32_t pkD, uint32_t& pos, uint32_t& cnt, uint32_t& ns, uint32_t& runL,
+__device__ __forceinline__ uint32_t rcx_inf_walk(uint32_t pk1, uint32_t pk2, uint32_t& pos, uint32_t& cnt, uint32_t& ns, uint32_t& runL,
                                                  uint32_t& otot, uint32_t& runsrc, uint32_t litn, uint32_t room, uint32_t& litv, uint32_t& dw0,
-                                                 uint32_t& dw1, uint32_t& flen, uint32_t& fdist)
+                                                 uint32_t& dw1)
 {
     uint32_t code, e, d, a, b, lim, rb;          // rb: cnt at the start of the open literal run; lim: cnt at which something happens
     asm volatile(
         "s_mov_b32 %[code], 0\n\t"
-        "s_mov_b32 %[flen], 0\n\t"
-        "s_mov_b32 %[fdist], 0\n\t"
         "s_sub_u32 %[rb], %[cnt], %[runL]\n\t"
         "s_sub_u32 %[otot], %[otot], %[cnt]\n\t"               /* otot - cnt only changes at matches */
         "s_add_u32 %[lim], %[rb], 32\n\t"
         "s_min_u32 %[lim], %[lim], %[room]\n\t"
         "L_top_%=:\n\t"
-        "s_cmp_gt_u32 %[pos], 63\n\t"
-        "s_cbranch_scc1 L_out_%=\n\t"
-        "v_readlane_b32 %[e], %[pkL], %[pos]\n\t"
-        "s_bitcmp1_b32 %[e], 9\n\t"
-        "s_cbranch_scc0 L_spec_%=\n\t"
-        "s_and_b32 %[a], %[e], 15\n\t"
+        "v_readlane_b32 %[e], %[pk1], %[pos]\n\t"
         "s_bitcmp1_b32 %[e], 8\n\t"
+        "s_cbranch_scc0 L_stop_%=\n\t"
+        "s_bitcmp1_b32 %[e], 7\n\t"
         "s_cbranch_scc1 L_len_%=\n\t"
         /* a literal */
-        "s_lshr_b32 %[b], %[e], 16\n\t"
+        "s_bfe_u32 %[b], %[e], 0x80010\n\t"
+        "s_and_b32 %[a], %[e], 0x7f\n\t"
         "s_mov_b32 m0, %[cnt]\n\t"
         "v_writelane_b32 %[litv], %[b], m0\n\t"
         "s_add_u32 %[cnt], %[cnt], 1\n\t"
@@ -82,31 +81,19 @@ __device__ __forceinline__ uint32_t rcx_inf_walk(uint32_t pkL, uint32_t pkD, uin
         "L_lim_%=:\n\t"
         "s_mov_b32 %[code], 5\n\t"
         "s_branch L_out_%=\n\t"
-        /* a length: its distance symbol was decoded by the lane where it starts */
+        /* a match of <= 64 bytes */
         "L_len_%=:\n\t"
-        "s_add_u32 %[a], %[pos], %[a]\n\t"
-        "s_cmp_gt_u32 %[a], 63\n\t"
-        "s_cbranch_scc1 L_out_%=\n\t"                          /* ... in the next window */
-        "v_readlane_b32 %[d], %[pkD], %[a]\n\t"
-        "s_bitcmp1_b32 %[d], 24\n\t"
-        "s_cbranch_scc0 L_slow_%=\n\t"
-        "s_and_b32 %[b], %[d], 0xffff\n\t"
-        "s_add_u32 %[code], %[otot], %[cnt]\n\t"               /* output so far */
-        "s_min_u32 %[code], %[code], 0x8000\n\t"
-        "s_cmp_gt_u32 %[b], %[code]\n\t"
-        "s_mov_b32 %[code], 0\n\t"
+        "v_readlane_b32 %[d], %[pk2], %[pos]\n\t"
+        "s_lshr_b32 %[b], %[d], 16\n\t"
+        "s_add_u32 %[a], %[otot], %[cnt]\n\t"                  /* output so far */
+        "s_cmp_gt_u32 %[b], %[a]\n\t"
         "s_cbranch_scc1 L_bad_%=\n\t"
-        "s_bfe_u32 %[d], %[d], 0x80010\n\t"
-        "s_add_u32 %[pos], %[a], %[d]\n\t"
-        "s_lshr_b32 %[e], %[e], 16\n\t"
-        "s_cmp_gt_u32 %[e], 64\n\t"
-        "s_cbranch_scc1 L_long_%=\n\t"
-        "s_add_u32 %[otot], %[otot], %[e]\n\t"
-        "s_sub_u32 %[d], %[cnt], %[rb]\n\t"                    /* the open run's length */
-        "s_lshl_b32 %[e], %[e], 8\n\t"
-        "s_or_b32 %[d], %[d], %[e]\n\t"
-        "s_lshl_b32 %[e], %[b], 16\n\t"
-        "s_or_b32 %[d], %[d], %[e]\n\t"
+        "s_and_b32 %[a], %[e], 0x7f\n\t"
+        "s_add_u32 %[pos], %[pos], %[a]\n\t"
+        "s_bfe_u32 %[b], %[d], 0x80008\n\t"
+        "s_add_u32 %[otot], %[otot], %[b]\n\t"
+        "s_sub_u32 %[b], %[cnt], %[rb]\n\t"                    /* the open run's length */
+        "s_or_b32 %[d], %[d], %[b]\n\t"
         "s_mov_b32 m0, %[ns]\n\t"
         "v_writelane_b32 %[dw0], %[runsrc], m0\n\t"
         "v_writelane_b32 %[dw1], %[d], m0\n\t"
@@ -119,31 +106,27 @@ __device__ __forceinline__ uint32_t rcx_inf_walk(uint32_t pkL, uint32_t pkD, uin
         "s_cbranch_scc1 L_top_%=\n\t"
         "s_mov_b32 %[code], 5\n\t"
         "s_branch L_out_%=\n\t"
-        "L_long_%=:\n\t"
-        "s_mov_b32 %[flen], %[e]\n\t"
-        "s_mov_b32 %[fdist], %[b]\n\t"
-        "s_mov_b32 %[code], 1\n\t"
-        "s_branch L_out_%=\n\t"
         "L_bad_%=:\n\t"
         "s_mov_b32 %[code], 4\n\t"
         "s_branch L_out_%=\n\t"
-        "L_spec_%=:\n\t"
-        "s_bfe_u32 %[a], %[e], 0x3000a\n\t"
-        "s_cmp_eq_u32 %[a], 1\n\t"
-        "s_cbranch_scc0 L_slow_%=\n\t"
-        "s_and_b32 %[a], %[e], 15\n\t"                         /* end of block */
-        "s_add_u32 %[pos], %[pos], %[a]\n\t"
-        "s_mov_b32 %[code], 2\n\t"
-        "s_branch L_out_%=\n\t"
-        "L_slow_%=:\n\t"
+        /* not a plain symbol: the window's end, the end of the block, the general path */
+        "L_stop_%=:\n\t"
+        "s_bfe_u32 %[a], %[e], 0x30009\n\t"
+        "s_cmp_eq_u32 %[a], 0\n\t"
+        "s_cbranch_scc1 L_out_%=\n\t"
         "s_mov_b32 %[code], 3\n\t"
+        "s_cmp_eq_u32 %[a], 1\n\t"
+        "s_cbranch_scc0 L_out_%=\n\t"
+        "s_and_b32 %[b], %[e], 0x7f\n\t"                       /* end of block */
+        "s_add_u32 %[pos], %[pos], %[b]\n\t"
+        "s_mov_b32 %[code], 2\n\t"
         "L_out_%=:\n\t"
         "s_sub_u32 %[runL], %[cnt], %[rb]\n\t"
         "s_add_u32 %[otot], %[otot], %[cnt]\n\t"
         : [code] "=&s"(code), [e] "=&s"(e), [d] "=&s"(d), [a] "=&s"(a), [b] "=&s"(b), [lim] "=&s"(lim), [rb] "=&s"(rb),
           [pos] "+s"(pos), [cnt] "+s"(cnt), [ns] "+s"(ns), [runL] "+s"(runL), [otot] "+s"(otot), [runsrc] "+s"(runsrc),
-          [litv] "+v"(litv), [dw0] "+v"(dw0), [dw1] "+v"(dw1), [flen] "=&s"(flen), [fdist] "=&s"(fdist)
-        : [pkL] "v"(pkL), [pkD] "v"(pkD), [litn] "s"(litn), [room] "s"(room)
+          [litv] "+v"(litv), [dw0] "+v"(dw0), [dw1] "+v"(dw1)
+        : [pk1] "v"(pk1), [pk2] "v"(pk2), [litn] "s"(litn), [room] "s"(room)
         : "scc", "m0");
     return code;
 }
@@ -197,7 +180,7 @@ struct Inf3 : Lz4V5<CB, 1536, 1024> {
     //   literal       0x0000 | value << 4 | code bits
     //   length        0x8000 | (base - 3) << 7 | extra bit count << 4 | code bits + extra bits      (EXTRALENS / EXTRABITS, flate.rs:265-273)
     //   end of block  0x1000 | code bits;   no code of <= 9 bits starts like this: 0x2000;   symbols 286 / 287: 0x3000 | code bits
-    __device__ __forceinline__ int build(const uint8_t* L, uint32_t nsym, uint16_t* lut, uint32_t lutbits, uint16_t* symtab, uint32_t* lim, uint32_t* base, bool fused)
+    __device__ __forceinline__ int build(const uint8_t* L, uint32_t nsym, uint16_t* lut, uint32_t lutbits, uint16_t* symtab, uint32_t* lim, uint32_t* base, bool fused, bool nodist30 = false)
     {
         const uint32_t lutn = 1u << lutbits;
         const unsigned lane = this->lane;
@@ -238,7 +221,7 @@ struct Inf3 : Lz4V5<CB, 1536, 1024> {
             }
             if (l) {
                 symtab[pos] = (uint16_t)s;
-                if (l <= lutbits) {
+                if (l <= lutbits && !(nodist30 && s >= 30u)) {
                     const uint32_t cd = pos - base[l];                          // first[l] + rank
                     const uint32_t r = __brev(cd) >> (32u - l);
                     uint32_t e32 = (s << 4) | l | (s >= 256u ? 0x8000u : 0u);
@@ -339,40 +322,52 @@ struct Inf3 : Lz4V5<CB, 1536, 1024> {
         const unsigned lane = this->lane;
         uint32_t bp = RCX_U(8u * (uint32_t)((int32_t)p - this->cbase) - bc);       // the next unread bit, relative to cbuf[0]
         const uint32_t a1 = (uint32_t)LITCAP - litn;
-        const uint32_t room = a1 < 64u ? a1 : 64u;
-        const int ns0 = ns;
-        uint32_t cnt = 0, litv = 0, dw0 = 0, dw1 = 0, status = 0;
+        const uint32_t room = RCX_U(a1 < 64u ? a1 : 64u);
+        const uint32_t ns0 = RCX_U((uint32_t)ns), litn0 = RCX_U(litn);
+        uint32_t ucnt = 0, uns = ns0, urunL = RCX_U(runL), uotot = RCX_U(otot), ursrc = RCX_U(runsrc);   // wave uniform: SGPRs across the windows
+        uint32_t litv = 0, dw0 = 0, dw1 = 0, status = 0;
         flen = 0; fdist = 0;
-        if (room && ns < 64)
+        const uint32_t l63 = 63u - lane;
+        if (room && uns < 64u)
             for (;;) {
                 if ((bp >> 3) + 16u > (uint32_t)CB) break;                             // restage
-                // ---- every lane: the symbol that would start at bit bp + lane
+                // ---- every lane: the symbol that would start at bit bp + lane.  Flags are computed arithmetically: a compare
+                // writes a lane mask to SGPRs through the same port the walk below lives on.
                 const uint32_t bl = bp + lane, ba = (bl >> 3) & ~3u;
                 const uint32_t wlo = *(const uint32_t*)(this->cbuf + ba), whi = *(const uint32_t*)(this->cbuf + ba + 4);
                 const uint32_t sh = (uint32_t)((((uint64_t)whi << 32) | wlo) >> (bl & 31u));
                 const uint32_t eL = lutL[sh & (uint32_t)(LUTN - 1)], eD = lutD[sh & (uint32_t)(DLUTN - 1)];
-                const uint32_t isLen = eL >> 15, sp = isLen ? 0u : (eL >> 12) & 7u;
+                const uint32_t isLen = eL >> 15;                                       // 0 / 1
+                const uint32_t spm = ((eL >> 12) & 7u) & (isLen - 1u);                 // 0 literal, 1 end of block, 2 long code, 3 symbol 286/287
                 const uint32_t tot = eL & 15u, xb = (eL >> 4) & 7u;
-                const uint32_t lenv = ((eL >> 7) & 0xffu) + 3u + ((sh >> (tot - xb)) & ((1u << xb) - 1u));
-                const uint32_t pkL = tot | (isLen << 8) | ((sp == 0u ? 1u : 0u) << 9) | (sp << 10) | ((isLen ? lenv : (eL >> 4) & 0xffu) << 16);
-                const uint32_t nbD = eD & 15u, dsy = (eD >> 4) & 0x7ffu;
-                const uint32_t xbD = dsy < 4u ? 0u : (dsy >> 1) - 1u;                 // EXTRADIST / EXTRADBITS (flate.rs:275-284), closed form
-                const uint32_t dbase = dsy < 4u ? dsy + 1u : ((2u + (dsy & 1u)) << (xbD & 15u)) + 1u;
-                const uint32_t okD = (nbD != 0u && dsy < 30u) ? 1u : 0u;
-                const uint32_t distv = dbase + ((sh >> nbD) & ((1u << (xbD & 15u)) - 1u));
-                const uint32_t pkD = (distv & 0xffffu) | ((nbD + xbD) << 16) | (okD << 24);
+                const uint32_t lenv = ((eL >> 7) & 0xffu) + 3u + ((sh >> ((tot - xb) & 15u)) & ((1u << xb) - 1u));
+                const uint32_t nbD = eD & 15u, dsy = (eD >> 4) & 31u;                  // the table holds no short code for symbols 30 / 31
+                const int32_t xs = (int32_t)(dsy >> 1) - 1;
+                const uint32_t xbD = (uint32_t)(xs < 0 ? 0 : xs);                      // EXTRADIST / EXTRADBITS (flate.rs:275-284), closed form
+                const uint32_t dbase = ((2u + (dsy & 1u)) << xbD) + 1u - (((dsy - 2u) >> 31) << 1);
+                const uint32_t distv = dbase + ((sh >> nbD) & ((1u << xbD) - 1u));
+                const uint32_t okD = nbD < 1u ? nbD : 1u;
+                // a length's distance symbol was decoded by the lane where it starts
+                const uint32_t dpk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + tot) << 2), (int)(distv | ((nbD + xbD) << 16) | (okD << 24)));
+                const uint32_t hop = tot + (((dpk >> 16) & 0xffu) & (0u - isLen));
+                const uint32_t iw = ((l63 - hop) >> 31) ^ 1u;                          // the whole symbol lies inside the window
+                const uint32_t okLit = (((spm + 7u) >> 3) ^ 1u);
+                const uint32_t okS = okLit ^ ((okLit ^ ((dpk >> 24) & 1u)) & (0u - isLen));          // its codes were in the tables
+                const uint32_t lg = ((64u - lenv) >> 31) & isLen;                      // a match longer than 64 bytes: general path
+                const uint32_t dec = iw & okS & (lg ^ 1u);
+                const uint32_t kbn = (0x2210u >> (spm << 2)) & 3u;                     // what else a lane is: 1 end of block, 2 general path
+                const uint32_t kind = (kbn ^ ((kbn ^ 2u) & (0u - isLen))) & (0u - iw); // 0: the window ends here
+                const uint32_t pk1 = hop | (isLen << 7) | (dec << 8) | (kind << 9) | (((eL >> 4) & 0xffu) << 16);
+                const uint32_t pk2 = ((lenv & 0xffu) << 8) | (dpk << 16);
                 // ---- the walk: wave-uniform, from symbol to symbol
-                uint32_t pos = 0, ucnt = RCX_U(cnt), uns = RCX_U((uint32_t)ns), urunL = RCX_U(runL), uotot = RCX_U(otot), ursrc = RCX_U(runsrc);
-                const uint32_t why = RCX_INF_WALK(pkL, pkD, pos, ucnt, uns, urunL, uotot, ursrc, RCX_U(litn), RCX_U(room), litv, dw0, dw1, flen, fdist);
-                cnt = ucnt; ns = (int)uns; runL = urunL; otot = uotot; runsrc = ursrc;
-                const bool leave = why != 0u;
-                if (why == 5u) status = 0; else if (why) status = why;
-                bp = RCX_U(bp + pos);
-                if (leave) break;
+                uint32_t pos = 0;
+                const uint32_t why = RCX_INF_WALK(pk1, pk2, pos, ucnt, uns, urunL, uotot, ursrc, litn0, room, litv, dw0, dw1);
+                bp += pos;
+                if (why) { status = why == 5u ? 0u : why; break; }
             }
-        if (cnt) if (lane < cnt) litbuf[litn + lane] = (uint8_t)litv;
-        if (ns > ns0) if ((int)lane >= ns0 && (int)lane < ns) { desc[2 * lane] = dw0; desc[2 * lane + 1] = dw1; }
-        litn = RCX_U(litn + cnt);
+        if (ucnt) if (lane < ucnt) litbuf[litn0 + lane] = (uint8_t)litv;
+        if (uns > ns0) if (lane >= ns0 && lane < uns) { desc[2 * lane] = dw0; desc[2 * lane + 1] = dw1; }
+        litn = litn0 + ucnt; ns = (int)uns; runL = urunL; otot = uotot; runsrc = ursrc;
         // the bit reader resumes at bit bp
         const uint32_t pa = (bp >> 3) & ~3u, drop = bp - 8u * pa;
         p = (uint32_t)(this->cbase + (int32_t)pa); bb = 0; bc = 0;
@@ -501,7 +496,7 @@ struct Inf3 : Lz4V5<CB, 1536, 1024> {
                     const bool isD = bjob == 0 || j == 1;
                     const uint8_t* Lp = bjob == 0 ? lens + 320 : (j == 0 ? lens : lens + hlit);
                     const uint32_t nsym = bjob == 0 ? 19u : (j == 0 ? hlit : hdist);
-                    const int r = build(Lp, nsym, isD ? lutD : lutL, isD ? (uint32_t)DBITS : (uint32_t)LUTBITS, isD ? symD : symL, isD ? limD : limL, isD ? baseD : baseL, !isD);
+                    const int r = build(Lp, nsym, isD ? lutD : lutL, isD ? (uint32_t)DBITS : (uint32_t)LUTBITS, isD ? symD : symL, isD ? limD : limL, isD ? baseD : baseL, !isD, isD && bjob == 1);
                     // no distance code at all is fine (:447-448, a block of literals only: its table stays empty);
                     // over-subscribed codes and an empty lit/len or code-length code go to the exact kernel
                     if (r == 1 || (r == 2 && !(bjob == 1 && j == 1))) st = RCX_ST_FALLBACK;

@@ -246,39 +246,35 @@ static inline void ws_lds_store16(uint8_t* p, uint32_t v0, uint32_t v1, uint32_t
 }
 
 // portable version of k_inflate3.hip's hand-written window walk (same contract: see rcx_inf_walk there)
-static inline uint32_t ws_inf_walk(uint32_t pkL, uint32_t pkD, uint32_t& pos, uint32_t& cnt, uint32_t& ns, uint32_t& runL, uint32_t& otot,
-                                   uint32_t& runsrc, uint32_t litn, uint32_t room, uint32_t& litv, uint32_t& dw0, uint32_t& dw1,
-                                   uint32_t& flen, uint32_t& fdist)
+static inline uint32_t ws_inf_walk(uint32_t pk1, uint32_t pk2, uint32_t& pos, uint32_t& cnt, uint32_t& ns, uint32_t& runL, uint32_t& otot,
+                                   uint32_t& runsrc, uint32_t litn, uint32_t room, uint32_t& litv, uint32_t& dw0, uint32_t& dw1)
 {
     const uint32_t lane = ws::cur->tid & 63;
-    flen = 0; fdist = 0;
-    auto post = [&](uint32_t L, uint32_t M, uint32_t dist) {
-        if (lane == ns) { dw0 = runsrc; dw1 = L | (M << 8) | (dist << 16); }
-        ns++; runL = 0; runsrc = litn + cnt;
-    };
     for (;;) {
-        if (pos > 63) return 0;
-        const uint32_t e = (uint32_t)ws::shfl((int)pkL, (int)pos);
-        if (!(e & 0x200u)) {
-            if (((e >> 10) & 7u) == 1u) { pos += e & 15u; return 2; }
-            return 3;
-        }
+        const uint32_t e = (uint32_t)ws::shfl((int)pk1, (int)pos);
         if (!(e & 0x100u)) {
-            if (lane == cnt) litv = e >> 16;
-            cnt++; runL++; otot++; pos += e & 15u;
+            const uint32_t kind = (e >> 9) & 7u;
+            if (kind == 0) return 0;
+            if (kind != 1) return 3;
+            pos += e & 0x7fu;
+            return 2;
+        }
+        if (!(e & 0x80u)) {
+            if (lane == cnt) litv = (e >> 16) & 0xffu;
+            cnt++; runL++; otot++; pos += e & 0x7fu;
             if (cnt >= room) return 5;
-            if (runL == 32) { post(32, 0, 0); if (ns >= 64) return 5; }
+            if (runL == 32) {
+                if (lane == ns) { dw0 = runsrc; dw1 = 32; }
+                ns++; runL = 0; runsrc = litn + cnt;
+                if (ns >= 64) return 5;
+            }
         } else {
-            const uint32_t p2 = pos + (e & 15u);
-            if (p2 > 63) return 0;
-            const uint32_t d = (uint32_t)ws::shfl((int)pkD, (int)p2);
-            if (!(d & (1u << 24))) return 3;
-            const uint32_t len = e >> 16, dist = d & 0xffffu;
-            if (dist > otot || dist > 32768u) return 4;
-            pos = p2 + ((d >> 16) & 0xffu);
-            if (len > 64) { flen = len; fdist = dist; return 1; }
-            otot += len;
-            post(runL, len, dist);
+            const uint32_t d = (uint32_t)ws::shfl((int)pk2, (int)pos);
+            if ((d >> 16) > otot) return 4;
+            pos += e & 0x7fu;
+            otot += (d >> 8) & 0xffu;
+            if (lane == ns) { dw0 = runsrc; dw1 = d | runL; }
+            ns++; runL = 0; runsrc = litn + cnt;
             if (ns >= 64) return 5;
         }
     }
