@@ -1,0 +1,124 @@
+//! BWT stream codecs and block functions (reference: src/bwt/mod.rs).
+pub mod dc;
+pub mod mtf;
+
+use crate::rcx_sys::*;
+use crate::{eof_error, le32, run_batch, Buffered, TailReader};
+use std::io::{self, Read, Write};
+
+/// bwt/mod.rs:214-219 -> (L, origin)
+pub fn encode_simple(input: &[u8]) -> (Vec<u8>, usize) {
+    let r = run_batch(&[input], &[input.len() as u64], |c, b, o| unsafe { rcx_bwt_forward_batch(c, b, o) }).check().unwrap();
+    (r.out[0].clone(), r.aux[0] as usize)
+}
+
+/// bwt/mod.rs:291-294
+pub fn decode_simple(input: &[u8], origin: usize) -> Vec<u8> {
+    if input.is_empty() {
+        return Vec::new();
+    }
+    let og = [origin as u32];
+    let r = run_batch(&[input], &[input.len() as u64], |c, b, _| unsafe { rcx_bwt_inverse_batch(c, b, og.as_ptr()) }).check().unwrap();
+    r.out[0].clone()
+}
+
+/// bwt/mod.rs:437-518: `u32 LE block_size`, then per block `u32 LE n`, n bytes of L, `u32 LE origin`.
+pub struct Encoder<W: Write> {
+    w: W,
+    buf: Vec<u8>,
+    block_size: usize,
+    wrote_header: bool,
+}
+
+impl<W: Write> Encoder<W> {
+    pub fn new(w: W, block_size: usize) -> Encoder<W> {
+        Encoder { w, buf: Vec::new(), block_size, wrote_header: false }
+    }
+    /// :485-489.  ONE batch call for all blocks of the stream.
+    pub fn finish(mut self) -> (W, io::Result<()>) {
+        let res = (|| {
+            let blocks: Vec<&[u8]> = self.buf.chunks(self.block_size).collect();
+            if blocks.is_empty() {
+                return Ok(());
+            }
+            let caps: Vec<u64> = blocks.iter().map(|b| b.len() as u64).collect();
+            let r = run_batch(&blocks, &caps, |c, b, o| unsafe { rcx_bwt_forward_batch(c, b, o) }).check()?;
+            for i in 0..blocks.len() {
+                self.w.write_all(&(blocks[i].len() as u32).to_le_bytes())?;
+                self.w.write_all(&r.out[i])?;
+                self.w.write_all(&r.aux[i].to_le_bytes())?;
+            }
+            Ok(())
+        })();
+        (self.w, res)
+    }
+}
+
+impl<W: Write> Write for Encoder<W> {
+    fn write(&mut self, buf: &[u8]) -> io::Result<usize> {
+        if !self.wrote_header {
+            self.w.write_all(&(self.block_size as u32).to_le_bytes())?; // :493-496
+            self.wrote_header = true;
+        }
+        self.buf.extend_from_slice(buf);
+        Ok(0) // the reference's Ok(0) quirk (:507): callers use write_all-free loops, kept for byte-for-byte behaviour
+    }
+    fn flush(&mut self) -> io::Result<()> {
+        self.w.flush()
+    }
+}
+
+/// bwt/mod.rs:321-432.  `extra_mem = false` selects the reference's `decode_minimal` (:298-315), which is wrong for general
+/// input; the flag is accepted for source compatibility and both settings decode correctly here.
+pub struct Decoder<R: Read> {
+    pub r: TailReader<R>,
+    buf: Buffered,
+    pub extra_memory: bool,
+    pub max_block_size: usize,
+}
+
+impl<R: Read> Decoder<R> {
+    pub fn new(r: R, extra_mem: bool) -> Decoder<R> {
+        Decoder { r: TailReader::new(r), buf: Buffered::new(), extra_memory: extra_mem, max_block_size: 0 }
+    }
+}
+
+impl<R: Read> Read for Decoder<R> {
+    fn read(&mut self, dst: &mut [u8]) -> io::Result<usize> {
+        let mbs = &mut self.max_block_size;
+        self.buf.ensure(&mut self.r, |d| {
+            let n = d.len();
+            let mut p = 0usize;
+            if n - p < 4 {
+                return Err(eof_error()); // :369
+            }
+            *mbs = le32(&d[p..]) as usize;
+            p += 4;
+            let (mut ls, mut origins): (Vec<&[u8]>, Vec<u32>) = (Vec::new(), Vec::new());
+            while n - p >= 4 {
+                // a clean EOF at a block boundary ends the stream (:374-377)
+                let bn = le32(&d[p..]) as usize;
+                p += 4;
+                if n - p < bn {
+                    return Err(eof_error());
+                }
+                let l = &d[p..p + bn];
+                p += bn;
+                if n - p < 4 {
+                    return Err(eof_error());
+                }
+                origins.push(le32(&d[p..]));
+                p += 4;
+                assert!(bn != 0, "index out of bounds"); // input[origin] panics (:230)
+                ls.push(l);
+            }
+            if ls.is_empty() {
+                return Ok((Vec::new(), None));
+            }
+            let caps: Vec<u64> = ls.iter().map(|l| l.len() as u64).collect();
+            let r = run_batch(&ls, &caps, |c, b, _| unsafe { rcx_bwt_inverse_batch(c, b, origins.as_ptr()) }).check()?;
+            Ok((r.out.concat(), None)) // the format runs to the reader's end
+        })?;
+        Ok(self.buf.serve(dst))
+    }
+}

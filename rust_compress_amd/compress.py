@@ -82,19 +82,63 @@ def _read_all(r):
     return b"".join(chunks)
 
 
-class _BufferedDecoder:
-    """Serves self._out through read(n); subclasses fill it in _decode_all() on first use."""
+class TailReader:
+    """A reader that takes bytes back.  The batch decoders have to read ahead (a stream's end is only known once it is
+    decoded); the reference's decoders stop reading exactly at the end of their stream (flate.rs:250-260 reads byte by
+    byte, ari/mod.rs:289-292 `finish`), and its tests rely on the reader being left there (ari/test.rs:52-89: two streams
+    back to back).  Every Decoder here wraps its reader in a TailReader and hands the bytes behind its stream back to
+    it, so `decoder.r` / `finish()` / `unwrap()` is a reader positioned exactly after the stream."""
 
     def __init__(self, r):
-        self.r = r
+        self.inner = r
+        self._tail = b""
+
+    def read(self, n=-1):
+        if n is None or n < 0:
+            out, self._tail = self._tail + _read_all(self.inner), b""
+            return out
+        if self._tail:
+            out, self._tail = self._tail[:n], self._tail[n:]
+            if len(out) < n:                           # like BufRead: top up from the inner reader
+                out += self.inner.read(n - len(out))
+            return out
+        return self.inner.read(n)
+
+    def unread(self, data):
+        if data:
+            self._tail = bytes(data) + self._tail
+
+
+def _grow_caps(call, first_cap, limit=1 << 33):
+    """Run `call(cap)` with growing output slots until the block fits.  A kernel stops at a full slot, so a failed attempt
+    costs its (8x smaller) slot: all the retries together cost a seventh of the decode that fits."""
+    cap = first_cap
+    while True:
+        res = call(cap)
+        if res.status[0] == N.E_OUTPUT_TOO_SMALL and cap < limit:
+            cap *= 8
+            continue
+        return res
+
+
+class _BufferedDecoder:
+    """Serves self._out through read(n); subclasses fill it in _decode_all() on first use and set self.consumed when
+    their stream ends before the input does (the rest goes back to the reader)."""
+
+    def __init__(self, r):
+        self.r = r if isinstance(r, TailReader) else TailReader(r)
         self._out = None
         self._pos = 0
 
     def _ensure(self):
         if self._out is None:
-            self._raw = _read_all(self.r)
+            self.consumed = None
+            self._raw = self.r.read(-1)
             self._out = self._decode_all(self._raw)
             self._pos = 0
+            if self.consumed is not None:
+                self.r.unread(self._raw[self.consumed:])
+                self._raw = self._raw[:self.consumed]
 
     def read(self, n=-1):
         self._ensure()
@@ -115,6 +159,13 @@ class _BufferedDecoder:
         self._out = None
         self._pos = 0
 
+    def finish(self):
+        """-> the reader, positioned exactly after this decoder's stream"""
+        self._ensure()
+        return self.r
+
+    unwrap = finish
+
 
 # ------------------------------------------------------------------------------------------------ lz4
 class lz4:
@@ -127,8 +178,10 @@ class lz4:
 
     @staticmethod
     def decode_block(input, output, max_output=None):  # lz4.rs:602-611: appends to `output`, returns the count
-        cap = max_output if max_output is not None else max(64, 255 * len(input) + 64)
-        res = _check(context().lz4_decode_blocks([bytes(input)], [cap]))
+        if max_output is not None:
+            res = _check(context().lz4_decode_blocks([bytes(input)], [max_output]))
+        else:                                          # the reference grows the Vec as the block decodes (:148-161)
+            res = _check(_grow_caps(lambda cap: context().lz4_decode_blocks([bytes(input)], [cap]), max(1 << 16, 8 * len(input))))
         output += res.outputs[0]
         return len(res.outputs[0])
 
@@ -188,8 +241,18 @@ class lz4:
             comp = [d for stored, d in parts if not stored]
             outs = iter(())
             if comp:                                                           # ONE batch call for every compressed block
-                caps = [max(self.max_block_size, 255 * len(d) + 64) for d in comp]
-                outs = iter(_check(context().lz4_decode_blocks(comp, caps)).outputs)
+                # a conforming frame's blocks decode to at most max_block_size bytes; only the blocks that do not fit get a second,
+                # larger slot (the reference would simply grow its Vec, :148-161)
+                mb = max(self.max_block_size, 1 << 16)
+                res = context().lz4_decode_blocks(comp, [mb] * len(comp))
+                outl = list(res.outputs)
+                redo = [i for i, st in enumerate(res.status) if st == N.E_OUTPUT_TOO_SMALL]
+                for i in redo:
+                    outl[i] = _check(_grow_caps(lambda cap, d=comp[i]: context().lz4_decode_blocks([d], [cap]), 8 * mb)).outputs[0]
+                for i, st in enumerate(res.status):
+                    if i not in redo:
+                        _raise(int(st))
+                outs = iter(outl)
             return b"".join(d if stored else next(outs) for stored, d in parts)
 
     class Encoder:                                     # lz4.rs:505-597: stored blocks only (compress() is false)
@@ -231,33 +294,18 @@ class lz4:
 class flate:
     class Decoder(_BufferedDecoder):                   # flate.rs:164-488; batch semantics: decoded to BFINAL
         def _decode_all(self, data):
-            cap = 1 << 16
-            while True:
-                res = context().inflate([data], [cap])
-                if res.status[0] == 2 and cap < (1 << 31):
-                    cap *= 8
-                    continue
-                _check(res)
-                self.consumed = int(res.in_used[0])
-                self.flags = int(res.aux[0])
-                return res.outputs[0]
+            res = _check(_grow_caps(lambda cap: context().inflate([data], [cap]), max(1 << 16, 4 * len(data))))
+            self.consumed = int(res.in_used[0])
+            self.flags = int(res.aux[0])
+            return res.outputs[0]
 
 
 class zlib:
     class Decoder(_BufferedDecoder):                   # zlib.rs:32-127
         def _decode_all(self, data):
-            cap = 1 << 16
-            while True:
-                res = context().zlib_decode([data], [cap])
-                if res.status[0] == 2 and cap < (1 << 31):
-                    cap *= 8
-                    continue
-                _check(res)
-                self.consumed = int(res.in_used[0])
-                return res.outputs[0]
-
-        def unwrap(self):
-            return self.r
+            res = _check(_grow_caps(lambda cap: context().zlib_decode([data], [cap]), max(1 << 16, 4 * len(data))))
+            self.consumed = int(res.in_used[0])
+            return res.outputs[0]
 
 
 class gzip:
@@ -269,13 +317,18 @@ class gzip:
         def _decode_all(self, data):
             out, pos = [], 0
             self.members = 0
+            view = memoryview(data)
+            window = 1 << 20                           # bytes handed to one call: a member's end is only known once it is decoded
             while pos < len(data):
-                member = data[pos:]
-                cap = 1 << 16
+                # ISIZE (the last four bytes, if the input is exactly one member) sizes the slot; otherwise it grows
+                hint = int.from_bytes(data[-4:], "little") if len(data) >= 18 else 0
+                first = hint if 0 < hint <= 1032 * len(data) and not out else max(1 << 16, 4 * min(window, len(data) - pos))
                 while True:
-                    res = context().gzip_decode([member], [cap])
-                    if res.status[0] == 2 and cap < (1 << 31):
-                        cap *= 8
+                    member = bytes(view[pos:pos + window])
+                    res = _grow_caps(lambda cap: context().gzip_decode([member], [cap]), max(first, 1))
+                    short = pos + window < len(data)
+                    if short and res.status[0] in (N.E_EOF, 17, N.E_MALFORMED, N.E_GZIP_CRC, N.E_GZIP_ISIZE):
+                        window *= 4                    # the window cut the member short: take more input
                         continue
                     break
                 _check(res)
@@ -284,9 +337,6 @@ class gzip:
                 self.members += 1
             self.consumed = pos
             return b"".join(out)
-
-        def unwrap(self):
-            return self.r
 
 
 class Crc32:                                           # extension, mirrors Adler32 below
@@ -334,9 +384,6 @@ class _mtf:
     class Decoder(_BufferedDecoder):                   # mtf.rs:133-169
         def _decode_all(self, data):
             return _check(context().mtf_decode([data])).outputs[0]
-
-        def finish(self):
-            return self.r
 
 
 class _dc:
@@ -389,6 +436,9 @@ class bwt:
 
     class Decoder(_BufferedDecoder):                   # bwt/mod.rs:321-432 (extra_mem = True path)
         def __init__(self, r, extra_mem=True):
+            # extra_mem = False selects the reference's `decode_minimal` (bwt/mod.rs:298-315), an O(n^2) in-place inverse that is
+            # wrong for general input and unused by its own application (main.rs:90).  The GPU inverse always has
+            # its jump table in HBM, so the flag is accepted for source compatibility and decodes CORRECTLY either way.
             super().__init__(r)
             self.extra_memory = extra_mem
 
@@ -434,19 +484,9 @@ class _ari:
 
     class ByteDecoder(_BufferedDecoder):               # table.rs:229-273; stops exactly at the stream's end
         def _decode_all(self, data):
-            cap = max(1 << 12, 4 * len(data))
-            while True:
-                res = context().ari_byte_decode([data], [cap])
-                if res.status[0] == 2 and cap < (1 << 31):
-                    cap *= 8
-                    continue
-                _check(res)
-                self.consumed = int(res.in_used[0])
-                return res.outputs[0]
-
-        def finish(self):
-            self._ensure()                             # mod.rs:289-292: the reader ends exactly after this stream
-            return io.BytesIO(self._raw[self.consumed:])
+            res = _check(_grow_caps(lambda cap: context().ari_byte_decode([data], [cap]), max(1 << 12, 4 * len(data))))
+            self.consumed = int(res.in_used[0])        # mod.rs:289-292: the reader ends exactly after this stream
+            return res.outputs[0]
 
 
 class entropy:
@@ -471,13 +511,7 @@ class rle:
 
     class Decoder(_BufferedDecoder):                   # rle.rs:176-281
         def _decode_all(self, data):
-            cap = max(1 << 12, 64 * len(data))
-            while True:
-                res = context().rle_decode([data], [cap])
-                if res.status[0] == 2 and cap < (1 << 33):
-                    cap *= 16
-                    continue
-                if res.status[0] == 30:
-                    raise CompressError(30)            # io::ErrorKind::Other "Overly long run"
-                _check(res)
-                return res.outputs[0]
+            res = _grow_caps(lambda cap: context().rle_decode([data], [cap]), max(1 << 12, 16 * len(data)), limit=1 << 36)
+            if res.status[0] == 30:
+                raise CompressError(30)                # io::ErrorKind::Other "Overly long run"
+            return _check(res).outputs[0]

@@ -247,6 +247,13 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
     hipStream_t s = c->stream;
     uint64_t in_span = 0, out_span = 0, max_block = 0;
     for (uint32_t i = 0; i < n; i++) {
+        // the kernels index a block with 32-bit offsets: a block of 4 GiB or more (or a range that wraps) is a caller error,
+        // not something to decode a prefix of
+        if (b->in_len[i] >> 32 || b->in_off[i] + b->in_len[i] < b->in_off[i] ||
+            (needs_out && (b->out_cap[i] >> 32 || b->out_off[i] + b->out_cap[i] < b->out_off[i]))) {
+            c->err = "block " + std::to_string(i) + ": lengths of 4 GiB or more are not supported (per-block limit 2^32 - 1 bytes)";
+            return RCX_RC_BAD_ARG;
+        }
         const uint64_t e = b->in_off[i] + b->in_len[i];
         if (e > in_span) in_span = e;
         if (b->in_len[i] > max_block) max_block = b->in_len[i];
@@ -300,9 +307,17 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
     int rc = launch_codec(c, codec, k);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(h64 + 5 * N, d64 + 5 * N, 2 * N * 8 + 2 * N * 4, hipMemcpyDeviceToHost, s));
-    if (b->mem == RCX_MEM_HOST && out_span)
-        HIPCHK(c, hipMemcpyAsync(b->out_base, c->d_out.p, out_span, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    if (b->mem == RCX_MEM_HOST && out_span) {
+        // only what was produced travels back: the span up to the last byte any block wrote, not the slots' capacity
+        uint64_t used_span = 0;
+        const uint64_t* ol = h64 + 5 * N;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint64_t l = ol[i] < b->out_cap[i] ? ol[i] : b->out_cap[i];
+            if (l && b->out_off[i] + l > used_span) used_span = b->out_off[i] + l;
+        }
+        if (used_span) HIPCHK(c, hipMemcpy(b->out_base, c->d_out.p, used_span, hipMemcpyDeviceToHost));
+    }
     if (b->out_len) memcpy(b->out_len, h64 + 5 * N, N * 8);
     if (b->in_used) memcpy(b->in_used, h64 + 6 * N, N * 8);
     memcpy(b->status, h_status, N * 4);

@@ -15,6 +15,7 @@
 //   compress::rle::{Encoder,Decoder}                                               src/rle.rs
 #pragma once
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <optional>
 #include <stdexcept>
@@ -103,6 +104,29 @@ struct VecWriter {                                // BufWriter::new(Vec::new())
     std::vector<uint8_t> v;
     void write(const uint8_t* d, size_t n) { v.insert(v.end(), d, d + n); }
 };
+// A reader that takes bytes back.  The batch decoders read ahead (a stream's end is only known once it is decoded); the
+// reference's decoders stop reading exactly at the end of their stream (flate.rs:250-260, ari/mod.rs:289-292) and its tests
+// rely on it (ari/test.rs:52-89).  Every Decoder keeps its reader as TailReader<R> `r` and hands the bytes behind its stream
+// back, so `decoder.r` / finish() / unwrap() is a reader positioned exactly after the stream.
+template <class R>
+struct TailReader {
+    R inner; std::vector<uint8_t> tail; size_t tpos = 0;
+    explicit TailReader(R r) : inner(std::move(r)) {}
+    size_t read(uint8_t* dst, size_t n)
+    {
+        size_t k = 0;
+        if (tpos < tail.size()) { k = n < tail.size() - tpos ? n : tail.size() - tpos; std::memcpy(dst, tail.data() + tpos, k); tpos += k; }
+        if (k < n) k += inner.read(dst + k, n - k);
+        return k;
+    }
+    void unread(const uint8_t* p, size_t n)
+    {
+        if (!n) return;
+        std::vector<uint8_t> t(p, p + n);
+        t.insert(t.end(), tail.begin() + tpos, tail.end());
+        tail.swap(t); tpos = 0;
+    }
+};
 template <class R> std::vector<uint8_t> read_all(R& r)
 {
     std::vector<uint8_t> v; uint8_t buf[65536]; size_t k;
@@ -116,7 +140,7 @@ inline void put32(std::vector<uint8_t>& v, uint32_t x) { for (int i = 0; i < 4; 
 template <class R, class Derived>
 class BufferedDecoder {
 public:
-    R r;                                          // `pub r: R`
+    TailReader<R> r;                              // `pub r: R`, left exactly after the stream once it is decoded
     explicit BufferedDecoder(R rd) : r(std::move(rd)) {}
     size_t read(uint8_t* dst, size_t n)
     {
@@ -129,9 +153,18 @@ public:
     std::vector<uint8_t> read_to_end() { ensure(); std::vector<uint8_t> v(out_.begin() + pos_, out_.end()); pos_ = out_.size(); return v; }
     bool eof() { ensure(); return pos_ == out_.size(); }
     void reset() { done_ = false; out_.clear(); pos_ = 0; }
-    size_t consumed = 0;                          // input bytes this stream used (in_used)
+    static constexpr size_t TO_EOF = ~(size_t)0;
+    size_t consumed = TO_EOF;                     // input bytes this stream used (in_used); TO_EOF: the format runs to the reader's end
+    TailReader<R>& finish() { ensure(); return r; }   // the reader, positioned exactly after this stream
+    TailReader<R>& unwrap() { return finish(); }
 protected:
-    void ensure() { if (!done_) { raw_ = read_all(r); out_ = static_cast<Derived*>(this)->decode_all(raw_); pos_ = 0; done_ = true; } }
+    void ensure()
+    {
+        if (done_) return;
+        consumed = TO_EOF;
+        raw_ = read_all(r); out_ = static_cast<Derived*>(this)->decode_all(raw_); pos_ = 0; done_ = true;
+        if (consumed != TO_EOF && consumed < raw_.size()) { r.unread(raw_.data() + consumed, raw_.size() - consumed); raw_.resize(consumed); }
+    }
     std::vector<uint8_t> raw_, out_; size_t pos_ = 0; bool done_ = false;
 };
 
@@ -144,10 +177,15 @@ inline std::optional<uint32_t> compression_bound(uint32_t size)                 
 }
 inline size_t decode_block(const std::vector<uint8_t>& input, std::vector<uint8_t>& output)   // lz4.rs:602-611
 {
-    auto r = run_batch({input}, {255 * input.size() + 64}, [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_lz4_decode_batch(c, b); });
-    check(r);
-    output.insert(output.end(), r.out[0].begin(), r.out[0].end());
-    return r.out[0].size();
+    // the reference grows its Vec as the block decodes (:148-161): slots grow 8x until the block fits (a kernel stops at a full
+    // slot, so the failed attempts together cost a seventh of the one that fits)
+    for (uint64_t cap = std::max<uint64_t>(1u << 16, 8 * input.size());; cap *= 8) {
+        auto r = run_batch({input}, {cap}, [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_lz4_decode_batch(c, b); });
+        if (r.status[0] == RCX_E_OUTPUT_TOO_SMALL && cap < (1ull << 33)) continue;
+        check(r);
+        output.insert(output.end(), r.out[0].begin(), r.out[0].end());
+        return r.out[0].size();
+    }
 }
 inline size_t encode_block(const std::vector<uint8_t>& input, std::vector<uint8_t>& output)   // lz4.rs:616-627
 {
@@ -190,9 +228,17 @@ public:
         }
         this->consumed = p;
         std::vector<std::vector<uint8_t>> comp; std::vector<uint64_t> caps;
-        for (auto& pr : parts) if (!pr.first) { comp.push_back(pr.second); caps.push_back(std::max(max_block, 255 * pr.second.size() + 64)); }
+        // a conforming frame's blocks decode to at most max_block bytes: that is every block's slot; only a block that does not
+        // fit is decoded again with a larger one (the reference would grow its Vec)
+        const uint64_t mb = std::max<size_t>(max_block, 1u << 16);
+        for (auto& pr : parts) if (!pr.first) { comp.push_back(pr.second); caps.push_back(mb); }
         BatchResult r;
-        if (!comp.empty()) { r = run_batch(comp, caps, [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_lz4_decode_batch(c, b); }); check(r); }
+        if (!comp.empty()) {
+            r = run_batch(comp, caps, [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_lz4_decode_batch(c, b); });
+            for (size_t i = 0; i < comp.size(); i++)
+                if (r.status[i] == RCX_E_OUTPUT_TOO_SMALL) { std::vector<uint8_t> o; decode_block(comp[i], o); r.out[i] = std::move(o); r.status[i] = RCX_OK; }
+            check(r);
+        }
         std::vector<uint8_t> out; size_t ci = 0;
         for (auto& pr : parts) { const auto& src = pr.first ? pr.second : r.out[ci++]; out.insert(out.end(), src.begin(), src.end()); }
         return out;
@@ -224,7 +270,7 @@ private:
 namespace detail {
 template <class Fn> std::vector<uint8_t> grow_decode(const std::vector<uint8_t>& d, size_t& consumed, Fn fn, uint32_t* flags = nullptr)
 {
-    for (uint64_t cap = 1u << 16;; cap *= 8) {
+    for (uint64_t cap = std::max<uint64_t>(1u << 16, 4 * d.size());; cap *= 8) {
         auto r = run_batch({d}, {cap}, fn);
         if (r.status[0] == RCX_E_OUTPUT_TOO_SMALL && cap < (1ull << 33)) continue;
         check(r);
@@ -251,7 +297,6 @@ public:
     using BufferedDecoder<R, Decoder<R>>::BufferedDecoder;
     std::vector<uint8_t> decode_all(const std::vector<uint8_t>& d)
     { return detail::grow_decode(d, this->consumed, [](rcx_ctx* c, rcx_batch* b, uint32_t* f) { return rcx_zlib_decode_batch(c, b, f); }); }
-    R unwrap() { return std::move(this->r); }
 };
 }  // namespace zlib
 class Adler32 {                                                                       // checksum/adler.rs:22-51
@@ -388,8 +433,7 @@ public:
     using BufferedDecoder<R, ByteDecoder<R>>::BufferedDecoder;
     std::vector<uint8_t> decode_all(const std::vector<uint8_t>& d)
     { return detail::grow_decode(d, this->consumed, [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_ari_byte_decode_batch(c, b); }); }
-    // finish(): the reader ends exactly after this stream (mod.rs:289-292)
-    std::vector<uint8_t> finish() { this->ensure(); return std::vector<uint8_t>(this->raw_.begin() + this->consumed, this->raw_.end()); }
+    // finish() (BufferedDecoder): the reader ends exactly after this stream (mod.rs:289-292)
 };
 }}  // namespace entropy::ari
 

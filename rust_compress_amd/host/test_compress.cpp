@@ -97,9 +97,11 @@ int main(int argc, char** argv)
         for (const Bytes& part : {B("abra"), B("cadabra")}) { entropy::ari::ByteEncoder<VecWriter> e{std::move(w)}; e.write(part.data(), part.size()); w = e.finish(); }
         entropy::ari::ByteDecoder<SliceReader> d1{SliceReader(w.v)};
         CHECK(d1.read_to_end() == B("abra"));
-        Bytes rest = d1.finish();
-        entropy::ari::ByteDecoder<SliceReader> d2{SliceReader(rest)};
+        // the second decoder continues on the SAME reader, left exactly after the first stream (ari/test.rs:52-89)
+        entropy::ari::ByteDecoder<TailReader<SliceReader>> d2{std::move(d1.finish())};
         CHECK(d2.read_to_end() == B("cadabra"));
+        uint8_t dummy;
+        CHECK(d2.finish().read(&dummy, 1) == 0);
     }
     // ---- rle (rle.rs:320-361)
     auto renc = [](const Bytes& b) { rle::Encoder<VecWriter> e{VecWriter()}; e.write_all(b.data(), b.size()); return e.finish().v; };

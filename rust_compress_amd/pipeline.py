@@ -27,6 +27,15 @@ HDR_WORDS = 3
 PARTS = 16
 
 
+class ContainerError(ValueError):
+    """A corrupt or truncated RCXQ container (raised, never asserted: the checks must survive python -O)."""
+
+
+def _need(cond, msg):
+    if not cond:
+        raise ContainerError(msg)
+
+
 class BwtDcAri:
     def __init__(self, ctx, device, parts=PARTS):
         import torch
@@ -99,19 +108,21 @@ class BwtDcAri:
         roff = np.arange(nb, dtype=np.int64) * slot
         praw = np.asarray(praw, dtype=np.int64).reshape(nb, -1)
         S = praw.shape[1]
-        assert (praw.sum(axis=1) <= slot).all(), "container piece lengths exceed the block record"
+        _need(nb == 0 or ((praw >= 0).all() and (praw.sum(axis=1) <= slot).all()), "container piece lengths exceed the block record")
         pstart = np.concatenate([np.zeros((nb, 1), np.int64), np.cumsum(praw, axis=1)[:, :-1]], axis=1)
         ar = DeviceBatch(comp, self._i64(np.asarray(comp_off).reshape(-1)), self._i64(np.asarray(comp_len).reshape(-1)),
                          torch.zeros(nb * slot + 64, dtype=torch.uint8, device=self.dev),
                          self._i64((roff[:, None] + pstart).reshape(-1)), self._i64(praw.reshape(-1)))
         self.ctx.launch_dev(N.ARI_BYTE_DECODE, ar)
         torch.cuda.synchronize()
-        assert int(ar.status[: nb * S].abs().max()) == 0, "ari decode failed"
-        assert bool((ar.out_len[: nb * S].cpu().numpy().astype(np.int64) == praw.reshape(-1)).all()), "container piece length mismatch"
+        _need(nb == 0 or int(ar.status[: nb * S].abs().max()) == 0, "ari decode failed")
+        _need(bool((ar.out_len[: nb * S].cpu().numpy().astype(np.int64) == praw.reshape(-1)).all()), "container piece length mismatch")
         rec32 = ar.out_base[: nb * slot].view(torch.int32).view(nb, slot // 4)
         hdr = rec32[:, :HDR_WORDS].cpu().numpy()
         n, origin, k = hdr[:, 0].astype(np.int64), hdr[:, 1].astype(np.uint32), hdr[:, 2].astype(np.int64)
-        assert (n == lens).all(), "container length mismatch"
+        _need(bool((n == lens).all()), "container length mismatch")
+        # k (the number of DC distances) comes from the decoded, untrusted record: it must be what the record's length says
+        _need(bool(((k >= 0) & (k <= n) & (4 * (HDR_WORDS + 256 + k) == praw.sum(axis=1))).all()), "container record: distance count does not match the record length")
         ooff = np.concatenate([[0], np.cumsum(lens)[:-1]]) if nb else np.zeros(0, np.int64)
         total = int(lens.sum())
         # DC decode through the host-descriptor entry point (it needs n_out)
@@ -125,13 +136,13 @@ class BwtDcAri:
         b = N.Batch(ar.out_base.data_ptr(), p(in_off), p(in_len), L.data_ptr(), p(out_off), p(out_cap), p(out_len), p(in_used),
                     p(status), nb, N.MEM_DEVICE)
         self.ctx._chk(N.lib().rcx_dc_decode_batch(self.ctx._h, C.byref(b), C.c_void_p(p(n_out))))
-        assert not status.any(), "dc decode failed"
+        _need(not status.any(), "dc decode failed")
         inv = DeviceBatch(L, self._i64(ooff), self._i64(lens), torch.empty(total + 64, dtype=torch.uint8, device=self.dev),
                           self._i64(ooff), self._i64(lens), aux=torch.as_tensor(origin.astype(np.int32), device=self.dev))
         sc = self._scratch(N.BWT_INVERSE, nb, maxn)
         self.ctx.launch_dev(N.BWT_INVERSE, inv, sc)
         torch.cuda.synchronize()
-        assert int(inv.status[:nb].abs().max()) == 0, "bwt inverse failed"
+        _need(nb == 0 or int(inv.status[:nb].abs().max()) == 0, "bwt inverse failed")
         return inv.out_base[:total]
 
 
@@ -158,18 +169,22 @@ def encode_stream(ctx, data, block_size=256 * 1024, device=None, parts=PARTS):
 def decode_stream(ctx, blob, device=None):
     import torch
     dev = device or torch.device("cuda", torch.cuda.current_device())
-    assert blob[:4] == MAGIC, "not an RCXQ container"
+    _need(len(blob) >= 16 and blob[:4] == MAGIC, "not an RCXQ container")
     block_size, nb, parts = struct.unpack_from("<III", blob, 4)
+    _need(parts >= 1 and block_size >= 1, "container header: bad block size / piece count")
+    _need(16 + nb * (4 + 8 * parts) <= len(blob), "container descriptor table is truncated")
     p = 16
     lens, clen, praw = [], [], []
     for _ in range(nb):
         (n,) = struct.unpack_from("<I", blob, p)
         p += 4
+        _need(n <= block_size, "container block longer than the block size")
         lens.append(n)
         for _s in range(parts):
             rl, cl = struct.unpack_from("<II", blob, p)
             p += 8
             praw.append(rl); clen.append(cl)
+    _need(p + sum(clen) <= len(blob), "container payload is truncated")
     if not nb:
         return b""
     clen = np.asarray(clen, dtype=np.int64)

@@ -153,3 +153,46 @@ def test_rle_known_answers():                              # rle.rs:320-361
     with pytest.raises(C.CompressError) as e:
         dec(b"aa" + bytes(10))
     assert str(e.value) == "Overly long run"
+
+
+def test_readers_are_left_exactly_after_the_stream(golden, oracle):
+    """The reference's decoders never read past their stream (flate.rs:250-260 byte-wise reads, ari/mod.rs:289-292 finish,
+    ari/test.rs:52-89): whatever follows a stream must still be readable from the same reader afterwards."""
+    import zlib as pyz
+    txt = golden("test.txt")
+    tail = b"TAIL-BYTES-" + bytes(range(40))
+    # zlib: the Adler-32 trailer belongs to the stream, the tail does not (zlib.rs:99-127)
+    r = io.BytesIO(pyz.compress(txt, 6) + tail)
+    d = C.zlib.Decoder(r)
+    assert d.read_to_end() == txt and d.unwrap().read(-1) == tail
+    # raw DEFLATE followed by bytes (what zlib::Decoder relies on to find its trailer)
+    raw = pyz.compress(txt, 9)[2:-4]
+    d = C.flate.Decoder(io.BytesIO(raw + tail))
+    assert d.read_to_end() == txt and d.r.read(5) == tail[:5] and d.r.read(-1) == tail[5:]
+    # three Ari streams back to back, each decoder picking up the previous one's reader
+    w = io.BytesIO()
+    parts = [b"abra", txt[:1500], b""]
+    for part in parts:
+        e = C.entropy.ari.ByteEncoder(w); e.write(part); e.finish()
+    r = io.BytesIO(w.getvalue() + tail)
+    for part in parts:
+        d = C.entropy.ari.ByteDecoder(r)
+        assert d.read_to_end() == part
+        r = d.finish()
+    assert r.read(-1) == tail
+    # an LZ4 frame ends at its end mark (the content checksum is never read, lz4.rs:384)
+    d = C.lz4.Decoder(io.BytesIO(golden("test.lz4.1")[:-4] + tail))       # fixture = frame + 4-byte content checksum
+    assert d.read_to_end() == txt and d.r.read(-1) == tail
+    # two gzip members then a tail: the members decode, the tail is not a member -> error, exactly like a second header check
+    import gzip as pyg
+    g = pyg.compress(txt[:3000], mtime=0) + pyg.compress(txt[3000:], mtime=0)
+    assert C.gzip.Decoder(io.BytesIO(g)).read_to_end() == txt
+
+
+def test_bwt_decoder_extra_mem_flag(golden):
+    """`extra_mem = false` selects the reference's decode_minimal (bwt/mod.rs:298-315), which is wrong for general input; the flag is
+    accepted and both settings decode correctly here."""
+    txt = golden("test.txt")
+    w = io.BytesIO(); e = C.bwt.Encoder(w, 1 << 10); e.write(txt); e.finish()
+    for flag in (True, False):
+        assert C.bwt.Decoder(io.BytesIO(w.getvalue()), extra_mem=flag).read_to_end() == txt

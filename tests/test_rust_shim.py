@@ -1,0 +1,113 @@
+"""CPU suite: the Rust shim crate under rust/ is source only (no Rust toolchain in the image), so it is kept honest
+mechanically: every export of include/rcx.h is declared in rust/src/rcx_sys.rs with the same argument count, the
+#[repr(C)] structs have the header's fields in the header's order, the enum constants carry the header's values, and
+every export the shim modules call is declared.  (The stream logic is transcribed from the tested C++ twin,
+rust_compress_amd/host/compress.hpp.)"""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _strip_c_comments(s):
+    return re.sub(r"/\*.*?\*/", "", s, flags=re.S)
+
+
+def _header():
+    h = _strip_c_comments(open(os.path.join(ROOT, "include", "rcx.h")).read())
+    funcs = {}
+    for m in re.finditer(r"^\s*(?:const\s+)?[A-Za-z_][A-Za-z0-9_ ]*?\**\s+\**(rcx_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", h, flags=re.M):
+        name, args = m.group(1), m.group(2).strip()
+        funcs[name] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+    structs = {}
+    for m in re.finditer(r"typedef\s+struct\s+(rcx_[a-z_]+)\s*\{(.*?)\}\s*\1\s*;", h, flags=re.S):
+        fields = [re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*$", f.strip()).group(1) for f in m.group(2).split(";") if f.strip()]
+        structs[m.group(1)] = fields
+    enums = {}
+    for m in re.finditer(r"enum\s+rcx_[a-z]+\s*\{(.*?)\}\s*;", h, flags=re.S):
+        val = -1
+        for item in m.group(1).split(","):
+            item = item.strip()
+            if not item:
+                continue
+            if "=" in item:
+                k, v = [x.strip() for x in item.split("=")]
+                val = int(v, 0)
+            else:
+                k, val = item, val + 1
+            enums[k] = val
+    return funcs, structs, enums
+
+
+def _rust():
+    s = re.sub(r"//[^\n]*", "", open(os.path.join(ROOT, "rust", "src", "rcx_sys.rs")).read())
+    funcs = {}
+    ext = re.search(r'extern\s+"C"\s*\{(.*)\}', s, flags=re.S).group(1)
+    for m in re.finditer(r"pub\s+fn\s+(rcx_[a-z0-9_]+)\s*\(([^)]*)\)", ext):
+        args = m.group(2).strip()
+        funcs[m.group(1)] = 0 if not args else len([a for a in args.split(",") if a.strip()])
+    structs = {}
+    for m in re.finditer(r"#\[repr\(C\)\]\s*pub\s+struct\s+(rcx_[a-z_]+)\s*\{(.*?)\}", s, flags=re.S):
+        structs[m.group(1)] = [f.group(1) for f in re.finditer(r"(?:pub\s+)?([a-z_][a-z0-9_]*)\s*:", m.group(2))]
+    consts = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"pub\s+const\s+(RCX_[A-Z0-9_]+)\s*:\s*[a-z0-9_]+\s*=\s*(-?[0-9xa-fA-F]+)\s*;", s)}
+    return funcs, structs, consts
+
+
+def test_every_export_is_declared_with_the_same_arity():
+    hf, _, _ = _header()
+    rf, _, _ = _rust()
+    assert len(hf) >= 36, sorted(hf)
+    assert set(hf) == set(rf), (sorted(set(hf) - set(rf)), sorted(set(rf) - set(hf)))
+    assert {k: hf[k] for k in hf} == {k: rf[k] for k in hf}
+
+
+def test_header_exports_match_the_ctypes_list_and_the_library():
+    from rust_compress_amd import _native as N
+    hf, _, _ = _header()
+    assert set(N.EXPORTS) == set(hf)
+
+
+def test_repr_c_structs_have_the_headers_fields_in_order():
+    _, hs, _ = _header()
+    _, rs, _ = _rust()
+    assert hs["rcx_batch"] == rs["rcx_batch"] and len(hs["rcx_batch"]) == 11
+    assert hs["rcx_dev_batch"] == rs["rcx_dev_batch"] and len(hs["rcx_dev_batch"]) == 11
+    assert rs["rcx_ctx"] == ["_private"]
+
+
+def test_enum_constants_carry_the_headers_values():
+    _, _, he = _header()
+    _, _, rc = _rust()
+    assert len(he) >= 50
+    missing = [k for k in he if k not in rc]
+    assert not missing, missing
+    assert all(rc[k] == v for k, v in he.items()), [(k, v, rc[k]) for k, v in he.items() if rc[k] != v]
+    assert rc["RCX_W_EMPTY_BLOCK_MIDSTREAM"] == 1
+
+
+def test_shim_modules_only_call_declared_exports_and_cover_the_crates_surface():
+    rf, _, _ = _rust()
+    src = os.path.join(ROOT, "rust", "src")
+    used = set()
+    text = {}
+    for dp, _, fs in os.walk(src):
+        for f in fs:
+            if f.endswith(".rs") and f != "rcx_sys.rs":
+                t = open(os.path.join(dp, f)).read()
+                text[os.path.relpath(os.path.join(dp, f), src)] = t
+                used |= set(re.findall(r"\b(rcx_[a-z0-9_]+)\s*\(", t))
+    assert used <= set(rf), sorted(used - set(rf))
+    # the reference's public names, one per module
+    want = {"lz4.rs": ["pub fn decode_block", "pub fn encode_block", "pub fn compression_bound", "pub struct Decoder", "pub struct Encoder"],
+            "flate.rs": ["pub struct Decoder", "pub fn eof", "pub fn reset"], "zlib.rs": ["pub struct Decoder", "pub fn unwrap"],
+            "bwt/mod.rs": ["pub fn encode_simple", "pub fn decode_simple", "pub struct Encoder", "pub struct Decoder"],
+            "bwt/mtf.rs": ["pub struct Encoder", "pub struct Decoder"], "bwt/dc.rs": ["pub fn encode_simple", "pub fn decode_simple"],
+            "entropy/ari/mod.rs": ["pub struct ByteEncoder", "pub struct ByteDecoder"], "rle.rs": ["pub struct Encoder", "pub struct Decoder"],
+            "checksum/adler.rs": ["pub struct State32"], "lib.rs": ["pub struct TailReader", "pub use checksum::adler::State32 as Adler32"]}
+    for f, names in want.items():
+        for nm in names:
+            assert nm in text[f], (f, nm)
+    # braces balance in every file (a cheap syntax sanity check without a compiler)
+    for f, t in text.items():
+        t2 = re.sub(r'"(?:\\.|[^"\\])*"', '""', re.sub(r"//[^\n]*", "", t))
+        assert t2.count("{") == t2.count("}") and t2.count("(") == t2.count(")"), f
