@@ -3,10 +3,9 @@
 // FORWARD replaces compute_suffixes + TransformIterator (src/bwt/mod.rs:136-204).  The reference sorts
 // suffixes by plain byte-slice order (a proper prefix sorts first == an implicit sentinel below every
 // byte), so the suffix array is unique and any correct sorter gives bit-identical (L, origin).  Here:
-// prefix doubling over the WHOLE batch at once -- one 64-bit key per suffix (block | rank[i] | rank[i+h],
-// rank 0 = "past the end"), a device-wide LSD radix sort per round (rocPRIM primitive), re-ranking by
-// group flags + max-scan, h = 4, 8, 16, ...; a suffix that is alone in its group is written to the suffix
-// array and dropped, so round k sorts only what h = 2^(k+1) bytes could not separate.
+// prefix doubling with the hand-written segmented sorter of k_bwt_sort.hip: round 0 orders the suffixes of a block by a
+// 64-bit key of their first <= 10 symbols (alphabet compacted), round r by rank[suffix + h]; groups are sorted where they
+// lie (radix partition / LDS bitonic sort / one lane per suffix), a suffix alone in its group is final and never moves again.
 //
 // INVERSE replaces compute_inversion_table + InverseIterator (src/bwt/mod.rs:223-282).  The reference's
 // n-step pointer chase is replaced by list ranking: the jump table is built with a stable wave-parallel
@@ -15,9 +14,9 @@
 // (4 independent chains per lane in flight), one lane ranks the marked nodes, and the walkers chase again
 // writing the text at their final offsets.
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 #include <string>
 #include "rcx_dev.h"
+#include "k_bwt_sort.hip"
 
 // ---------------------------------------------------------------------------------------------------
 // forward
@@ -85,71 +84,6 @@ __global__ void k_bwtf_init(BwtfArgs a, uint64_t* keys, uint32_t* vals, const ui
         vals[g0 + i] = g0 + i;
     }
 }
-// ---- one refinement round over the still-unresolved suffixes U (sorted by key = block | rank | next rank) ----
-// pair[j] = (index of the first element of j's OLD group, index of the first element of j's NEW group), as
-// "j if a group starts here else 0" for a component-wise max-scan.  `so`: key >> so identifies the old group.
-struct BwtfPair { uint32_t s, g; };
-struct BwtfPairMax {
-    __device__ __host__ BwtfPair operator()(const BwtfPair& a, const BwtfPair& b) const
-    {
-        BwtfPair r; r.s = a.s > b.s ? a.s : b.s; r.g = a.g > b.g ? a.g : b.g; return r;
-    }
-};
-struct BwtfFlagOf {                                           // the same pair, computed on the fly as the scan's input
-    const uint64_t* keys; uint32_t so;
-    __device__ BwtfPair operator()(uint32_t j) const
-    {
-        const uint64_t k = keys[j], kp = j ? keys[j - 1] : ~k;
-        BwtfPair p; p.s = (j && (k >> so) == (kp >> so)) ? 0u : j; p.g = (j && k == kp) ? 0u : j;
-        return p;
-    }
-};
-__global__ void k_bwtf_flags(const uint64_t* keys, BwtfPair* pair, uint32_t n, uint32_t so)
-{
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const uint64_t k = keys[j], kp = j ? keys[j - 1] : ~k;
-    BwtfPair p; p.s = (j && (k >> so) == (kp >> so)) ? 0u : j; p.g = (j && k == kp) ? 0u : j;
-    pair[j] = p;
-}
-// new rank of element j = rank of its old group + (start of its new group - start of its old group); a new group
-// of one element is final: its suffix goes to SA[new rank] and leaves U.
-__global__ void k_bwtf_rank(const uint64_t* keys, const uint32_t* vals, const BwtfPair* pair, const uint32_t* bstart,
-                            uint32_t* rank, uint32_t* sa, uint32_t* keep, uint32_t n, uint32_t sb, uint32_t br, uint32_t br1, int round0)
-{
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const uint64_t k = keys[j];
-    const BwtfPair p = pair[j];
-    const uint32_t b = (uint32_t)(k >> sb);
-    const uint32_t base = round0 ? bstart[b] : bstart[b] + (uint32_t)((k >> br) & ((1ull << br1) - 1ull));
-    const uint32_t nr = base + (p.g - p.s);
-    const uint32_t g = vals[j];
-    rank[g] = nr;
-    const bool single = p.g == j && (j + 1 == n || keys[j + 1] != k);
-    if (single) sa[nr] = g;
-    keep[j] = single ? 0u : 1u;
-}
-// compact the survivors and give them their next key: block | new local rank | local rank + 1 of suffix + h (0 = past the end)
-__global__ void k_bwtf_next(const uint64_t* keys, const uint32_t* vals, const uint32_t* keep, const uint32_t* pos,
-                            const uint32_t* rank, const uint32_t* bstart, uint64_t* keys_out, uint32_t* vals_out,
-                            uint32_t n, uint32_t sb, uint32_t br, uint32_t br1, uint32_t h)
-{
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n || !keep[j]) return;
-    const uint32_t b = (uint32_t)(keys[j] >> sb);
-    const uint32_t g = vals[j];
-    const uint32_t g0 = bstart[b], e = bstart[b + 1];
-    const uint64_t r1 = rank[g] - g0;                             // local rank, br1 bits (no sentinel needed here)
-    const uint64_t r2 = (g + h < e) ? rank[g + h] - g0 + 1u : 0u;
-    const uint32_t o = pos[j];
-    keys_out[o] = ((uint64_t)b << (br1 + br)) | (r1 << br) | r2;
-    vals_out[o] = g;
-}
-__global__ void k_bwtf_count(const uint32_t* keep, const uint32_t* pos, uint32_t n, uint32_t* out)
-{
-    if (blockIdx.x == 0 && threadIdx.x == 0) *out = n ? pos[n - 1] + keep[n - 1] : 0u;
-}
 // L[j] = T[SA[j]-1], or T[n-1] where SA[j] == 0 (that j is `origin`), mod.rs:193-203
 __global__ void k_bwtf_emit(BwtfArgs a, const uint32_t* sa, uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap, uint32_t* origin)
 {
@@ -160,7 +94,7 @@ __global__ void k_bwtf_emit(BwtfArgs a, const uint32_t* sa, uint8_t* out_base, c
     const uint8_t* T = a.in_base + a.in_off[b];
     uint8_t* out = out_base + out_off[b];
     for (uint32_t jl = blockIdx.x * blockDim.x + threadIdx.x; jl < n; jl += gridDim.x * blockDim.x) {
-        const uint32_t i = sa[g0 + jl] - g0;
+        const uint32_t i = (sa[g0 + jl] & BWS_IDX) - g0;
         if (i == 0) { out[jl] = T[n - 1]; if (origin) origin[b] = jl; }
         else out[jl] = T[i - 1];
     }
@@ -179,129 +113,113 @@ __global__ void k_bwtf_finish(rcx_kargs a)
 
 static inline uint32_t bits_for(uint64_t v) { uint32_t b = 1; while ((1ull << b) <= v && b < 63) b++; return b; }
 
-// Blocks per suffix-sort pass: with <= 1024 the block index takes 10 key bits, which keeps the refinement rounds of 256 KiB
-// blocks at 6 radix passes (47 key bits) and the scratch at 13 GB; larger batches are sorted 1024 blocks at a time.
-#define BWTF_CHUNK 1024u
+// Suffixes per sorting pass: a suffix index shares its SA word with three flags, so a pass takes < 2^28 suffixes (1024 blocks of
+// 256 KiB); larger batches are sorted pass after pass.
+#define BWTF_MAXN 0x0fffffffu
 
 static uint64_t bwt_forward_scratch_bytes(uint32_t nblocks, uint64_t max_block)
 {
-    const uint64_t N = (uint64_t)(nblocks < BWTF_CHUNK ? nblocks : BWTF_CHUNK) * max_block;
-    // keys 2x8N, vals 2x4N, rank 4N, SA 4N, group pairs 8N, keep 4N, positions 4N, bstart, counters, sort/scan temp
-    return 48 * N + N / 16 + (uint64_t)(nblocks + 2) * 4 + (64ull << 20);
+    uint64_t N = (uint64_t)nblocks * max_block;
+    if (N > (uint64_t)BWTF_MAXN) N = BWTF_MAXN;
+    // keys 2 x 8N, SA 2 x 4N, rank 4N, group lists, bstart, counters, histogram
+    return 28 * N + 3 * (N / BWS_WAVE + nblocks + 1024) * sizeof(BwsSeg) + 2 * (N / 16 + 4096) * sizeof(BwsSeg) + (uint64_t)(nblocks + 2) * 4 + (1ull << 20);
 }
 
 static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::string& err)
 {
     (void)variant;
-    if (k.nblocks > BWTF_CHUNK) {
-        for (uint32_t lo = 0; lo < k.nblocks; lo += BWTF_CHUNK) {
-            rcx_kargs kk = k;
-            kk.in_off += lo; kk.in_len += lo; kk.out_off += lo; kk.out_cap += lo; kk.out_len += lo; kk.status += lo;
-            if (kk.in_used) kk.in_used += lo;
-            if (kk.aux) kk.aux += lo;
-            if (kk.n_out) kk.n_out += lo;
-            kk.nblocks = k.nblocks - lo < BWTF_CHUNK ? k.nblocks - lo : BWTF_CHUNK;
-            const int rc = launch_bwt_forward(s, kk, variant, err);
-            if (rc) return rc;
-        }
-        return RCX_RC_OK;
-    }
-    const uint32_t nb = k.nblocks;
-    std::vector<uint64_t> h_len(nb);
-    if (hipMemcpyAsync(h_len.data(), k.in_len, nb * 8ull, hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipStreamSynchronize(s) != hipSuccess) { err = "bwt forward: cannot read in_len"; return RCX_RC_HIP_ERROR; }
-    std::vector<uint32_t> h_bstart(nb + 1);
-    uint64_t N64 = 0, maxn = 0;
-    for (uint32_t b = 0; b < nb; b++) { h_bstart[b] = (uint32_t)N64; N64 += h_len[b]; if (h_len[b] > maxn) maxn = h_len[b]; }
-    h_bstart[nb] = (uint32_t)N64;
-    if (N64 >= 0xffffffffull) { err = "bwt forward: batch larger than 4 Gi suffixes"; return RCX_RC_BAD_ARG; }
-    const uint32_t N = (uint32_t)N64;
-    // key fields: block index (0 .. nb-1), local rank (0 .. maxn-1), local rank + 1 with 0 = past the end (0 .. maxn)
-    const uint32_t bblk = bits_for(nb ? nb - 1 : 0), br = bits_for(maxn), br1 = bits_for(maxn ? maxn - 1 : 0);
-    if (bblk + br1 + br > 64 || bblk + 36 > 64) { err = "bwt forward: block too large for 64-bit keys"; return RCX_RC_BAD_ARG; }
-    uint32_t nsym = 4, sbits = 9; bool plain_bytes = true;
-    if (N) {
-        // carve scratch
-        uint8_t* p = (uint8_t*)k.scratch;
-        auto carve = [&](size_t bytes) { uint8_t* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
-        uint64_t* keysA = (uint64_t*)carve(8ull * N); uint64_t* keysB = (uint64_t*)carve(8ull * N);
-        uint32_t* valsA = (uint32_t*)carve(4ull * N); uint32_t* valsB = (uint32_t*)carve(4ull * N);
-        uint32_t* rank = (uint32_t*)carve(4ull * N);  uint32_t* sa = (uint32_t*)carve(4ull * N);
-        BwtfPair* pair = (BwtfPair*)carve(8ull * N);
-        uint32_t* keep = (uint32_t*)carve(4ull * N);  uint32_t* pos = (uint32_t*)carve(4ull * N);
-        uint32_t* bstart = (uint32_t*)carve(4ull * (nb + 1)); uint32_t* counter = (uint32_t*)carve(256);
-        uint32_t* hist = (uint32_t*)carve(1056); uint8_t* symmap = (uint8_t*)carve(256);
-        size_t sort_tmp = 0, scan_tmp = 0, scan2_tmp = 0;
-        {
-            rocprim::double_buffer<uint64_t> dk(keysA, keysB); rocprim::double_buffer<uint32_t> dv(valsA, valsB);
-            (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, dk, dv, N, 0, 64, s);
-            (void)rocprim::inclusive_scan(nullptr, scan_tmp, rocprim::make_transform_iterator(rocprim::make_counting_iterator(0u), BwtfFlagOf{keysA, 36u}),
-                                          pair, N, BwtfPairMax(), s);
-            (void)rocprim::exclusive_scan(nullptr, scan2_tmp, keep, pos, 0u, N, rocprim::plus<uint32_t>(), s);
-        }
-        size_t tmp_bytes = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
-        if (scan2_tmp > tmp_bytes) tmp_bytes = scan2_tmp;
-        void* tmp = carve(tmp_bytes);
-        if ((uint64_t)(p - (uint8_t*)k.scratch) > k.scratch_bytes) { err = "bwt forward: scratch too small"; return RCX_RC_BAD_ARG; }
-        if (hipMemcpyAsync(bstart, h_bstart.data(), 4ull * (nb + 1), hipMemcpyHostToDevice, s) != hipSuccess) { err = "bwt forward: H2D"; return RCX_RC_HIP_ERROR; }
-        BwtfArgs fa{k.in_base, k.in_off, k.in_len, bstart, nb};
-        const uint32_t gx = (uint32_t)((maxn + 255) / 256 < 1024 ? (maxn + 255) / 256 : 1024);
-        // Alphabet compaction: the bytes that occur get dense, order-preserving codes, so that more symbols fit the first
-        // key when the alphabet is small and skewed (text: 7 of 7 bits instead of 4 of 9; DNA: 16).  High-entropy data is
-        // resolved by 4 bytes anyway and keeps the shorter key (fewer radix passes).
-        {
-            uint32_t h_hist[264];
-            if (hipMemsetAsync(hist, 0, 1056, s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
-            hipLaunchKernelGGL(k_bwtf_hist, dim3(gx ? gx : 1, nb), dim3(256), 0, s, fa, hist);
-            if (hipMemcpyAsync(h_hist, hist, 1056, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-                err = "bwt forward: histogram"; return RCX_RC_HIP_ERROR; }
-            uint8_t h_map[256]; uint32_t sigma = 0; double H0 = 0;
-            auto present = [&](int v) { return (h_hist[256 + (v >> 5)] >> (v & 31)) & 1u; };
-            uint64_t sampled = 0;
-            for (int v = 0; v < 256; v++) { h_map[v] = present(v) ? (uint8_t)(++sigma > 255 ? 255 : sigma) : 0; sampled += h_hist[v]; }
-            if (sigma == 256) for (int v = 0; v < 256; v++) h_map[v] = (uint8_t)v;          // codes 1..256 do not fit a byte: keep byte + 1 below
-            for (int v = 0; v < 256; v++) if (h_hist[v]) { const double pr = (double)h_hist[v] / (double)sampled; H0 -= pr * log2(pr); }
-            if (!sampled) H0 = 8.0;
-            if (sigma < 256 && H0 < 6.0) {
-                sbits = bits_for(sigma);
-                nsym = (64 - bblk - 1) / sbits; if (nsym > 16) nsym = 16; if (nsym < 4) nsym = 4;
-                while (nsym > 4 && nsym * sbits + bblk > 60) nsym--;                      // at most 8 radix passes in round 0
-            } else {
-                for (int v = 0; v < 256; v++) h_map[v] = (uint8_t)v;                         // plain bytes: symbol = byte + 1 (9 bits) via the +1 below
+    const uint32_t nb_all = k.nblocks;
+    std::vector<uint64_t> h_len(nb_all);
+    if (nb_all && (hipMemcpyAsync(h_len.data(), k.in_len, nb_all * 8ull, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                   hipStreamSynchronize(s) != hipSuccess)) { err = "bwt forward: cannot read in_len"; return RCX_RC_HIP_ERROR; }
+    for (uint32_t lo = 0; lo < nb_all;) {
+        // the next pass: as many blocks as stay below BWTF_MAXN suffixes
+        uint32_t nb = 0; uint64_t N64 = 0, maxn = 0;
+        while (lo + nb < nb_all && N64 + h_len[lo + nb] <= (uint64_t)BWTF_MAXN) { N64 += h_len[lo + nb]; if (h_len[lo + nb] > maxn) maxn = h_len[lo + nb]; nb++; }
+        if (nb == 0) { err = "bwt forward: a block of 2^28 bytes or more"; return RCX_RC_BAD_ARG; }
+        rcx_kargs kk = k;
+        kk.in_off += lo; kk.in_len += lo; kk.out_off += lo; kk.out_cap += lo; kk.out_len += lo; kk.status += lo;
+        if (kk.in_used) kk.in_used += lo;
+        if (kk.aux) kk.aux += lo;
+        kk.nblocks = nb;
+        std::vector<uint32_t> h_bstart(nb + 1);
+        { uint32_t a = 0; for (uint32_t b = 0; b < nb; b++) { h_bstart[b] = a; a += (uint32_t)h_len[lo + b]; } h_bstart[nb] = a; }
+        const uint32_t N = (uint32_t)N64;
+        if (N) {
+            uint8_t* p = (uint8_t*)k.scratch;
+            auto carve = [&](size_t bytes) { uint8_t* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+            BwsState st;
+            st.keyA = (uint64_t*)carve(8ull * N); st.keyB = (uint64_t*)carve(8ull * N);
+            st.saA = (uint32_t*)carve(4ull * N); st.saB = (uint32_t*)carve(4ull * N);
+            st.rank = (uint32_t*)carve(4ull * N);
+            const size_t nlarge = (size_t)N / BWS_WAVE + nb + 1024, nmid = (size_t)N / 16 + 4096;
+            st.large[0] = (BwsSeg*)carve(nlarge * sizeof(BwsSeg)); st.large[1] = (BwsSeg*)carve(nlarge * sizeof(BwsSeg)); st.nlarge = (BwsSeg*)carve(nlarge * sizeof(BwsSeg));
+            st.small = (BwsSeg*)carve(nmid * sizeof(BwsSeg)); st.nsmall = (BwsSeg*)carve(nmid * sizeof(BwsSeg));
+            uint32_t* bstart = (uint32_t*)carve(4ull * (nb + 1));
+            st.cnt = (uint32_t*)carve(4 * (64 + BWS_NFLAG));
+            uint32_t* hist = (uint32_t*)carve(1056); uint8_t* symmap = (uint8_t*)carve(256);
+            st.n = N; st.par = 0;
+            if ((uint64_t)(p - (uint8_t*)k.scratch) > k.scratch_bytes) { err = "bwt forward: scratch too small"; return RCX_RC_BAD_ARG; }
+            if (hipMemcpyAsync(bstart, h_bstart.data(), 4ull * (nb + 1), hipMemcpyHostToDevice, s) != hipSuccess) { err = "bwt forward: H2D"; return RCX_RC_HIP_ERROR; }
+            BwtfArgs fa{kk.in_base, kk.in_off, kk.in_len, bstart, nb};
+            const uint32_t gx = (uint32_t)((maxn + 255) / 256 < 1024 ? (maxn + 255) / 256 : 1024);
+            // Alphabet compaction: the bytes that occur get dense, order-preserving codes, so that more symbols fit the first
+            // key when the alphabet is small and skewed (text: 10 symbols of 6 bits instead of 7 of 9; DNA: 16).
+            uint32_t nsym = 7, sbits = 9; bool plain_bytes = true;
+            {
+                uint32_t h_hist[264];
+                if (hipMemsetAsync(hist, 0, 1056, s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
+                hipLaunchKernelGGL(k_bwtf_hist, dim3(gx ? gx : 1, nb), dim3(256), 0, s, fa, hist);
+                if (hipMemcpyAsync(h_hist, hist, 1056, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+                    err = "bwt forward: histogram"; return RCX_RC_HIP_ERROR; }
+                uint8_t h_map[256]; uint32_t sigma = 0;
+                auto present = [&](int v) { return (h_hist[256 + (v >> 5)] >> (v & 31)) & 1u; };
+                for (int v = 0; v < 256; v++) h_map[v] = present(v) ? (uint8_t)(++sigma > 255 ? 255 : sigma) : 0;
+                if (sigma < 256) { sbits = bits_for(sigma); nsym = 64 / sbits; if (nsym > 16) nsym = 16; plain_bytes = false; }
+                else for (int v = 0; v < 256; v++) h_map[v] = (uint8_t)v;                  // codes 1..256 do not fit a byte: symbol = byte + 1 (9 bits)
+                if (hipMemcpyAsync(symmap, h_map, 256, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+                    err = "bwt forward: symbol map"; return RCX_RC_HIP_ERROR; }
             }
-            plain_bytes = !(sigma < 256 && H0 < 6.0);
-            if (hipMemcpyAsync(symmap, h_map, 256, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-                err = "bwt forward: symbol map"; return RCX_RC_HIP_ERROR; }
+            hipLaunchKernelGGL(k_bwtf_init, dim3(gx ? gx : 1, nb), dim3(256), 0, s, fa, st.keyA, st.saA, symmap, nsym, sbits, plain_bytes ? 1u : 0u);
+            if (hipMemsetAsync(st.cnt, 0, 4 * (64 + BWS_NFLAG), s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
+            const uint32_t kbits0 = nsym * sbits, top0 = kbits0 > 8 ? kbits0 - 8 : 0;
+            const uint32_t kbits1 = bits_for(maxn), top1 = kbits1 > 8 ? kbits1 - 8 : 0;           // later keys: local rank + 1 <= maxn
+            hipLaunchKernelGGL(k_bws_seed, dim3((nb + 255) / 256), dim3(256), 0, s, st, bstart, nb, top0);
+            uint32_t h = nsym;
+            const uint32_t gdense = (N + 255) / 256;
+            bool converged = false;
+            for (int round = 0; round < 64; round++) {
+                st.par = (round & 1) ? BWS_PAR : 0u;
+                const uint32_t top = round == 0 ? top0 : top1, topn = top1;
+                if (round) hipLaunchKernelGGL(k_bws_gather, dim3(gx ? gx : 1, nb), dim3(256), 0, s, st, bstart, nb, h);
+                const int levels = (int)((top + 7) / 8) + 1;
+                for (int lv = 0; lv < levels; lv++) {
+                    if (hipMemsetAsync(&st.cnt[(lv + 1) & 1], 0, 4, s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
+                    if (round == 0) hipLaunchKernelGGL(k_bws_partition<uint64_t>, dim3(2048), dim3(512), 0, s, st, lv, topn);
+                    else hipLaunchKernelGGL(k_bws_partition<uint32_t>, dim3(2048), dim3(512), 0, s, st, lv, topn);
+                }
+                if (round == 0) { hipLaunchKernelGGL(k_bws_small<uint64_t>, dim3(2048), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_dense<uint64_t>, dim3(gdense), dim3(256), 0, s, st, 0u); hipLaunchKernelGGL(k_bws_dense<uint64_t>, dim3(gdense), dim3(256), 0, s, st, 32u); }
+                else { hipLaunchKernelGGL(k_bws_small<uint32_t>, dim3(2048), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_dense<uint32_t>, dim3(gdense), dim3(256), 0, s, st, 0u); hipLaunchKernelGGL(k_bws_dense<uint32_t>, dim3(gdense), dim3(256), 0, s, st, 32u); }
+                std::vector<uint32_t> hcv(64 + BWS_NFLAG);
+                uint32_t* hc = hcv.data();
+                if (hipMemcpyAsync(hc, st.cnt, 4 * (64 + BWS_NFLAG), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { err = "bwt forward: sync failed"; return RCX_RC_HIP_ERROR; }
+                hc[5] = 0;
+                for (uint32_t f = 0; f < BWS_NFLAG; f++) hc[5] |= hc[64 + f];
+                if (getenv("RCX_BWT_TRACE")) fprintf(stderr, "bwt forward round %d: h=%u unresolved %u (listed: %u large, %u small)\n", round, h, hc[5], hc[3], hc[4]);
+                if (hc[5] == 0) { converged = true; break; }
+                if (hc[3] > nlarge || hc[4] > nmid) { err = "bwt forward: group list overflow"; return RCX_RC_HIP_ERROR; }
+                std::swap(st.large[0], st.nlarge); std::swap(st.small, st.nsmall);
+                const uint32_t nc[8] = {hc[3], 0, hc[4], 0, 0, 0, 0, 0};
+                if (hipMemsetAsync(st.cnt + 64, 0, 4 * BWS_NFLAG, s) != hipSuccess ||
+                    hipMemcpyAsync(st.cnt, nc, 32, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { err = "bwt forward: H2D"; return RCX_RC_HIP_ERROR; }
+                h = round == 0 ? nsym : 2 * h;
+            }
+            if (!converged) { err = "bwt forward: did not converge"; return RCX_RC_HIP_ERROR; }
+            hipLaunchKernelGGL(k_bwtf_emit, dim3(gx ? gx : 1, nb), dim3(256), 0, s, fa, st.saA, kk.out_base, kk.out_off, kk.out_cap, kk.aux);
         }
-        hipLaunchKernelGGL(k_bwtf_init, dim3(gx ? gx : 1, nb), dim3(256), 0, s, fa, keysA, valsA, symmap, nsym, sbits, plain_bytes ? 1u : 0u);
-        rocprim::double_buffer<uint64_t> dk(keysA, keysB); rocprim::double_buffer<uint32_t> dv(valsA, valsB);
-        // Round 0 sorts every suffix by its first 4 bytes; each later round sorts only the suffixes whose group
-        // is still larger than one (Larsson-Sadakane style discarding) by (group rank, rank of suffix + h).
-        uint32_t sb = nsym * sbits, so = nsym * sbits, end_bit = nsym * sbits + bblk, h = nsym, n = N;
-        for (int round = 0; round < 40 && n; round++) {
-            const uint32_t gn = (n + 255) / 256;
-            size_t tb = tmp_bytes;
-            if (rocprim::radix_sort_pairs(tmp, tb, dk, dv, n, 0, end_bit, s) != hipSuccess) { err = "bwt forward: radix sort failed"; return RCX_RC_HIP_ERROR; }
-            tb = tmp_bytes;                                      // group flags computed inside the scan's loads (no flag array round trip)
-            if (rocprim::inclusive_scan(tmp, tb, rocprim::make_transform_iterator(rocprim::make_counting_iterator(0u), BwtfFlagOf{dk.current(), so}),
-                                        pair, n, BwtfPairMax(), s) != hipSuccess) { err = "bwt forward: scan failed"; return RCX_RC_HIP_ERROR; }
-            hipLaunchKernelGGL(k_bwtf_rank, dim3(gn), dim3(256), 0, s, dk.current(), dv.current(), pair, bstart, rank, sa, keep, n, sb, br, br1, round == 0 ? 1 : 0);
-            tb = tmp_bytes;
-            if (rocprim::exclusive_scan(tmp, tb, keep, pos, 0u, n, rocprim::plus<uint32_t>(), s) != hipSuccess) { err = "bwt forward: scan failed"; return RCX_RC_HIP_ERROR; }
-            hipLaunchKernelGGL(k_bwtf_count, dim3(1), dim3(64), 0, s, keep, pos, n, counter);
-            hipLaunchKernelGGL(k_bwtf_next, dim3(gn), dim3(256), 0, s, dk.current(), dv.current(), keep, pos, rank, bstart,
-                               dk.alternate(), dv.alternate(), n, sb, br, br1, h);
-            uint32_t left = 0;
-            (void)hipMemcpyAsync(&left, counter, 4, hipMemcpyDeviceToHost, s);
-            if (hipStreamSynchronize(s) != hipSuccess) { err = "bwt forward: sync failed"; return RCX_RC_HIP_ERROR; }
-            if (getenv("RCX_BWT_TRACE")) fprintf(stderr, "bwt forward round %d: h=%u elements %u -> survivors %u\n", round, h, n, left);
-            dk.swap(); dv.swap();
-            n = left; sb = br1 + br; so = br; end_bit = br1 + br + bblk; h *= 2;
-        }
-        if (n) { err = "bwt forward: did not converge"; return RCX_RC_HIP_ERROR; }
-        hipLaunchKernelGGL(k_bwtf_emit, dim3(gx ? gx : 1, nb), dim3(256), 0, s, fa, sa, k.out_base, k.out_off, k.out_cap, k.aux);
+        hipLaunchKernelGGL(k_bwtf_finish, dim3((nb + 255) / 256), dim3(256), 0, s, kk);
+        lo += nb;
     }
-    hipLaunchKernelGGL(k_bwtf_finish, dim3((nb + 255) / 256), dim3(256), 0, s, k);
     return RCX_RC_OK;
 }
 

@@ -1,0 +1,434 @@
+// k_bwt_sort.hip -- the suffix sorter of the forward BWT (reference: bwt::compute_suffixes, src/bwt/mod.rs:136-166), hand-written.
+//
+// Prefix doubling, but the groups of a round are sorted WHERE THEY LIE instead of by device-wide sorts of (block | rank | rank)
+// keys (the first version: rocPRIM radix sorts + scans, ~250 bytes of HBM traffic per suffix and round).  SA[j] holds a suffix
+// (global index) plus three flags: HEAD (a group starts at j), FINAL (the group is this one suffix: its place is final) and the
+// parity of the round that made the group.  Round 0 sorts by a 64-bit key of the first <= 10 symbols, round r > 0 by the 32-bit
+// key `rank[suffix + h]` (0 = past the end: the reference's "a proper prefix sorts first"), gathered for every non-final
+// position before anything is moved.  A group is then sorted by the path that fits its size:
+//   * more than 64 suffixes: k_bws_partition, one workgroup per group: MSD radix step on 8 key bits (per-wave histograms in
+//     LDS, scatter to the other buffer); bins of more than 64 are groups of the next level, singletons are final at once,
+//     everything in between is marked in place for the wave-level sorts;
+//   * at most 64, inside a 64-suffix window (aligned, or shifted by 32) -- nearly all groups of a text: k_bws_dense, ONE LANE
+//     PER SUFFIX over the whole array: the HEAD bits of a window give every lane its group, a wave-wide bitonic sort over
+//     ds_bpermute by (group, key) orders every group of the window at once.  No descriptors, no launch per group;
+//   * the few groups of 33..64 that straddle both window grids: k_bws_small, one wave per group, the same wave sort.
+// Every path ends the same way: runs of equal keys are the new groups (rank = position of the run's first suffix, written in
+// place -- the keys of the round were gathered before), runs of one are FINAL.  Groups that the dense pass cannot take are
+// appended to the next round's lists.  Per suffix and round: one gather of a rank (random), one scatter of a rank (random) and
+// ~30 bytes of streaming traffic.
+#include <hip/hip_runtime.h>
+#include "rcx_dev.h"
+
+#define BWS_FINAL 0x80000000u
+#define BWS_HEAD  0x40000000u
+#define BWS_PAR   0x20000000u
+#define BWS_IDX   0x0fffffffu            /* suffix index: batches of < 2^28 suffixes per pass */
+#define BWS_WAVE  32u                    /* the largest group left to the wave-level sorts: it always lies inside a 64-suffix window, aligned or shifted by 32 */
+
+struct BwsSeg { uint32_t start, len, info; };                 // info: key shift of the next radix step | buffer << 8
+// counters: [0] large list A, [1] large list B, [2] small list, [3] next round's large list, [4] next round's small list, [5] unresolved groups
+struct BwsState {
+    uint64_t* keyA; uint64_t* keyB;          // u64 keys (round 0); the u32 keys of later rounds use the first half of each
+    uint32_t* saA; uint32_t* saB;            // saA is the suffix array proper, saB the partition steps' other buffer
+    uint32_t* rank;
+    BwsSeg* large[2]; BwsSeg* small; BwsSeg* nlarge; BwsSeg* nsmall;
+    uint32_t* cnt;
+    uint32_t n;                               // suffixes in this pass
+    uint32_t par;                             // parity bit groups made in THIS round carry (BWS_PAR or 0)
+};
+
+template <class K> __device__ __forceinline__ K* bws_keys(const BwsState& s, int buf) { return (K*)(buf ? s.keyB : s.keyA); }
+__device__ __forceinline__ uint32_t* bws_sa(const BwsState& s, int buf) { return buf ? s.saB : s.saA; }
+// a group the dense passes sort: it lies inside a 64-suffix window, either aligned or shifted by 32
+__device__ __forceinline__ bool bws_dense_ok(uint32_t a, uint32_t len)
+{
+    const uint32_t z = a + len - 1u;
+    return len <= BWS_WAVE && ((a >> 6) == (z >> 6) || ((a + 32u) >> 6) == ((z + 32u) >> 6));
+}
+
+// Append `seg` to a list for the lanes with `want`: ONE atomic per wave (a single word takes ~88 atomics per microsecond on
+// this chip: one atomic per group made the first version's passes take 40 ms whatever else they did).  Wave-uniform call.
+__device__ __forceinline__ void bws_append(BwsSeg* list, uint32_t* counter, bool want, const BwsSeg& seg)
+{
+    const unsigned long long m = __ballot(want);
+    if (!m) return;
+    const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll(m) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(leader << 2), (int)base);
+    if (want) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = seg;
+}
+// "Some group is still unresolved": 1024 flag words (cnt[64 ..]), each wave stores to its own -- a single word that every wave
+// reads or writes is a hot spot of the memory system just like an atomic.  The host ORs them after the round.
+#define BWS_NFLAG 1024u
+__device__ __forceinline__ void bws_flag_unresolved(const BwsState& s)
+{
+    s.cnt[64u + ((blockIdx.x * 8u + (threadIdx.x >> 6)) & (BWS_NFLAG - 1u))] = 1u;
+}
+// A finished run of equal keys [a, a + len) in saA (for the lanes with `is`): hand it to the next round unless the dense passes
+// find it by themselves.  Wave-uniform call.
+__device__ __forceinline__ void bws_new_group(const BwsState& s, bool is, uint32_t a, uint32_t len, uint32_t top_shift)
+{
+    if (__ballot(is)) { if ((threadIdx.x & 63u) == 0) bws_flag_unresolved(s); }
+    const bool listed = is && !bws_dense_ok(a, len);
+    bws_append(s.nlarge, &s.cnt[3], listed && len > BWS_WAVE, BwsSeg{a, len, top_shift});
+    bws_append(s.nsmall, &s.cnt[4], listed && len <= BWS_WAVE, BwsSeg{a, len, 0u});
+}
+
+// x of lane ^ J2.  Partners at distance 1, 2, 4, 8 come over DPP (quad permutes; row shifts + a select): VALU work -- a
+// ds_bpermute holds the CU's LDS crossbar for ~16 cycles, and a wave sort would issue 84 of them.  Distances 16 and 32 keep it.
+template <int J2>
+__device__ __forceinline__ uint32_t bws_xchg(uint32_t x, uint32_t lane)
+{
+    if (J2 == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false);        // quad_perm [1,0,3,2]
+    if (J2 == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false);        // quad_perm [2,3,0,1]
+    if (J2 == 4 || J2 == 8) {
+        const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x100 + J2, 0xf, 0xf, false);   // row_shl: lane i <- i + J2
+        const uint32_t dn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x110 + J2, 0xf, 0xf, false);   // row_shr: lane i <- i - J2
+        return (lane & (uint32_t)J2) ? dn : up;
+    }
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ^ (uint32_t)J2) << 2), (int)x);
+}
+template <class K, int K2, int J2>
+__device__ __forceinline__ void bws_cmpx(uint32_t lane, uint32_t& c0, uint32_t& klo, uint32_t& khi, uint32_t& val, uint32_t& was)
+{
+    const uint32_t oc = sizeof(K) == 8 ? bws_xchg<J2>(c0, lane) : 0u;          // u32 keys carry the group in their top bits
+    const uint32_t ol = bws_xchg<J2>(klo, lane);
+    const uint32_t oh = sizeof(K) == 8 ? bws_xchg<J2>(khi, lane) : 0u;
+    const uint32_t ov = bws_xchg<J2>(val | (was << 31), lane);
+    // is the partner's element smaller than mine? (ties by suffix index: deterministic)
+    const bool ol_lt = oc < c0 || (oc == c0 && (oh < khi || (oh == khi && (ol < klo || (ol == klo && (ov & BWS_IDX) < val)))));
+    const bool lower = (lane & (uint32_t)J2) == 0, up = (lane & (uint32_t)K2) == 0;
+    const bool take = (lower == up) ? ol_lt : !ol_lt;          // the lower lane of an ascending pair keeps the smaller element
+    if (take) { c0 = oc; klo = ol; khi = oh; val = ov & BWS_IDX; was = ov >> 31; }
+}
+// Wave-wide bitonic sort of one element per lane by (c0, key, suffix): 21 compare-exchange steps.  `was` rides along.
+template <class K>
+__device__ __forceinline__ void bws_wave_sort(uint32_t lane, uint32_t& c0, uint32_t& klo, uint32_t& khi, uint32_t& val, uint32_t& was)
+{
+#define BWS_S(K2, J2) bws_cmpx<K, K2, J2>(lane, c0, klo, khi, val, was);
+    BWS_S(2, 1)
+    BWS_S(4, 2) BWS_S(4, 1)
+    BWS_S(8, 4) BWS_S(8, 2) BWS_S(8, 1)
+    BWS_S(16, 8) BWS_S(16, 4) BWS_S(16, 2) BWS_S(16, 1)
+    BWS_S(32, 16) BWS_S(32, 8) BWS_S(32, 4) BWS_S(32, 2) BWS_S(32, 1)
+    BWS_S(64, 32) BWS_S(64, 16) BWS_S(64, 8) BWS_S(64, 4) BWS_S(64, 2) BWS_S(64, 1)
+#undef BWS_S
+}
+// After the sort: the run of equal (c0, key) a lane belongs to, as [rs, re) in lanes; rhead: the lane opens its run.
+template <class K>
+__device__ __forceinline__ void bws_wave_runs(uint32_t lane, uint32_t c0, uint32_t klo, uint32_t khi, bool& rhead, uint32_t& rs, uint32_t& re)
+{
+    const int pa = (int)(((lane + 63u) & 63u) << 2);
+    const uint32_t pc = sizeof(K) == 8 ? (uint32_t)__builtin_amdgcn_ds_bpermute(pa, (int)c0) : c0;
+    const uint32_t pl = (uint32_t)__builtin_amdgcn_ds_bpermute(pa, (int)klo);
+    const uint32_t ph = sizeof(K) == 8 ? (uint32_t)__builtin_amdgcn_ds_bpermute(pa, (int)khi) : 0u;
+    rhead = lane == 0 || pc != c0 || pl != klo || ph != khi;
+    const unsigned long long rh = __ballot(rhead);
+    const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    const unsigned long long rb = rh & le, ra = rh & ~le;
+    rs = 63u - (uint32_t)__clzll(rb);
+    re = ra ? (uint32_t)__ffsll(ra) - 1u : 64u;
+}
+
+// ---- keys of a doubling round: key[j] = local rank + 1 of (suffix at j) + h, 0 = past the end of its block ------------------
+__global__ __launch_bounds__(256) void k_bws_gather(BwsState s, const uint32_t* bstart, uint32_t nblocks, uint32_t h)
+{
+    const uint32_t b = blockIdx.y;
+    const uint32_t g0 = bstart[b], e = bstart[b + 1];
+    uint32_t* key = (uint32_t*)s.keyA;
+    for (uint32_t j = g0 + blockIdx.x * blockDim.x + threadIdx.x; j < e; j += gridDim.x * blockDim.x) {
+        const uint32_t v = s.saA[j];
+        if (v & BWS_FINAL) continue;
+        const uint32_t g = v & BWS_IDX;
+        key[j] = (g + h < e) ? s.rank[g + h] - g0 + 1u : 0u;
+    }
+}
+
+// ---- round 0 seed: every block is one group, identity order -----------------------------------------------------------------
+__global__ void k_bws_seed(BwsState s, const uint32_t* bstart, uint32_t nblocks, uint32_t top_shift)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const uint32_t a = bstart[b], len = bstart[b + 1] - a;
+    if (len == 0) return;
+    if (len == 1) { s.saA[a] = a | BWS_HEAD | BWS_FINAL; s.rank[a] = a; return; }
+    // the seed groups carry the parity of "the round before round 0" so that the dense passes take the small ones
+    s.saA[a] |= BWS_HEAD | (s.par ^ BWS_PAR);
+    if (len > BWS_WAVE) { const uint32_t i = atomicAdd(&s.cnt[0], 1u); s.large[0][i] = BwsSeg{a, len, top_shift}; }
+    else if (!bws_dense_ok(a, len)) { const uint32_t i = atomicAdd(&s.cnt[2], 1u); s.small[i] = BwsSeg{a, len, 0u}; }
+}
+
+// ---- groups of more than BWS_WAVE suffixes: one MSD radix step (8 key bits) per launch --------------------------------------
+// Small groups (<= BWS_WSEG suffixes: most groups of the deeper levels) are partitioned by ONE WAVE each, eight side by side in
+// a workgroup with wave-level synchronisation only; large groups by a whole workgroup.
+#define BWS_WSEG 1024u
+
+// what became of bin `d` of group sg (count c, first place a): the list it goes to.  Wave-uniform call (64 bins at a time).
+__device__ __forceinline__ void bws_route_bin(const BwsState& s, BwsSeg* lnext, uint32_t* clnext, bool done, uint32_t c, uint32_t a,
+                                              uint32_t shift, int dst, uint32_t top_shift)
+{
+    bws_new_group(s, done && c >= 2u, a, c, top_shift);
+    bws_append(lnext, clnext, !done && c > BWS_WAVE, BwsSeg{a, c, (shift > 8u ? shift - 8u : 0u) | ((uint32_t)dst << 8)});
+    bws_append(s.small, &s.cnt[2], !done && c >= 2u && c <= BWS_WAVE && !bws_dense_ok(a, c), BwsSeg{a, c, 0u});
+}
+// the element pass after the scatter: a singleton is final; a bin of equal keys (every bit used) is a finished group; a bin of
+// <= BWS_WAVE goes to saA / keyA marked for the wave-level sorts; a larger one stays where it is for the next level.
+template <class K>
+__device__ __forceinline__ void bws_mark(const BwsState& s, const BwsSeg& sg, uint32_t p, K k, uint32_t g, uint32_t c, uint32_t beg, bool done, int dst)
+{
+    if (c > BWS_WAVE && !done) return;
+    const uint32_t a = sg.start + p;
+    if (c == 1u) { s.saA[a] = g | BWS_HEAD | BWS_FINAL; s.rank[g] = a; }
+    else if (done) { s.saA[a] = g | (p == beg ? (BWS_HEAD | s.par) : 0u); s.rank[g] = sg.start + beg; }
+    else { s.saA[a] = g | (p == beg ? (BWS_HEAD | (s.par ^ BWS_PAR)) : 0u); if (dst != 0) bws_keys<K>(s, 0)[a] = k; }
+}
+// digit peers of a wave: the lanes (among `ok`) that hold the same digit as mine
+__device__ __forceinline__ unsigned long long bws_peers(bool ok, uint32_t d)
+{
+    unsigned long long peers = __ballot(ok);
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++) { const unsigned long long m = __ballot((d >> bit) & 1u); peers &= ((d >> bit) & 1u) ? m : ~m; }
+    return peers;
+}
+
+template <class K>
+__global__ __launch_bounds__(512) void k_bws_partition(BwsState s, int level, uint32_t top_shift)
+{
+    __shared__ uint32_t s_hist[8][256];           // per wave; after the scan: the wave's next free place in each bin
+    __shared__ uint32_t s_wbeg[8][256];           // wave path: where each bin begins
+    __shared__ uint32_t s_tot[256], s_beg[256];
+    __shared__ uint32_t s_one;
+    const BwsSeg* list = s.large[level & 1];
+    BwsSeg* lnext = s.large[(level + 1) & 1];
+    uint32_t* clnext = &s.cnt[(level + 1) & 1];
+    const uint32_t nseg = s.cnt[level & 1];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    // ---------------------------------------------------------------- small groups: one wave each, eight entries per workgroup and turn
+    for (uint32_t base = blockIdx.x * 8u; base < nseg; base += gridDim.x * 8u) {
+        if (base + wave < nseg && list[base + wave].len <= BWS_WSEG) {
+            const BwsSeg sg = list[base + wave];
+            uint32_t shift = sg.info & 0xffu;
+            const int src = (int)((sg.info >> 8) & 1u), dst = src ^ 1;
+            const K* ks = bws_keys<K>(s, src) + sg.start; K* kd = bws_keys<K>(s, dst) + sg.start;
+            const uint32_t* ss = bws_sa(s, src) + sg.start; uint32_t* sd = bws_sa(s, dst) + sg.start;
+            uint32_t* hist = s_hist[wave]; uint32_t* wbeg = s_wbeg[wave];
+            for (;;) {                                     // steps in which every suffix falls into one bin move nothing: skipped
+#pragma unroll
+                for (int q = 0; q < 4; q++) hist[lane + 64 * q] = 0;
+                rcx_wave_sync();
+                for (uint32_t i0 = 0; i0 < sg.len; i0 += 64) {
+                    const uint32_t i = i0 + lane; const bool ok = i < sg.len;
+                    const uint32_t d = ok ? (uint32_t)(ks[i] >> shift) & 0xffu : 0x100u;
+                    const unsigned long long peers = bws_peers(ok, d);
+                    if (ok && (uint32_t)__ffsll(peers) - 1u == lane) hist[d] += (uint32_t)__popcll(peers);
+                    rcx_wave_sync();
+                }
+                const bool one = hist[lane] == sg.len || hist[lane + 64] == sg.len || hist[lane + 128] == sg.len || hist[lane + 192] == sg.len;
+                if (!__ballot(one) || shift == 0u) break;
+                shift = shift > 8u ? shift - 8u : 0u;
+                rcx_wave_sync();
+            }
+            const bool done = shift == 0u;
+            {
+                const uint32_t t0 = hist[4 * lane], t1 = hist[4 * lane + 1], t2 = hist[4 * lane + 2], t3 = hist[4 * lane + 3];
+                const uint32_t ex = rcx_wave_incl_scan(t0 + t1 + t2 + t3) - (t0 + t1 + t2 + t3);
+                wbeg[4 * lane] = ex; wbeg[4 * lane + 1] = ex + t0; wbeg[4 * lane + 2] = ex + t0 + t1; wbeg[4 * lane + 3] = ex + t0 + t1 + t2;
+            }
+            rcx_wave_sync();
+            uint32_t cnt4[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { cnt4[q] = hist[lane + 64 * q]; }
+            rcx_wave_sync();
+#pragma unroll
+            for (int q = 0; q < 4; q++) hist[lane + 64 * q] = wbeg[lane + 64 * q];           // the cursors
+            rcx_wave_sync();
+            for (uint32_t i0 = 0; i0 < sg.len; i0 += 64) {
+                const uint32_t i = i0 + lane; const bool ok = i < sg.len;
+                const K k = ok ? ks[i] : (K)0;
+                const uint32_t d = ok ? (uint32_t)(k >> shift) & 0xffu : 0x100u;
+                const unsigned long long peers = bws_peers(ok, d);
+                const uint32_t leader = (uint32_t)__ffsll(peers) - 1u;
+                uint32_t bse = 0;
+                if (ok && leader == lane) { bse = hist[d]; hist[d] = bse + (uint32_t)__popcll(peers); }
+                bse = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((leader & 63u) << 2), (int)bse);
+                if (ok) { const uint32_t p = bse + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull)); kd[p] = k; sd[p] = ss[i] & BWS_IDX; }
+                rcx_wave_sync();
+            }
+            __threadfence_block();
+            rcx_wave_sync();
+            for (uint32_t p0 = 0; p0 < sg.len; p0 += 64) {
+                const uint32_t p = p0 + lane;
+                if (p < sg.len) {
+                    const K k = kd[p];
+                    const uint32_t d = (uint32_t)(k >> shift) & 0xffu;
+                    // bin sizes: the cursors now stand at the bins' ends
+                    bws_mark<K>(s, sg, p, k, sd[p], hist[d] - wbeg[d], wbeg[d], done, dst);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) bws_route_bin(s, lnext, clnext, done, cnt4[q], sg.start + wbeg[lane + 64 * q], shift, dst, top_shift);
+        }
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- large groups: one workgroup each
+    {
+        for (uint32_t e = blockIdx.x; e < nseg; e += gridDim.x) {
+            const BwsSeg sg = list[e];
+            if (sg.len <= BWS_WSEG) continue;
+            uint32_t shift = sg.info & 0xffu;
+            const int src = (int)((sg.info >> 8) & 1u), dst = src ^ 1;
+            const K* ks = bws_keys<K>(s, src) + sg.start; K* kd = bws_keys<K>(s, dst) + sg.start;
+            const uint32_t* ss = bws_sa(s, src) + sg.start; uint32_t* sd = bws_sa(s, dst) + sg.start;
+            for (;;) {
+                for (uint32_t i = tid; i < 8 * 256; i += 512) ((uint32_t*)s_hist)[i] = 0;
+                if (tid == 0) s_one = 0;
+                __syncthreads();
+                for (uint32_t i0 = 0; i0 < sg.len; i0 += 512) {            // text digits are skewed: lanes with the same digit count once
+                    const uint32_t i = i0 + tid; const bool ok = i < sg.len;
+                    const uint32_t d = ok ? (uint32_t)(ks[i] >> shift) & 0xffu : 0x100u;
+                    const unsigned long long peers = bws_peers(ok, d);
+                    if (ok && (uint32_t)__ffsll(peers) - 1u == lane) atomicAdd(&s_hist[wave][d], (uint32_t)__popcll(peers));
+                }
+                __syncthreads();
+                if (tid < 256) {
+                    uint32_t t = 0;
+#pragma unroll
+                    for (int w = 0; w < 8; w++) t += s_hist[w][tid];
+                    s_tot[tid] = t;
+                    if (t == sg.len) s_one = 1;
+                }
+                __syncthreads();
+                if (!s_one || shift == 0u) break;
+                shift = shift > 8u ? shift - 8u : 0u;
+                __syncthreads();
+            }
+            const bool done = shift == 0u;                     // every key bit used after this step: a bin is a group of equal keys
+            if (tid < 64) {                            // exclusive scan of the 256 totals: 4 per lane + a wave scan
+                const uint32_t t0 = s_tot[4 * tid], t1 = s_tot[4 * tid + 1], t2 = s_tot[4 * tid + 2], t3 = s_tot[4 * tid + 3];
+                const uint32_t ex = rcx_wave_incl_scan(t0 + t1 + t2 + t3) - (t0 + t1 + t2 + t3);
+                s_beg[4 * tid] = ex; s_beg[4 * tid + 1] = ex + t0; s_beg[4 * tid + 2] = ex + t0 + t1; s_beg[4 * tid + 3] = ex + t0 + t1 + t2;
+            }
+            __syncthreads();
+            if (tid < 256) {
+                uint32_t o = s_beg[tid];
+#pragma unroll
+                for (int w = 0; w < 8; w++) { const uint32_t c = s_hist[w][tid]; s_hist[w][tid] = o; o += c; }
+            }
+            __syncthreads();
+            for (uint32_t i0 = 0; i0 < sg.len; i0 += 512) {
+                const uint32_t i = i0 + tid; const bool ok = i < sg.len;
+                const K k = ok ? ks[i] : (K)0;
+                const uint32_t d = ok ? (uint32_t)(k >> shift) & 0xffu : 0x100u;
+                const unsigned long long peers = bws_peers(ok, d);
+                const uint32_t leader = (uint32_t)__ffsll(peers) - 1u;
+                uint32_t bse = 0;
+                if (ok && leader == lane) bse = atomicAdd(&s_hist[wave][d], (uint32_t)__popcll(peers));
+                bse = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((leader & 63u) << 2), (int)bse);
+                if (ok) { const uint32_t p = bse + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull)); kd[p] = k; sd[p] = ss[i] & BWS_IDX; }
+            }
+            __syncthreads();
+            for (uint32_t p = tid; p < sg.len; p += 512) {
+                const K k = kd[p];
+                const uint32_t d = (uint32_t)(k >> shift) & 0xffu;
+                bws_mark<K>(s, sg, p, k, sd[p], s_tot[d], s_beg[d], done, dst);
+            }
+            if (tid < 256) bws_route_bin(s, lnext, clnext, done, s_tot[tid], sg.start + s_beg[tid], shift, dst, top_shift);
+            __syncthreads();
+        }
+    }
+}
+
+// ---- the few groups of <= 64 the dense passes cannot take (33..64 suffixes across both window grids): one wave per group ----
+template <class K>
+__global__ __launch_bounds__(256) void k_bws_small(BwsState s, uint32_t top_shift)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nseg = s.cnt[2];
+    for (uint32_t si = blockIdx.x * 4u + (threadIdx.x >> 6); si < nseg; si += gridDim.x * 4u) {
+        const BwsSeg sg = s.small[si];
+        const bool in = lane < sg.len;
+        const uint32_t v = in ? s.saA[sg.start + lane] : 0u;
+        const K key = in ? bws_keys<K>(s, 0)[sg.start + lane] : (K)0;
+        uint32_t c0 = in ? 0u : 1u;                         // the padding lanes sort behind the group
+        uint32_t klo = (uint32_t)key, khi = sizeof(K) == 8 ? (uint32_t)((uint64_t)key >> 32) : 0u;
+        uint32_t val = in ? (v & BWS_IDX) : (BWS_IDX - lane), was = in ? 1u : 0u;
+        if (sizeof(K) == 4) { klo = (in ? klo : 0u) | (c0 << 24); c0 = 0; }
+        bws_wave_sort<K>(lane, c0, klo, khi, val, was);
+        bool rhead; uint32_t rs, re;
+        bws_wave_runs<K>(lane, c0, klo, khi, rhead, rs, re);
+        if (was) {
+            const bool single = re - rs == 1u;
+            s.saA[sg.start + lane] = val | (rhead ? (BWS_HEAD | s.par) : 0u) | (single ? BWS_FINAL : 0u);
+            s.rank[val] = sg.start + rs;
+        }
+        bws_new_group(s, was && rhead && re - rs >= 2u, sg.start + rs, re - rs, top_shift);
+    }
+}
+
+// ---- groups of <= 64 inside a window: one lane per suffix over the whole array ----------------------------------------------
+// Windows of 64 suffixes starting at `off` (0 or 32: a group of <= 32 suffixes that straddles an aligned window lies inside a
+// shifted one).  The lanes of a window sort by (start of my group, key, lane): that orders every group the window contains
+// and moves nothing else -- a wave-wide bitonic sort over ds_bpermute (21 compare-exchange steps whatever the group sizes).
+template <class K>
+__global__ __launch_bounds__(256) void k_bws_dense(BwsState s, uint32_t off)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t j0 = off + (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u;
+    if (j0 >= s.n) return;
+    const uint32_t j = j0 + lane;
+    const bool in = j < s.n;
+    const uint32_t v = in ? s.saA[j] : (BWS_HEAD | BWS_FINAL);
+    const bool nexthead = (j0 + 64u >= s.n) || (s.saA[j0 + 64u] & BWS_HEAD);
+    const unsigned long long heads = __ballot((v & BWS_HEAD) != 0);
+    const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    const unsigned long long hb = heads & le, ha = heads & ~le;
+    const bool has_head = hb != 0;
+    const uint32_t gs = has_head ? 63u - (uint32_t)__clzll(hb) : 0u;
+    const uint32_t ge = ha ? (uint32_t)__ffsll(ha) - 1u : 64u;
+    // my group lies inside this window, is not final, and was made BEFORE this round (this round's groups are sorted already)
+    const uint32_t hv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(gs << 2), (int)v);
+    const bool mine = in && has_head && (ha != 0 || nexthead) && ge - gs >= 2u && (hv & BWS_PAR) != s.par && !(hv & BWS_FINAL);
+    if (!__ballot(mine)) return;
+    const K key = in ? bws_keys<K>(s, 0)[j] : (K)0;
+    const uint32_t maxlen = rcx_wave_max(mine ? ge - gs : 0u);
+    uint32_t val = v & BWS_IDX, was = mine ? 1u : 0u;
+    bool rhead; uint32_t rs, re;
+    if (maxlen <= 12u) {
+        // small groups only (the usual case after the first rounds): a rank sort, 2-3 ds_bpermute per member of the largest group
+        const uint32_t klo = (uint32_t)key, khi = sizeof(K) == 8 ? (uint32_t)((uint64_t)key >> 32) : 0u;
+        uint32_t less = 0, lt = 0, eq = 0;
+        for (uint32_t t = 0; t < maxlen; t++) {
+            const uint32_t srcl = gs + t;
+            const int pa = (int)((srcl & 63u) << 2);
+            const uint32_t ol = (uint32_t)__builtin_amdgcn_ds_bpermute(pa, (int)klo);
+            const uint32_t oh = sizeof(K) == 8 ? (uint32_t)__builtin_amdgcn_ds_bpermute(pa, (int)khi) : 0u;
+            const uint32_t ov = (uint32_t)__builtin_amdgcn_ds_bpermute(pa, (int)val);
+            if (mine && srcl < ge) {
+                const bool l = oh < khi || (oh == khi && ol < klo), e = oh == khi && ol == klo;
+                lt += l ? 1u : 0u; eq += e ? 1u : 0u;
+                less += (l || (e && ov < val)) ? 1u : 0u;
+            }
+        }
+        if (mine) {
+            const bool single = eq == 1u;
+            s.saA[j0 + gs + less] = val | (less == lt ? (BWS_HEAD | s.par) : 0u) | (single ? BWS_FINAL : 0u);
+            s.rank[val] = j0 + gs + lt;
+        }
+        rhead = less == lt; rs = 0; re = eq;
+    } else {
+        uint32_t c0 = mine ? gs : lane;                          // composite sort key: (group start or my own lane, key)
+        uint32_t klo = (uint32_t)key, khi = sizeof(K) == 8 ? (uint32_t)((uint64_t)key >> 32) : 0u;
+        if (sizeof(K) == 4) { klo = (mine ? klo : 0u) | (c0 << 24); c0 = 0; }   // 32-bit keys are local ranks (< 2^24): the group rides in the key's top bits (a bystander's stale key must not)
+        bws_wave_sort<K>(lane, c0, klo, khi, val, was);
+        bws_wave_runs<K>(lane, c0, klo, khi, rhead, rs, re);
+        if (was) {
+            const bool single = re - rs == 1u;
+            s.saA[j] = val | (rhead ? (BWS_HEAD | s.par) : 0u) | (single ? BWS_FINAL : 0u);
+            s.rank[val] = j0 + rs;
+        }
+    }
+    const unsigned long long newgroups = __ballot(was && rhead && re - rs >= 2u);       // (rank-sort path: rs = 0, re = run length)
+    if (lane == 0 && newgroups) bws_flag_unresolved(s);
+}
