@@ -118,3 +118,37 @@ def test_config5_pipeline_roundtrip_and_stage_parity(ctx, oracle):
         assert P.decode_stream(ctx, blob) == data[: BLOCK + 5].tobytes()
     assert P.decode_stream(ctx, P.encode_stream(ctx, b"")) == b"" and P.decode_stream(ctx, P.encode_stream(ctx, b"x")) == b"x"
     ctx.set_stream(0)
+
+
+def test_config5_pipeline_1e9_bytes(ctx, oracle):
+    """BASELINE configs[4] at its full size: 10^9 bytes of G-text in 3815 blocks of 256 KiB through BWT -> DC -> Ari and back,
+    decode(encode(x)) == x over the whole gigabyte, and three sampled blocks compared with the oracle stage by stage."""
+    import struct
+    import torch
+    from rust_compress_amd import pipeline as P
+    BLOCK, total = 262144, 1000000000
+    dev = torch.device("cuda", 0)
+    lens = [BLOCK] * (total // BLOCK) + [total % BLOCK]
+    data = np.concatenate([synth.gen("text", min(BLOCK * 256, total - s), 0xC0 + s) for s in range(0, total, BLOCK * 256)])[:total]
+    raw = torch.from_numpy(data).to(dev)
+    pipe = P.BwtDcAri(ctx, dev)
+    comp, coff, clen, praw, st = pipe.encode(raw, lens, keep_stages=True)
+    back = pipe.decode(comp, coff, clen, praw, lens)
+    assert torch.equal(back, raw)
+    assert int(clen.sum()) < 0.3 * total
+    Lall, rec, compn = st["bwt"].out_base, st["rec"], comp
+    for i in (7, 1900, len(lens) - 1):                                  # a full block early, one in the middle, the ragged last one
+        o0 = i * BLOCK
+        src = data[o0:o0 + lens[i]].tobytes()
+        eL, eo = oracle.bwt_encode(src)
+        assert Lall[o0:o0 + lens[i]].cpu().numpy().tobytes() == eL
+        words = oracle.dc_encode(eL)
+        record = struct.pack("<III", lens[i], eo, len(words) - 256) + words.tobytes()
+        o = int(st["rec_off"][i])
+        assert rec[o:o + len(record)].cpu().numpy().tobytes() == record
+        cut = 0
+        for s_ in range(praw.shape[1]):
+            piece = record[cut:cut + int(praw[i, s_])]; cut += int(praw[i, s_])
+            a = int(coff[i, s_])
+            assert compn[a:a + int(clen[i, s_])].cpu().numpy().tobytes() == oracle.ari_byte_encode(piece)
+    ctx.set_stream(0)

@@ -1,4 +1,4 @@
-"""Bulk randomized decoder parity (the same code as benchmarks/fuzz_gpu.py, a smaller count): mutated LZ4 / zlib / raw
+"""Bulk randomized decoder parity (the same code as benchmarks/fuzz_gpu.py, 100 000 streams): mutated LZ4 / zlib / raw
 DEFLATE / RLE / Ari streams through every decoder kernel and the oracle -- statuses everywhere, bytes and consumed counts
 wherever the oracle succeeds."""
 import os
@@ -12,4 +12,4 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 @pytest.mark.gpu
 def test_bulk_decoder_fuzz(ctx):
     import fuzz_gpu
-    assert fuzz_gpu.main(16000, 7, ctx) == 0
+    assert fuzz_gpu.main(100000, 7, ctx) == 0

@@ -82,7 +82,7 @@ def test_decode_malformed_statuses(ctx, oracle, variant):
     ctx.set_variant(N.LZ4_DECODE, 0)
 
 
-@pytest.mark.parametrize("kind", ["text", "mix"])
+@pytest.mark.parametrize("kind", ["text", "mix", "runs", "rand"])
 def test_full_size_roundtrip_device_resident(ctx, oracle, kind):
     """BASELINE configs[1]: 4096 x 64 KiB, device-resident: decode(encode(x)) == x for every block, and a
     sample of blocks is compared with the oracle's encoder/decoder bytes."""
