@@ -41,6 +41,8 @@ __global__ __launch_bounds__(64) void k(uint32_t* o, const uint32_t* addr, int i
                 if (W == 4) asm volatile("ds_write_b32 %0, %1" :: "v"(a), "v"(v0) : "memory");
                 if (W == 8) { uint64_t v = ((uint64_t)v0 << 32) | v0; asm volatile("ds_write_b64 %0, %1" :: "v"(a), "v"(v) : "memory"); }
                 if (W == 16) { __attribute__((ext_vector_type(4))) uint32_t v = {v0, v0, v0, v0}; asm volatile("ds_write_b128 %0, %1" :: "v"(a), "v"(v) : "memory"); }
+                if (W == 20) asm volatile("ds_or_b32 %0, %1" :: "v"(a & ~3u), "v"(v0) : "memory");          // LDS atomic without return, aligned dword
+                if (W == 21) asm volatile("ds_write_b32 %0, %1" :: "v"(a & ~3u), "v"(v0) : "memory");       // the same addresses, plain store
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -92,5 +94,7 @@ int main()
     run<17, false>("b128 random unaligned", rnd, daddr, o, cyc); run<17, false>("b128 stride12+1", str, daddr, o, cyc);
     run<18, false>("read2_b32 random 4-al", rnd, daddr, o, cyc); run<18, false>("read2_b32 stride12+1", str, daddr, o, cyc);
     run<19, false>("bpermute random", rnd, daddr, o, cyc);
+    run<20, true>("ds_or_b32 random", rnd, daddr, o, cyc); run<20, true>("ds_or_b32 stride12+1", str, daddr, o, cyc);
+    run<21, true>("ds_write_b32 random", rnd, daddr, o, cyc); run<21, true>("ds_write_b32 stride12+1", str, daddr, o, cyc);
     return 0;
 }

@@ -122,7 +122,7 @@ static uint64_t bwt_forward_scratch_bytes(uint32_t nblocks, uint64_t max_block)
     uint64_t N = (uint64_t)nblocks * max_block;
     if (N > (uint64_t)BWTF_MAXN) N = BWTF_MAXN;
     // keys 2 x 8N, SA 2 x 4N, rank 4N, group lists, bstart, counters, histogram
-    return 28 * N + 3 * (N / BWS_WAVE + nblocks + 1024) * sizeof(BwsSeg) + 2 * (N / 16 + 4096) * sizeof(BwsSeg) + (uint64_t)(nblocks + 2) * 4 + (1ull << 20);
+    return 28 * N + 5 * (N / BWS_WAVE + nblocks + 1024) * sizeof(BwsSeg) + 2 * (N / 16 + 4096) * sizeof(BwsSeg) + (uint64_t)(nblocks + 2) * 4 + (1ull << 20);
 }
 
 static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::string& err)
@@ -154,6 +154,7 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
             st.rank = (uint32_t*)carve(4ull * N);
             const size_t nlarge = (size_t)N / BWS_WAVE + nb + 1024, nmid = (size_t)N / 16 + 4096;
             st.large[0] = (BwsSeg*)carve(nlarge * sizeof(BwsSeg)); st.large[1] = (BwsSeg*)carve(nlarge * sizeof(BwsSeg)); st.nlarge = (BwsSeg*)carve(nlarge * sizeof(BwsSeg));
+            st.local = (BwsSeg*)carve(nlarge * sizeof(BwsSeg)); st.nlocal = (BwsSeg*)carve(nlarge * sizeof(BwsSeg));
             st.small = (BwsSeg*)carve(nmid * sizeof(BwsSeg)); st.nsmall = (BwsSeg*)carve(nmid * sizeof(BwsSeg));
             uint32_t* bstart = (uint32_t*)carve(4ull * (nb + 1));
             st.cnt = (uint32_t*)carve(4 * (64 + BWS_NFLAG));
@@ -198,6 +199,8 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                     if (round == 0) hipLaunchKernelGGL(k_bws_partition<uint64_t>, dim3(2048), dim3(512), 0, s, st, lv, topn);
                     else hipLaunchKernelGGL(k_bws_partition<uint32_t>, dim3(2048), dim3(512), 0, s, st, lv, topn);
                 }
+                if (round == 0) hipLaunchKernelGGL(k_bws_local<uint64_t>, dim3(4096), dim3(256), 0, s, st, topn);
+                else hipLaunchKernelGGL(k_bws_local<uint32_t>, dim3(4096), dim3(256), 0, s, st, topn);
                 if (round == 0) { hipLaunchKernelGGL(k_bws_small<uint64_t>, dim3(2048), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_dense<uint64_t>, dim3(gdense), dim3(256), 0, s, st, 0u); hipLaunchKernelGGL(k_bws_dense<uint64_t>, dim3(gdense), dim3(256), 0, s, st, 32u); }
                 else { hipLaunchKernelGGL(k_bws_small<uint32_t>, dim3(2048), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_dense<uint32_t>, dim3(gdense), dim3(256), 0, s, st, 0u); hipLaunchKernelGGL(k_bws_dense<uint32_t>, dim3(gdense), dim3(256), 0, s, st, 32u); }
                 std::vector<uint32_t> hcv(64 + BWS_NFLAG);
@@ -205,11 +208,11 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                 if (hipMemcpyAsync(hc, st.cnt, 4 * (64 + BWS_NFLAG), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { err = "bwt forward: sync failed"; return RCX_RC_HIP_ERROR; }
                 hc[5] = 0;
                 for (uint32_t f = 0; f < BWS_NFLAG; f++) hc[5] |= hc[64 + f];
-                if (getenv("RCX_BWT_TRACE")) fprintf(stderr, "bwt forward round %d: h=%u unresolved %u (listed: %u large, %u small)\n", round, h, hc[5], hc[3], hc[4]);
+                if (getenv("RCX_BWT_TRACE")) fprintf(stderr, "bwt forward round %d: h=%u unresolved %u (listed: %u large, %u local, %u small)\n", round, h, hc[5], hc[3], hc[7], hc[4]);
                 if (hc[5] == 0) { converged = true; break; }
-                if (hc[3] > nlarge || hc[4] > nmid) { err = "bwt forward: group list overflow"; return RCX_RC_HIP_ERROR; }
-                std::swap(st.large[0], st.nlarge); std::swap(st.small, st.nsmall);
-                const uint32_t nc[8] = {hc[3], 0, hc[4], 0, 0, 0, 0, 0};
+                if (hc[3] > nlarge || hc[7] > nlarge || hc[6] > nlarge || hc[4] > nmid) { err = "bwt forward: group list overflow"; return RCX_RC_HIP_ERROR; }
+                std::swap(st.large[0], st.nlarge); std::swap(st.small, st.nsmall); std::swap(st.local, st.nlocal);
+                const uint32_t nc[8] = {hc[3], 0, hc[4], 0, 0, 0, hc[7], 0};
                 if (hipMemsetAsync(st.cnt + 64, 0, 4 * BWS_NFLAG, s) != hipSuccess ||
                     hipMemcpyAsync(st.cnt, nc, 32, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { err = "bwt forward: H2D"; return RCX_RC_HIP_ERROR; }
                 h = round == 0 ? nsym : 2 * h;

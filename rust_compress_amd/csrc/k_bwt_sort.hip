@@ -25,14 +25,17 @@
 #define BWS_PAR   0x20000000u
 #define BWS_IDX   0x0fffffffu            /* suffix index: batches of < 2^28 suffixes per pass */
 #define BWS_WAVE  32u                    /* the largest group left to the wave-level sorts: it always lies inside a 64-suffix window, aligned or shifted by 32 */
+#define BWS_LMAX  2048u                  /* the largest group sorted to the end of its key inside LDS (k_bws_local), by a workgroup ... */
+#define BWS_LWAVE 512u                   /* ... or, up to this size, by one wave */
 
 struct BwsSeg { uint32_t start, len, info; };                 // info: key shift of the next radix step | buffer << 8
-// counters: [0] large list A, [1] large list B, [2] small list, [3] next round's large list, [4] next round's small list, [5] unresolved groups
+// counters: [0] large list A, [1] large list B, [2] small list, [3] next round's large list, [4] next round's small list,
+// [6] local list (groups of BWS_WAVE+1 .. BWS_LMAX: sorted in LDS), [7] next round's local list
 struct BwsState {
     uint64_t* keyA; uint64_t* keyB;          // u64 keys (round 0); the u32 keys of later rounds use the first half of each
     uint32_t* saA; uint32_t* saB;            // saA is the suffix array proper, saB the partition steps' other buffer
     uint32_t* rank;
-    BwsSeg* large[2]; BwsSeg* small; BwsSeg* nlarge; BwsSeg* nsmall;
+    BwsSeg* large[2]; BwsSeg* small; BwsSeg* nlarge; BwsSeg* nsmall; BwsSeg* local; BwsSeg* nlocal;
     uint32_t* cnt;
     uint32_t n;                               // suffixes in this pass
     uint32_t par;                             // parity bit groups made in THIS round carry (BWS_PAR or 0)
@@ -72,7 +75,8 @@ __device__ __forceinline__ void bws_new_group(const BwsState& s, bool is, uint32
 {
     if (__ballot(is)) { if ((threadIdx.x & 63u) == 0) bws_flag_unresolved(s); }
     const bool listed = is && !bws_dense_ok(a, len);
-    bws_append(s.nlarge, &s.cnt[3], listed && len > BWS_WAVE, BwsSeg{a, len, top_shift});
+    bws_append(s.nlarge, &s.cnt[3], listed && len > BWS_LMAX, BwsSeg{a, len, top_shift});
+    bws_append(s.nlocal, &s.cnt[7], listed && len > BWS_WAVE && len <= BWS_LMAX, BwsSeg{a, len, top_shift});
     bws_append(s.nsmall, &s.cnt[4], listed && len <= BWS_WAVE, BwsSeg{a, len, 0u});
 }
 
@@ -156,21 +160,22 @@ __global__ void k_bws_seed(BwsState s, const uint32_t* bstart, uint32_t nblocks,
     if (len == 1) { s.saA[a] = a | BWS_HEAD | BWS_FINAL; s.rank[a] = a; return; }
     // the seed groups carry the parity of "the round before round 0" so that the dense passes take the small ones
     s.saA[a] |= BWS_HEAD | (s.par ^ BWS_PAR);
-    if (len > BWS_WAVE) { const uint32_t i = atomicAdd(&s.cnt[0], 1u); s.large[0][i] = BwsSeg{a, len, top_shift}; }
+    if (len > BWS_LMAX) { const uint32_t i = atomicAdd(&s.cnt[0], 1u); s.large[0][i] = BwsSeg{a, len, top_shift}; }
+    else if (len > BWS_WAVE) { const uint32_t i = atomicAdd(&s.cnt[6], 1u); s.local[i] = BwsSeg{a, len, top_shift}; }
     else if (!bws_dense_ok(a, len)) { const uint32_t i = atomicAdd(&s.cnt[2], 1u); s.small[i] = BwsSeg{a, len, 0u}; }
 }
 
-// ---- groups of more than BWS_WAVE suffixes: one MSD radix step (8 key bits) per launch --------------------------------------
-// Small groups (<= BWS_WSEG suffixes: most groups of the deeper levels) are partitioned by ONE WAVE each, eight side by side in
-// a workgroup with wave-level synchronisation only; large groups by a whole workgroup.
-#define BWS_WSEG 1024u
+// ---- groups of more than BWS_LMAX suffixes: one MSD radix step (8 key bits) per launch, one workgroup per group ---------------
+// A bin of at most BWS_LMAX suffixes leaves the level structure: k_bws_local sorts it to the end of its key inside LDS.
 
 // what became of bin `d` of group sg (count c, first place a): the list it goes to.  Wave-uniform call (64 bins at a time).
 __device__ __forceinline__ void bws_route_bin(const BwsState& s, BwsSeg* lnext, uint32_t* clnext, bool done, uint32_t c, uint32_t a,
                                               uint32_t shift, int dst, uint32_t top_shift)
 {
     bws_new_group(s, done && c >= 2u, a, c, top_shift);
-    bws_append(lnext, clnext, !done && c > BWS_WAVE, BwsSeg{a, c, (shift > 8u ? shift - 8u : 0u) | ((uint32_t)dst << 8)});
+    const BwsSeg nx{a, c, (shift > 8u ? shift - 8u : 0u) | ((uint32_t)dst << 8)};
+    bws_append(lnext, clnext, !done && c > BWS_LMAX, nx);
+    bws_append(s.local, &s.cnt[6], !done && c > BWS_WAVE && c <= BWS_LMAX, nx);
     bws_append(s.small, &s.cnt[2], !done && c >= 2u && c <= BWS_WAVE && !bws_dense_ok(a, c), BwsSeg{a, c, 0u});
 }
 // the element pass after the scatter: a singleton is final; a bin of equal keys (every bit used) is a finished group; a bin of
@@ -197,7 +202,6 @@ template <class K>
 __global__ __launch_bounds__(512) void k_bws_partition(BwsState s, int level, uint32_t top_shift)
 {
     __shared__ uint32_t s_hist[8][256];           // per wave; after the scan: the wave's next free place in each bin
-    __shared__ uint32_t s_wbeg[8][256];           // wave path: where each bin begins
     __shared__ uint32_t s_tot[256], s_beg[256];
     __shared__ uint32_t s_one;
     const BwsSeg* list = s.large[level & 1];
@@ -205,78 +209,9 @@ __global__ __launch_bounds__(512) void k_bws_partition(BwsState s, int level, ui
     uint32_t* clnext = &s.cnt[(level + 1) & 1];
     const uint32_t nseg = s.cnt[level & 1];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    // ---------------------------------------------------------------- small groups: one wave each, eight entries per workgroup and turn
-    for (uint32_t base = blockIdx.x * 8u; base < nseg; base += gridDim.x * 8u) {
-        if (base + wave < nseg && list[base + wave].len <= BWS_WSEG) {
-            const BwsSeg sg = list[base + wave];
-            uint32_t shift = sg.info & 0xffu;
-            const int src = (int)((sg.info >> 8) & 1u), dst = src ^ 1;
-            const K* ks = bws_keys<K>(s, src) + sg.start; K* kd = bws_keys<K>(s, dst) + sg.start;
-            const uint32_t* ss = bws_sa(s, src) + sg.start; uint32_t* sd = bws_sa(s, dst) + sg.start;
-            uint32_t* hist = s_hist[wave]; uint32_t* wbeg = s_wbeg[wave];
-            for (;;) {                                     // steps in which every suffix falls into one bin move nothing: skipped
-#pragma unroll
-                for (int q = 0; q < 4; q++) hist[lane + 64 * q] = 0;
-                rcx_wave_sync();
-                for (uint32_t i0 = 0; i0 < sg.len; i0 += 64) {
-                    const uint32_t i = i0 + lane; const bool ok = i < sg.len;
-                    const uint32_t d = ok ? (uint32_t)(ks[i] >> shift) & 0xffu : 0x100u;
-                    const unsigned long long peers = bws_peers(ok, d);
-                    if (ok && (uint32_t)__ffsll(peers) - 1u == lane) hist[d] += (uint32_t)__popcll(peers);
-                    rcx_wave_sync();
-                }
-                const bool one = hist[lane] == sg.len || hist[lane + 64] == sg.len || hist[lane + 128] == sg.len || hist[lane + 192] == sg.len;
-                if (!__ballot(one) || shift == 0u) break;
-                shift = shift > 8u ? shift - 8u : 0u;
-                rcx_wave_sync();
-            }
-            const bool done = shift == 0u;
-            {
-                const uint32_t t0 = hist[4 * lane], t1 = hist[4 * lane + 1], t2 = hist[4 * lane + 2], t3 = hist[4 * lane + 3];
-                const uint32_t ex = rcx_wave_incl_scan(t0 + t1 + t2 + t3) - (t0 + t1 + t2 + t3);
-                wbeg[4 * lane] = ex; wbeg[4 * lane + 1] = ex + t0; wbeg[4 * lane + 2] = ex + t0 + t1; wbeg[4 * lane + 3] = ex + t0 + t1 + t2;
-            }
-            rcx_wave_sync();
-            uint32_t cnt4[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) { cnt4[q] = hist[lane + 64 * q]; }
-            rcx_wave_sync();
-#pragma unroll
-            for (int q = 0; q < 4; q++) hist[lane + 64 * q] = wbeg[lane + 64 * q];           // the cursors
-            rcx_wave_sync();
-            for (uint32_t i0 = 0; i0 < sg.len; i0 += 64) {
-                const uint32_t i = i0 + lane; const bool ok = i < sg.len;
-                const K k = ok ? ks[i] : (K)0;
-                const uint32_t d = ok ? (uint32_t)(k >> shift) & 0xffu : 0x100u;
-                const unsigned long long peers = bws_peers(ok, d);
-                const uint32_t leader = (uint32_t)__ffsll(peers) - 1u;
-                uint32_t bse = 0;
-                if (ok && leader == lane) { bse = hist[d]; hist[d] = bse + (uint32_t)__popcll(peers); }
-                bse = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((leader & 63u) << 2), (int)bse);
-                if (ok) { const uint32_t p = bse + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull)); kd[p] = k; sd[p] = ss[i] & BWS_IDX; }
-                rcx_wave_sync();
-            }
-            __threadfence_block();
-            rcx_wave_sync();
-            for (uint32_t p0 = 0; p0 < sg.len; p0 += 64) {
-                const uint32_t p = p0 + lane;
-                if (p < sg.len) {
-                    const K k = kd[p];
-                    const uint32_t d = (uint32_t)(k >> shift) & 0xffu;
-                    // bin sizes: the cursors now stand at the bins' ends
-                    bws_mark<K>(s, sg, p, k, sd[p], hist[d] - wbeg[d], wbeg[d], done, dst);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++) bws_route_bin(s, lnext, clnext, done, cnt4[q], sg.start + wbeg[lane + 64 * q], shift, dst, top_shift);
-        }
-    }
-    __syncthreads();
-    // ---------------------------------------------------------------- large groups: one workgroup each
     {
         for (uint32_t e = blockIdx.x; e < nseg; e += gridDim.x) {
             const BwsSeg sg = list[e];
-            if (sg.len <= BWS_WSEG) continue;
             uint32_t shift = sg.info & 0xffu;
             const int src = (int)((sg.info >> 8) & 1u), dst = src ^ 1;
             const K* ks = bws_keys<K>(s, src) + sg.start; K* kd = bws_keys<K>(s, dst) + sg.start;
@@ -336,6 +271,173 @@ __global__ __launch_bounds__(512) void k_bws_partition(BwsState s, int level, ui
             }
             if (tid < 256) bws_route_bin(s, lnext, clnext, done, s_tot[tid], sg.start + s_beg[tid], shift, dst, top_shift);
             __syncthreads();
+        }
+    }
+}
+
+// ---- groups of BWS_WAVE+1 .. BWS_LMAX suffixes: sorted to the END of their key inside LDS, one pass over HBM -----------------
+// A team (one wave for <= BWS_LWAVE suffixes, else the workgroup's four waves) loads the group's keys and suffixes into LDS and
+// sorts a 16-bit permutation by the key bits the levels above have not used: stable LSD radix passes of 8 bits (a wave owns a
+// contiguous quarter of the group, so wave-major order is group order; lanes with the same digit are ranked by ballots, as in the
+// partition step), passes whose digit is the same for the whole group are skipped.  Then the runs of equal keys are read off a
+// bitmap of run heads and saA / rank are written once: this round is over for the group.
+template <class K, int NW>
+struct BwsLocal {
+    static constexpr uint32_t CAP = NW == 1 ? BWS_LWAVE : BWS_LMAX;
+    static constexpr uint32_t MAXSTEP = CAP / (64u * NW);
+    K* key; uint32_t* val; uint16_t* pa; uint16_t* pb; uint32_t* hist;      // hist: [NW][256]
+    uint32_t* tot; uint32_t* beg; uint32_t* bits; uint32_t* misc;           // NW > 1: tot[256], beg[256]; bits[CAP / 32 + 1]; misc[8]
+    uint32_t t, w, lane;                                                     // thread, wave and lane inside the team
+
+    __device__ __forceinline__ void sync() const { if (NW == 1) rcx_wave_sync(); else __syncthreads(); }
+
+    __device__ void run(const BwsState& s, const BwsSeg sg, uint32_t top_shift)
+    {
+        const uint32_t len = sg.len, T = 64u * NW;
+        const uint32_t shift = sg.info & 0xffu;                              // bits [0, shift + 8) of the key are still unsorted
+        const int src = (int)((sg.info >> 8) & 1u);
+        const K* ks = bws_keys<K>(s, src) + sg.start;
+        const uint32_t* ss = bws_sa(s, src) + sg.start;
+        for (uint32_t i = t; i < len; i += T) { key[i] = ks[i]; val[i] = ss[i] & BWS_IDX; pa[i] = (uint16_t)i; }
+        const uint32_t cs = (((len + NW - 1u) / NW) + 63u) & ~63u;           // a wave's contiguous share
+        const uint32_t w0 = w * cs, w1 = (w0 + cs < len) ? w0 + cs : len;
+        sync();
+        for (uint32_t sh = 0; sh < shift + 8u; sh += 8) {
+            uint32_t* myh = hist + 256u * w;
+#pragma unroll
+            for (int q = 0; q < 4; q++) myh[lane + 64 * q] = 0;
+            if (NW > 1 && t == 0) misc[0] = 0;
+            rcx_wave_sync();
+            // ---- count: digit, peers, rank among the peers; the wave's histogram
+            uint32_t inf[MAXSTEP], el[MAXSTEP];
+#pragma unroll
+            for (uint32_t st = 0; st < MAXSTEP; st++) {
+                inf[st] = 0; el[st] = 0;
+                const uint32_t i = w0 + 64u * st + lane;
+                if (w0 + 64u * st < w1) {                                    // wave-uniform
+                    const bool ok = i < w1;
+                    const uint32_t e = ok ? pa[i] : 0u;
+                    const uint32_t d = ok ? (uint32_t)(key[e] >> sh) & 0xffu : 0x100u;
+                    const unsigned long long peers = bws_peers(ok, d);
+                    const uint32_t leader = (uint32_t)__ffsll(peers) - 1u, cnt = (uint32_t)__popcll(peers);
+                    const uint32_t rk = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+                    if (ok && leader == lane) myh[d] += cnt;
+                    inf[st] = (d & 0xffu) | (rk << 8) | ((leader & 63u) << 14) | (cnt << 20) | ((uint32_t)ok << 28);
+                    el[st] = e;
+                    rcx_wave_sync();
+                }
+            }
+            sync();
+            // ---- totals, "one digit only", exclusive scan, per-wave cursors
+            bool one;
+            if (NW == 1) {
+                const uint32_t t0 = myh[4 * lane], t1 = myh[4 * lane + 1], t2 = myh[4 * lane + 2], t3 = myh[4 * lane + 3];
+                one = __ballot(t0 == len || t1 == len || t2 == len || t3 == len) != 0;
+                const uint32_t ex = rcx_wave_incl_scan(t0 + t1 + t2 + t3) - (t0 + t1 + t2 + t3);
+                rcx_wave_sync();
+                if (!one) { myh[4 * lane] = ex; myh[4 * lane + 1] = ex + t0; myh[4 * lane + 2] = ex + t0 + t1; myh[4 * lane + 3] = ex + t0 + t1 + t2; }
+                rcx_wave_sync();
+            } else {
+                uint32_t c[NW], sum = 0;
+#pragma unroll
+                for (int k = 0; k < NW; k++) { c[k] = hist[256 * k + t]; sum += c[k]; }
+                if (sum == len) misc[0] = 1;
+                const uint32_t inc = rcx_wave_incl_scan(sum);
+                if (lane == 63) misc[1 + w] = inc;
+                __syncthreads();
+                one = misc[0] != 0;
+                uint32_t o = inc - sum;
+#pragma unroll
+                for (int k = 0; k < NW; k++) o += ((uint32_t)k < w) ? misc[1 + k] : 0u;
+                if (!one) {
+#pragma unroll
+                    for (int k = 0; k < NW; k++) { hist[256 * k + t] = o; o += c[k]; }
+                }
+                __syncthreads();
+            }
+            if (one) continue;                                               // the whole group shares this digit: nothing moves
+            // ---- scatter (stable): the wave's cursor of the digit + rank among the peers
+#pragma unroll
+            for (uint32_t st = 0; st < MAXSTEP; st++) {
+                if (w0 + 64u * st < w1) {
+                    const uint32_t f = inf[st];
+                    const bool ok = (f >> 28) & 1u;
+                    const uint32_t d = f & 0xffu, rk = (f >> 8) & 63u, leader = (f >> 14) & 63u, cnt = (f >> 20) & 0x7fu;
+                    uint32_t bse = 0;
+                    if (ok && leader == lane) { bse = myh[d]; myh[d] = bse + cnt; }
+                    bse = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(leader << 2), (int)bse);
+                    if (ok) pb[bse + rk] = (uint16_t)el[st];
+                    rcx_wave_sync();
+                }
+            }
+            sync();
+            { uint16_t* x = pa; pa = pb; pb = x; }
+        }
+        // ---- runs of equal keys: a bitmap of run heads, then every position looks up its run
+        const uint32_t nwords = (len + 31u) >> 5;
+        for (uint32_t c0 = 64u * w; c0 < len; c0 += T) {
+            const uint32_t p = c0 + lane;
+            bool head = false;
+            if (p < len) head = p == 0 || key[pa[p]] != key[pa[p - 1]];
+            const unsigned long long hm = __ballot(head);
+            if (lane == 0) { bits[c0 >> 5] = (uint32_t)hm; bits[(c0 >> 5) + 1] = (uint32_t)(hm >> 32); }
+        }
+        sync();
+        for (uint32_t c0 = 64u * w; c0 < len; c0 += T) {
+            const uint32_t p = c0 + lane;
+            const bool in = p < len;
+            uint32_t rs = 0, re = len, g = 0;
+            if (in) {
+                uint32_t wi = p >> 5;
+                uint32_t m = bits[wi] & (0xffffffffu >> (31u - (p & 31u)));                  // heads at or before p
+                while (!m && wi) m = bits[--wi];
+                rs = (wi << 5) + 31u - (uint32_t)__clz((int)m);
+                wi = p >> 5;
+                m = (p & 31u) == 31u ? 0u : bits[wi] & (0xffffffffu << ((p & 31u) + 1u));    // heads after p
+                while (!m && wi + 1u < nwords) m = bits[++wi];
+                if (m) re = (wi << 5) + (uint32_t)__ffs((int)m) - 1u;
+                g = val[pa[p]];
+                const bool single = re - rs == 1u;
+                s.saA[sg.start + p] = g | (rs == p ? (BWS_HEAD | s.par) : 0u) | (single ? BWS_FINAL : 0u);
+                s.rank[g] = sg.start + rs;
+            }
+            bws_new_group(s, in && rs == p && re - rs >= 2u, sg.start + rs, re - rs, top_shift);
+        }
+        sync();
+    }
+};
+
+template <class K>
+__global__ __launch_bounds__(256) void k_bws_local(BwsState s, uint32_t top_shift)
+{
+    __shared__ __align__(16) K s_key[BWS_LMAX];
+    __shared__ uint32_t s_val[BWS_LMAX];
+    __shared__ uint16_t s_pa[BWS_LMAX], s_pb[BWS_LMAX];
+    __shared__ uint32_t s_hist[4][256];
+    __shared__ uint32_t s_tot[256], s_beg[256];
+    __shared__ uint32_t s_bits[BWS_LMAX / 32 + 4 * 2];
+    __shared__ uint32_t s_misc[8];
+    const uint32_t nseg = s.cnt[6];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    // groups of at most BWS_LWAVE: one wave each, four side by side
+    {
+        BwsLocal<K, 1> L;
+        L.key = s_key + BWS_LWAVE * wave; L.val = s_val + BWS_LWAVE * wave; L.pa = s_pa + BWS_LWAVE * wave; L.pb = s_pb + BWS_LWAVE * wave;
+        L.hist = s_hist[wave]; L.tot = nullptr; L.beg = nullptr; L.bits = s_bits + (BWS_LWAVE / 32 + 2) * wave; L.misc = nullptr;
+        L.t = lane; L.w = 0; L.lane = lane;
+        for (uint32_t base = blockIdx.x * 4u; base < nseg; base += gridDim.x * 4u) {
+            if (base + wave < nseg && s.local[base + wave].len <= BWS_LWAVE) L.run(s, s.local[base + wave], top_shift);
+        }
+    }
+    __syncthreads();
+    {
+        BwsLocal<K, 4> L;
+        L.key = s_key; L.val = s_val; L.pa = s_pa; L.pb = s_pb; L.hist = &s_hist[0][0]; L.tot = s_tot; L.beg = s_beg; L.bits = s_bits; L.misc = s_misc;
+        L.t = tid; L.w = wave; L.lane = lane;
+        for (uint32_t e = blockIdx.x; e < nseg; e += gridDim.x) {
+            const BwsSeg sg = s.local[e];
+            if (sg.len <= BWS_LWAVE) continue;
+            L.run(s, sg, top_shift);
         }
     }
 }
