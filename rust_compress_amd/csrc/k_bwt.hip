@@ -68,20 +68,27 @@ __global__ __launch_bounds__(256) void k_bwtf_hist(BwtfArgs a, uint32_t* hist)
 }
 // first key of suffix i: block | `nsym` symbols of `bits` bits each, a symbol = 1 + rank of the byte among the bytes that
 // occur in the batch (order preserving), 0 = past the end (the reference's implicit sentinel order)
-__global__ void k_bwtf_init(BwtfArgs a, uint64_t* keys, uint32_t* vals, const uint8_t* map, uint32_t nsym, uint32_t bits, uint32_t plus1)
+__global__ __launch_bounds__(256) void k_bwtf_init(BwtfArgs a, uint64_t* keys, uint32_t* vals, const uint8_t* map, uint32_t nsym, uint32_t bits, uint32_t plus1)
 {
     __shared__ uint32_t s_map[256];
+    __shared__ uint16_t s_sym[256 + 16];                          // the symbols of a tile of 256 suffixes and the 16 that follow
     s_map[threadIdx.x] = (uint32_t)map[threadIdx.x] + plus1;      // plus1: the map is the identity and a symbol is byte + 1
     __syncthreads();
     const uint32_t b = blockIdx.y;
     const uint32_t n = (uint32_t)a.in_len[b];
     const uint8_t* T = a.in_base + a.in_off[b];
     const uint32_t g0 = a.bstart[b];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        uint64_t k = b;
-        for (uint32_t c = 0; c < nsym; c++) k = (k << bits) | (i + c < n ? (uint64_t)s_map[T[i + c]] : 0u);
-        keys[g0 + i] = k;
-        vals[g0 + i] = g0 + i;
+    for (uint32_t i0 = blockIdx.x * 256u; i0 < n; i0 += gridDim.x * 256u) {
+        for (uint32_t t = threadIdx.x; t < 256u + 16u; t += 256u) s_sym[t] = (i0 + t < n) ? (uint16_t)s_map[T[i0 + t]] : (uint16_t)0;
+        __syncthreads();
+        const uint32_t i = i0 + threadIdx.x;
+        if (i < n) {
+            uint64_t k = b;
+            for (uint32_t c = 0; c < nsym; c++) k = (k << bits) | (uint64_t)s_sym[threadIdx.x + c];
+            keys[g0 + i] = k;
+            vals[g0 + i] = g0 + i;
+        }
+        __syncthreads();
     }
 }
 // L[j] = T[SA[j]-1], or T[n-1] where SA[j] == 0 (that j is `origin`), mod.rs:193-203
@@ -122,7 +129,7 @@ static uint64_t bwt_forward_scratch_bytes(uint32_t nblocks, uint64_t max_block)
     uint64_t N = (uint64_t)nblocks * max_block;
     if (N > (uint64_t)BWTF_MAXN) N = BWTF_MAXN;
     // keys 2 x 8N, SA 2 x 4N, rank 4N, group lists, bstart, counters, histogram
-    return 28 * N + 5 * (N / BWS_WAVE + nblocks + 1024) * sizeof(BwsSeg) + 2 * (N / 16 + 4096) * sizeof(BwsSeg) + (uint64_t)(nblocks + 2) * 4 + (1ull << 20);
+    return 28 * N + 5 * (N / BWS_WAVE + nblocks + 1024) * sizeof(BwsSeg) + 2 * (N / 16 + 4096) * sizeof(BwsSeg) + (uint64_t)(nblocks + 2) * 4 + 4 * (N / 64 + 512) + (1ull << 20);
 }
 
 static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::string& err)
@@ -159,7 +166,10 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
             uint32_t* bstart = (uint32_t*)carve(4ull * (nb + 1));
             st.cnt = (uint32_t*)carve(4 * (64 + BWS_NFLAG));
             uint32_t* hist = (uint32_t*)carve(1056); uint8_t* symmap = (uint8_t*)carve(256);
-            st.n = N; st.par = 0;
+            const size_t nact = ((size_t)N / 64 + 64 + 7) & ~(size_t)7;
+            uint8_t* act0 = (uint8_t*)carve(4 * nact);
+            for (int q = 0; q < 4; q++) st.act[q] = act0 + q * nact;
+            st.n = N; st.par = 0; st.rs = 0;
             if ((uint64_t)(p - (uint8_t*)k.scratch) > k.scratch_bytes) { err = "bwt forward: scratch too small"; return RCX_RC_BAD_ARG; }
             if (hipMemcpyAsync(bstart, h_bstart.data(), 4ull * (nb + 1), hipMemcpyHostToDevice, s) != hipSuccess) { err = "bwt forward: H2D"; return RCX_RC_HIP_ERROR; }
             BwtfArgs fa{kk.in_base, kk.in_off, kk.in_len, bstart, nb};
@@ -182,15 +192,15 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                     err = "bwt forward: symbol map"; return RCX_RC_HIP_ERROR; }
             }
             hipLaunchKernelGGL(k_bwtf_init, dim3(gx ? gx : 1, nb), dim3(256), 0, s, fa, st.keyA, st.saA, symmap, nsym, sbits, plain_bytes ? 1u : 0u);
-            if (hipMemsetAsync(st.cnt, 0, 4 * (64 + BWS_NFLAG), s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
+            if (hipMemsetAsync(st.cnt, 0, 4 * (64 + BWS_NFLAG), s) != hipSuccess || hipMemsetAsync(act0, 0, 4 * nact, s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
             const uint32_t kbits0 = nsym * sbits, top0 = kbits0 > 8 ? kbits0 - 8 : 0;
             const uint32_t kbits1 = bits_for(maxn), top1 = kbits1 > 8 ? kbits1 - 8 : 0;           // later keys: local rank + 1 <= maxn
             hipLaunchKernelGGL(k_bws_seed, dim3((nb + 255) / 256), dim3(256), 0, s, st, bstart, nb, top0);
             uint32_t h = nsym;
-            const uint32_t gdense = (N + 255) / 256;
+            const uint32_t gdense = (N / 64 + 2 + 4 * BWS_DW - 1) / (4 * BWS_DW);
             bool converged = false;
             for (int round = 0; round < 64; round++) {
-                st.par = (round & 1) ? BWS_PAR : 0u;
+                st.par = (round & 1) ? BWS_PAR : 0u; st.rs = (uint32_t)(round & 1);
                 const uint32_t top = round == 0 ? top0 : top1, topn = top1;
                 if (round) hipLaunchKernelGGL(k_bws_gather, dim3(gx ? gx : 1, nb), dim3(256), 0, s, st, bstart, nb, h);
                 const int levels = (int)((top + 7) / 8) + 1;

@@ -39,6 +39,8 @@ struct BwsState {
     uint32_t* cnt;
     uint32_t n;                               // suffixes in this pass
     uint32_t par;                             // parity bit groups made in THIS round carry (BWS_PAR or 0)
+    uint8_t* act[4];                          // "a group for the dense passes lies in this window": [round parity * 2 + grid], one byte
+    uint32_t rs;                              // per 64-suffix window (grid 0: aligned, grid 1: shifted by 32); rs = round & 1
 };
 
 template <class K> __device__ __forceinline__ K* bws_keys(const BwsState& s, int buf) { return (K*)(buf ? s.keyB : s.keyA); }
@@ -50,6 +52,13 @@ __device__ __forceinline__ bool bws_dense_ok(uint32_t a, uint32_t len)
     return len <= BWS_WAVE && ((a >> 6) == (z >> 6) || ((a + 32u) >> 6) == ((z + 32u) >> 6));
 }
 
+// Tell the dense passes of round parity `set` about the group [a, a + len) (which bws_dense_ok): the aligned window if it lies
+// inside one (the aligned pass runs first and takes it), else the shifted one.
+__device__ __forceinline__ void bws_flag_dense(const BwsState& s, uint32_t set, uint32_t a, uint32_t len)
+{
+    const uint32_t z = a + len - 1u;
+    if ((a >> 6) == (z >> 6)) s.act[set * 2u][a >> 6] = 1; else s.act[set * 2u + 1u][(a + 32u) >> 6] = 1;
+}
 // Append `seg` to a list for the lanes with `want`: ONE atomic per wave (a single word takes ~88 atomics per microsecond on
 // this chip: one atomic per group made the first version's passes take 40 ms whatever else they did).  Wave-uniform call.
 __device__ __forceinline__ void bws_append(BwsSeg* list, uint32_t* counter, bool want, const BwsSeg& seg)
@@ -75,6 +84,7 @@ __device__ __forceinline__ void bws_new_group(const BwsState& s, bool is, uint32
 {
     if (__ballot(is)) { if ((threadIdx.x & 63u) == 0) bws_flag_unresolved(s); }
     const bool listed = is && !bws_dense_ok(a, len);
+    if (is && !listed) bws_flag_dense(s, s.rs ^ 1u, a, len);
     bws_append(s.nlarge, &s.cnt[3], listed && len > BWS_LMAX, BwsSeg{a, len, top_shift});
     bws_append(s.nlocal, &s.cnt[7], listed && len > BWS_WAVE && len <= BWS_LMAX, BwsSeg{a, len, top_shift});
     bws_append(s.nsmall, &s.cnt[4], listed && len <= BWS_WAVE, BwsSeg{a, len, 0u});
@@ -163,6 +173,7 @@ __global__ void k_bws_seed(BwsState s, const uint32_t* bstart, uint32_t nblocks,
     if (len > BWS_LMAX) { const uint32_t i = atomicAdd(&s.cnt[0], 1u); s.large[0][i] = BwsSeg{a, len, top_shift}; }
     else if (len > BWS_WAVE) { const uint32_t i = atomicAdd(&s.cnt[6], 1u); s.local[i] = BwsSeg{a, len, top_shift}; }
     else if (!bws_dense_ok(a, len)) { const uint32_t i = atomicAdd(&s.cnt[2], 1u); s.small[i] = BwsSeg{a, len, 0u}; }
+    else bws_flag_dense(s, s.rs, a, len);
 }
 
 // ---- groups of more than BWS_LMAX suffixes: one MSD radix step (8 key bits) per launch, one workgroup per group ---------------
@@ -187,7 +198,11 @@ __device__ __forceinline__ void bws_mark(const BwsState& s, const BwsSeg& sg, ui
     const uint32_t a = sg.start + p;
     if (c == 1u) { s.saA[a] = g | BWS_HEAD | BWS_FINAL; s.rank[g] = a; }
     else if (done) { s.saA[a] = g | (p == beg ? (BWS_HEAD | s.par) : 0u); s.rank[g] = sg.start + beg; }
-    else { s.saA[a] = g | (p == beg ? (BWS_HEAD | (s.par ^ BWS_PAR)) : 0u); if (dst != 0) bws_keys<K>(s, 0)[a] = k; }
+    else {
+        s.saA[a] = g | (p == beg ? (BWS_HEAD | (s.par ^ BWS_PAR)) : 0u);
+        if (dst != 0) bws_keys<K>(s, 0)[a] = k;
+        if (p == beg && bws_dense_ok(a, c)) bws_flag_dense(s, s.rs, a, c);          // this round's dense passes take it
+    }
 }
 // digit peers of a wave: the lanes (among `ok`) that hold the same digit as mine
 __device__ __forceinline__ unsigned long long bws_peers(bool ok, uint32_t d)
@@ -474,11 +489,8 @@ __global__ __launch_bounds__(256) void k_bws_small(BwsState s, uint32_t top_shif
 // shifted one).  The lanes of a window sort by (start of my group, key, lane): that orders every group the window contains
 // and moves nothing else -- a wave-wide bitonic sort over ds_bpermute (21 compare-exchange steps whatever the group sizes).
 template <class K>
-__global__ __launch_bounds__(256) void k_bws_dense(BwsState s, uint32_t off)
+__device__ __forceinline__ void bws_dense_window(const BwsState& s, uint32_t j0, uint32_t lane)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t j0 = off + (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u;
-    if (j0 >= s.n) return;
     const uint32_t j = j0 + lane;
     const bool in = j < s.n;
     const uint32_t v = in ? s.saA[j] : (BWS_HEAD | BWS_FINAL);
@@ -496,7 +508,7 @@ __global__ __launch_bounds__(256) void k_bws_dense(BwsState s, uint32_t off)
     const K key = in ? bws_keys<K>(s, 0)[j] : (K)0;
     const uint32_t maxlen = rcx_wave_max(mine ? ge - gs : 0u);
     uint32_t val = v & BWS_IDX, was = mine ? 1u : 0u;
-    bool rhead; uint32_t rs, re;
+    bool rhead; uint32_t rs, re, gpos;
     if (maxlen <= 12u) {
         // small groups only (the usual case after the first rounds): a rank sort, 2-3 ds_bpermute per member of the largest group
         const uint32_t klo = (uint32_t)key, khi = sizeof(K) == 8 ? (uint32_t)((uint64_t)key >> 32) : 0u;
@@ -518,7 +530,7 @@ __global__ __launch_bounds__(256) void k_bws_dense(BwsState s, uint32_t off)
             s.saA[j0 + gs + less] = val | (less == lt ? (BWS_HEAD | s.par) : 0u) | (single ? BWS_FINAL : 0u);
             s.rank[val] = j0 + gs + lt;
         }
-        rhead = less == lt; rs = 0; re = eq;
+        rhead = less == lt; rs = 0; re = eq; gpos = j0 + gs + lt;
     } else {
         uint32_t c0 = mine ? gs : lane;                          // composite sort key: (group start or my own lane, key)
         uint32_t klo = (uint32_t)key, khi = sizeof(K) == 8 ? (uint32_t)((uint64_t)key >> 32) : 0u;
@@ -530,7 +542,31 @@ __global__ __launch_bounds__(256) void k_bws_dense(BwsState s, uint32_t off)
             s.saA[j] = val | (rhead ? (BWS_HEAD | s.par) : 0u) | (single ? BWS_FINAL : 0u);
             s.rank[val] = j0 + rs;
         }
+        gpos = j0 + rs;
     }
-    const unsigned long long newgroups = __ballot(was && rhead && re - rs >= 2u);       // (rank-sort path: rs = 0, re = run length)
+    const bool newg = was && rhead && re - rs >= 2u;                                    // (rank-sort path: rs = 0, re = run length)
+    if (newg) bws_flag_dense(s, s.rs ^ 1u, gpos, re - rs);                              // next round's dense passes
+    const unsigned long long newgroups = __ballot(newg);
     if (lane == 0 && newgroups) bws_flag_unresolved(s);
+}
+
+// One wave per BWS_DW consecutive windows of the grid `off` (0: aligned, 32: shifted); only windows somebody flagged are looked at.
+#define BWS_DW 8u
+template <class K>
+__global__ __launch_bounds__(256) void k_bws_dense(BwsState s, uint32_t off)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * BWS_DW;              // first window (in the grid's own numbering)
+    if ((uint64_t)w0 * 64u >= (uint64_t)s.n + 64u) return;
+    uint8_t* act = s.act[s.rs * 2u + (off ? 1u : 0u)];
+    const unsigned long long f = *(const unsigned long long*)(act + w0);
+    if (!f) return;
+    for (uint32_t k = 0; k < BWS_DW; k++) {
+        if (!((f >> (8u * k)) & 0xffu)) continue;
+        const uint32_t win = w0 + k;
+        if (off && win == 0) continue;                           // the shifted window [-32, 32) holds nothing the aligned pass cannot take
+        const uint32_t j0 = off ? win * 64u - 32u : win * 64u;
+        if (j0 < s.n) bws_dense_window<K>(s, j0, lane);
+    }
+    if (lane == 0) *(unsigned long long*)(act + w0) = 0ull;
 }
