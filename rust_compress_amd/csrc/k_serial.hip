@@ -183,14 +183,61 @@ __global__ __launch_bounds__(64 * WAVES) void k_mtf(rcx_kargs a, int decode)
 // DC -- src/bwt/dc.rs.  encode :110-149 (+ EncodeIterator order :88-104, encode_simple :153-159),
 // decode :162-233 driven as decode_simple :236-252.  Words are little-endian u32.
 // =================================================================================================
+// Both DC loops are serial chains of one step per run of the input (~75 K steps for a 256 KiB block of BWT output), one wave per
+// block, so what counts is the LATENCY of a step.  The first version kept `last[]` / `next[]` in LDS: two dependent LDS round trips
+// per step (~1100 cycles per step, 35-38 ms per batch whatever its size).  Here everything a step touches lives in registers, rank
+// ordered like the list itself -- lane l holds entries 4l .. 4l+3: their symbols in the bytes of one dword (MtfRegs) and one
+// position per entry in four more registers -- and a step is readlane / compare / ballot / DPP shift, no memory on the chain.
+struct DcRegs : MtfRegs {
+    uint32_t v[4];                                            // a position per entry (encode: last occurrence, decode: next occurrence)
+    // entries 1..rank = old entries 0..rank-1, entry 0 = (sym, val)
+    __device__ __forceinline__ void front_v(uint32_t rank, uint32_t sym, uint32_t val)
+    {
+        const uint32_t prev3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[3], 0x138, 0xf, 0xf, false);   // wave_shr:1: lane l-1's v[3]
+        const uint32_t p0 = 4u * lane;
+        const uint32_t o0 = v[0], o1 = v[1], o2 = v[2];
+        v[3] = (p0 + 3u <= rank) ? o2 : v[3];
+        v[2] = (p0 + 2u <= rank) ? o1 : v[2];
+        v[1] = (p0 + 1u <= rank) ? o0 : v[1];
+        v[0] = lane == 0 ? val : (p0 <= rank ? prev3 : v[0]);
+        front(rank, sym);
+    }
+    // entries 0..rank-2 = old entries 1..rank-1, entry rank-1 = (sym, val); rank >= 1
+    __device__ __forceinline__ void back_v(uint32_t rank, uint32_t sym, uint32_t val)
+    {
+        const uint32_t next0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[0], 0x130, 0xf, 0xf, false);   // wave_shl:1: lane l+1's v[0]
+        const uint32_t p0 = 4u * lane, q = rank - 1u;         // positions below q take their right neighbour, position q the new entry
+        const uint32_t o1 = v[1], o2 = v[2], o3 = v[3];
+        v[0] = (p0 < q) ? o1 : (p0 == q ? val : v[0]);
+        v[1] = (p0 + 1u < q) ? o2 : (p0 + 1u == q ? val : v[1]);
+        v[2] = (p0 + 2u < q) ? o3 : (p0 + 2u == q ? val : v[2]);
+        v[3] = (p0 + 3u < q) ? next0 : (p0 + 3u == q ? val : v[3]);
+        back(rank, sym);
+    }
+    // first entry below `count` that holds sym: its rank and its position value; false if there is none
+    __device__ __forceinline__ bool find_v(uint32_t sym, uint32_t count, uint32_t& rank, uint32_t& val) const
+    {
+        const uint32_t p0 = 4u * lane;
+        uint32_t hit = 4, hv = 0;
+        if (((w >> 24) & 0xff) == sym && p0 + 3u < count) { hit = 3; hv = v[3]; }
+        if (((w >> 16) & 0xff) == sym && p0 + 2u < count) { hit = 2; hv = v[2]; }
+        if (((w >> 8) & 0xff) == sym && p0 + 1u < count) { hit = 1; hv = v[1]; }
+        if ((w & 0xff) == sym && p0 < count) { hit = 0; hv = v[0]; }
+        const unsigned long long m = __ballot(hit < 4);
+        if (!m) return false;
+        const int first = __ffsll(m) - 1;
+        rank = 4u * (uint32_t)first + (uint32_t)__builtin_amdgcn_readlane((int)hit, first);
+        val = (uint32_t)__builtin_amdgcn_readlane((int)hv, first);
+        return true;
+    }
+};
+
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a)
 {
-    __shared__ uint32_t s_last[WAVES][256];
     const unsigned w = threadIdx.x >> 6, lane = rcx_lane();
     const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + w));   // wave-uniform: keeps descriptors in SGPRs
     if (b >= a.nblocks) return;
-    uint32_t* last = s_last[w];
     const uint8_t* in = a.in_base + a.in_off[b];
     const uint32_t n = (uint32_t)a.in_len[b];
     uint32_t* words = (uint32_t*)(a.out_base + a.out_off[b]);
@@ -200,47 +247,40 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a)
         return;
     }
     uint32_t* dist = words + 256;
-    for (int k = 0; k < 4; k++) { last[lane + 64 * k] = n; words[lane + 64 * k] = n; }   // :114-115
-    MtfRegs L; L.zero(lane);                                  // MTF::new()
+    for (int k = 0; k < 4; k++) words[lane + 64 * k] = n;     // :114-115 (init[]: first occurrences, n = absent)
+    DcRegs L; L.zero(lane);                                    // MTF::new(); v[] = last occurrence of each listed symbol
+    for (int k = 0; k < 4; k++) L.v[k] = 0;
     rcx_wave_sync();
     uint32_t num_unique = 0, i = 0;
     SeqWin<uint8_t> win; win.start(in, n, lane);
     while (i < n) {                                           // :117-138
         const uint32_t sym = win.get(i);
-        const uint32_t base = __builtin_amdgcn_readfirstlane(last[sym]);
-        if (base == n) {                                      // first occurrence, :121-128
-            if (lane == 0) { words[sym] = i; last[sym] = i; dist[i] = n; }
-            rcx_wave_sync();
-            L.set(num_unique, sym);
-            // mtf.encode(sym): the symbols ahead of it are unique and differ from it (first occurrence), zero-filled slots
-            // behind it may equal it -- the first hit is the one to take, and that is what find returns
-            const uint32_t rank = L.find(sym);
-            if (rank) L.front(rank, sym);
+        uint32_t rank = 0, base = 0;
+        if (!L.find_v(sym, num_unique, rank, base)) {         // first occurrence, :121-128: insert behind the others, move to front
+            if (lane == 0) { words[sym] = i; dist[i] = n; }
+            L.front_v(num_unique, sym, i);
             num_unique++;
             i += 1;
         } else if (base == i - 1) {                           // inside a run: rank 0, nothing is emitted
             const uint32_t rl = win.run(i, sym);
             for (uint32_t t = lane; t < rl; t += 64) dist[i + t] = n;
-            if (lane == 0) last[sym] = i + rl - 1;
-            rcx_wave_sync();
+            if (lane == 0) L.v[0] = i + rl - 1;
             i += rl;
-        } else {                                              // :129-136
-            const uint32_t rank = L.find(sym);
-            if (lane == 0) { dist[i] = n; last[sym] = i; if (rank) dist[base] = i - base - rank - 1; }
-            rcx_wave_sync();
-            if (rank) L.front(rank, sym);
+        } else {                                              // :129-136 (rank >= 1: the front symbol is the one at i - 1)
+            if (lane == 0) { dist[i] = n; dist[base] = i - base - rank - 1; }
+            L.front_v(rank, sym, i);
             i += 1;
         }
     }
-    rcx_wave_sync();
+    rcx_wave_sync();                                           // every filler store precedes the sweep's stores (same wave: in order)
     for (uint32_t k2 = 0; k2 < 4; k2++) {                      // sweep, :139-144 (lane l holds ranks 4l .. 4l+3)
         const uint32_t rank = 4u * lane + k2;
         if (rank < num_unique) {
-            const uint32_t sym = (L.w >> (8u * k2)) & 0xffu;
-            const uint32_t base = last[sym];
+            const uint32_t base = L.v[k2];
             dist[base] = n - base - rank - 1;
         }
     }
+    __threadfence_block();
     rcx_wave_sync();
     // compact the non-filler distances in position order (EncodeIterator :88-104): ballot + prefix popcount
     uint32_t k = 0;
@@ -292,10 +332,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_decode(rcx_kargs a)
             }
         }
         uint32_t cnt = 0;
+        bool absent_bad = false;                               // :230 for the symbols the loop never touches
         for (int k = 0; k < 4; k++) cnt += (next[lane + 64 * k] < n) ? 1u : 0u;
         A = rcx_wave_sum(cnt);
+        for (int k = 0; k < 4; k++) { const uint32_t x = next[lane + 64 * k]; absent_bad = absent_bad || (x >= n && x >= n + A); }
         rcx_wave_sync();
-        MtfRegs L; L.lane = lane; L.w = *(const uint32_t*)(lst + 4 * lane);
+        DcRegs L; L.lane = lane; L.w = *(const uint32_t*)(lst + 4 * lane);
+        for (int k = 0; k < 4; k++) L.v[k] = (4u * lane + (uint32_t)k < A) ? next[lst[4 * lane + k]] : 0xffffffffu;   // next occurrence per entry
         if (A <= 1) {                                          // :180-187 redundant alphabet: no distance is read
             const uint8_t sym = lst[0];
             for (uint32_t t = lane; t < n; t += 64) out[t] = sym;
@@ -304,7 +347,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_decode(rcx_kargs a)
         SeqWin<uint32_t> wwin; wwin.start(words, nwords, lane);
         while (i < n) {                                        // :199-229
             const uint32_t sym = L.at(0);
-            const uint32_t stop = __builtin_amdgcn_readfirstlane(next[L.at(1)]);
+            const uint32_t stop = (uint32_t)__builtin_amdgcn_readlane((int)L.v[1], 0);
             if (stop > n) { st = RCX_E_MALFORMED; break; }     // output[i] index panic
             for (uint32_t t = i + lane; t < stop; t += 64) out[t] = (uint8_t)sym;
             if (stop > i) i = stop;
@@ -321,19 +364,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_decode(rcx_kargs a)
 #pragma unroll
                 for (int k = 3; k >= 0; k--) {
                     const uint32_t r = 4u * lane + (uint32_t)k;
-                    const uint32_t sy = (L.w >> (8 * k)) & 0xffu;
-                    if (r >= 1u && r < A && !(future + r > next[sy])) cand = r;
+                    if (r >= 1u && r < A && !((uint64_t)future + r > (uint64_t)L.v[k])) cand = r;
                 }
                 const unsigned long long m = __ballot(cand != 0xffffffffu);
                 if (m) rank = (uint32_t)__builtin_amdgcn_readlane((int)cand, __ffsll(m) - 1);
             }
-            L.back(rank, sym);                                  // lst[0..rank-2] = lst[1..rank-1]; lst[rank-1] = sym
-            if (lane == 0) next[sym] = future + rank - 1;       // :225-227
-            rcx_wave_sync();
+            L.back_v(rank, sym, future + rank - 1);             // lst[0..rank-2] = lst[1..rank-1]; lst[rank-1] = sym, :225-227
         }
         if (!st && A > 1) {                                    // :230 assert over all 256 entries
-            bool bad = false;
-            for (int k = 0; k < 4; k++) { const uint32_t x = next[lane + 64 * k]; bad = bad || x < n || x >= n + A; }
+            bool bad = absent_bad;
+            for (int k = 0; k < 4; k++) { const uint32_t x = L.v[k]; bad = bad || (4u * lane + (uint32_t)k < A && (x < n || x >= n + A)); }
             if (__ballot(bad)) st = RCX_E_MALFORMED;
         }
     }
