@@ -90,25 +90,29 @@ struct MtfRegs {
     }
 };
 
-// Sequential input of one stream held 64 elements at a time across the lanes (lane j: element base + j), the following 64
-// requested one window early: a serial loop that did `x = in[i]` paid a full global-memory round trip (~700 ns) per step
-// (34 ms for one 256 KiB block of BWT output, whatever the batch size); readlane from the window costs a few cycles.
+// Sequential input of one stream held across the lanes (lane j: element base + j), 128 elements per refill: a serial loop that
+// did `x = in[i]` paid a full global-memory round trip (~700 ns) per step (34 ms for one 256 KiB block of BWT output, whatever
+// the batch size); readlane from the window costs a few cycles.  The refill WAITS for its two loads on the spot (once per 128
+// elements, ~1 us): a load left in flight across iterations makes the compiler put `s_waitcnt vmcnt(0)` in front of every use
+// of the window in the caller's loop, and vmcnt counts the caller's STORES too -- each step of a serial MTF / DC loop then waited
+// for the stores of the step before to reach the L2 (~1000 cycles per step: that was the "25 ms per block" floor of round 1).
 template <typename T>
 struct SeqWin {
-    const T* in; uint32_t n, base; uint32_t cur, nxt; unsigned lane;
-    __device__ __forceinline__ void start(const T* in_, uint32_t n_, unsigned lane_)
+    const T* in; uint32_t n, base; uint32_t cur, nxt; unsigned lane; bool have;
+    __device__ __forceinline__ void refill(uint32_t b)
     {
-        in = in_; n = n_; lane = lane_; base = 0;
-        cur = lane < n ? (uint32_t)in[lane] : 0u;
-        nxt = 64u + lane < n ? (uint32_t)in[64u + lane] : 0u;
+        base = b;
+        cur = b + lane < n ? (uint32_t)in[b + lane] : 0u;
+        nxt = b + 64u + lane < n ? (uint32_t)in[b + 64u + lane] : 0u;
+        RCX_WAIT_VMEM();
+        have = true;
     }
+    __device__ __forceinline__ void start(const T* in_, uint32_t n_, unsigned lane_) { in = in_; n = n_; lane = lane_; refill(0); }
     __device__ __forceinline__ void seek(uint32_t i)           // make element i (uniform, >= base) addressable
     {
         if (i < base + 64u) return;
-        if (i < base + 128u) { base += 64u; cur = nxt; }
-        else { base = i & ~63u; cur = base + lane < n ? (uint32_t)in[base + lane] : 0u; }
-        const uint32_t q = base + 64u + lane;
-        nxt = q < n ? (uint32_t)in[q] : 0u;
+        if (have && i < base + 128u) { base += 64u; cur = nxt; have = false; return; }
+        refill(i & ~63u);
     }
     __device__ __forceinline__ uint32_t get(uint32_t i)        // i uniform, i < n
     {

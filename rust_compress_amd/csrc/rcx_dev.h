@@ -134,6 +134,11 @@ __device__ __forceinline__ void rcx_lds_store16(uint8_t* p, uint32_t v0, uint32_
 #define RCX_LDS_STORE16 rcx_lds_store16
 #endif
 
+// s_waitcnt vmcnt(0): every vector memory operation of the wave so far has completed (the simulator defines it away)
+#ifndef RCX_WAIT_VMEM
+#define RCX_WAIT_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
+#endif
+
 #ifndef RCX_UNI
 #define RCX_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x)))   // wave-uniform value -> SGPR
 #endif

@@ -281,6 +281,7 @@ static inline uint32_t ws_inf_walk(uint32_t pk1, uint32_t pk2, uint32_t& pos, ui
 }
 #define RCX_LDS_STORE16 ws_lds_store16
 #define RCX_INF_WALK ws_inf_walk
+#define RCX_WAIT_VMEM() ((void)0)
 #define RCX_VGPR(x) ((uint32_t)(x))
 #define RCX_ALIGNBYTE(hi, lo, sh) ((uint32_t)(((((uint64_t)(hi)) << 32) | (uint32_t)(lo)) >> (8 * ((sh) & 3u))))
 #define RCX_INV_BALLOT(m) ((((m) >> (threadIdx.x & 63u)) & 1ull) != 0)
