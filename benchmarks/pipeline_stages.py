@@ -20,7 +20,7 @@ if os.environ.get("ARI_VARIANT"):
     ctx.set_variant(N.ARI_BYTE_ENCODE, int(os.environ["ARI_VARIANT"])); ctx.set_variant(N.ARI_BYTE_DECODE, int(os.environ["ARI_VARIANT"]))
 orig = ctx.launch_dev
 names = {N.BWT_FORWARD: "bwt_forward", N.DC_ENCODE: "dc_encode", N.ARI_BYTE_ENCODE: "ari_encode", N.ARI_BYTE_DECODE: "ari_decode",
-         N.BWT_INVERSE: "bwt_inverse"}
+         N.BWT_INVERSE: "bwt_inverse", N.DC_DECODE: "dc_decode"}
 acc = {}
 def timed(codec, *a, **k):
     torch.cuda.synchronize(); t0 = time.perf_counter()

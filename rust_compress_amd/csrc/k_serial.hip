@@ -236,6 +236,118 @@ struct DcRegs : MtfRegs {
     }
 };
 
+// The same list with ONE entry per lane, for alphabets of at most 64 symbols (any text): find is one compare + ballot, a move
+// is one DPP shift + one select per register -- a quarter of the vector work of the general layout, and with ~4000 blocks in
+// flight these serial loops are bound by the CUs' vector issue slots (each step is a wave64 instruction stream in which a few
+// lanes do useful work), not by latency.
+struct DcRegs1 {
+    uint32_t sy, v; unsigned lane;                            // lane l: the symbol at rank l and its position
+    __device__ __forceinline__ void zero(unsigned lane_) { lane = lane_; sy = 0; v = 0; }
+    __device__ __forceinline__ uint32_t sym_at(uint32_t pos) const { return (uint32_t)__builtin_amdgcn_readlane((int)sy, (int)pos); }
+    __device__ __forceinline__ uint32_t val_at(uint32_t pos) const { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)pos); }
+    __device__ __forceinline__ void set_val0(uint32_t val) { v = lane == 0 ? val : v; }
+    __device__ __forceinline__ void front_v(uint32_t rank, uint32_t sym, uint32_t val)
+    {
+        const uint32_t ps = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sy, 0x138, 0xf, 0xf, false);    // wave_shr:1
+        const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+        const bool mv = lane <= rank;
+        sy = lane == 0 ? sym : (mv ? ps : sy);
+        v = lane == 0 ? val : (mv ? pv : v);
+    }
+    __device__ __forceinline__ void back_v(uint32_t rank, uint32_t sym, uint32_t val)      // rank >= 1
+    {
+        const uint32_t ns = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sy, 0x130, 0xf, 0xf, false);    // wave_shl:1
+        const uint32_t nv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false);
+        const uint32_t q = rank - 1u;
+        sy = lane < q ? ns : (lane == q ? sym : sy);
+        v = lane < q ? nv : (lane == q ? val : v);
+    }
+    __device__ __forceinline__ bool find_v(uint32_t sym, uint32_t count, uint32_t& rank, uint32_t& val) const
+    {
+        const unsigned long long m = __ballot(sy == sym && lane < count);
+        if (!m) return false;
+        rank = (uint32_t)__ffsll(m) - 1u;
+        val = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)rank);
+        return true;
+    }
+    // first rank r in [1, A) with !(future + r > v[r]), else A   (dc.rs:214-218)
+    __device__ __forceinline__ uint32_t first_fit(uint32_t future, uint32_t A) const
+    {
+        const unsigned long long m = __ballot(lane >= 1u && lane < A && !((uint64_t)future + lane > (uint64_t)v));
+        return m ? (uint32_t)__ffsll(m) - 1u : A;
+    }
+    template <class F> __device__ __forceinline__ void each(uint32_t count, F f) const { if (lane < count) f(lane, sy, v); }
+};
+// (the general layout's versions of the same interface)
+struct DcRegs4 : DcRegs {
+    __device__ __forceinline__ void zero(unsigned lane_) { MtfRegs::zero(lane_); v[0] = v[1] = v[2] = v[3] = 0; }
+    __device__ __forceinline__ uint32_t sym_at(uint32_t pos) const { return at(pos); }
+    __device__ __forceinline__ uint32_t val_at(uint32_t pos) const
+    {
+        const uint32_t k = pos & 3u;
+        const uint32_t x = k == 0 ? v[0] : k == 1 ? v[1] : k == 2 ? v[2] : v[3];          // pos is uniform: scalar selects
+        return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)(pos >> 2));
+    }
+    __device__ __forceinline__ void set_val0(uint32_t val) { v[0] = lane == 0 ? val : v[0]; }
+    __device__ __forceinline__ uint32_t first_fit(uint32_t future, uint32_t A) const
+    {
+        uint32_t cand = 0xffffffffu;
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            const uint32_t r = 4u * lane + (uint32_t)k;
+            if (r >= 1u && r < A && !((uint64_t)future + r > (uint64_t)v[k])) cand = r;
+        }
+        const unsigned long long m = __ballot(cand != 0xffffffffu);
+        return m ? (uint32_t)__builtin_amdgcn_readlane((int)cand, __ffsll(m) - 1) : A;
+    }
+    template <class F> __device__ __forceinline__ void each(uint32_t count, F f) const
+    {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) { const uint32_t r = 4u * lane + k; if (r < count) f(r, (w >> (8u * k)) & 0xffu, v[k]); }
+    }
+    // take over a one-entry-per-lane list (its entries 0 .. 63)
+    __device__ __forceinline__ void from1(const DcRegs1& o)
+    {
+        lane = o.lane; w = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int srcl = (int)(((4u * lane + (uint32_t)k) & 63u) << 2);
+            const uint32_t sk = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl, (int)o.sy), vk = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl, (int)o.v);
+            const bool have = lane < 16u;
+            w |= have ? (sk & 0xffu) << (8 * k) : 0u;
+            v[k] = have ? vk : 0u;
+        }
+    }
+};
+
+// dc.rs:117-138 from position i on, until the input ends or a (limit+1)-th distinct symbol turns up; returns where it stopped
+template <class LT>
+__device__ __forceinline__ uint32_t dc_encode_steps(LT& L, SeqWin<uint8_t>& win, uint32_t i, uint32_t n, uint32_t& num_unique, uint32_t limit,
+                                                    uint32_t* words, uint32_t* dist, unsigned lane)
+{
+    while (i < n) {
+        const uint32_t sym = win.get(i);
+        uint32_t rank = 0, base = 0;
+        if (!L.find_v(sym, num_unique, rank, base)) {         // first occurrence, :121-128: insert behind the others, move to front
+            if (num_unique == limit) break;
+            if (lane == 0) { words[sym] = i; dist[i] = n; }
+            L.front_v(num_unique, sym, i);
+            num_unique++;
+            i += 1;
+        } else if (base == i - 1) {                           // inside a run: rank 0, nothing is emitted
+            const uint32_t rl = win.run(i, sym);
+            for (uint32_t t = lane; t < rl; t += 64) dist[i + t] = n;
+            L.set_val0(i + rl - 1);
+            i += rl;
+        } else {                                              // :129-136 (rank >= 1: the front symbol is the one at i - 1)
+            if (lane == 0) { dist[i] = n; dist[base] = i - base - rank - 1; }
+            L.front_v(rank, sym, i);
+            i += 1;
+        }
+    }
+    return i;
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a)
 {
@@ -252,37 +364,21 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a)
     }
     uint32_t* dist = words + 256;
     for (int k = 0; k < 4; k++) words[lane + 64 * k] = n;     // :114-115 (init[]: first occurrences, n = absent)
-    DcRegs L; L.zero(lane);                                    // MTF::new(); v[] = last occurrence of each listed symbol
-    for (int k = 0; k < 4; k++) L.v[k] = 0;
     rcx_wave_sync();
-    uint32_t num_unique = 0, i = 0;
+    uint32_t num_unique = 0;
     SeqWin<uint8_t> win; win.start(in, n, lane);
-    while (i < n) {                                           // :117-138
-        const uint32_t sym = win.get(i);
-        uint32_t rank = 0, base = 0;
-        if (!L.find_v(sym, num_unique, rank, base)) {         // first occurrence, :121-128: insert behind the others, move to front
-            if (lane == 0) { words[sym] = i; dist[i] = n; }
-            L.front_v(num_unique, sym, i);
-            num_unique++;
-            i += 1;
-        } else if (base == i - 1) {                           // inside a run: rank 0, nothing is emitted
-            const uint32_t rl = win.run(i, sym);
-            for (uint32_t t = lane; t < rl; t += 64) dist[i + t] = n;
-            if (lane == 0) L.v[0] = i + rl - 1;
-            i += rl;
-        } else {                                              // :129-136 (rank >= 1: the front symbol is the one at i - 1)
-            if (lane == 0) { dist[i] = n; dist[base] = i - base - rank - 1; }
-            L.front_v(rank, sym, i);
-            i += 1;
-        }
-    }
-    rcx_wave_sync();                                           // every filler store precedes the sweep's stores (same wave: in order)
-    for (uint32_t k2 = 0; k2 < 4; k2++) {                      // sweep, :139-144 (lane l holds ranks 4l .. 4l+3)
-        const uint32_t rank = 4u * lane + k2;
-        if (rank < num_unique) {
-            const uint32_t base = L.v[k2];
-            dist[base] = n - base - rank - 1;
-        }
+    // MTF::new(); the position of an entry = the last occurrence of its symbol.  One entry per lane while <= 64 symbols have turned up.
+    DcRegs1 L1; L1.zero(lane);
+    uint32_t i = dc_encode_steps(L1, win, 0, n, num_unique, 64u, words, dist, lane);
+    auto sweep = [&](uint32_t rank, uint32_t, uint32_t base) { dist[base] = n - base - rank - 1; };      // :139-144
+    if (i < n) {
+        DcRegs4 L4; L4.from1(L1);
+        i = dc_encode_steps(L4, win, i, n, num_unique, 256u, words, dist, lane);
+        rcx_wave_sync();                                       // every filler store precedes the sweep's stores (same wave: in order)
+        L4.each(num_unique, sweep);
+    } else {
+        rcx_wave_sync();
+        L1.each(num_unique, sweep);
     }
     __threadfence_block();
     rcx_wave_sync();
@@ -298,6 +394,28 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a)
         k += (uint32_t)__popcll(m);
     }
     if (lane == 0) { a.status[b] = RCX_OK; a.out_len[b] = 4ull * (256ull + k); if (a.in_used) a.in_used[b] = n; }
+}
+
+// dc.rs:199-229 driven as decode_simple :236-252; returns the status
+template <class LT>
+__device__ __forceinline__ int dc_decode_steps(LT& L, SeqWin<uint32_t>& wwin, uint32_t& i, uint32_t n, uint32_t A, uint32_t& di, uint32_t nwords, uint8_t* out, unsigned lane)
+{
+    while (i < n) {
+        const uint32_t sym = L.sym_at(0);
+        const uint32_t stop = L.val_at(1);
+        if (stop > n) return RCX_E_MALFORMED;                  // output[i] index panic
+        for (uint32_t t = i + lane; t < stop; t += 64) out[t] = (uint8_t)sym;
+        if (stop > i) i = stop;
+        di++;                                                  // decode_simple closure :243-249
+        if (di > nwords) return RCX_E_EOF;
+        const uint32_t d = wwin.get(di - 1);
+        const uint64_t future64 = (uint64_t)stop + d;
+        if (future64 > n) return RCX_E_MALFORMED;              /* :213 assert */
+        const uint32_t future = (uint32_t)future64;
+        const uint32_t rank = L.first_fit(future, A);          // :214-218
+        L.back_v(rank, sym, future + rank - 1);                // lst[0..rank-2] = lst[1..rank-1]; lst[rank-1] = sym, :225-227
+    }
+    return RCX_OK;
 }
 
 template <int WAVES>
@@ -341,45 +459,25 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_decode(rcx_kargs a)
         A = rcx_wave_sum(cnt);
         for (int k = 0; k < 4; k++) { const uint32_t x = next[lane + 64 * k]; absent_bad = absent_bad || (x >= n && x >= n + A); }
         rcx_wave_sync();
-        DcRegs L; L.lane = lane; L.w = *(const uint32_t*)(lst + 4 * lane);
-        for (int k = 0; k < 4; k++) L.v[k] = (4u * lane + (uint32_t)k < A) ? next[lst[4 * lane + k]] : 0xffffffffu;   // next occurrence per entry
         if (A <= 1) {                                          // :180-187 redundant alphabet: no distance is read
             const uint8_t sym = lst[0];
             for (uint32_t t = lane; t < n; t += 64) out[t] = sym;
             i = n;
         }
         SeqWin<uint32_t> wwin; wwin.start(words, nwords, lane);
-        while (i < n) {                                        // :199-229
-            const uint32_t sym = L.at(0);
-            const uint32_t stop = (uint32_t)__builtin_amdgcn_readlane((int)L.v[1], 0);
-            if (stop > n) { st = RCX_E_MALFORMED; break; }     // output[i] index panic
-            for (uint32_t t = i + lane; t < stop; t += 64) out[t] = (uint8_t)sym;
-            if (stop > i) i = stop;
-            di++;                                              // decode_simple closure :243-249
-            if (di > nwords) { st = RCX_E_EOF; break; }
-            const uint32_t d = wwin.get(di - 1);
-            const uint64_t future64 = (uint64_t)stop + d;
-            if (future64 > n) { st = RCX_E_MALFORMED; break; } /* :213 assert */
-            const uint32_t future = (uint32_t)future64;
-            // :214-218 first rank r >= 1 with !(future + r > next[lst[r]]), else A
-            uint32_t rank = A;                                  // lane l tests its own ranks 4l .. 4l+3 (ranks grow with the lane)
-            {
-                uint32_t cand = 0xffffffffu;
-#pragma unroll
-                for (int k = 3; k >= 0; k--) {
-                    const uint32_t r = 4u * lane + (uint32_t)k;
-                    if (r >= 1u && r < A && !((uint64_t)future + r > (uint64_t)L.v[k])) cand = r;
-                }
-                const unsigned long long m = __ballot(cand != 0xffffffffu);
-                if (m) rank = (uint32_t)__builtin_amdgcn_readlane((int)cand, __ffsll(m) - 1);
-            }
-            L.back_v(rank, sym, future + rank - 1);             // lst[0..rank-2] = lst[1..rank-1]; lst[rank-1] = sym, :225-227
+        bool bad = absent_bad;
+        auto check = [&](uint32_t, uint32_t, uint32_t x) { bad = bad || x < n || x >= n + A; };           // :230 assert, listed symbols
+        if (A <= 64) {                                         // one entry per lane (v = the symbol's next occurrence)
+            DcRegs1 L; L.lane = lane; L.sy = lst[lane]; L.v = lane < A ? next[lst[lane]] : 0xffffffffu;
+            st = dc_decode_steps(L, wwin, i, n, A, di, nwords, out, lane);
+            L.each(A, check);
+        } else {
+            DcRegs4 L; L.lane = lane; L.w = *(const uint32_t*)(lst + 4 * lane);
+            for (int k = 0; k < 4; k++) L.v[k] = (4u * lane + (uint32_t)k < A) ? next[lst[4 * lane + k]] : 0xffffffffu;
+            st = dc_decode_steps(L, wwin, i, n, A, di, nwords, out, lane);
+            L.each(A, check);
         }
-        if (!st && A > 1) {                                    // :230 assert over all 256 entries
-            bool bad = absent_bad;
-            for (int k = 0; k < 4; k++) { const uint32_t x = L.v[k]; bad = bad || (4u * lane + (uint32_t)k < A && (x < n || x >= n + A)); }
-            if (__ballot(bad)) st = RCX_E_MALFORMED;
-        }
+        if (!st && A > 1 && __ballot(bad)) st = RCX_E_MALFORMED;
     }
     if (lane == 0) {
         a.status[b] = st; a.out_len[b] = st ? 0 : n;
