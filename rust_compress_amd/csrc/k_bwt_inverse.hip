@@ -9,16 +9,18 @@
 // ---------------------------------------------------------------------------------------------------
 #define BWTI_THREADS 1024
 #define BWTI_WAVES (BWTI_THREADS / 64)
-#define BWTI_MAXMARK 4096        /* marked nodes per block (<= 4 per thread) */
+#define BWTI_MAXMARK 16384       /* marked nodes per block */
+#define BWTI_SLOTS 8             /* chains a thread chases at once */
 #define BWTI_CHUNK 1024u         /* blocks per launch: bounds the jump-table scratch */
 
 // per in-flight block: the 4n-byte jump table + BWTI_CAPX n bytes where the walkers park what they emit on the first chase
 #define BWTI_CAPX 16u
 static uint64_t bwti_table_bytes(uint64_t max_block) { return (max_block * 4 + 255) & ~255ull; }
+static __host__ __device__ inline uint64_t bwti_cap(uint64_t stride) { const uint64_t c = BWTI_CAPX * (stride ? stride : 1); return c < 0xfff0u ? c : 0xfff0u; }   // a parked length fits 16 bits
 static uint64_t bwti_slot_bytes(uint64_t max_block)
 {
     const uint64_t stride = (max_block + BWTI_MAXMARK - 1) / BWTI_MAXMARK;
-    return bwti_table_bytes(max_block) + (((uint64_t)BWTI_CAPX * (stride ? stride : 1) * (BWTI_MAXMARK + 1) + 255) & ~255ull);
+    return bwti_table_bytes(max_block) + ((bwti_cap(stride) * (BWTI_MAXMARK + 1) + 255) & ~255ull);
 }
 static uint64_t bwt_inverse_scratch_bytes(uint32_t nblocks, uint64_t max_block)
 {
@@ -26,14 +28,21 @@ static uint64_t bwt_inverse_scratch_bytes(uint32_t nblocks, uint64_t max_block)
     return nb * bwti_slot_bytes(max_block) + 256;
 }
 
-// One workgroup (16 waves) per block.
+// One workgroup (16 waves) per block.  List ranking: every `stride`-th slot of the jump table (and origin) is a marked node; a
+// walker chases from its marked node to the next one (parking the bytes it passes), the marked nodes are ranked among themselves
+// by pointer jumping in LDS, and the parked chains are copied to their places.  The chase is a chain of dependent random loads,
+// so what counts is the LONGEST chain of a block (gaps between marked nodes are geometric: mean `stride`, maximum about
+// stride x ln(marked nodes)): 16384 marked nodes instead of 4096 cut it from ~530 to ~150 steps, and a thread keeps 8 chains in
+// flight and starts its next marked node the moment one of them ends.
 __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint32_t block0, uint64_t table_stride, uint64_t table_bytes)
 {
-    __shared__ uint32_t s_cnt[BWTI_WAVES][256];       // per-wave symbol counters -> running slots
-    __shared__ uint32_t s_next[BWTI_MAXMARK + 1];     // marked node -> next marked node id (or NONE)
-    __shared__ uint32_t s_len[BWTI_MAXMARK + 1];      // emissions of that walker
-    __shared__ uint32_t s_base[BWTI_MAXMARK + 1];     // chain position of its first emission
-    __shared__ uint32_t s_total;
+    __shared__ uint32_t s_rk[BWTI_MAXMARK + 16];      // walker's emissions, then (pointer jumping) emissions from this node to the chain's end
+    __shared__ uint16_t s_next[BWTI_MAXMARK + 16];    // marked node -> next marked node id (or NONE16)
+    __shared__ uint16_t s_len[BWTI_MAXMARK + 16];     // min(emissions, 0xffff): parked chains are shorter than that
+    __shared__ uint32_t s_tot[256];
+    __shared__ uint32_t s_ok;
+    uint32_t (*s_cnt)[256] = (uint32_t (*)[256])s_rk;  // phases 1-2: per-wave symbol counters -> running slots (16 KiB of s_rk)
+    static_assert(BWTI_WAVES * 256 <= BWTI_MAXMARK, "the counters live in s_rk");
     const uint32_t slot = blockIdx.x;
     const uint32_t b = block0 + slot;
     if (b >= a.nblocks) return;
@@ -64,19 +73,19 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
     if (tid < 256) {
         uint32_t tot = 0;
         for (int ww = 0; ww < BWTI_WAVES; ww++) tot += s_cnt[ww][tid];
-        s_base[tid] = tot;                                   // reuse s_base as the 256-bin totals
+        s_tot[tid] = tot;
     }
     __syncthreads();
-    if (tid == 0) { uint32_t acc = 0; for (int c = 0; c < 256; c++) { const uint32_t t = s_base[c]; s_base[c] = acc; acc += t; } }
+    if (tid == 0) { uint32_t acc = 0; for (int c = 0; c < 256; c++) { const uint32_t t = s_tot[c]; s_tot[c] = acc; acc += t; } }
     __syncthreads();
     if (tid < 256) {
-        uint32_t acc = s_base[tid] + (tid == osym ? 1u : 0u);     // slot 0 of osym is reserved for origin
+        uint32_t acc = s_tot[tid] + (tid == osym ? 1u : 0u);      // slot 0 of osym is reserved for origin
         for (int ww = 0; ww < BWTI_WAVES; ww++) { const uint32_t t = s_cnt[ww][tid]; s_cnt[ww][tid] = acc; acc += t; }
     }
     __syncthreads();
     // the origin element itself was counted in its wave's slice: take it out of that slice's budget
     if (tid == 0) {
-        table[s_base[osym]] = packed ? (osym << 24) : 0u;         // table[place(L[origin])] = 0 (+ the byte there, see below)
+        table[s_tot[osym]] = packed ? (osym << 24) : 0u;          // table[place(L[origin])] = 0 (+ the byte there, see below)
         const uint32_t ow = origin / per;
         for (int ww = (int)ow + 1; ww < BWTI_WAVES; ww++) s_cnt[ww][osym] -= 1u;
     }
@@ -112,78 +121,104 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
     const uint32_t M0 = (n + stride - 1) / stride;
     const bool origin_marked = (origin % stride) == 0;
     const uint32_t M = M0 + (origin_marked ? 0u : 1u);
-    const uint32_t NONE = 0xffffffffu;
+    const uint32_t NONE = 0xffffffffu, NONE16 = 0xffffu;
     // First chase: a walker also parks the bytes it emits (up to `cap`, 16 times the mean chain length); once the marked
     // nodes are ranked, a parked chain is COPIED to its place -- only a chain longer than `cap` is chased a second time.
-    const uint32_t cap = BWTI_CAPX * stride;
-    // each thread owns marked nodes tid, tid+1024, ... (<= 4 + 1), chased 4 at a time
+    const uint32_t cap = (uint32_t)bwti_cap(stride);
+    // a thread owns the marked nodes tid, tid + 1024, ...; it chases BWTI_SLOTS of them at once and refills a slot when its chain ends
     for (int pass = 0; pass < 2; pass++) {
-        for (uint32_t m0 = tid; m0 < M; m0 += 4 * BWTI_THREADS) {
-            uint32_t cur[4], cnt[4], wr[4]; bool live[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t m = m0 + q * BWTI_THREADS;
-                live[q] = m < M;
-                cur[q] = live[q] ? (m < M0 ? m * stride : origin) : 0u;
-                cnt[q] = 0;
-                wr[q] = (pass == 1 && live[q]) ? s_base[m] : NONE;
-                if (pass == 1 && wr[q] == NONE) live[q] = false;          // not reachable from origin
-                if (pass == 1 && live[q] && s_len[m] <= cap) {             // parked on the first chase: copy, no second chase
+        uint32_t cur[BWTI_SLOTS], cnt[BWTI_SLOTS], wr[BWTI_SLOTS], mid[BWTI_SLOTS]; bool live[BWTI_SLOTS];
+        uint64_t pk[BWTI_SLOTS];                                          // pass 0: the chain's bytes, parked eight at a time
+        uint32_t nextm = tid;
+        auto start = [&](int q) {                                         // the thread's next marked node -> slot q
+            live[q] = false; wr[q] = NONE; cnt[q] = 0; cur[q] = 0; mid[q] = 0; pk[q] = 0;
+            while (nextm < M) {
+                const uint32_t m = nextm; nextm += BWTI_THREADS;
+                if (pass == 1 && s_len[m] <= cap) {                       // parked on the first chase: copy, no second chase
                     const uint8_t* src = park + (size_t)m * cap;
-                    const uint32_t len = s_len[m];
+                    const uint32_t len = s_len[m], dstp = n - s_rk[m];
                     uint32_t t = 0;
-                    for (; t + 16 <= len && wr[q] + t + 16 <= n; t += 16)          // park slots are 16-byte aligned, `out` need not be
-                        *(rcx_u32x4_u*)(out + wr[q] + t) = *(const rcx_u32x4*)(src + t);
-                    for (; t < len; t++) if (wr[q] + t < n) out[wr[q] + t] = src[t];
-                    live[q] = false;
+                    for (; t + 16 <= len && dstp + t + 16 <= n; t += 16)          // park slots are 16-byte aligned, `out` need not be
+                        *(rcx_u32x4_u*)(out + dstp + t) = *(const rcx_u32x4*)(src + t);
+                    for (; t < len; t++) if (dstp + t < n) out[dstp + t] = src[t];
+                    continue;
                 }
+                live[q] = true; mid[q] = m; cur[q] = m < M0 ? m * stride : origin;
+                if (pass == 1) wr[q] = n - s_rk[m];
+                break;
             }
-            for (;;) {
-                if (!(live[0] || live[1] || live[2] || live[3])) break;
-                uint32_t v[4], c2[4]; uint8_t ch[4];
+        };
 #pragma unroll
-                for (int q = 0; q < 4; q++) v[q] = live[q] ? table[cur[q]] : 0u;          // 4 jump-table loads in flight
+        for (int q = 0; q < BWTI_SLOTS; q++) start(q);
+        for (;;) {
+            bool any = false;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    if (packed) { ch[q] = (uint8_t)(v[q] >> 24); v[q] &= 0xffffffu; c2[q] = v[q] ? v[q] - 1u : origin; }
-                    else { c2[q] = v[q] ? v[q] - 1u : origin; ch[q] = live[q] ? L[c2[q]] : (uint8_t)0; }
+            for (int q = 0; q < BWTI_SLOTS; q++) any = any || live[q];
+            if (!any) break;
+            uint32_t v[BWTI_SLOTS], c2[BWTI_SLOTS]; uint8_t ch[BWTI_SLOTS];
+#pragma unroll
+            for (int q = 0; q < BWTI_SLOTS; q++) v[q] = live[q] ? table[cur[q]] : 0u;    // the jump-table loads, all in flight
+#pragma unroll
+            for (int q = 0; q < BWTI_SLOTS; q++) {
+                if (packed) { ch[q] = (uint8_t)(v[q] >> 24); v[q] &= 0xffffffu; c2[q] = v[q] ? v[q] - 1u : origin; }
+                else { c2[q] = v[q] ? v[q] - 1u : origin; ch[q] = live[q] ? L[c2[q]] : (uint8_t)0; }
+            }
+#pragma unroll
+            for (int q = 0; q < BWTI_SLOTS; q++) {
+                if (!live[q]) continue;
+                uint32_t nxt = NONE16;
+                bool stop;
+                if (v[q] == 0) stop = true;                               // wrapped: L[origin] was emitted, chain ends
+                else {
+                    const bool mk = (c2[q] % stride) == 0 || c2[q] == origin;
+                    stop = mk || cnt[q] + 1 >= n;
+                    if (mk) nxt = (c2[q] == origin && !origin_marked) ? M0 : c2[q] / stride;
+                    cur[q] = c2[q];
                 }
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    if (!live[q]) continue;
-                    uint32_t nxt = NONE;
-                    bool stop;
-                    if (v[q] == 0) stop = true;                           // wrapped: L[origin] was emitted, chain ends
-                    else {
-                        const bool mk = (c2[q] % stride) == 0 || c2[q] == origin;
-                        stop = mk || cnt[q] + 1 >= n;
-                        if (mk) nxt = (c2[q] == origin && !origin_marked) ? M0 : c2[q] / stride;
-                        cur[q] = c2[q];
-                    }
-                    if (pass == 1) { if (wr[q] + cnt[q] < n) out[wr[q] + cnt[q]] = ch[q]; }
-                    else if (cnt[q] < cap) park[(size_t)(m0 + q * BWTI_THREADS) * cap + cnt[q]] = ch[q];
-                    cnt[q]++;
-                    if (stop) {
-                        live[q] = false;
-                        if (pass == 0) { const uint32_t m = m0 + q * BWTI_THREADS; s_next[m] = nxt; s_len[m] = cnt[q]; }
-                    }
+                if (pass == 1) { if (wr[q] + cnt[q] < n) out[wr[q] + cnt[q]] = ch[q]; }
+                else {
+                    // a byte store per step kept ~260 K partial-line writes per block on their way to HBM (the lines leave the L2
+                    // long before a walker comes back to them): 8 bytes per store
+                    pk[q] |= (uint64_t)ch[q] << (8u * (cnt[q] & 7u));
+                    if (((cnt[q] & 7u) == 7u || stop) && (cnt[q] & ~7u) < cap) { *(uint64_t*)(park + (size_t)mid[q] * cap + (cnt[q] & ~7u)) = pk[q]; pk[q] = 0; }
+                }
+                cnt[q]++;
+                if (stop) {
+                    if (pass == 0) { const uint32_t m = mid[q]; s_next[m] = (uint16_t)nxt; s_rk[m] = cnt[q]; s_len[m] = (uint16_t)(cnt[q] < 0xffffu ? cnt[q] : 0xffffu); }
+                    start(q);
                 }
             }
         }
         __syncthreads();
         if (pass == 0) {
-            for (uint32_t m = tid; m < M; m += BWTI_THREADS) s_base[m] = NONE;
-            __syncthreads();
-            if (tid == 0) {                                               // rank the marked nodes along the chain
-                uint32_t m = origin_marked ? origin / stride : M0, pos = 0, steps = 0;
-                while (m != NONE && steps <= M && pos < n) { s_base[m] = pos; pos += s_len[m]; m = s_next[m]; steps++; }
-                s_total = pos;
+            // rank the marked nodes: pointer jumping, s_rk[m] becomes the number of bytes emitted from m to the end of its chain
+            constexpr int PER = (BWTI_MAXMARK + 1 + BWTI_THREADS - 1) / BWTI_THREADS;
+            for (uint32_t span = 1; span < M; span <<= 1) {
+                uint32_t add[PER]; uint16_t nn[PER];
+#pragma unroll
+                for (int j = 0; j < PER; j++) {
+                    const uint32_t m = tid + (uint32_t)j * BWTI_THREADS;
+                    add[j] = 0; nn[j] = (uint16_t)NONE16;
+                    if (m < M) { const uint32_t nx = s_next[m]; if (nx != NONE16) { add[j] = s_rk[nx]; nn[j] = s_next[nx]; } }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < PER; j++) {
+                    const uint32_t m = tid + (uint32_t)j * BWTI_THREADS;
+                    if (m < M && s_next[m] != NONE16) { s_rk[m] += add[j]; s_next[m] = nn[j]; }
+                }
+                __syncthreads();
+            }
+            if (tid == 0) {                                               // origin's chain must end (no loop) and cover the block: else not a BWT
+                const uint32_t m = origin_marked ? origin / stride : M0;
+                s_ok = (s_next[m] == NONE16 && s_rk[m] == n) ? 1u : 0u;
             }
             __syncthreads();
+            if (!s_ok) break;
         }
     }
     if (tid == 0) {
-        const bool ok = s_total == n;                                     // else the chain ended early / looped: not a BWT
+        const bool ok = s_ok != 0;
         a.status[b] = ok ? RCX_OK : RCX_E_MALFORMED;
         a.out_len[b] = ok ? n : 0;
         if (a.in_used) a.in_used[b] = n;
