@@ -91,6 +91,128 @@ __global__ __launch_bounds__(256) void k_bwtf_init(BwtfArgs a, uint64_t* keys, u
         __syncthreads();
     }
 }
+// Round 0, first radix level, fused with the key construction: one workgroup per block reads the TEXT (an LDS tile of symbols
+// at a time), builds each suffix's key on the fly, counts and scatters by the key's top 8 bits.  Against k_bwtf_init + k_bws_seed +
+// the generic level (which reads the 8-byte keys twice and the 4-byte suffixes once, writes 12 bytes and reads them again to mark
+// the small bins) a suffix costs two reads of its text byte and ONE 12-byte write: a bin of one is final, a bin of <= BWS_WAVE is
+// written to saA / keyA marked for the dense passes, a larger bin goes to the other buffer and on the list its size asks for.
+#define BWS_FT 2048u            /* suffixes per LDS tile of k_bws_first */
+__global__ __launch_bounds__(512) void k_bws_first(BwsState s, BwtfArgs a, const uint8_t* map, uint32_t nsym, uint32_t bits, uint32_t plus1,
+                                                   uint32_t top_shift, uint32_t topn)
+{
+    __shared__ uint32_t s_map[256];
+    __shared__ uint16_t s_sym[BWS_FT + 16];
+    __shared__ uint32_t s_hist[8][256], s_tot[256], s_beg[256];
+    __shared__ uint32_t s_one;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t n = (uint32_t)a.in_len[b];
+    if (n == 0) return;
+    const uint8_t* T = a.in_base + a.in_off[b];
+    const uint32_t g0 = a.bstart[b];
+    if (tid < 256) s_map[tid] = (uint32_t)map[tid] + plus1;
+    for (uint32_t i = tid; i < 8 * 256; i += 512) ((uint32_t*)s_hist)[i] = 0;
+    if (tid == 0) s_one = 0;
+    __syncthreads();
+    auto tile = [&](uint32_t i0) {                             // symbols of suffixes i0 .. i0+BWS_FT-1 and the 16 that follow (0 = past the end)
+        __syncthreads();
+        for (uint32_t t = tid; t < BWS_FT + 16u; t += 512u) s_sym[t] = (i0 + t < n) ? (uint16_t)s_map[T[i0 + t]] : (uint16_t)0;
+        __syncthreads();
+    };
+    auto key_at = [&](uint32_t t) {
+        uint64_t k = b;
+        for (uint32_t c = 0; c < nsym; c++) k = (k << bits) | (uint64_t)s_sym[t + c];
+        return k;
+    };
+    const uint32_t nshift = top_shift > 8u ? top_shift - 8u : 0u;
+    if (n <= BWS_LMAX) {                                       // a small block: keys and identity order, listed as one group (what k_bws_seed did)
+        for (uint32_t i0 = 0; i0 < n; i0 += BWS_FT) {
+            tile(i0);
+            for (uint32_t t = tid; t < BWS_FT; t += 512u) {
+                const uint32_t i = i0 + t;
+                if (i < n) { s.keyA[g0 + i] = key_at(t); s.saA[g0 + i] = (g0 + i) | (i == 0 ? (BWS_HEAD | (s.par ^ BWS_PAR)) : 0u); }
+            }
+        }
+        if (tid == 0) {
+            if (n == 1) { s.saA[g0] = g0 | BWS_HEAD | BWS_FINAL; s.rank[g0] = g0; }
+            else if (n > BWS_WAVE) { const uint32_t q = atomicAdd(&s.cnt[6], 1u); s.local[q] = BwsSeg{g0, n, top_shift}; }
+            else if (!bws_dense_ok(g0, n)) { const uint32_t q = atomicAdd(&s.cnt[2], 1u); s.small[q] = BwsSeg{g0, n, 0u}; }
+            else bws_flag_dense(s, s.rs, g0, n);
+        }
+        return;
+    }
+    // ---- count
+    for (uint32_t i0 = 0; i0 < n; i0 += BWS_FT) {
+        tile(i0);
+        for (uint32_t t = tid; t < BWS_FT; t += 512u) {
+            const uint32_t i = i0 + t; const bool ok = i < n;
+            const uint32_t d = ok ? (uint32_t)(key_at(t) >> top_shift) & 0xffu : 0x100u;
+            const unsigned long long peers = bws_peers(ok, d);
+            if (ok && (uint32_t)__ffsll(peers) - 1u == lane) atomicAdd(&s_hist[wave][d], (uint32_t)__popcll(peers));
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) t += s_hist[w][tid];
+        s_tot[tid] = t;
+        if (t == n) s_one = 1;
+    }
+    __syncthreads();
+    if (s_one) {                                               // every suffix starts with the same digit: the generic levels go on from the next one
+        for (uint32_t i0 = 0; i0 < n; i0 += BWS_FT) {
+            tile(i0);
+            for (uint32_t t = tid; t < BWS_FT; t += 512u) {
+                const uint32_t i = i0 + t;
+                if (i < n) { s.keyA[g0 + i] = key_at(t); s.saA[g0 + i] = (g0 + i) | (i == 0 ? (BWS_HEAD | (s.par ^ BWS_PAR)) : 0u); }
+            }
+        }
+        if (tid == 0) { const uint32_t q = atomicAdd(&s.cnt[1], 1u); s.large[1][q] = BwsSeg{g0, n, nshift}; }
+        return;
+    }
+    if (tid < 64) {
+        const uint32_t t0 = s_tot[4 * tid], t1 = s_tot[4 * tid + 1], t2 = s_tot[4 * tid + 2], t3 = s_tot[4 * tid + 3];
+        const uint32_t ex = rcx_wave_incl_scan(t0 + t1 + t2 + t3) - (t0 + t1 + t2 + t3);
+        s_beg[4 * tid] = ex; s_beg[4 * tid + 1] = ex + t0; s_beg[4 * tid + 2] = ex + t0 + t1; s_beg[4 * tid + 3] = ex + t0 + t1 + t2;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        uint32_t o = s_beg[tid];
+#pragma unroll
+        for (int w = 0; w < 8; w++) { const uint32_t c = s_hist[w][tid]; s_hist[w][tid] = o; o += c; }
+    }
+    // ---- place (tile() synchronises)
+    for (uint32_t i0 = 0; i0 < n; i0 += BWS_FT) {
+        tile(i0);
+        for (uint32_t t = tid; t < BWS_FT; t += 512u) {
+        const uint32_t i = i0 + t; const bool ok = i < n;
+        const uint64_t k = ok ? key_at(t) : 0ull;
+        const uint32_t d = ok ? (uint32_t)(k >> top_shift) & 0xffu : 0x100u;
+        const unsigned long long peers = bws_peers(ok, d);
+        const uint32_t leader = (uint32_t)__ffsll(peers) - 1u;
+        uint32_t bse = 0;
+        if (ok && leader == lane) bse = atomicAdd(&s_hist[wave][d], (uint32_t)__popcll(peers));
+        bse = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((leader & 63u) << 2), (int)bse);
+        if (ok) {
+            const uint32_t p = bse + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull)), g = g0 + i;
+            const uint32_t c = s_tot[d], b0 = s_beg[d], at = g0 + p;
+            if (c == 1u) { s.saA[at] = g | BWS_HEAD | BWS_FINAL; s.rank[g] = at; }
+            else if (c <= BWS_WAVE) {
+                s.saA[at] = g | (p == b0 ? (BWS_HEAD | (s.par ^ BWS_PAR)) : 0u); s.keyA[at] = k;
+                if (p == b0 && bws_dense_ok(at, c)) bws_flag_dense(s, s.rs, at, c);
+            } else { s.keyB[at] = k; s.saB[at] = g; }
+        }
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {                                           // where each bin goes (waves 0-3 whole: wave-uniform calls)
+        const uint32_t c = s_tot[tid], at = g0 + s_beg[tid];
+        const BwsSeg nx{at, c, nshift | (1u << 8)};
+        bws_append(s.large[1], &s.cnt[1], c > BWS_LMAX, nx);
+        bws_append(s.local, &s.cnt[6], c > BWS_WAVE && c <= BWS_LMAX, nx);
+        bws_append(s.small, &s.cnt[2], c >= 2u && c <= BWS_WAVE && !bws_dense_ok(at, c), BwsSeg{at, c, 0u});
+    }
+}
 // L[j] = T[SA[j]-1], or T[n-1] where SA[j] == 0 (that j is `origin`), mod.rs:193-203
 __global__ void k_bwtf_emit(BwtfArgs a, const uint32_t* sa, uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap, uint32_t* origin)
 {
@@ -191,11 +313,15 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                 if (hipMemcpyAsync(symmap, h_map, 256, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
                     err = "bwt forward: symbol map"; return RCX_RC_HIP_ERROR; }
             }
-            hipLaunchKernelGGL(k_bwtf_init, dim3(gx ? gx : 1, nb), dim3(256), 0, s, fa, st.keyA, st.saA, symmap, nsym, sbits, plain_bytes ? 1u : 0u);
             if (hipMemsetAsync(st.cnt, 0, 4 * (64 + BWS_NFLAG), s) != hipSuccess || hipMemsetAsync(act0, 0, 4 * nact, s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
             const uint32_t kbits0 = nsym * sbits, top0 = kbits0 > 8 ? kbits0 - 8 : 0;
             const uint32_t kbits1 = bits_for(maxn), top1 = kbits1 > 8 ? kbits1 - 8 : 0;           // later keys: local rank + 1 <= maxn
-            hipLaunchKernelGGL(k_bws_seed, dim3((nb + 255) / 256), dim3(256), 0, s, st, bstart, nb, top0);
+            const bool fused_first = top0 > 0;                    // keys of more than 8 bits: the first level is built straight from the text
+            if (fused_first) hipLaunchKernelGGL(k_bws_first, dim3(nb), dim3(512), 0, s, st, fa, symmap, nsym, sbits, plain_bytes ? 1u : 0u, top0, top1);
+            else {
+                hipLaunchKernelGGL(k_bwtf_init, dim3(gx ? gx : 1, nb), dim3(256), 0, s, fa, st.keyA, st.saA, symmap, nsym, sbits, plain_bytes ? 1u : 0u);
+                hipLaunchKernelGGL(k_bws_seed, dim3((nb + 255) / 256), dim3(256), 0, s, st, bstart, nb, top0);
+            }
             uint32_t h = nsym;
             const uint32_t gdense = (N / 64 + 2 + 4 * BWS_DW - 1) / (4 * BWS_DW);
             bool converged = false;
@@ -204,7 +330,7 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                 const uint32_t top = round == 0 ? top0 : top1, topn = top1;
                 if (round) hipLaunchKernelGGL(k_bws_gather, dim3(gx ? gx : 1, nb), dim3(256), 0, s, st, bstart, nb, h);
                 const int levels = (int)((top + 7) / 8) + 1;
-                for (int lv = 0; lv < levels; lv++) {
+                for (int lv = (round == 0 && fused_first) ? 1 : 0; lv < levels; lv++) {
                     if (hipMemsetAsync(&st.cnt[(lv + 1) & 1], 0, 4, s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
                     if (round == 0) hipLaunchKernelGGL(k_bws_partition<uint64_t>, dim3(2048), dim3(512), 0, s, st, lv, topn);
                     else hipLaunchKernelGGL(k_bws_partition<uint32_t>, dim3(2048), dim3(512), 0, s, st, lv, topn);
