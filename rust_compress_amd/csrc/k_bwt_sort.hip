@@ -200,7 +200,7 @@ __device__ __forceinline__ void bws_mark(const BwsState& s, const BwsSeg& sg, ui
     else if (done) { s.saA[a] = g | (p == beg ? (BWS_HEAD | s.par) : 0u); s.rank[g] = sg.start + beg; }
     else {
         s.saA[a] = g | (p == beg ? (BWS_HEAD | (s.par ^ BWS_PAR)) : 0u);
-        if (dst != 0) bws_keys<K>(s, 0)[a] = k;
+        bws_keys<K>(s, 0)[a] = k;
         if (p == beg && bws_dense_ok(a, c)) bws_flag_dense(s, s.rs, a, c);          // this round's dense passes take it
     }
 }
@@ -276,13 +276,21 @@ __global__ __launch_bounds__(512) void k_bws_partition(BwsState s, int level, ui
                 uint32_t bse = 0;
                 if (ok && leader == lane) bse = atomicAdd(&s_hist[wave][d], (uint32_t)__popcll(peers));
                 bse = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((leader & 63u) << 2), (int)bse);
-                if (ok) { const uint32_t p = bse + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull)); kd[p] = k; sd[p] = ss[i] & BWS_IDX; }
+                if (ok) {
+                    const uint32_t p = bse + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull)), g = ss[i] & BWS_IDX;
+                    // the group lies in buffer B: a bin that is finished or goes to the dense passes is written to saA / keyA at once
+                    // (from buffer A that would overwrite suffixes other threads have yet to read: the pass below does it then)
+                    if (src == 1 && (s_tot[d] <= BWS_WAVE || done)) bws_mark<K>(s, sg, p, k, g, s_tot[d], s_beg[d], done, dst);
+                    else { kd[p] = k; sd[p] = g; }
+                }
             }
             __syncthreads();
-            for (uint32_t p = tid; p < sg.len; p += 512) {
-                const K k = kd[p];
-                const uint32_t d = (uint32_t)(k >> shift) & 0xffu;
-                bws_mark<K>(s, sg, p, k, sd[p], s_tot[d], s_beg[d], done, dst);
+            if (src == 0) {
+                for (uint32_t p = tid; p < sg.len; p += 512) {
+                    const K k = kd[p];
+                    const uint32_t d = (uint32_t)(k >> shift) & 0xffu;
+                    bws_mark<K>(s, sg, p, k, sd[p], s_tot[d], s_beg[d], done, dst);
+                }
             }
             if (tid < 256) bws_route_bin(s, lnext, clnext, done, s_tot[tid], sg.start + s_beg[tid], shift, dst, top_shift);
             __syncthreads();
