@@ -146,7 +146,7 @@ __global__ __launch_bounds__(512) void k_bws_first(BwsState s, BwtfArgs a, const
         for (uint32_t t = tid; t < BWS_FT; t += 512u) {
             const uint32_t i = i0 + t; const bool ok = i < n;
             const uint32_t d = ok ? (uint32_t)(key_at(t) >> top_shift) & 0xffu : 0x100u;
-            const unsigned long long peers = bws_peers(ok, d);
+            const unsigned long long peers = BWS_PEERS(ok, d);
             if (ok && (uint32_t)__ffsll(peers) - 1u == lane) atomicAdd(&s_hist[wave][d], (uint32_t)__popcll(peers));
         }
     }
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(512) void k_bws_first(BwsState s, BwtfArgs a, const
         const uint32_t i = i0 + t; const bool ok = i < n;
         const uint64_t k = ok ? key_at(t) : 0ull;
         const uint32_t d = ok ? (uint32_t)(k >> top_shift) & 0xffu : 0x100u;
-        const unsigned long long peers = bws_peers(ok, d);
+        const unsigned long long peers = BWS_PEERS(ok, d);
         const uint32_t leader = (uint32_t)__ffsll(peers) - 1u;
         uint32_t bse = 0;
         if (ok && leader == lane) bse = atomicAdd(&s_hist[wave][d], (uint32_t)__popcll(peers));

@@ -204,14 +204,37 @@ __device__ __forceinline__ void bws_mark(const BwsState& s, const BwsSeg& sg, ui
         if (p == beg && bws_dense_ok(a, c)) bws_flag_dense(s, s.rs, a, c);          // this round's dense passes take it
     }
 }
-// digit peers of a wave: the lanes (among `ok`) that hold the same digit as mine
+// digit peers of a wave: the lanes (among `ok`) that hold the same digit as mine.  Per digit bit: nm = -bit (v_bfe_i32), the
+// ballot of the bit (v_cmp into vcc), and peers &= ~(ballot ^ nm) on both halves (one v_bitop3_b32 each, truth table 0x90 =
+// a & ~(b ^ c)): 5 issue slots per bit.  Hand-written: the compiler's version of the same C took 9-11 instructions per bit, and
+// the sorter's LDS passes are made of this.
+#ifndef BWS_PEERS
 __device__ __forceinline__ unsigned long long bws_peers(bool ok, uint32_t d)
 {
-    unsigned long long peers = __ballot(ok);
-#pragma unroll
-    for (int bit = 0; bit < 8; bit++) { const unsigned long long m = __ballot((d >> bit) & 1u); peers &= ((d >> bit) & 1u) ? m : ~m; }
-    return peers;
+    const unsigned long long okm = __ballot(ok);
+    uint32_t plo = (uint32_t)okm, phi = (uint32_t)(okm >> 32), n0, n1;
+#define BWS_PB(B, NA, NB)                                           \
+        "v_cmp_ne_u32_e32 vcc, 0, %[" NA "]\n\t"                     \
+        "v_bfe_i32 %[" NB "], %[d], " #B " + 1, 1\n\t"               \
+        "s_nop 0\n\t"                                               \
+        "v_bitop3_b32 %[plo], %[plo], vcc_lo, %[" NA "] bitop3:0x90\n\t" \
+        "v_bitop3_b32 %[phi], %[phi], vcc_hi, %[" NA "] bitop3:0x90\n\t"
+    asm volatile(
+        "v_bfe_i32 %[n0], %[d], 0, 1\n\t"
+        BWS_PB(0, "n0", "n1") BWS_PB(1, "n1", "n0") BWS_PB(2, "n0", "n1") BWS_PB(3, "n1", "n0")
+        BWS_PB(4, "n0", "n1") BWS_PB(5, "n1", "n0") BWS_PB(6, "n0", "n1")
+        "v_cmp_ne_u32_e32 vcc, 0, %[n1]\n\t"
+        "s_nop 1\n\t"
+        "v_bitop3_b32 %[plo], %[plo], vcc_lo, %[n1] bitop3:0x90\n\t"
+        "v_bitop3_b32 %[phi], %[phi], vcc_hi, %[n1] bitop3:0x90\n\t"
+        : [plo] "+v"(plo), [phi] "+v"(phi), [n0] "=&v"(n0), [n1] "=&v"(n1)
+        : [d] "v"(d)
+        : "vcc");
+#undef BWS_PB
+    return ((unsigned long long)phi << 32) | plo;
 }
+#define BWS_PEERS bws_peers
+#endif
 
 template <class K>
 __global__ __launch_bounds__(512) void k_bws_partition(BwsState s, int level, uint32_t top_shift)
@@ -238,7 +261,7 @@ __global__ __launch_bounds__(512) void k_bws_partition(BwsState s, int level, ui
                 for (uint32_t i0 = 0; i0 < sg.len; i0 += 512) {            // text digits are skewed: lanes with the same digit count once
                     const uint32_t i = i0 + tid; const bool ok = i < sg.len;
                     const uint32_t d = ok ? (uint32_t)(ks[i] >> shift) & 0xffu : 0x100u;
-                    const unsigned long long peers = bws_peers(ok, d);
+                    const unsigned long long peers = BWS_PEERS(ok, d);
                     if (ok && (uint32_t)__ffsll(peers) - 1u == lane) atomicAdd(&s_hist[wave][d], (uint32_t)__popcll(peers));
                 }
                 __syncthreads();
@@ -271,7 +294,7 @@ __global__ __launch_bounds__(512) void k_bws_partition(BwsState s, int level, ui
                 const uint32_t i = i0 + tid; const bool ok = i < sg.len;
                 const K k = ok ? ks[i] : (K)0;
                 const uint32_t d = ok ? (uint32_t)(k >> shift) & 0xffu : 0x100u;
-                const unsigned long long peers = bws_peers(ok, d);
+                const unsigned long long peers = BWS_PEERS(ok, d);
                 const uint32_t leader = (uint32_t)__ffsll(peers) - 1u;
                 uint32_t bse = 0;
                 if (ok && leader == lane) bse = atomicAdd(&s_hist[wave][d], (uint32_t)__popcll(peers));
@@ -341,7 +364,7 @@ struct BwsLocal {
                     const bool ok = i < w1;
                     const uint32_t e = ok ? pa[i] : 0u;
                     const uint32_t d = ok ? (uint32_t)(key[e] >> sh) & 0xffu : 0x100u;
-                    const unsigned long long peers = bws_peers(ok, d);
+                    const unsigned long long peers = BWS_PEERS(ok, d);
                     const uint32_t leader = (uint32_t)__ffsll(peers) - 1u, cnt = (uint32_t)__popcll(peers);
                     const uint32_t rk = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
                     if (ok && leader == lane) myh[d] += cnt;
