@@ -134,6 +134,7 @@ __global__ __launch_bounds__(512) void k_bws_first(BwsState s, BwtfArgs a, const
         }
         if (tid == 0) {
             if (n == 1) { s.saA[g0] = g0 | BWS_HEAD | BWS_FINAL; s.rank[g0] = g0; }
+            else if (n > BWS_LWAVE) { const uint32_t q = atomicAdd(&s.cnt[9], 1u); s.localw[q] = BwsSeg{g0, n, top_shift}; }
             else if (n > BWS_WAVE) { const uint32_t q = atomicAdd(&s.cnt[6], 1u); s.local[q] = BwsSeg{g0, n, top_shift}; }
             else if (!bws_dense_ok(g0, n)) { const uint32_t q = atomicAdd(&s.cnt[2], 1u); s.small[q] = BwsSeg{g0, n, 0u}; }
             else bws_flag_dense(s, s.rs, g0, n);
@@ -209,7 +210,8 @@ __global__ __launch_bounds__(512) void k_bws_first(BwsState s, BwtfArgs a, const
         const uint32_t c = s_tot[tid], at = g0 + s_beg[tid];
         const BwsSeg nx{at, c, nshift | (1u << 8)};
         bws_append(s.large[1], &s.cnt[1], c > BWS_LMAX, nx);
-        bws_append(s.local, &s.cnt[6], c > BWS_WAVE && c <= BWS_LMAX, nx);
+        bws_append(s.local, &s.cnt[6], c > BWS_WAVE && c <= BWS_LWAVE, nx);
+        bws_append(s.localw, &s.cnt[9], c > BWS_LWAVE && c <= BWS_LMAX, nx);
         bws_append(s.small, &s.cnt[2], c >= 2u && c <= BWS_WAVE && !bws_dense_ok(at, c), BwsSeg{at, c, 0u});
     }
 }
@@ -251,7 +253,7 @@ static uint64_t bwt_forward_scratch_bytes(uint32_t nblocks, uint64_t max_block)
     uint64_t N = (uint64_t)nblocks * max_block;
     if (N > (uint64_t)BWTF_MAXN) N = BWTF_MAXN;
     // keys 2 x 8N, SA 2 x 4N, rank 4N, group lists, bstart, counters, histogram
-    return 28 * N + 5 * (N / BWS_WAVE + nblocks + 1024) * sizeof(BwsSeg) + 2 * (N / 16 + 4096) * sizeof(BwsSeg) + (uint64_t)(nblocks + 2) * 4 + 4 * (N / 64 + 512) + (1ull << 20);
+    return 28 * N + 5 * (N / BWS_WAVE + nblocks + 1024) * sizeof(BwsSeg) + 2 * (N / 16 + 4096) * sizeof(BwsSeg) + 2 * (N / BWS_LWAVE + nblocks + 1024) * sizeof(BwsSeg) + (uint64_t)(nblocks + 2) * 4 + 4 * (N / 64 + 512) + (1ull << 20);
 }
 
 static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::string& err)
@@ -284,6 +286,8 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
             const size_t nlarge = (size_t)N / BWS_WAVE + nb + 1024, nmid = (size_t)N / 16 + 4096;
             st.large[0] = (BwsSeg*)carve(nlarge * sizeof(BwsSeg)); st.large[1] = (BwsSeg*)carve(nlarge * sizeof(BwsSeg)); st.nlarge = (BwsSeg*)carve(nlarge * sizeof(BwsSeg));
             st.local = (BwsSeg*)carve(nlarge * sizeof(BwsSeg)); st.nlocal = (BwsSeg*)carve(nlarge * sizeof(BwsSeg));
+            const size_t nlw = (size_t)N / BWS_LWAVE + nb + 1024;
+            st.localw = (BwsSeg*)carve(nlw * sizeof(BwsSeg)); st.nlocalw = (BwsSeg*)carve(nlw * sizeof(BwsSeg));
             st.small = (BwsSeg*)carve(nmid * sizeof(BwsSeg)); st.nsmall = (BwsSeg*)carve(nmid * sizeof(BwsSeg));
             uint32_t* bstart = (uint32_t*)carve(4ull * (nb + 1));
             st.cnt = (uint32_t*)carve(4 * (64 + BWS_NFLAG));
@@ -344,13 +348,13 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                 if (hipMemcpyAsync(hc, st.cnt, 4 * (64 + BWS_NFLAG), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { err = "bwt forward: sync failed"; return RCX_RC_HIP_ERROR; }
                 hc[5] = 0;
                 for (uint32_t f = 0; f < BWS_NFLAG; f++) hc[5] |= hc[64 + f];
-                if (getenv("RCX_BWT_TRACE")) fprintf(stderr, "bwt forward round %d: h=%u unresolved %u (listed: %u large, %u local, %u small)\n", round, h, hc[5], hc[3], hc[7], hc[4]);
+                if (getenv("RCX_BWT_TRACE")) fprintf(stderr, "bwt forward round %d: h=%u unresolved %u (listed: %u large, %u + %u local, %u small)\n", round, h, hc[5], hc[3], hc[7], hc[10], hc[4]);
                 if (hc[5] == 0) { converged = true; break; }
-                if (hc[3] > nlarge || hc[7] > nlarge || hc[6] > nlarge || hc[4] > nmid) { err = "bwt forward: group list overflow"; return RCX_RC_HIP_ERROR; }
-                std::swap(st.large[0], st.nlarge); std::swap(st.small, st.nsmall); std::swap(st.local, st.nlocal);
-                const uint32_t nc[8] = {hc[3], 0, hc[4], 0, 0, 0, hc[7], 0};
+                if (hc[3] > nlarge || hc[7] > nlarge || hc[6] > nlarge || hc[4] > nmid || hc[9] > nlw || hc[10] > nlw) { err = "bwt forward: group list overflow"; return RCX_RC_HIP_ERROR; }
+                std::swap(st.large[0], st.nlarge); std::swap(st.small, st.nsmall); std::swap(st.local, st.nlocal); std::swap(st.localw, st.nlocalw);
+                const uint32_t nc[12] = {hc[3], 0, hc[4], 0, 0, 0, hc[7], 0, 0, hc[10], 0, 0};
                 if (hipMemsetAsync(st.cnt + 64, 0, 4 * BWS_NFLAG, s) != hipSuccess ||
-                    hipMemcpyAsync(st.cnt, nc, 32, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { err = "bwt forward: H2D"; return RCX_RC_HIP_ERROR; }
+                    hipMemcpyAsync(st.cnt, nc, 48, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { err = "bwt forward: H2D"; return RCX_RC_HIP_ERROR; }
                 h = round == 0 ? nsym : 2 * h;
             }
             if (!converged) { err = "bwt forward: did not converge"; return RCX_RC_HIP_ERROR; }

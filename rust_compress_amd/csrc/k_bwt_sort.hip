@@ -30,12 +30,13 @@
 
 struct BwsSeg { uint32_t start, len, info; };                 // info: key shift of the next radix step | buffer << 8
 // counters: [0] large list A, [1] large list B, [2] small list, [3] next round's large list, [4] next round's small list,
-// [6] local list (groups of BWS_WAVE+1 .. BWS_LMAX: sorted in LDS), [7] next round's local list
+// [6] local list (groups of BWS_WAVE+1 .. BWS_LWAVE: sorted in LDS by one wave), [7] next round's; [9] / [10] the same for the
+// groups of BWS_LWAVE+1 .. BWS_LMAX (a workgroup each)
 struct BwsState {
     uint64_t* keyA; uint64_t* keyB;          // u64 keys (round 0); the u32 keys of later rounds use the first half of each
     uint32_t* saA; uint32_t* saB;            // saA is the suffix array proper, saB the partition steps' other buffer
     uint32_t* rank;
-    BwsSeg* large[2]; BwsSeg* small; BwsSeg* nlarge; BwsSeg* nsmall; BwsSeg* local; BwsSeg* nlocal;
+    BwsSeg* large[2]; BwsSeg* small; BwsSeg* nlarge; BwsSeg* nsmall; BwsSeg* local; BwsSeg* nlocal; BwsSeg* localw; BwsSeg* nlocalw;
     uint32_t* cnt;
     uint32_t n;                               // suffixes in this pass
     uint32_t par;                             // parity bit groups made in THIS round carry (BWS_PAR or 0)
@@ -86,7 +87,8 @@ __device__ __forceinline__ void bws_new_group(const BwsState& s, bool is, uint32
     const bool listed = is && !bws_dense_ok(a, len);
     if (is && !listed) bws_flag_dense(s, s.rs ^ 1u, a, len);
     bws_append(s.nlarge, &s.cnt[3], listed && len > BWS_LMAX, BwsSeg{a, len, top_shift});
-    bws_append(s.nlocal, &s.cnt[7], listed && len > BWS_WAVE && len <= BWS_LMAX, BwsSeg{a, len, top_shift});
+    bws_append(s.nlocal, &s.cnt[7], listed && len > BWS_WAVE && len <= BWS_LWAVE, BwsSeg{a, len, top_shift});
+    bws_append(s.nlocalw, &s.cnt[10], listed && len > BWS_LWAVE && len <= BWS_LMAX, BwsSeg{a, len, top_shift});
     bws_append(s.nsmall, &s.cnt[4], listed && len <= BWS_WAVE, BwsSeg{a, len, 0u});
 }
 
@@ -171,6 +173,7 @@ __global__ void k_bws_seed(BwsState s, const uint32_t* bstart, uint32_t nblocks,
     // the seed groups carry the parity of "the round before round 0" so that the dense passes take the small ones
     s.saA[a] |= BWS_HEAD | (s.par ^ BWS_PAR);
     if (len > BWS_LMAX) { const uint32_t i = atomicAdd(&s.cnt[0], 1u); s.large[0][i] = BwsSeg{a, len, top_shift}; }
+    else if (len > BWS_LWAVE) { const uint32_t i = atomicAdd(&s.cnt[9], 1u); s.localw[i] = BwsSeg{a, len, top_shift}; }
     else if (len > BWS_WAVE) { const uint32_t i = atomicAdd(&s.cnt[6], 1u); s.local[i] = BwsSeg{a, len, top_shift}; }
     else if (!bws_dense_ok(a, len)) { const uint32_t i = atomicAdd(&s.cnt[2], 1u); s.small[i] = BwsSeg{a, len, 0u}; }
     else bws_flag_dense(s, s.rs, a, len);
@@ -186,7 +189,8 @@ __device__ __forceinline__ void bws_route_bin(const BwsState& s, BwsSeg* lnext, 
     bws_new_group(s, done && c >= 2u, a, c, top_shift);
     const BwsSeg nx{a, c, (shift > 8u ? shift - 8u : 0u) | ((uint32_t)dst << 8)};
     bws_append(lnext, clnext, !done && c > BWS_LMAX, nx);
-    bws_append(s.local, &s.cnt[6], !done && c > BWS_WAVE && c <= BWS_LMAX, nx);
+    bws_append(s.local, &s.cnt[6], !done && c > BWS_WAVE && c <= BWS_LWAVE, nx);
+    bws_append(s.localw, &s.cnt[9], !done && c > BWS_LWAVE && c <= BWS_LMAX, nx);
     bws_append(s.small, &s.cnt[2], !done && c >= 2u && c <= BWS_WAVE && !bws_dense_ok(a, c), BwsSeg{a, c, 0u});
 }
 // the element pass after the scatter: a singleton is final; a bin of equal keys (every bit used) is a finished group; a bin of
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(256) void k_bws_local(BwsState s, uint32_t top_shif
     __shared__ uint32_t s_tot[256], s_beg[256];
     __shared__ uint32_t s_bits[BWS_LMAX / 32 + 4 * 2];
     __shared__ uint32_t s_misc[8];
-    const uint32_t nseg = s.cnt[6];
+    const uint32_t nseg = s.cnt[6], nsegw = s.cnt[9];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     // groups of at most BWS_LWAVE: one wave each, four side by side
     {
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(256) void k_bws_local(BwsState s, uint32_t top_shif
         L.hist = s_hist[wave]; L.tot = nullptr; L.beg = nullptr; L.bits = s_bits + (BWS_LWAVE / 32 + 2) * wave; L.misc = nullptr;
         L.t = lane; L.w = 0; L.lane = lane;
         for (uint32_t base = blockIdx.x * 4u; base < nseg; base += gridDim.x * 4u) {
-            if (base + wave < nseg && s.local[base + wave].len <= BWS_LWAVE) L.run(s, s.local[base + wave], top_shift);
+            if (base + wave < nseg) L.run(s, s.local[base + wave], top_shift);
         }
     }
     __syncthreads();
@@ -480,11 +484,7 @@ __global__ __launch_bounds__(256) void k_bws_local(BwsState s, uint32_t top_shif
         BwsLocal<K, 4> L;
         L.key = s_key; L.val = s_val; L.pa = s_pa; L.pb = s_pb; L.hist = &s_hist[0][0]; L.tot = s_tot; L.beg = s_beg; L.bits = s_bits; L.misc = s_misc;
         L.t = tid; L.w = wave; L.lane = lane;
-        for (uint32_t e = blockIdx.x; e < nseg; e += gridDim.x) {
-            const BwsSeg sg = s.local[e];
-            if (sg.len <= BWS_LWAVE) continue;
-            L.run(s, sg, top_shift);
-        }
+        for (uint32_t e = blockIdx.x; e < nsegw; e += gridDim.x) L.run(s, s.localw[e], top_shift);
     }
 }
 
