@@ -339,8 +339,8 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                     if (round == 0) hipLaunchKernelGGL(k_bws_partition<uint64_t>, dim3(2048), dim3(512), 0, s, st, lv, topn);
                     else hipLaunchKernelGGL(k_bws_partition<uint32_t>, dim3(2048), dim3(512), 0, s, st, lv, topn);
                 }
-                if (round == 0) hipLaunchKernelGGL(k_bws_local<uint64_t>, dim3(4096), dim3(256), 0, s, st, topn);
-                else hipLaunchKernelGGL(k_bws_local<uint32_t>, dim3(4096), dim3(256), 0, s, st, topn);
+                if (round == 0) { hipLaunchKernelGGL(k_bws_local_wave<uint64_t>, dim3(8192), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_local_wg<uint64_t>, dim3(4096), dim3(256), 0, s, st, topn); }
+                else { hipLaunchKernelGGL(k_bws_local_wave<uint32_t>, dim3(8192), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_local_wg<uint32_t>, dim3(4096), dim3(256), 0, s, st, topn); }
                 if (round == 0) { hipLaunchKernelGGL(k_bws_small<uint64_t>, dim3(2048), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_dense<uint64_t>, dim3(gdense), dim3(256), 0, s, st, 0u); hipLaunchKernelGGL(k_bws_dense<uint64_t>, dim3(gdense), dim3(256), 0, s, st, 32u); }
                 else { hipLaunchKernelGGL(k_bws_small<uint32_t>, dim3(2048), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_dense<uint32_t>, dim3(gdense), dim3(256), 0, s, st, 0u); hipLaunchKernelGGL(k_bws_dense<uint32_t>, dim3(gdense), dim3(256), 0, s, st, 32u); }
                 std::vector<uint32_t> hcv(64 + BWS_NFLAG);

@@ -26,7 +26,7 @@
 #define BWS_IDX   0x0fffffffu            /* suffix index: batches of < 2^28 suffixes per pass */
 #define BWS_WAVE  32u                    /* the largest group left to the wave-level sorts: it always lies inside a 64-suffix window, aligned or shifted by 32 */
 #define BWS_LMAX  2048u                  /* the largest group sorted to the end of its key inside LDS (k_bws_local), by a workgroup ... */
-#define BWS_LWAVE 512u                   /* ... or, up to this size, by one wave */
+#define BWS_LWAVE 256u                   /* ... or, up to this size, by one wave */
 
 struct BwsSeg { uint32_t start, len, info; };                 // info: key shift of the next radix step | buffer << 8
 // counters: [0] large list A, [1] large list B, [2] small list, [3] next round's large list, [4] next round's small list,
@@ -331,6 +331,50 @@ __global__ __launch_bounds__(512) void k_bws_partition(BwsState s, int level, ui
 // contiguous quarter of the group, so wave-major order is group order; lanes with the same digit are ranked by ballots, as in the
 // partition step), passes whose digit is the same for the whole group are skipped.  Then the runs of equal keys are read off a
 // bitmap of run heads and saA / rank are written once: this round is over for the group.
+// The new groups a wave finds are queued in LDS and appended to the next round's lists 64+ at a time.  Appending them as they
+// turn up (one atomic with return per 64-suffix chunk that holds a listed group) made the finishing phase 70 % of these
+// kernels: the wait for the atomic is an s_waitcnt vmcnt(0), and that also waits for the chunk's scattered saA / rank stores.
+#define BWS_QCAP 128u
+struct BwsQueue {
+    uint32_t* q; uint32_t n;                                  // q: LDS, BWS_QCAP x 3 words; n: entries waiting (wave-uniform)
+    // wave-uniform call: the lanes with `is` hand in the group [a, a + len) made this round
+    __device__ __forceinline__ void push(const BwsState& s, bool is, uint32_t a, uint32_t len, uint32_t top_shift)
+    {
+        const uint32_t lane = threadIdx.x & 63u;
+        if (__ballot(is)) { if (lane == 0) bws_flag_unresolved(s); }
+        const bool listed = is && !bws_dense_ok(a, len);
+        if (is && !listed) bws_flag_dense(s, s.rs ^ 1u, a, len);
+        const unsigned long long m = __ballot(listed);
+        if (!m) return;
+        if (n + 64u > BWS_QCAP) flush(s);
+        const uint32_t tag = len > BWS_LMAX ? 0u : len > BWS_LWAVE ? 2u : len > BWS_WAVE ? 1u : 3u;
+        if (listed) {
+            const uint32_t i = n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            q[3 * i] = a; q[3 * i + 1] = len; q[3 * i + 2] = (len > BWS_WAVE ? top_shift : 0u) | (tag << 16);
+        }
+        n += (uint32_t)__popcll(m);
+        rcx_wave_sync();
+    }
+    __device__ __forceinline__ void flush(const BwsState& s)
+    {
+        const uint32_t lane = threadIdx.x & 63u;
+        rcx_wave_sync();
+        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const bool have = i < n;
+            const uint32_t a = have ? q[3 * i] : 0u, len = have ? q[3 * i + 1] : 0u, info = have ? q[3 * i + 2] : 0u;
+            const uint32_t tag = info >> 16;
+            const BwsSeg seg{a, len, info & 0xffffu};
+            bws_append(s.nlarge, &s.cnt[3], have && tag == 0u, seg);
+            bws_append(s.nlocal, &s.cnt[7], have && tag == 1u, seg);
+            bws_append(s.nlocalw, &s.cnt[10], have && tag == 2u, seg);
+            bws_append(s.nsmall, &s.cnt[4], have && tag == 3u, seg);
+        }
+        n = 0;
+        rcx_wave_sync();
+    }
+};
+
 template <class K, int NW>
 struct BwsLocal {
     static constexpr uint32_t CAP = NW == 1 ? BWS_LWAVE : BWS_LMAX;
@@ -338,6 +382,7 @@ struct BwsLocal {
     K* key; uint32_t* val; uint16_t* pa; uint16_t* pb; uint32_t* hist;      // hist: [NW][256]
     uint32_t* tot; uint32_t* beg; uint32_t* bits; uint32_t* misc;           // NW > 1: tot[256], beg[256]; bits[CAP / 32 + 1]; misc[8]
     uint32_t t, w, lane;                                                     // thread, wave and lane inside the team
+    BwsQueue* Q;                                                             // the calling wave's queue of new groups
 
     __device__ __forceinline__ void sync() const { if (NW == 1) rcx_wave_sync(); else __syncthreads(); }
 
@@ -451,41 +496,52 @@ struct BwsLocal {
                 s.saA[sg.start + p] = g | (rs == p ? (BWS_HEAD | s.par) : 0u) | (single ? BWS_FINAL : 0u);
                 s.rank[g] = sg.start + rs;
             }
-            bws_new_group(s, in && rs == p && re - rs >= 2u, sg.start + rs, re - rs, top_shift);
+            Q->push(s, in && rs == p && re - rs >= 2u, sg.start + rs, re - rs, top_shift);
         }
         sync();
     }
 };
 
+// The wave-sized groups and the workgroup-sized ones get a kernel each: the first keeps 20 KiB of LDS per workgroup (four
+// waves, a group each) so that seven workgroups share a CU -- these passes are chains of dependent LDS round trips, what
+// they need is waves in flight (with one kernel for both, 38 KiB per workgroup: four per CU, the vector ALU 21 % busy).
 template <class K>
-__global__ __launch_bounds__(256) void k_bws_local(BwsState s, uint32_t top_shift)
+__global__ __launch_bounds__(256) void k_bws_local_wave(BwsState s, uint32_t top_shift)
+{
+    __shared__ __align__(16) K s_key[4 * BWS_LWAVE];
+    __shared__ uint32_t s_val[4 * BWS_LWAVE];
+    __shared__ uint16_t s_pa[4 * BWS_LWAVE], s_pb[4 * BWS_LWAVE];
+    __shared__ uint32_t s_hist[4][256];
+    __shared__ uint32_t s_bits[4 * (BWS_LWAVE / 32 + 2)];
+    __shared__ uint32_t s_q[4][3 * BWS_QCAP];
+    const uint32_t nseg = s.cnt[6];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    BwsQueue Q; Q.q = s_q[wave]; Q.n = 0;
+    BwsLocal<K, 1> L; L.Q = &Q;
+    L.key = s_key + BWS_LWAVE * wave; L.val = s_val + BWS_LWAVE * wave; L.pa = s_pa + BWS_LWAVE * wave; L.pb = s_pb + BWS_LWAVE * wave;
+    L.hist = s_hist[wave]; L.tot = nullptr; L.beg = nullptr; L.bits = s_bits + (BWS_LWAVE / 32 + 2) * wave; L.misc = nullptr;
+    L.t = lane; L.w = 0; L.lane = lane;
+    for (uint32_t e = blockIdx.x * 4u + wave; e < nseg; e += gridDim.x * 4u) L.run(s, s.local[e], top_shift);
+    Q.flush(s);
+}
+template <class K>
+__global__ __launch_bounds__(256) void k_bws_local_wg(BwsState s, uint32_t top_shift)
 {
     __shared__ __align__(16) K s_key[BWS_LMAX];
     __shared__ uint32_t s_val[BWS_LMAX];
     __shared__ uint16_t s_pa[BWS_LMAX], s_pb[BWS_LMAX];
     __shared__ uint32_t s_hist[4][256];
     __shared__ uint32_t s_tot[256], s_beg[256];
-    __shared__ uint32_t s_bits[BWS_LMAX / 32 + 4 * 2];
+    __shared__ uint32_t s_bits[BWS_LMAX / 32 + 2];
     __shared__ uint32_t s_misc[8];
-    const uint32_t nseg = s.cnt[6], nsegw = s.cnt[9];
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    // groups of at most BWS_LWAVE: one wave each, four side by side
-    {
-        BwsLocal<K, 1> L;
-        L.key = s_key + BWS_LWAVE * wave; L.val = s_val + BWS_LWAVE * wave; L.pa = s_pa + BWS_LWAVE * wave; L.pb = s_pb + BWS_LWAVE * wave;
-        L.hist = s_hist[wave]; L.tot = nullptr; L.beg = nullptr; L.bits = s_bits + (BWS_LWAVE / 32 + 2) * wave; L.misc = nullptr;
-        L.t = lane; L.w = 0; L.lane = lane;
-        for (uint32_t base = blockIdx.x * 4u; base < nseg; base += gridDim.x * 4u) {
-            if (base + wave < nseg) L.run(s, s.local[base + wave], top_shift);
-        }
-    }
-    __syncthreads();
-    {
-        BwsLocal<K, 4> L;
-        L.key = s_key; L.val = s_val; L.pa = s_pa; L.pb = s_pb; L.hist = &s_hist[0][0]; L.tot = s_tot; L.beg = s_beg; L.bits = s_bits; L.misc = s_misc;
-        L.t = tid; L.w = wave; L.lane = lane;
-        for (uint32_t e = blockIdx.x; e < nsegw; e += gridDim.x) L.run(s, s.localw[e], top_shift);
-    }
+    __shared__ uint32_t s_q[4][3 * BWS_QCAP];
+    const uint32_t nsegw = s.cnt[9];
+    BwsQueue Q; Q.q = s_q[threadIdx.x >> 6]; Q.n = 0;
+    BwsLocal<K, 4> L; L.Q = &Q;
+    L.key = s_key; L.val = s_val; L.pa = s_pa; L.pb = s_pb; L.hist = &s_hist[0][0]; L.tot = s_tot; L.beg = s_beg; L.bits = s_bits; L.misc = s_misc;
+    L.t = threadIdx.x; L.w = threadIdx.x >> 6; L.lane = threadIdx.x & 63u;
+    for (uint32_t e = blockIdx.x; e < nsegw; e += gridDim.x) L.run(s, s.localw[e], top_shift);
+    Q.flush(s);
 }
 
 // ---- the few groups of <= 64 the dense passes cannot take (33..64 suffixes across both window grids): one wave per group ----
