@@ -327,7 +327,7 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                 hipLaunchKernelGGL(k_bws_seed, dim3((nb + 255) / 256), dim3(256), 0, s, st, bstart, nb, top0);
             }
             uint32_t h = nsym;
-            const uint32_t gdense = (N / 64 + 2 + 4 * BWS_DW - 1) / (4 * BWS_DW);
+            const uint32_t gdense = (((N / 64 + 2 + 4 * BWS_DW - 1) / (4 * BWS_DW)) + 7u) & ~7u;      // a multiple of 8: see k_bws_dense
             bool converged = false;
             for (int round = 0; round < 64; round++) {
                 st.par = (round & 1) ? BWS_PAR : 0u; st.rs = (uint32_t)(round & 1);

@@ -656,7 +656,11 @@ template <class K>
 __global__ __launch_bounds__(256) void k_bws_dense(BwsState s, uint32_t off)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t w0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * BWS_DW;              // first window (in the grid's own numbering)
+    // Workgroups go round-robin to the 8 XCDs, each with its own 4 MiB L2: XCD x takes the x-th EIGHTH of the windows, so that the
+    // workgroups resident on it at any time sit in two or three blocks and their scattered rank[] stores (one per suffix moved,
+    // anywhere in the block's 1 MiB) meet in that L2 instead of leaving it as partial lines.  (gridDim.x is a multiple of 8.)
+    const uint32_t vwg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint32_t w0 = (vwg * 4u + (threadIdx.x >> 6)) * BWS_DW;                      // first window (in the grid's own numbering)
     if ((uint64_t)w0 * 64u >= (uint64_t)s.n + 64u) return;
     uint8_t* act = s.act[s.rs * 2u + (off ? 1u : 0u)];
     const unsigned long long f = *(const unsigned long long*)(act + w0);
