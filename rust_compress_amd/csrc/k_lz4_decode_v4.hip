@@ -23,6 +23,12 @@
 #ifndef RCX_ALIGNBYTE
 #define RCX_ALIGNBYTE(hi, lo, sh) __builtin_amdgcn_alignbyte((hi), (lo), (sh))   // ({hi,lo} >> 8*sh) & 0xffffffff
 #endif
+#ifndef RCX_LDS_AS
+#define RCX_LDS_AS __attribute__((address_space(3)))
+#endif
+#ifndef RCX_GLOBAL_AS
+#define RCX_GLOBAL_AS __attribute__((address_space(1)))
+#endif
 #ifndef RCX_U
 #define RCX_U(x) ((uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x)))
 #endif
@@ -107,7 +113,8 @@ struct Lz4V4 {
     __device__ __forceinline__ uint32_t peek(uint32_t q) const
     {
         const int32_t idx = (int32_t)q - cbase;
-        uint32_t v = (idx >= 0 && q < cend) ? (uint32_t)cbuf[idx] : (uint32_t)in[q];
+        uint32_t v;                                             // two loads kept apart: a select between the two POINTERS is a flat load
+        if (idx >= 0 && q < cend) v = ((const RCX_LDS_AS uint8_t*)cbuf)[idx]; else v = ((const RCX_GLOBAL_AS uint8_t*)in)[q];
         return RCX_U(v);
     }
 
@@ -152,7 +159,8 @@ struct Lz4V4 {
             from += head;
         }
         const uint32_t nch = (to - from) >> 4;
-        for (uint32_t c = lane; c < nch; c += 64) {
+        #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+        for (uint32_t c = RCX_VGPR(lane); c < nch; c += 64) {      // (laundered: `out + 16 * lane` hoisted to the kernel's top is a spill)
             const uint32_t p = from + 16 * c;
             *(rcx_u32x4*)(out + p) = *(const rcx_u32x4*)(wb_ + ((int32_t)p - lbase));
         }
@@ -170,6 +178,7 @@ struct Lz4V4 {
         lbase = (int32_t)RCX_U(lbase_for(oend));
         rlo = oend > (uint32_t)RH ? oend - RH : 0u;
         rcx_wave_sync();
+        #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
         for (uint32_t p = rlo + lane; p < oend; p += 64) wb_[(int32_t)p - lbase] = out[p];
         rcx_wave_sync();
     }
@@ -183,7 +192,8 @@ struct Lz4V4 {
         if (head > len) head = len;
         if (lane < head) d[lane] = s[lane];
         const uint32_t nb = (len - head) >> 4;
-        for (uint32_t c = lane; c < nb; c += 64)
+        #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+        for (uint32_t c = RCX_VGPR(lane); c < nb; c += 64)
             *(rcx_u32x4*)(d + head + 16 * c) = *(const rcx_u32x4_u*)(s + head + 16 * c);
         const uint32_t done = head + nb * 16;
         if (lane < len - done) d[done + lane] = s[done + lane];
@@ -195,7 +205,7 @@ struct Lz4V4 {
         while (rem) {
             uint32_t C = rem < e ? rem : e;
             if (C > 1024) C = 1024;
-            const uint32_t i0 = 16 * lane;
+            const uint32_t i0 = 16 * RCX_VGPR(lane);
             if (i0 + 16 <= C) {
                 *(rcx_u32x4_u*)(out + d + i0) = *(const rcx_u32x4_u*)(out + d - e + i0);
             } else if (i0 < C) {
@@ -222,6 +232,7 @@ struct Lz4V4 {
         }
         make_room(L + M);
         const int32_t li = (int32_t)oend - lbase;
+        #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
         for (uint32_t i = lane; i < L; i += 64) wb_[li + (int32_t)i] = in[lit_src + i];
         rcx_wave_sync();
         if (M) {
@@ -230,13 +241,17 @@ struct Lz4V4 {
             if (slo >= rlo_eff()) {                                   // source in the window (may overlap itself)
                 const int32_t ls = (int32_t)slo - lbase;
                 if (off >= M) {
+                    #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
                     for (uint32_t i = lane; i < M; i += 64) wb_[lm + (int32_t)i] = wb_[ls + (int32_t)i];
                 } else {                                              // periodic: only finished bytes are read
+                    #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
                     for (uint32_t i = lane; i < M; i += 64) wb_[lm + (int32_t)i] = wb_[ls + (int32_t)(i % off)];
                 }
             } else if (off >= M) {                                    // drained long ago: HBM -> window
+                #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
                 for (uint32_t i = lane; i < M; i += 64) wb_[lm + (int32_t)i] = out[slo + i];
             } else {
+                #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
                 for (uint32_t i = lane; i < M; i += 64) wb_[lm + (int32_t)i] = out[slo + (i % off)];
             }
             rcx_wave_sync();

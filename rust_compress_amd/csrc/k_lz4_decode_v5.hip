@@ -325,7 +325,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_decode_v5(rcx_kargs a, int only_
     const uint32_t b = blockIdx.x;
     if (b >= a.nblocks) return;
     if (only_status && a.status[b] != only_status) return;       // second pass over the blocks another kernel handed back
-    if (threadIdx.x == 0) { s_ring.head = 0; s_ring.tail = 0; s_ring.abort_ = 0; }
+    if (threadIdx.x == 0) { RCX_LDS_AS typename S::Ring* r0 = (RCX_LDS_AS typename S::Ring*)&s_ring; r0->head = 0; r0->tail = 0; r0->abort_ = 0; }   // (through the LDS pointer: volatile stores through the generic one are flat)
     __syncthreads();
     const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     S s;

@@ -223,6 +223,7 @@ static inline unsigned __byte_perm_(unsigned a, unsigned b, unsigned s) { (void)
 #define __builtin_amdgcn_s_sleep(n) ws::yield_()        // spin-wait loops let the other waves of the block run
 #define __builtin_amdgcn_s_setprio(n) ((void)0)
 #define RCX_LDS_AS
+#define RCX_GLOBAL_AS
 #define __builtin_amdgcn_sched_barrier(n) ((void)0)
 #define __builtin_amdgcn_mbcnt_lo(m, b) ((int)(ws::cur->tid & 63) < 32 ? (int)(ws::cur->tid & 63) + (b) : 32 + (b))
 #define __builtin_amdgcn_mbcnt_hi(m, b) ((int)(ws::cur->tid & 63) < 32 ? (b) : (int)(ws::cur->tid & 63) - 32 + (b))
