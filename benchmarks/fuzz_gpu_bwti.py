@@ -8,34 +8,42 @@ import numpy as np
 import rust_compress_amd as R
 from rust_compress_amd import _native as N, synth, batch as B
 import oracle_py as O
-rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 4)
-ctx = R.Context(0)
-Ls, origins = [], []
-for it in range(6000):
-    n = int(rng.integers(1, 40)) if it % 3 == 0 else int(rng.integers(1, 3000)) if it % 3 == 1 else int(rng.integers(1, 70000))
-    k = ("text", "runs", "dna4", "rand")[it % 4]
-    src = synth.gen(k, n, int(rng.integers(1 << 30))).tobytes()
-    L, og = O.bwt_encode(src)
-    m = it % 4
-    if m == 1:
-        b = bytearray(L); b[int(rng.integers(n))] = int(rng.integers(256)); L = bytes(b)
-    elif m == 2:
-        og = int(rng.integers(0, n + 2))
-    elif m == 3:
-        L = bytes(rng.permutation(np.frombuffer(L, np.uint8)))
-    Ls.append(L); origins.append(og)
-base, off, lens = B.pack(Ls)
-total, ooff, ocap = B.layout([len(x) for x in Ls])
-out = np.zeros(total + 64, np.uint8)
-aux = np.asarray(origins, np.uint32)
-_, olen, used, st = O.batch_run(N.BWT_INVERSE, base, off, lens, out, ooff, ocap, aux=aux.copy(), threads=64)
-res = ctx.bwt_inverse(Ls, origins)
-bad = 0
-for i in range(len(Ls)):
-    ok = int(res.status[i]) == int(st[i])
-    if ok and st[i] == 0:
-        ok = res.outputs[i] == out[int(ooff[i]):int(ooff[i]) + int(olen[i])].tobytes()
-    if not ok:
-        bad += 1
-        if bad < 5: print("MISMATCH", i, res.status[i], st[i], len(Ls[i]), origins[i])
-print("bwt inverse fuzz:", len(Ls), "pairs,", int((st == 0).sum()), "ok status,", bad, "mismatches")
+
+
+def main(count=6000, seed=4, ctx=None):
+    rng = np.random.default_rng(seed)
+    ctx = ctx or R.Context(0)
+    Ls, origins = [], []
+    for it in range(count):
+        n = int(rng.integers(1, 40)) if it % 3 == 0 else int(rng.integers(1, 3000)) if it % 3 == 1 else int(rng.integers(1, 70000))
+        k = ("text", "runs", "dna4", "rand")[it % 4]
+        src = synth.gen(k, n, int(rng.integers(1 << 30))).tobytes()
+        L, og = O.bwt_encode(src)
+        m = it % 4
+        if m == 1:
+            b = bytearray(L); b[int(rng.integers(n))] = int(rng.integers(256)); L = bytes(b)
+        elif m == 2:
+            og = int(rng.integers(0, n + 2))
+        elif m == 3:
+            L = bytes(rng.permutation(np.frombuffer(L, np.uint8)))
+        Ls.append(L); origins.append(og)
+    base, off, lens = B.pack(Ls)
+    total, ooff, ocap = B.layout([len(x) for x in Ls])
+    out = np.zeros(total + 64, np.uint8)
+    aux = np.asarray(origins, np.uint32)
+    _, olen, used, st = O.batch_run(N.BWT_INVERSE, base, off, lens, out, ooff, ocap, aux=aux.copy(), threads=64)
+    res = ctx.bwt_inverse(Ls, origins)
+    bad = 0
+    for i in range(len(Ls)):
+        ok = int(res.status[i]) == int(st[i])
+        if ok and st[i] == 0:
+            ok = res.outputs[i] == out[int(ooff[i]):int(ooff[i]) + int(olen[i])].tobytes()
+        if not ok:
+            bad += 1
+            if bad < 5: print("MISMATCH", i, res.status[i], st[i], len(Ls[i]), origins[i])
+    print("bwt inverse fuzz:", len(Ls), "pairs,", int((st == 0).sum()), "ok status,", bad, "mismatches")
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main(6000, int(sys.argv[1]) if len(sys.argv) > 1 else 4) else 0)

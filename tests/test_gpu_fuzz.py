@@ -1,6 +1,6 @@
-"""Bulk randomized decoder parity (the same code as benchmarks/fuzz_gpu.py, 100 000 streams): mutated LZ4 / zlib / raw
-DEFLATE / RLE / Ari streams through every decoder kernel and the oracle -- statuses everywhere, bytes and consumed counts
-wherever the oracle succeeds."""
+"""Bulk randomized decoder parity (the same code as benchmarks/fuzz_gpu*.py): 100 000 mutated LZ4 / zlib / raw DEFLATE / RLE /
+Ari streams, 6000 mutated DC streams and 2000 arbitrary (L, origin) pairs for the inverse BWT, through the decoder kernels and the
+oracle -- statuses everywhere, bytes and consumed counts wherever the oracle succeeds."""
 import os
 import sys
 
@@ -13,3 +13,15 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 def test_bulk_decoder_fuzz(ctx):
     import fuzz_gpu
     assert fuzz_gpu.main(100000, 7, ctx) == 0
+
+
+@pytest.mark.gpu
+def test_dc_decode_fuzz(ctx):
+    import fuzz_gpu_dc
+    assert fuzz_gpu_dc.main(6000, 5, ctx) == 0
+
+
+@pytest.mark.gpu
+def test_bwt_inverse_fuzz(ctx):
+    import fuzz_gpu_bwti
+    assert fuzz_gpu_bwti.main(2000, 6, ctx) == 0
