@@ -26,7 +26,9 @@
 #define BWS_IDX   0x0fffffffu            /* suffix index: batches of < 2^28 suffixes per pass */
 #define BWS_WAVE  32u                    /* the largest group left to the wave-level sorts: it always lies inside a 64-suffix window, aligned or shifted by 32 */
 #define BWS_LMAX  2048u                  /* the largest group sorted to the end of its key inside LDS (k_bws_local), by a workgroup ... */
+#ifndef BWS_LWAVE
 #define BWS_LWAVE 256u                   /* ... or, up to this size, by one wave */
+#endif
 
 struct BwsSeg { uint32_t start, len, info; };                 // info: key shift of the next radix step | buffer << 8
 // counters: [0] large list A, [1] large list B, [2] small list, [3] next round's large list, [4] next round's small list,
@@ -651,7 +653,9 @@ __device__ __forceinline__ void bws_dense_window(const BwsState& s, uint32_t j0,
 }
 
 // One wave per BWS_DW consecutive windows of the grid `off` (0: aligned, 32: shifted); only windows somebody flagged are looked at.
+#ifndef BWS_DW
 #define BWS_DW 8u
+#endif
 template <class K>
 __global__ __launch_bounds__(256) void k_bws_dense(BwsState s, uint32_t off)
 {
