@@ -332,16 +332,18 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
             for (int round = 0; round < 64; round++) {
                 st.par = (round & 1) ? BWS_PAR : 0u; st.rs = (uint32_t)(round & 1);
                 const uint32_t top = round == 0 ? top0 : top1, topn = top1;
-                if (round) hipLaunchKernelGGL(k_bws_gather, dim3(gx ? gx : 1, nb), dim3(256), 0, s, st, bstart, nb, h);
+                // (the 32-bit key path packs the group id above a 24-bit rank in the wave sorts: blocks of 2^24 bytes and more take the 64-bit one)
+                const bool wide = round == 0 || kbits1 > 24;
+                if (round) { if (wide) hipLaunchKernelGGL(k_bws_gather<uint64_t>, dim3(gx ? gx : 1, nb), dim3(256), 0, s, st, bstart, nb, h); else hipLaunchKernelGGL(k_bws_gather<uint32_t>, dim3(gx ? gx : 1, nb), dim3(256), 0, s, st, bstart, nb, h); }
                 const int levels = (int)((top + 7) / 8) + 1;
                 for (int lv = (round == 0 && fused_first) ? 1 : 0; lv < levels; lv++) {
                     if (hipMemsetAsync(&st.cnt[(lv + 1) & 1], 0, 4, s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
-                    if (round == 0) hipLaunchKernelGGL(k_bws_partition<uint64_t>, dim3(2048), dim3(512), 0, s, st, lv, topn);
+                    if (wide) hipLaunchKernelGGL(k_bws_partition<uint64_t>, dim3(2048), dim3(512), 0, s, st, lv, topn);
                     else hipLaunchKernelGGL(k_bws_partition<uint32_t>, dim3(2048), dim3(512), 0, s, st, lv, topn);
                 }
-                if (round == 0) { hipLaunchKernelGGL(k_bws_local_wave<uint64_t>, dim3(8192), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_local_wg<uint64_t>, dim3(4096), dim3(256), 0, s, st, topn); }
+                if (wide) { hipLaunchKernelGGL(k_bws_local_wave<uint64_t>, dim3(8192), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_local_wg<uint64_t>, dim3(4096), dim3(256), 0, s, st, topn); }
                 else { hipLaunchKernelGGL(k_bws_local_wave<uint32_t>, dim3(8192), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_local_wg<uint32_t>, dim3(4096), dim3(256), 0, s, st, topn); }
-                if (round == 0) { hipLaunchKernelGGL(k_bws_small<uint64_t>, dim3(2048), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_dense<uint64_t>, dim3(gdense), dim3(256), 0, s, st, 0u); hipLaunchKernelGGL(k_bws_dense<uint64_t>, dim3(gdense), dim3(256), 0, s, st, 32u); }
+                if (wide) { hipLaunchKernelGGL(k_bws_small<uint64_t>, dim3(2048), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_dense<uint64_t>, dim3(gdense), dim3(256), 0, s, st, 0u); hipLaunchKernelGGL(k_bws_dense<uint64_t>, dim3(gdense), dim3(256), 0, s, st, 32u); }
                 else { hipLaunchKernelGGL(k_bws_small<uint32_t>, dim3(2048), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_dense<uint32_t>, dim3(gdense), dim3(256), 0, s, st, 0u); hipLaunchKernelGGL(k_bws_dense<uint32_t>, dim3(gdense), dim3(256), 0, s, st, 32u); }
                 std::vector<uint32_t> hcv(64 + BWS_NFLAG);
                 uint32_t* hc = hcv.data();

@@ -151,11 +151,12 @@ __device__ __forceinline__ void bws_wave_runs(uint32_t lane, uint32_t c0, uint32
 }
 
 // ---- keys of a doubling round: key[j] = local rank + 1 of (suffix at j) + h, 0 = past the end of its block ------------------
+template <class K>
 __global__ __launch_bounds__(256) void k_bws_gather(BwsState s, const uint32_t* bstart, uint32_t nblocks, uint32_t h)
 {
     const uint32_t b = blockIdx.y;
     const uint32_t g0 = bstart[b], e = bstart[b + 1];
-    uint32_t* key = (uint32_t*)s.keyA;
+    K* key = (K*)s.keyA;
     for (uint32_t j = g0 + blockIdx.x * blockDim.x + threadIdx.x; j < e; j += gridDim.x * blockDim.x) {
         const uint32_t v = s.saA[j];
         if (v & BWS_FINAL) continue;

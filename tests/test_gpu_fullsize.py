@@ -80,6 +80,17 @@ def test_config4_bwt_1024x256k(ctx, oracle):
     ctx.set_stream(0)
 
 
+def test_bwt_single_block_of_2_24_bytes_and_more(ctx, oracle):
+    """Ranks of a block this long do not fit the 24 bits the 32-bit key path gives them (the sorter switches to 64-bit keys), and the
+    inverse transform's table entries no longer carry the byte (index + 1 needs more than 24 bits)."""
+    r = synth.gen("text", (1 << 24) + 200_001, 77).tobytes()
+    fw = ctx.bwt_forward([r]).check()
+    eL, eo = oracle.bwt_encode(r)
+    assert fw.outputs[0] == eL and int(fw.aux[0]) == eo
+    inv = ctx.bwt_inverse([eL], [eo]).check()
+    assert inv.outputs[0] == r
+
+
 def test_config5_pipeline_roundtrip_and_stage_parity(ctx, oracle):
     """BWT -> DC -> Ari over 96 blocks x 256 KiB (+ a ragged tail): decode(encode(x)) == x, per-stage parity on samples."""
     import struct
