@@ -25,3 +25,11 @@ def test_dc_decode_fuzz(ctx):
 def test_bwt_inverse_fuzz(ctx):
     import fuzz_gpu_bwti
     assert fuzz_gpu_bwti.main(2000, 6, ctx) == 0
+
+
+@pytest.mark.gpu
+def test_boundary_sizes_every_codec(ctx):
+    """Sizes at the powers of two and at the kernels' wave / tile / window sizes (-1, 0, +1), four distributions, every codec
+    against the oracle (benchmarks/edge_sizes.py)."""
+    import edge_sizes
+    assert edge_sizes.main(ctx) == 0
