@@ -13,8 +13,8 @@
 // origin) is a marked node, up to 4096 walkers per block chase from one marked node to the next
 // (4 independent chains per lane in flight), one lane ranks the marked nodes, and the walkers chase again
 // writing the text at their final offsets.
-#include <hip/hip_runtime.h>
 #include <string>
+#include <vector>
 #include "rcx_dev.h"
 #include "k_bwt_sort.hip"
 
@@ -328,6 +328,9 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
             }
             uint32_t h = nsym;
             const uint32_t gdense = (((N / 64 + 2 + 4 * BWS_DW - 1) / (4 * BWS_DW)) + 7u) & ~7u;      // a multiple of 8: see k_bws_dense
+            // grid-stride kernels over the group lists: no more workgroups than there can be groups
+            auto grid_for = [&](uint32_t min_group, uint32_t per_wg, uint32_t cap) { const uint32_t g = N / min_group / per_wg + 8u; return g < cap ? g : cap; };
+            const uint32_t gpart = grid_for(BWS_LMAX, 1, 2048), glw = grid_for(BWS_WAVE, 4, 8192), glg = grid_for(BWS_LWAVE, 1, 4096), gsm = grid_for(BWS_WAVE, 4, 2048);
             bool converged = false;
             for (int round = 0; round < 64; round++) {
                 st.par = (round & 1) ? BWS_PAR : 0u; st.rs = (uint32_t)(round & 1);
@@ -338,13 +341,13 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                 const int levels = (int)((top + 7) / 8) + 1;
                 for (int lv = (round == 0 && fused_first) ? 1 : 0; lv < levels; lv++) {
                     if (hipMemsetAsync(&st.cnt[(lv + 1) & 1], 0, 4, s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
-                    if (wide) hipLaunchKernelGGL(k_bws_partition<uint64_t>, dim3(2048), dim3(512), 0, s, st, lv, topn);
-                    else hipLaunchKernelGGL(k_bws_partition<uint32_t>, dim3(2048), dim3(512), 0, s, st, lv, topn);
+                    if (wide) hipLaunchKernelGGL(k_bws_partition<uint64_t>, dim3(gpart), dim3(512), 0, s, st, lv, topn);
+                    else hipLaunchKernelGGL(k_bws_partition<uint32_t>, dim3(gpart), dim3(512), 0, s, st, lv, topn);
                 }
-                if (wide) { hipLaunchKernelGGL(k_bws_local_wave<uint64_t>, dim3(8192), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_local_wg<uint64_t>, dim3(4096), dim3(256), 0, s, st, topn); }
-                else { hipLaunchKernelGGL(k_bws_local_wave<uint32_t>, dim3(8192), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_local_wg<uint32_t>, dim3(4096), dim3(256), 0, s, st, topn); }
-                if (wide) { hipLaunchKernelGGL(k_bws_small<uint64_t>, dim3(2048), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_dense<uint64_t>, dim3(gdense), dim3(256), 0, s, st, 0u); hipLaunchKernelGGL(k_bws_dense<uint64_t>, dim3(gdense), dim3(256), 0, s, st, 32u); }
-                else { hipLaunchKernelGGL(k_bws_small<uint32_t>, dim3(2048), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_dense<uint32_t>, dim3(gdense), dim3(256), 0, s, st, 0u); hipLaunchKernelGGL(k_bws_dense<uint32_t>, dim3(gdense), dim3(256), 0, s, st, 32u); }
+                if (wide) { hipLaunchKernelGGL(k_bws_local_wave<uint64_t>, dim3(glw), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_local_wg<uint64_t>, dim3(glg), dim3(256), 0, s, st, topn); }
+                else { hipLaunchKernelGGL(k_bws_local_wave<uint32_t>, dim3(glw), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_local_wg<uint32_t>, dim3(glg), dim3(256), 0, s, st, topn); }
+                if (wide) { hipLaunchKernelGGL(k_bws_small<uint64_t>, dim3(gsm), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_dense<uint64_t>, dim3(gdense), dim3(256), 0, s, st, 0u); hipLaunchKernelGGL(k_bws_dense<uint64_t>, dim3(gdense), dim3(256), 0, s, st, 32u); }
+                else { hipLaunchKernelGGL(k_bws_small<uint32_t>, dim3(gsm), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_dense<uint32_t>, dim3(gdense), dim3(256), 0, s, st, 0u); hipLaunchKernelGGL(k_bws_dense<uint32_t>, dim3(gdense), dim3(256), 0, s, st, 32u); }
                 std::vector<uint32_t> hcv(64 + BWS_NFLAG);
                 uint32_t* hc = hcv.data();
                 if (hipMemcpyAsync(hc, st.cnt, 4 * (64 + BWS_NFLAG), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { err = "bwt forward: sync failed"; return RCX_RC_HIP_ERROR; }

@@ -17,7 +17,6 @@
 // place -- the keys of the round were gathered before), runs of one are FINAL.  Groups that the dense pass cannot take are
 // appended to the next round's lists.  Per suffix and round: one gather of a rank (random), one scatter of a rank (random) and
 // ~30 bytes of streaming traffic.
-#include <hip/hip_runtime.h>
 #include "rcx_dev.h"
 
 #define BWS_FINAL 0x80000000u

@@ -162,6 +162,23 @@ def test_bwt_inverse(oracle):
     assert not st.any() and outs == raws
 
 
+def test_bwt_forward(oracle):
+    """The hand-written suffix sorter (k_bwt.hip + k_bwt_sort.hip: first level from the text, radix levels, LDS local sorts, dense
+    passes, list queues) on the simulator: (L, origin) against the oracle for every key layout a batch can take."""
+    import simrun
+    from rust_compress_amd import synth
+    def check(raws):
+        total = sum(len(r) for r in raws)
+        outs, olen, _, st, aux = simrun.run(N.BWT_FORWARD, 0, raws, [len(r) for r in raws], scratch_bytes=64 * total + (8 << 20))
+        assert not st.any()
+        for r, L, og in zip(raws, outs, aux):
+            eL, eo = oracle.bwt_encode(r)
+            assert L == eL and (not r or int(og) == eo), len(r)
+    check(corpus.small_corpus(sizes=(17, 1000, 9000)))                                   # text, runs, rand, dna: 9-bit plain-byte keys (all 256 bytes occur)
+    check([synth.gen("dna4", 6000, 1).tobytes(), b"ab" * 2500, bytes(3000), b"abracadabra" * 300])     # 1-4 symbols: 16+ per key, long shared prefixes
+    check([synth.gen("text", 30000, 2).tobytes(), synth.gen("words", 5000, 3).tobytes(), b"", b"x"])   # ~6 bits per symbol, groups of every size class
+
+
 def _gzip_members(raws):
     """gzip members with every optional header field (RFC 1952), made with Python's gzip/zlib (the checker here:
     the reference crate has no gzip code, see include/rcx.h)."""

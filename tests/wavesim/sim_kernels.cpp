@@ -18,7 +18,10 @@
 #define hipMemcpyDeviceToHost 0
 static inline int hipMemcpyAsync(void* d, const void* s, size_t n, int, int) { memcpy(d, s, n); return 0; }
 static inline int hipStreamSynchronize(int) { return 0; }
+#define hipMemcpyHostToDevice 1
+static inline int hipMemsetAsync(void* d, int v, size_t n, int) { memset(d, v, n); return 0; }
 #include "../../rust_compress_amd/csrc/k_bwt_inverse.hip"
+#include "../../rust_compress_amd/csrc/k_bwt.hip"
 
 extern "C" int sim_launch(int codec, int variant, const rcx_kargs* a)
 {
@@ -59,6 +62,7 @@ extern "C" int sim_launch(int codec, int variant, const rcx_kargs* a)
     case RCX_CRC32: launch_crc32(0, k); return 0;
     case RCX_GZIP_DECODE: launch_gzip_decode(0, k, variant); return 0;
     case RCX_BWT_INVERSE: { std::string err; int st = 0; return launch_bwt_inverse(st, k, variant, err); }
+    case RCX_BWT_FORWARD: { std::string err; int st = 0; const int rc = launch_bwt_forward(st, k, variant, err); if (rc) fprintf(stderr, "wavesim: %s\n", err.c_str()); return rc; }
     default:
         return -1;
     }

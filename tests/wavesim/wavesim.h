@@ -146,7 +146,8 @@ inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, b
     const int l = (int)(cur->tid & 63), row = l >> 4, pos = l & 15;
     if (!((row_mask >> row) & 1) || !((bank_mask >> (pos >> 2)) & 1)) return old;
     int s = -1;
-    if (ctrl >= 0x111 && ctrl <= 0x11f) { int n = ctrl - 0x110; if (pos >= n) s = l - n; }
+    if (ctrl >= 0 && ctrl <= 0xff) s = (l & ~3) + ((ctrl >> (2 * (l & 3))) & 3);                       // quad_perm
+    else if (ctrl >= 0x111 && ctrl <= 0x11f) { int n = ctrl - 0x110; if (pos >= n) s = l - n; }
     else if (ctrl >= 0x101 && ctrl <= 0x10f) { int n = ctrl - 0x100; if (pos + n < 16) s = l + n; }
     else if (ctrl == 0x142) { if (row >= 1) s = row * 16 - 1; }
     else if (ctrl == 0x143) { if (row >= 2) s = 31; }
@@ -246,6 +247,17 @@ static inline void ws_lds_store16(uint8_t* p, uint32_t v0, uint32_t v1, uint32_t
     for (uint32_t i = 0; i < nv && i < 16; i++) p[i] = (uint8_t)(v[i >> 2] >> (8 * (i & 3)));
 }
 
+// portable version of k_bwt_sort.hip's hand-written digit-peers routine: the lanes among `ok` that hold the same digit as mine
+static inline unsigned long long ws_bws_peers(bool ok, uint32_t d)
+{
+    unsigned long long peers = ws::ballot(ok);
+    for (int bit = 0; bit < 8; bit++) {
+        const unsigned long long m = ws::ballot(((d >> bit) & 1u) != 0);
+        peers &= ((d >> bit) & 1u) ? m : ~m;
+    }
+    return peers;
+}
+
 // portable version of k_inflate3.hip's hand-written window walk (same contract: see rcx_inf_walk there)
 static inline uint32_t ws_inf_walk(uint32_t pk1, uint32_t pk2, uint32_t& pos, uint32_t& cnt, uint32_t& ns, uint32_t& runL, uint32_t& otot,
                                    uint32_t& runsrc, uint32_t litn, uint32_t room, uint32_t& litv, uint32_t& dw0, uint32_t& dw1)
@@ -282,6 +294,7 @@ static inline uint32_t ws_inf_walk(uint32_t pk1, uint32_t pk2, uint32_t& pos, ui
 }
 #define RCX_LDS_STORE16 ws_lds_store16
 #define RCX_INF_WALK ws_inf_walk
+#define BWS_PEERS ws_bws_peers
 #define RCX_WAIT_VMEM() ((void)0)
 #define RCX_VGPR(x) ((uint32_t)(x))
 #define RCX_ALIGNBYTE(hi, lo, sh) ((uint32_t)(((((uint64_t)(hi)) << 32) | (uint32_t)(lo)) >> (8 * ((sh) & 3u))))
