@@ -310,34 +310,31 @@ __global__ __launch_bounds__(64 * WAVES) void k_adler32(rcx_kargs a)
     if (b >= a.nblocks) return;
     const uint8_t* in = a.in_base + a.in_off[b];
     const uint64_t n = a.in_len[b];
-    const uint64_t per = (n + 63) / 64;
-    const uint64_t s0 = per * lane < n ? per * lane : n;
-    const uint64_t s1 = s0 + per < n ? s0 + per : n;
-    // local sums over [s0, s1): A = sum x, B = sum (s1 - i) x_i   (i.e. Adler's b with a starting at 0)
-    uint32_t A = 0, B = 0, pend = 0;
-    uint64_t i = s0;
-    for (; i + 16 <= s1; i += 16) {                            // 16 bytes per load (a byte load per byte was the whole cost)
-        const rcx_u32x4 v = *(const rcx_u32x4_u*)(in + i);
+    // With a starting at 0:  a = sum x_i,  b = sum (n - i) x_i.  The wave reads 1 KiB per step, lane l the 16-byte chunk at
+    // p = 1024 * step + 16 * l (coalesced: a slice per lane read 16 of every 256 bytes per request and ran at a quarter of
+    // the bandwidth); a chunk adds  A_c = sum x_j  to a and  (n - p - 16) * A_c + sum (16 - j) x_j  to b.
+    const uint64_t nch = n >> 4;
+    uint64_t SA = 0, SB = 0;
+    uint32_t r = (uint32_t)((n - 16ull * lane - 16ull) % 65521ull);     // (n - p - 16) mod 65521 for the lane's first chunk (wraps harmlessly when n < 16)
+    for (uint64_t c = lane; c < nch; c += 64) {
+        const rcx_u32x4 v = *(const rcx_u32x4_u*)(in + 16 * c);
+        uint32_t A = 0, W = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             uint32_t x = v[k];
 #pragma unroll
-            for (int j = 0; j < 4; j++) { A += x & 0xffu; B += A; x >>= 8; }
+            for (int j = 0; j < 4; j++) { A += x & 0xffu; W += A; x >>= 8; }          // W = sum (16 - j) x_j
         }
-        pend += 16;
-        if (pend >= 5536) { A %= 65521u; B %= 65521u; pend = 0; }
+        SA += A; SB += (uint64_t)W + (uint64_t)r * A;                    // < 2^29 per chunk: no overflow in 2^35 chunks
+        r = r >= 1024u ? r - 1024u : r + 65521u - 1024u;
     }
-    for (; i < s1; i++) {
-        A += in[i]; B += A;
-        if (++pend >= 5536) { A %= 65521u; B %= 65521u; pend = 0; }
+    uint32_t sa = (uint32_t)(SA % 65521ull), sb = (uint32_t)(SB % 65521ull);
+    if (lane == 0) {                                                     // the last n % 16 bytes
+        uint32_t A = 0, B = 0;
+        for (uint64_t i = nch << 4; i < n; i++) { A += in[i]; B += (uint32_t)(n - i) * in[i]; }
+        sa = (sa + A) % 65521u; sb = (sb + B) % 65521u;
     }
-    A %= 65521u; B %= 65521u;
-    // contribution to the global b: B + (n - s1) * A
-    const uint64_t tail = (n - s1) % 65521u;
-    uint32_t Bc = (uint32_t)((B + tail * A) % 65521u);
-    // sums over lanes (values < 65521, 64 of them: no overflow in u32)
-    const uint32_t sa = rcx_wave_sum(A);
-    const uint32_t sb = rcx_wave_sum(Bc);
+    sa = rcx_wave_sum(sa); sb = rcx_wave_sum(sb);                        // 64 values < 65521: no overflow in u32
     if (lane == 0) {
         const uint32_t ra = (1u + sa) % 65521u;
         const uint32_t rb = (uint32_t)((n % 65521u + sb) % 65521u);
