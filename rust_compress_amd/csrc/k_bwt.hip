@@ -306,7 +306,9 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
             {
                 uint32_t h_hist[264];
                 if (hipMemsetAsync(hist, 0, 1056, s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
-                hipLaunchKernelGGL(k_bwtf_hist, dim3(gx ? gx : 1, nb), dim3(256), 0, s, fa, hist);
+                // (eight 16-byte chunks per thread: a workgroup per 4 KiB ended in 1 M workgroups' worth of atomics on the same 264 words)
+                const uint32_t gxh = (uint32_t)((maxn + 32767) / 32768 < 1024 ? (maxn + 32767) / 32768 : 1024);
+                hipLaunchKernelGGL(k_bwtf_hist, dim3(gxh ? gxh : 1, nb), dim3(256), 0, s, fa, hist);
                 if (hipMemcpyAsync(h_hist, hist, 1056, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
                     err = "bwt forward: histogram"; return RCX_RC_HIP_ERROR; }
                 uint8_t h_map[256]; uint32_t sigma = 0;
