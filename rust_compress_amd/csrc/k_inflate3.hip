@@ -134,10 +134,12 @@ __device__ __forceinline__ uint32_t rcx_inf_walk(uint32_t pk1, uint32_t pk2, uin
 #endif
 
 template <int CB>
-struct Inf3 : Lz4V5<CB, 1536, 1024> {
-    // LDS per wave must stay below 10 KB for 16 waves per CU: 1536-byte batch output cap, 1 KiB of history in the window,
-    // 512 literal bytes per batch, an 8-bit table for the distance code
-    typedef Lz4V4<CB, false, 1536, 1024> B;
+struct Inf3 : Lz4V5<CB, 1024, 1024, false, 16> {
+    // LDS per wave must stay at or below 8 KiB for 20 waves per CU (the kernel is bound by the latency of its dependent phases:
+    // 12 / 16 waves per CU take 18.5 / 14.3 ms for config 3): 1024-byte batch output cap, 1 KiB of history in the window, 16 bytes
+    // of staging per gathered match, 512 literal bytes per batch, an 8-bit table for the distance code, and the code lengths of a
+    // block header share the literal buffer (the batch is emitted before a header is read)
+    typedef Lz4V4<CB, false, 1024, 1024> B;
     static constexpr int LITCAP = 512;       // literal bytes per batch
     static constexpr int LUTBITS = 9, LUTN = 1 << LUTBITS;     // lit/len table
     static constexpr int DBITS = 8, DLUTN = 1 << DBITS;        // distance (and code-length) table
@@ -443,6 +445,7 @@ struct Inf3 : Lz4V5<CB, 1536, 1024> {
             refill();
 
             if (phase == P_BLOCK) {
+                if (ns || litn || runL) { want_flush = true; continue; }   // `lens` lives in the literal buffer: no open batch across a header
                 before = otot;
                 eof = bits(1) == 1;                                    // :198
                 const uint32_t type = bits(2);                         // :199
@@ -607,7 +610,7 @@ struct Inf3 : Lz4V5<CB, 1536, 1024> {
 #define INF3_LDS_EXTRA (2 * 1024 + 2 * 288 + 2 * 32 + 352 + 4 * 80 + (1024 + 64) + 4 * 128)
 
 template <int CB>
-__global__ __launch_bounds__(64) void k_inflate3(rcx_kargs a, int zlib)
+__global__ __launch_bounds__(64, 5) void k_inflate3(rcx_kargs a, int zlib)
 {
     typedef Inf3<CB> S;
     __shared__ __align__(16) uint8_t s_cbuf[CB + 96];
@@ -616,9 +619,9 @@ __global__ __launch_bounds__(64) void k_inflate3(rcx_kargs a, int zlib)
     __shared__ __align__(16) uint16_t s_lutD[S::DLUTN];
     __shared__ uint16_t s_symL[288];
     __shared__ uint16_t s_symD[32];
-    __shared__ __align__(16) uint8_t s_lens[352];
     __shared__ uint32_t s_tab[80];
-    __shared__ __align__(16) uint8_t s_lit[S::LITCAP + 64];
+    __shared__ __align__(16) uint8_t s_lit[S::LITCAP + 64];   // (also the 352 bytes of code lengths while a block header is read)
+    static_assert(S::LITCAP + 64 >= 352, "code lengths share the literal buffer");
     __shared__ __align__(16) uint32_t s_desc[128];
     const uint32_t b = blockIdx.x;
     if (b >= a.nblocks) return;
@@ -629,7 +632,7 @@ __global__ __launch_bounds__(64) void k_inflate3(rcx_kargs a, int zlib)
     s.out = a.out_base + a.out_off[b];
     s.cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;
     s.cbuf = s_cbuf; s.wb_ = s_wbuf; s.epos = nullptr; s.ring = nullptr;
-    s.lutL = s_lutL; s.lutD = s_lutD; s.symL = s_symL; s.symD = s_symD; s.lens = s_lens; s.tab = s_tab; s.litbuf = s_lit; s.desc = s_desc;
+    s.lutL = s_lutL; s.lutD = s_lutD; s.symL = s_symL; s.symD = s_symD; s.lens = s_lit; s.tab = s_tab; s.litbuf = s_lit; s.desc = s_desc;
     int32_t st; uint32_t olen, used, flags;
     s.run(zlib, &st, &olen, &used, &flags);
     if ((threadIdx.x & 63u) == 0) {

@@ -37,14 +37,16 @@
 #endif
 #include <type_traits>
 
-template <int CB, int TC = 2560, int HH = 2048, bool PROF5 = false>
+// SB: bytes of a gathered (old) match that are staged per lane and ride the copy rounds; the rest is stored straight to its place
+template <int CB, int TC = 2560, int HH = 2048, bool PROF5 = false, int SB = 32>
 struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
+    static_assert(SB == 16 || SB == 32, "staging slot");
     typedef Lz4V4<CB, false, TC, HH> B;
     static constexpr int NSLOT = 3;
     struct Slot { uint32_t hdr[16]; uint32_t desc[64][2]; };
     struct Ring { Slot slot[NSLOT]; volatile uint32_t head, tail, abort_, pad; };
     static constexpr int STAGE5 = B::LIN + 64;         // 64 lanes x 32 bytes of old-match staging (bytes 32.. of a longer
-    static constexpr int WBUF5 = STAGE5 + 64 * 32;     // gathered match go straight to their place): 16 blocks per CU fit
+    static constexpr int WBUF5 = STAGE5 + 64 * SB;     // gathered match go straight to their place): 16 blocks per CU fit
     RCX_LDS_AS Ring* ring;                         // address space 3: the volatile head / tail accesses must be ds_read / ds_write, not flat
     uint64_t pw[4] = {0, 0, 0, 0};                 // PROF5: cycles waiting on the ring, cycles working, batches, -
 
@@ -215,7 +217,8 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
         if (__ballot(isfar)) {
             uint8_t* d = wb_ + li_m;
             const uint32_t mf = far16 ? M : 0u;
-            if (far16) { uint8_t* sl = wb_ + STAGE5 + 32 * (int32_t)lane; *(rcx_u32x4*)sl = f0; *(rcx_u32x4*)(sl + 16) = f1; }
+            if (far16) { uint8_t* sl = wb_ + STAGE5 + SB * (int32_t)lane; *(rcx_u32x4*)sl = f0; if (SB == 32) *(rcx_u32x4*)(sl + 16) = f1; }
+            if (SB == 16 && __ballot(mf > 16)) RCX_LDS_STORE16(d + 16, f1[0], f1[1], f1[2], f1[3], mf > 16u ? (mf < 32u ? mf - 16u : 16u) : 0u);
             if (__ballot(mf > 32)) RCX_LDS_STORE16(d + 32, f2[0], f2[1], f2[2], f2[3], mf > 32u ? (mf < 48u ? mf - 32u : 16u) : 0u);
             if (__ballot(mf > 48)) RCX_LDS_STORE16(d + 48, f3[0], f3[1], f3[2], f3[3], mf > 48u ? mf - 48u : 0u);
             for (uint32_t i = 0; __ballot(farb && i < M); i++)
@@ -228,9 +231,9 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
         // behind (same period, no overlap) on the plain path.  Batches without such a match (nearly all of a text) run the
         // loop instantiated without that switch: its `sbase` / `ovl` stay loop invariant.
         {
-            const int32_t sbase0 = far16 ? STAGE5 + 32 * (int32_t)lane : (int32_t)(mdst - S) - lbase;
+            const int32_t sbase0 = far16 ? STAGE5 + SB * (int32_t)lane : (int32_t)(mdst - S) - lbase;
             const bool ovl0 = M && !isfar && off < 16u && off < M;
-            const uint32_t Mc = far16 ? (M < 32u ? M : 32u) : M;     // staged gathers ride the rounds for their first 32 bytes
+            const uint32_t Mc = far16 ? (M < (uint32_t)SB ? M : (uint32_t)SB) : M;     // staged gathers ride the rounds for their first SB bytes
             auto rounds = [&](auto conv) __attribute__((always_inline)) {
                 constexpr bool CONV = decltype(conv)::value;
                 int32_t sbase = sbase0;
