@@ -133,14 +133,27 @@ __device__ __forceinline__ uint32_t rcx_inf_walk(uint32_t pk1, uint32_t pk2, uin
 #define RCX_INF_WALK rcx_inf_walk
 #endif
 
+#ifndef INF3_TCAP
+#define INF3_TCAP 1024
+#endif
+#ifndef INF3_H
+#define INF3_H 1024
+#endif
+#ifndef INF3_LITCAP
+#define INF3_LITCAP 320
+#endif
+#ifndef INF3_OCC
+#define INF3_OCC 5
+#endif
 template <int CB>
-struct Inf3 : Lz4V5<CB, 1024, 1024, false, 16> {
-    // LDS per wave must stay at or below 8 KiB for 20 waves per CU (the kernel is bound by the latency of its dependent phases:
-    // 12 / 16 waves per CU take 18.5 / 14.3 ms for config 3): 1024-byte batch output cap, 1 KiB of history in the window, 16 bytes
-    // of staging per gathered match, 512 literal bytes per batch, an 8-bit table for the distance code, and the code lengths of a
-    // block header share the literal buffer (the batch is emitted before a header is read)
-    typedef Lz4V4<CB, false, 1024, 1024> B;
-    static constexpr int LITCAP = 512;       // literal bytes per batch
+struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, 16> {
+    // LDS per wave must stay at or below 7680 bytes for 20 waves per CU (LDS is handed out in 1280-byte granules: 7872 bytes were
+    // 18 waves; and the kernel is bound by the latency of its dependent phases: 12 / 16 / 18 / 20 waves per CU take 18.5 / 14.3 /
+    // 13.1 / 12.4 ms for config 3): 1024-byte batch output cap, 1 KiB of history in the window, 16 bytes of staging per gathered
+    // match, 320 literal bytes per batch, an 8-bit table for the distance code, and the code lengths of a block header share the
+    // literal buffer (the batch is emitted before a header is read).  84 VGPRs: five waves per SIMD.
+    typedef Lz4V4<CB, false, INF3_TCAP, INF3_H> B;
+    static constexpr int LITCAP = INF3_LITCAP;       // literal bytes per batch
     static constexpr int LUTBITS = 9, LUTN = 1 << LUTBITS;     // lit/len table
     static constexpr int DBITS = 8, DLUTN = 1 << DBITS;        // distance (and code-length) table
     // LDS views
@@ -610,7 +623,10 @@ struct Inf3 : Lz4V5<CB, 1024, 1024, false, 16> {
 #define INF3_LDS_EXTRA (2 * 1024 + 2 * 288 + 2 * 32 + 352 + 4 * 80 + (1024 + 64) + 4 * 128)
 
 template <int CB>
-__global__ __launch_bounds__(64, 5) void k_inflate3(rcx_kargs a, int zlib)
+#ifndef INF3_VGPR
+#define INF3_VGPR 96
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INF3_OCC, 8))) void k_inflate3(rcx_kargs a, int zlib)
 {
     typedef Inf3<CB> S;
     __shared__ __align__(16) uint8_t s_cbuf[CB + 96];

@@ -44,7 +44,7 @@ struct Lz4V4 {
     static constexpr int LCAP = 32, MCAP = 64;     // per-lane caps of a batched sequence
     static constexpr int WINMAX = 22 * (14 + MCAP);// most output one 64-byte token window can add (22 tokens)
     static constexpr int TCAP = TC;                // output bytes per batch (2560 for LZ4; the inflate front end uses less LDS)
-    static constexpr int SOLO = 1024;              // wave-cooperative in-window copy up to this many bytes
+    static constexpr int SOLO = TC < 1024 ? TC : 1024;   // wave-cooperative in-window copy up to this many bytes
     static constexpr int LIN = H + 16 + TCAP;
     static constexpr int STAGE = LIN + 64;         // 64 bytes of read slack, then 64 lanes x MCAP bytes of old-match staging
     static constexpr int WBUF = STAGE + 64 * MCAP;
