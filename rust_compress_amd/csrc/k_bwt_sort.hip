@@ -336,9 +336,9 @@ __global__ __launch_bounds__(512) void k_bws_partition(BwsState s, int level, ui
 // The new groups a wave finds are queued in LDS and appended to the next round's lists 64+ at a time.  Appending them as they
 // turn up (one atomic with return per 64-suffix chunk that holds a listed group) made the finishing phase 70 % of these
 // kernels: the wait for the atomic is an s_waitcnt vmcnt(0), and that also waits for the chunk's scattered saA / rank stores.
-#define BWS_QCAP 128u
+#define BWS_QCAP 120u                     /* (with the rest of k_bws_local_wg's LDS: 32 granules of 1280 bytes, four workgroups per CU) */
 struct BwsQueue {
-    uint32_t* q; uint32_t n;                                  // q: LDS, BWS_QCAP x 3 words; n: entries waiting (wave-uniform)
+    uint32_t* q; uint32_t n; uint32_t ts;                     // q: LDS, BWS_QCAP x 2 words (start, len | list << 28); n: entries waiting (wave-uniform); ts: top_shift
     // wave-uniform call: the lanes with `is` hand in the group [a, a + len) made this round
     __device__ __forceinline__ void push(const BwsState& s, bool is, uint32_t a, uint32_t len, uint32_t top_shift)
     {
@@ -348,11 +348,12 @@ struct BwsQueue {
         if (is && !listed) bws_flag_dense(s, s.rs ^ 1u, a, len);
         const unsigned long long m = __ballot(listed);
         if (!m) return;
+        ts = top_shift;
         if (n + 64u > BWS_QCAP) flush(s);
         const uint32_t tag = len > BWS_LMAX ? 0u : len > BWS_LWAVE ? 2u : len > BWS_WAVE ? 1u : 3u;
         if (listed) {
             const uint32_t i = n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            q[3 * i] = a; q[3 * i + 1] = len; q[3 * i + 2] = (len > BWS_WAVE ? top_shift : 0u) | (tag << 16);
+            q[2 * i] = a; q[2 * i + 1] = len | (tag << 28);                  // (a group is shorter than 2^28: BWS_IDX)
         }
         n += (uint32_t)__popcll(m);
         rcx_wave_sync();
@@ -364,9 +365,9 @@ struct BwsQueue {
         for (uint32_t i0 = 0; i0 < n; i0 += 64) {
             const uint32_t i = i0 + lane;
             const bool have = i < n;
-            const uint32_t a = have ? q[3 * i] : 0u, len = have ? q[3 * i + 1] : 0u, info = have ? q[3 * i + 2] : 0u;
-            const uint32_t tag = info >> 16;
-            const BwsSeg seg{a, len, info & 0xffffu};
+            const uint32_t a = have ? q[2 * i] : 0u, lt = have ? q[2 * i + 1] : 0u;
+            const uint32_t tag = lt >> 28, len = lt & 0x0fffffffu;
+            const BwsSeg seg{a, len, tag == 3u ? 0u : ts};
             bws_append(s.nlarge, &s.cnt[3], have && tag == 0u, seg);
             bws_append(s.nlocal, &s.cnt[7], have && tag == 1u, seg);
             bws_append(s.nlocalw, &s.cnt[10], have && tag == 2u, seg);
@@ -382,7 +383,8 @@ struct BwsLocal {
     static constexpr uint32_t CAP = NW == 1 ? BWS_LWAVE : BWS_LMAX;
     static constexpr uint32_t MAXSTEP = CAP / (64u * NW);
     K* key; uint32_t* val; uint16_t* pa; uint16_t* pb; uint32_t* hist;      // hist: [NW][256]
-    uint32_t* tot; uint32_t* beg; uint32_t* bits; uint32_t* misc;           // NW > 1: tot[256], beg[256]; bits[CAP / 32 + 1]; misc[8]
+    uint32_t* bits; uint32_t* misc;                                          // bits[CAP / 32 + 2]: hist + 128, free once the passes are over (the
+                                                                             // run lookup's two scan arrays take hist[0 .. 128)); misc[8] (NW > 1)
     uint32_t t, w, lane;                                                     // thread, wave and lane inside the team
     BwsQueue* Q;                                                             // the calling wave's queue of new groups
 
@@ -527,14 +529,13 @@ __global__ __launch_bounds__(256) void k_bws_local_wave(BwsState s, uint32_t top
     __shared__ uint32_t s_val[4 * BWS_LWAVE];
     __shared__ uint16_t s_pa[4 * BWS_LWAVE], s_pb[4 * BWS_LWAVE];
     __shared__ uint32_t s_hist[4][256];
-    __shared__ uint32_t s_bits[4 * (BWS_LWAVE / 32 + 2)];
-    __shared__ uint32_t s_q[4][3 * BWS_QCAP];
+    __shared__ uint32_t s_q[4][2 * BWS_QCAP];
     const uint32_t nseg = s.cnt[6];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    BwsQueue Q; Q.q = s_q[wave]; Q.n = 0;
+    BwsQueue Q; Q.q = s_q[wave]; Q.n = 0; Q.ts = top_shift;
     BwsLocal<K, 1> L; L.Q = &Q;
     L.key = s_key + BWS_LWAVE * wave; L.val = s_val + BWS_LWAVE * wave; L.pa = s_pa + BWS_LWAVE * wave; L.pb = s_pb + BWS_LWAVE * wave;
-    L.hist = s_hist[wave]; L.tot = nullptr; L.beg = nullptr; L.bits = s_bits + (BWS_LWAVE / 32 + 2) * wave; L.misc = nullptr;
+    L.hist = s_hist[wave]; L.bits = s_hist[wave] + 128; L.misc = nullptr;
     L.t = lane; L.w = 0; L.lane = lane;
     for (uint32_t e = blockIdx.x * 4u + wave; e < nseg; e += gridDim.x * 4u) L.run(s, s.local[e], top_shift);
     Q.flush(s);
@@ -546,14 +547,12 @@ __global__ __launch_bounds__(256) void k_bws_local_wg(BwsState s, uint32_t top_s
     __shared__ uint32_t s_val[BWS_LMAX];
     __shared__ uint16_t s_pa[BWS_LMAX], s_pb[BWS_LMAX];
     __shared__ uint32_t s_hist[4][256];
-    __shared__ uint32_t s_tot[256], s_beg[256];
-    __shared__ uint32_t s_bits[BWS_LMAX / 32 + 2];
     __shared__ uint32_t s_misc[8];
-    __shared__ uint32_t s_q[4][3 * BWS_QCAP];
+    __shared__ uint32_t s_q[4][2 * BWS_QCAP];
     const uint32_t nsegw = s.cnt[9];
-    BwsQueue Q; Q.q = s_q[threadIdx.x >> 6]; Q.n = 0;
+    BwsQueue Q; Q.q = s_q[threadIdx.x >> 6]; Q.n = 0; Q.ts = top_shift;
     BwsLocal<K, 4> L; L.Q = &Q;
-    L.key = s_key; L.val = s_val; L.pa = s_pa; L.pb = s_pb; L.hist = &s_hist[0][0]; L.tot = s_tot; L.beg = s_beg; L.bits = s_bits; L.misc = s_misc;
+    L.key = s_key; L.val = s_val; L.pa = s_pa; L.pb = s_pb; L.hist = &s_hist[0][0]; L.bits = &s_hist[0][0] + 128; L.misc = s_misc;
     L.t = threadIdx.x; L.w = threadIdx.x >> 6; L.lane = threadIdx.x & 63u;
     for (uint32_t e = blockIdx.x; e < nsegw; e += gridDim.x) L.run(s, s.localw[e], top_shift);
     Q.flush(s);
