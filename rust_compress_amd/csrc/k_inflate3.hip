@@ -139,6 +139,9 @@ __device__ __forceinline__ uint32_t rcx_inf_walk(uint32_t pk1, uint32_t pk2, uin
 #ifndef INF3_H
 #define INF3_H 1024
 #endif
+#ifndef INF3_SB
+#define INF3_SB 16
+#endif
 #ifndef INF3_LITCAP
 #define INF3_LITCAP 320
 #endif
@@ -146,7 +149,7 @@ __device__ __forceinline__ uint32_t rcx_inf_walk(uint32_t pk1, uint32_t pk2, uin
 #define INF3_OCC 5
 #endif
 template <int CB>
-struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, 16> {
+struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
     // LDS per wave must stay at or below 7680 bytes for 20 waves per CU (LDS is handed out in 1280-byte granules: 7872 bytes were
     // 18 waves; and the kernel is bound by the latency of its dependent phases: 12 / 16 / 18 / 20 waves per CU take 18.5 / 14.3 /
     // 13.1 / 12.4 ms for config 3): 1024-byte batch output cap, 1 KiB of history in the window, 16 bytes of staging per gathered
@@ -626,7 +629,7 @@ template <int CB>
 #ifndef INF3_VGPR
 #define INF3_VGPR 96
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(INF3_OCC, 8))) void k_inflate3(rcx_kargs a, int zlib)
+__global__ __launch_bounds__(64, INF3_OCC) void k_inflate3(rcx_kargs a, int zlib)
 {
     typedef Inf3<CB> S;
     __shared__ __align__(16) uint8_t s_cbuf[CB + 96];

@@ -40,7 +40,7 @@
 // SB: bytes of a gathered (old) match that are staged per lane and ride the copy rounds; the rest is stored straight to its place
 template <int CB, int TC = 2560, int HH = 2048, bool PROF5 = false, int SB = 32>
 struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
-    static_assert(SB == 16 || SB == 32, "staging slot");
+    static_assert(SB == 0 || SB == 16 || SB == 32, "staging slot");
     typedef Lz4V4<CB, false, TC, HH> B;
     static constexpr int NSLOT = 3;
     struct Slot { uint32_t hdr[16]; uint32_t desc[64][2]; };
@@ -217,8 +217,9 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
         if (__ballot(isfar)) {
             uint8_t* d = wb_ + li_m;
             const uint32_t mf = far16 ? M : 0u;
-            if (far16) { uint8_t* sl = wb_ + STAGE5 + SB * (int32_t)lane; *(rcx_u32x4*)sl = f0; if (SB == 32) *(rcx_u32x4*)(sl + 16) = f1; }
-            if (SB == 16 && __ballot(mf > 16)) RCX_LDS_STORE16(d + 16, f1[0], f1[1], f1[2], f1[3], mf > 16u ? (mf < 32u ? mf - 16u : 16u) : 0u);
+            if (SB != 0 && far16) { uint8_t* sl = wb_ + STAGE5 + SB * (int32_t)lane; *(rcx_u32x4*)sl = f0; if (SB == 32) *(rcx_u32x4*)(sl + 16) = f1; }
+            if (SB == 0) RCX_LDS_STORE16(d, f0[0], f0[1], f0[2], f0[3], mf < 16u ? mf : 16u);     // no staging: every gathered byte goes straight to its place
+            if (SB <= 16 && __ballot(mf > 16)) RCX_LDS_STORE16(d + 16, f1[0], f1[1], f1[2], f1[3], mf > 16u ? (mf < 32u ? mf - 16u : 16u) : 0u);
             if (__ballot(mf > 32)) RCX_LDS_STORE16(d + 32, f2[0], f2[1], f2[2], f2[3], mf > 32u ? (mf < 48u ? mf - 32u : 16u) : 0u);
             if (__ballot(mf > 48)) RCX_LDS_STORE16(d + 48, f3[0], f3[1], f3[2], f3[3], mf > 48u ? mf - 48u : 0u);
             for (uint32_t i = 0; __ballot(farb && i < M); i++)
@@ -238,7 +239,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
                 constexpr bool CONV = decltype(conv)::value;
                 int32_t sbase = sbase0;
                 bool ovl = ovl0;
-                bool pending = M != 0 && !farb;
+                bool pending = M != 0 && !farb && !(SB == 0 && far16);
                 uint32_t prog = 0, r = 0;
                 for (;;) {
                     const unsigned long long pm = __ballot(pending);
