@@ -345,8 +345,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_adler32(rcx_kargs a)
     }
 }
 
-template <int SPW, int LG, int MINW> __global__ void k_inflate2(rcx_kargs a, int zlib);
-template <int CB> __global__ void k_inflate3(rcx_kargs a, int zlib);
+// (the launch bounds must stand on these first declarations: put on the definitions only, they were silently dropped and the
+// kernels were compiled for 1024-thread workgroups -- no occupancy target reached the register allocator)
+#ifndef INF3_OCC
+#define INF3_OCC 6
+#endif
+template <int SPW, int LG, int MINW> __global__ __launch_bounds__(64, MINW) void k_inflate2(rcx_kargs a, int zlib);
+template <int CB> __global__ __launch_bounds__(64, INF3_OCC) void k_inflate3(rcx_kargs a, int zlib);
 __global__ void k_zlib_tail3(rcx_kargs a, const uint32_t* adler);
 template <int WAVES> __global__ void k_adler32(rcx_kargs a);
 

@@ -137,24 +137,25 @@ __device__ __forceinline__ uint32_t rcx_inf_walk(uint32_t pk1, uint32_t pk2, uin
 #define INF3_TCAP 1024
 #endif
 #ifndef INF3_H
-#define INF3_H 1024
+#define INF3_H 768
 #endif
 #ifndef INF3_SB
-#define INF3_SB 16
+#define INF3_SB 0
 #endif
 #ifndef INF3_LITCAP
 #define INF3_LITCAP 320
 #endif
 #ifndef INF3_OCC
-#define INF3_OCC 5
+#define INF3_OCC 6
 #endif
 template <int CB>
 struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
-    // LDS per wave must stay at or below 7680 bytes for 20 waves per CU (LDS is handed out in 1280-byte granules: 7872 bytes were
-    // 18 waves; and the kernel is bound by the latency of its dependent phases: 12 / 16 / 18 / 20 waves per CU take 18.5 / 14.3 /
-    // 13.1 / 12.4 ms for config 3): 1024-byte batch output cap, 1 KiB of history in the window, 16 bytes of staging per gathered
-    // match, 320 literal bytes per batch, an 8-bit table for the distance code, and the code lengths of a block header share the
-    // literal buffer (the batch is emitted before a header is read).  84 VGPRs: five waves per SIMD.
+    // The kernel is bound by the latency of its dependent phases, so what it needs is waves: 12 / 16 / 18 / 20 / 24 waves per CU take
+    // 18.5 / 14.3 / 13.1 / 12.4 / 11.6 ms for config 3.  24 waves = 6400 bytes of LDS each (handed out in 1280-byte granules) and
+    // 80 VGPRs: 1024-byte batch output cap, 768 bytes of history in the window, NO staging of gathered matches (every byte goes
+    // straight to its place), 320 literal bytes per batch, an 8-bit table for the distance code, and the code lengths of a block
+    // header share the literal buffer (the batch is emitted before a header is read).  History / batch cap splits of the same
+    // 1808 bytes (512 + 1280, 640 + 1152, 768 + 1024, 896 + 896) measure within 1 %.
     typedef Lz4V4<CB, false, INF3_TCAP, INF3_H> B;
     static constexpr int LITCAP = INF3_LITCAP;       // literal bytes per batch
     static constexpr int LUTBITS = 9, LUTN = 1 << LUTBITS;     // lit/len table
