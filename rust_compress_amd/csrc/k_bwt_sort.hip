@@ -522,8 +522,11 @@ struct BwsLocal {
 // The wave-sized groups and the workgroup-sized ones get a kernel each: the first keeps 20 KiB of LDS per workgroup (four
 // waves, a group each) so that seven workgroups share a CU -- these passes are chains of dependent LDS round trips, what
 // they need is waves in flight (with one kernel for both, 38 KiB per workgroup: four per CU, the vector ALU 21 % busy).
+#ifndef BWS_LW_OCC
+#define BWS_LW_OCC 6
+#endif
 template <class K>
-__global__ __launch_bounds__(256) void k_bws_local_wave(BwsState s, uint32_t top_shift)
+__global__ __launch_bounds__(256, BWS_LW_OCC) void k_bws_local_wave(BwsState s, uint32_t top_shift)
 {
     __shared__ __align__(16) K s_key[4 * BWS_LWAVE];
     __shared__ uint32_t s_val[4 * BWS_LWAVE];
