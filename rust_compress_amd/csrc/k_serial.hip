@@ -677,6 +677,34 @@ struct AriTab {
         for (int j = 0; j < 16; j++) { l += (uint32_t)j < jb ? fe[j] : 0u; fv = (uint32_t)j == jb ? fe[j] : fv; }
         lo = l; hi = l + fv;
     }
+    // find_value for offset = x / range WITHOUT the division: c <= x / range  <=>  c * range <= x  (integers, range > 0), and every
+    // product is a 24 x 24-bit one (c <= total < 2^13; range <= (2^32 - 1) / 257 < 2^24; c * range <= hai - low < 2^32): v_mul_u32_u24.
+    __device__ __forceinline__ uint32_t find_x(uint32_t x, uint32_t range, uint32_t& lo, uint32_t& hi)
+    {
+        uint32_t sk[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) sk[k] = s((uint32_t)k);
+        uint32_t c = 0, l = 0, kb = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { c += sk[k]; const bool below = __umul24(c, range) <= x; kb += below ? 1u : 0u; l = below ? c : l; }
+        const uint32_t e0 = 16u * kb;
+        uint32_t fe[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) { const uint32_t e = e0 + (uint32_t)j; fe[j] = f(e < ARI_N ? e : ARI_N - 1); }
+        uint32_t jb = 0, h = 0;
+        c = l;
+        bool found = false;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t nc = c + fe[j];
+            const bool hit = !found && __umul24(nc, range) > x;
+            if (hit) { lo = c; h = nc; jb = (uint32_t)j; }
+            found = found || hit;
+            c = nc;
+        }
+        hi = h;
+        return e0 + jb;
+    }
     __device__ __forceinline__ uint32_t find(uint32_t offset, uint32_t& lo, uint32_t& hi)  // find_value, table.rs:105-117
     {
         uint32_t sk[16];
@@ -789,10 +817,17 @@ __global__ __launch_bounds__(64) void k_ari_byte(rcx_kargs a, int decode)
             if (st) break;
             const uint32_t total = T.total;
             const uint32_t range = (R.hai - R.low) / total;    // query(), mod.rs:153-159
+#ifdef RCX_ARI_DIV2
             const uint32_t offset = (code - R.low) / range;
             if (offset >= total) { st = RCX_E_MALFORMED; break; }   // table.rs:106 assert
             uint32_t lo, hi;
             const uint32_t v = T.find(offset, lo, hi);
+#else
+            const uint32_t x = code - R.low;                   // offset = x / range is never formed (see find_x)
+            if (x >= __umul24(total, range)) { st = RCX_E_MALFORMED; break; }   // offset >= total: table.rs:106 assert (hai - low > 2^14 > total, so range >= 4)
+            uint32_t lo, hi;
+            const uint32_t v = T.find_x(x, range, lo, hi);
+#endif
             pending = R.process(total, lo, hi, tmp);
             if (v == 256) break;
             if (o >= cap) { st = RCX_E_OUTPUT_TOO_SMALL; break; }

@@ -203,6 +203,7 @@ static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
 #define __shfl_up(x, d, ...) ws::shfl_up((x), (unsigned)(d))
 #define __shfl_down(x, d, ...) ws::shfl_down((x), (unsigned)(d))
 #define __shfl_xor(x, m, ...) ws::shfl_xor((x), (int)(m))
+static inline unsigned __umul24(unsigned a, unsigned b) { return (unsigned)((unsigned long long)(a & 0xffffffu) * (b & 0xffffffu)); }
 #define __popcll(x) __builtin_popcountll((unsigned long long)(x))
 #define __popc(x) __builtin_popcount((unsigned)(x))
 static inline int __ffsll(unsigned long long x) { return x ? __builtin_ctzll(x) + 1 : 0; }
