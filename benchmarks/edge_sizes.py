@@ -42,6 +42,9 @@ def main(ctx=None, limit=(1 << 20) + 1, kinds=("text", "runs", "dna4", "rand")):
         nz = [i for i, r in enumerate(raws) if r]
         inv = ctx.bwt_inverse([exp[i][0] for i in nz], [exp[i][1] for i in nz]).check()
         check("bwt inverse " + kind, inv.outputs, [raws[i] for i in nz])
+        sm = [i for i in nz if len(raws[i]) <= 70000]                                 # the O(n^2) restatement of decode_minimal
+        mn = ctx.bwt_inverse_minimal([exp[i][0] for i in sm], [exp[i][1] for i in sm]).check()
+        check("bwt inverse (minimal) " + kind, mn.outputs, [O.bwt_decode(exp[i][0], exp[i][1], minimal=True) for i in sm])
         Ls = [e[0] for e in exp]
         check("mtf enc " + kind, ctx.mtf_encode(Ls).check().outputs, [O.mtf_encode(x) for x in Ls])
         check("mtf dec " + kind, ctx.mtf_decode([O.mtf_encode(x) for x in Ls]).check().outputs, Ls)

@@ -155,6 +155,12 @@ int rcx_gzip_decode_batch(rcx_ctx*, const rcx_batch*, uint32_t* flags);
 int rcx_bwt_forward_batch(rcx_ctx*, const rcx_batch*, uint32_t* origin);
 /* reference: src/bwt/mod.rs:223-294 compute_inversion_table + InverseIterator */
 int rcx_bwt_inverse_batch(rcx_ctx*, const rcx_batch*, const uint32_t* origin);
+/* reference: src/bwt/mod.rs:298-315 decode_minimal, what bwt::Decoder runs with extra_mem = false (:397-399): n steps of
+ * i <- C[L[i]] + #{k < i : L[k] == L[i]} from i = origin, the text written backwards.  Reproduced as the reference computes
+ * it, which is NOT the inverse of rcx_bwt_forward_batch in general (wrong whenever T[n-1] also occurs in L[..origin]; right
+ * for e.g. "abracadabra", the reference's only test of it, :549-551).  status: origin >= n is RCX_E_MALFORMED (:310),
+ * n == 0 is RCX_OK only with origin == 0 (:300-302); there is no other failure. */
+int rcx_bwt_inverse_minimal_batch(rcx_ctx*, const rcx_batch*, const uint32_t* origin);
 /* reference: src/bwt/mtf.rs:63-90 with the stream codecs' identity start :103,141 */
 int rcx_mtf_encode_batch(rcx_ctx*, const rcx_batch*);
 int rcx_mtf_decode_batch(rcx_ctx*, const rcx_batch*);
@@ -223,7 +229,7 @@ enum rcx_codec {
     RCX_DC_ENCODE, RCX_DC_DECODE, RCX_ARI_BYTE_ENCODE, RCX_ARI_BYTE_DECODE,
     RCX_RLE_ENCODE, RCX_RLE_DECODE, RCX_CRC32, RCX_GZIP_DECODE,
     RCX_ARI_BINARY_ENCODE, RCX_ARI_BINARY_DECODE, RCX_ARI_PROXY_ENCODE, RCX_ARI_PROXY_DECODE,
-    RCX_ARI_APM_ENCODE, RCX_ARI_APM_DECODE, RCX_CODEC_COUNT
+    RCX_ARI_APM_ENCODE, RCX_ARI_APM_DECODE, RCX_BWT_INVERSE_MINIMAL, RCX_CODEC_COUNT
 };
 /* scratch bytes (HBM) the codec needs for nblocks blocks of <= max_block bytes.  Required for LZ4 encode, BWT and gzip
  * decode; for RCX_INFLATE / RCX_ZLIB_DECODE it is what the default (wave-per-stream) decoder needs -- without it

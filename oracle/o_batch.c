@@ -40,6 +40,10 @@ static void run_one(job_t* j, uint32_t i)
         if (cap < n) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
         if (n == 0) { olen = 0; break; }
         st = o_bwt_decode(in, n, j->aux ? j->aux[i] : 0, out); olen = n; break;
+    case RCX_BWT_INVERSE_MINIMAL: {
+        const uint32_t origin = j->aux ? j->aux[i] : 0;
+        if (cap < n && origin < n) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
+        st = o_bwt_decode_minimal(in, n, origin, out); olen = st ? 0 : n; break; }
     case RCX_MTF_ENCODE: if (cap < n) { st = RCX_E_OUTPUT_TOO_SMALL; break; } o_mtf_encode(in, n, out); olen = n; break;
     case RCX_MTF_DECODE: if (cap < n) { st = RCX_E_OUTPUT_TOO_SMALL; break; } o_mtf_decode(in, n, out); olen = n; break;
     case RCX_DC_ENCODE: {

@@ -68,8 +68,9 @@ impl<W: Write> Write for Encoder<W> {
     }
 }
 
-/// bwt/mod.rs:321-432.  `extra_mem = false` selects the reference's `decode_minimal` (:298-315), which is wrong for general
-/// input; the flag is accepted for source compatibility and both settings decode correctly here.
+/// bwt/mod.rs:321-432.  `extra_mem = false` selects the reference's `decode_minimal` (:298-315, called at :397-399), which is not
+/// the inverse of the encoder in general; it is reproduced as the reference computes it
+/// (`rcx_bwt_inverse_minimal_batch`), so this type returns what the reference's returns for either setting.
 pub struct Decoder<R: Read> {
     pub r: TailReader<R>,
     buf: Buffered,
@@ -86,6 +87,7 @@ impl<R: Read> Decoder<R> {
 impl<R: Read> Read for Decoder<R> {
     fn read(&mut self, dst: &mut [u8]) -> io::Result<usize> {
         let mbs = &mut self.max_block_size;
+        let extra = self.extra_memory;
         self.buf.ensure(&mut self.r, |d| {
             let n = d.len();
             let mut p = 0usize;
@@ -109,14 +111,17 @@ impl<R: Read> Read for Decoder<R> {
                 }
                 origins.push(le32(&d[p..]));
                 p += 4;
-                assert!(bn != 0, "index out of bounds"); // input[origin] panics (:230)
+                assert!(bn != 0 || !extra, "index out of bounds"); // input[origin] panics (:230); decode_minimal asserts origin == 0 (:300-302)
                 ls.push(l);
             }
             if ls.is_empty() {
                 return Ok((Vec::new(), None));
             }
             let caps: Vec<u64> = ls.iter().map(|l| l.len() as u64).collect();
-            let r = run_batch(&ls, &caps, |c, b, _| unsafe { rcx_bwt_inverse_batch(c, b, origins.as_ptr()) }).check()?;
+            let r = run_batch(&ls, &caps, |c, b, _| unsafe {
+                if extra { rcx_bwt_inverse_batch(c, b, origins.as_ptr()) } else { rcx_bwt_inverse_minimal_batch(c, b, origins.as_ptr()) }
+            })
+            .check()?;
             Ok((r.out.concat(), None)) // the format runs to the reader's end
         })?;
         Ok(self.buf.serve(dst))

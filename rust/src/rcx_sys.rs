@@ -102,7 +102,8 @@ pub const RCX_ARI_PROXY_ENCODE: c_int = 19;
 pub const RCX_ARI_PROXY_DECODE: c_int = 20;
 pub const RCX_ARI_APM_ENCODE: c_int = 21;
 pub const RCX_ARI_APM_DECODE: c_int = 22;
-pub const RCX_CODEC_COUNT: c_int = 23;
+pub const RCX_BWT_INVERSE_MINIMAL: c_int = 23;
+pub const RCX_CODEC_COUNT: c_int = 24;
 
 #[link(name = "rcx")]
 extern "C" {
@@ -126,6 +127,7 @@ extern "C" {
     // ---- BWT / MTF / DC (src/bwt/mod.rs, mtf.rs, dc.rs)
     pub fn rcx_bwt_forward_batch(ctx: *mut rcx_ctx, b: *const rcx_batch, origin: *mut u32) -> c_int;
     pub fn rcx_bwt_inverse_batch(ctx: *mut rcx_ctx, b: *const rcx_batch, origin: *const u32) -> c_int;
+    pub fn rcx_bwt_inverse_minimal_batch(ctx: *mut rcx_ctx, b: *const rcx_batch, origin: *const u32) -> c_int;
     pub fn rcx_mtf_encode_batch(ctx: *mut rcx_ctx, b: *const rcx_batch) -> c_int;
     pub fn rcx_mtf_decode_batch(ctx: *mut rcx_ctx, b: *const rcx_batch) -> c_int;
     pub fn rcx_dc_encode_batch(ctx: *mut rcx_ctx, b: *const rcx_batch) -> c_int;

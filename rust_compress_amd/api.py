@@ -125,6 +125,10 @@ class Context:
     def bwt_inverse(self, blobs, origins):
         return self._run_host("rcx_bwt_inverse_batch", blobs, [len(b) for b in blobs], extra_in=origins)
 
+    def bwt_inverse_minimal(self, blobs, origins):
+        """The reference's decode_minimal (src/bwt/mod.rs:298-315), reproduced as it computes -- not the inverse of bwt_forward in general."""
+        return self._run_host("rcx_bwt_inverse_minimal_batch", blobs, [len(b) for b in blobs], extra_in=origins)
+
     def mtf_encode(self, blobs):
         return self._run_host("rcx_mtf_encode_batch", blobs, [len(b) for b in blobs])
 

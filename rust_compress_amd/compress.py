@@ -434,11 +434,12 @@ class bwt:
             self._buf.clear()
             return self.w
 
-    class Decoder(_BufferedDecoder):                   # bwt/mod.rs:321-432 (extra_mem = True path)
+    class Decoder(_BufferedDecoder):                   # bwt/mod.rs:321-432
         def __init__(self, r, extra_mem=True):
-            # extra_mem = False selects the reference's `decode_minimal` (bwt/mod.rs:298-315), an O(n^2) in-place inverse that is
-            # wrong for general input and unused by its own application (main.rs:90).  The GPU inverse always has
-            # its jump table in HBM, so the flag is accepted for source compatibility and decodes CORRECTLY either way.
+            # extra_mem = False selects the reference's `decode_minimal` (bwt/mod.rs:298-315, called at :397-399), which is NOT
+            # the inverse of the encoder in general and is unused by the reference's own application
+            # (main.rs:90).  It is reproduced as the reference computes it (rcx_bwt_inverse_minimal_batch): a drop-in returns
+            # what the reference returns.  Use extra_mem = True to get the text back.
             super().__init__(r)
             self.extra_memory = extra_mem
 
@@ -460,12 +461,13 @@ class bwt:
                     raise UnexpectedEof(1)
                 origins.append(struct.unpack_from("<I", data, p)[0])
                 p += 4
-                if bn == 0:
-                    raise Malformed(3)                 # input[origin] panics, :230
+                if bn == 0 and self.extra_memory:
+                    raise Malformed(3)                 # input[origin] panics, :230 (decode_minimal: only if origin != 0, :300-302)
                 Ls.append(L)
             if not Ls:
                 return b""
-            return b"".join(_check(context().bwt_inverse(Ls, origins)).outputs)
+            inv = context().bwt_inverse if self.extra_memory else context().bwt_inverse_minimal
+            return b"".join(_check(inv(Ls, origins)).outputs)
 
 
 # ------------------------------------------------------------------------------------------------ ari

@@ -34,7 +34,16 @@ static uint64_t bwt_inverse_scratch_bytes(uint32_t nblocks, uint64_t max_block)
 // so what counts is the LONGEST chain of a block (gaps between marked nodes are geometric: mean `stride`, maximum about
 // stride x ln(marked nodes)): 16384 marked nodes instead of 4096 cut it from ~530 to ~150 steps, and a thread keeps 8 chains in
 // flight and starts its next marked node the moment one of them ends.
-__global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint32_t block0, uint64_t table_stride, uint64_t table_bytes)
+//
+// MIN = true is the reference's OTHER inverse, decode_minimal (src/bwt/mod.rs:298-315): i = origin; n times { ch = L[i]; the text is
+// written BACKWARDS from its end; i = C[ch] + #{k < i : L[k] == ch} }.  That is a walk of n steps along the LF permutation
+// (table[i] = LF(i), a coalesced store here), with no special slot for origin -- which is why the reference's function returns a
+// wrong text whenever T[n-1] also occurs in L[..origin], and why the walk can close a cycle shorter than n (the output is then
+// periodic).  Both are reproduced: the marked-node list is cut where it returns to origin's node, ranked the same way, the parked
+// chains are copied in reverse, and a short cycle is replicated down the block.  The reference has no "not a BWT" check on this
+// path: every (L, origin < n) has an answer.
+template <bool MIN>
+__global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint32_t block0, uint64_t table_stride, uint64_t table_bytes, uint32_t capx)
 {
     __shared__ uint32_t s_rk[BWTI_MAXMARK + 16];      // walker's emissions, then (pointer jumping) emissions from this node to the chain's end
     __shared__ uint16_t s_next[BWTI_MAXMARK + 16];    // marked node -> next marked node id (or NONE16)
@@ -56,7 +65,8 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
     const bool packed = n < 0xffffffu;                        // index + 1 fits 24 bits: the entry also holds the byte
     if (n == 0 || a.out_cap[b] < n || origin >= n) {
         if (tid == 0) {
-            a.status[b] = n == 0 ? RCX_OK : (origin >= n ? RCX_E_MALFORMED : RCX_E_OUTPUT_TOO_SMALL);   // mod.rs:230 index panic
+            // mod.rs:230 index panic; decode_minimal: n == 0 is Ok only with origin == 0 (:300-302), `i >= n` is an error (:310)
+            a.status[b] = n == 0 ? ((MIN && origin != 0) ? RCX_E_MALFORMED : RCX_OK) : (origin >= n ? RCX_E_MALFORMED : RCX_E_OUTPUT_TOO_SMALL);
             a.out_len[b] = 0; if (a.in_used) a.in_used[b] = n;
         }
         return;
@@ -79,12 +89,12 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
     if (tid == 0) { uint32_t acc = 0; for (int c = 0; c < 256; c++) { const uint32_t t = s_tot[c]; s_tot[c] = acc; acc += t; } }
     __syncthreads();
     if (tid < 256) {
-        uint32_t acc = s_tot[tid] + (tid == osym ? 1u : 0u);      // slot 0 of osym is reserved for origin
+        uint32_t acc = s_tot[tid] + ((!MIN && tid == osym) ? 1u : 0u);      // slot 0 of osym is reserved for origin
         for (int ww = 0; ww < BWTI_WAVES; ww++) { const uint32_t t = s_cnt[ww][tid]; s_cnt[ww][tid] = acc; acc += t; }
     }
     __syncthreads();
     // the origin element itself was counted in its wave's slice: take it out of that slice's budget
-    if (tid == 0) {
+    if (!MIN && tid == 0) {
         table[s_tot[osym]] = packed ? (osym << 24) : 0u;          // table[place(L[origin])] = 0 (+ the byte there, see below)
         const uint32_t ow = origin / per;
         for (int ww = (int)ow + 1; ww < BWTI_WAVES; ww++) s_cnt[ww][osym] -= 1u;
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
     // ---- 2. stable scatter: 64 positions per step, rank among equal bytes by 8 ballots (mod.rs:231-236)
     for (uint32_t i0 = w0; i0 < w1; i0 += 64) {
         const uint32_t i = i0 + lane;
-        const bool valid = i < w1 && i != origin;
+        const bool valid = i < w1 && (MIN || i != origin);
         const uint32_t c = i < w1 ? L[i] : 0u;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -108,7 +118,8 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
         if (valid) {
             // the entry carries the byte the walker will emit from there (L[i]) in its top 8 bits when the block is shorter
             // than 2^24: the chase then costs ONE random load per step instead of two (the kernel is bound by random accesses)
-            table[basec + before] = packed ? (i + 1u) | (c << 24) : i + 1u;
+            if (MIN) table[i] = packed ? (basec + before) | (c << 24) : basec + before;   // LF(i), and the byte emitted AT i
+            else table[basec + before] = packed ? (i + 1u) | (c << 24) : i + 1u;
             if (before == 0) s_cnt[w][c] = basec + (uint32_t)__popcll(peers);   // group leader advances the counter
         }
         rcx_wave_sync();
@@ -124,7 +135,9 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
     const uint32_t NONE = 0xffffffffu, NONE16 = 0xffffu;
     // First chase: a walker also parks the bytes it emits (up to `cap`, 16 times the mean chain length); once the marked
     // nodes are ranked, a parked chain is COPIED to its place -- only a chain longer than `cap` is chased a second time.
-    const uint32_t cap = (uint32_t)bwti_cap(stride);
+    // (`capx` < BWTI_CAPX is the test knob, variant 1: it parks less, so that second chases happen on ordinary inputs)
+    const uint32_t pitch = (uint32_t)bwti_cap(stride);
+    const uint32_t cap = capx >= BWTI_CAPX ? pitch : (((capx * stride + 7u) & ~7u) < pitch ? ((capx * stride + 7u) & ~7u) : pitch);
     // a thread owns the marked nodes tid, tid + 1024, ...; it chases BWTI_SLOTS of them at once and refills a slot when its chain ends
     for (int pass = 0; pass < 2; pass++) {
         uint32_t cur[BWTI_SLOTS], cnt[BWTI_SLOTS], wr[BWTI_SLOTS], mid[BWTI_SLOTS]; bool live[BWTI_SLOTS];
@@ -134,8 +147,18 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
             live[q] = false; wr[q] = NONE; cnt[q] = 0; cur[q] = 0; mid[q] = 0; pk[q] = 0;
             while (nextm < M) {
                 const uint32_t m = nextm; nextm += BWTI_THREADS;
+                if (MIN && pass == 1 && s_next[m] != NONE16) continue;    // not on origin's cycle: the walk never comes here
+                if (MIN && pass == 1 && s_len[m] <= cap) {                // step j of the walk writes out[n - 1 - j] (mod.rs:312)
+                    const uint8_t* src = park + (size_t)m * pitch;
+                    const uint32_t len = s_len[m];
+                    uint8_t* dst = out + (n - 1u - (s_tot[0] - s_rk[m]));
+                    uint32_t t = 0;
+                    for (; t + 8 <= len; t += 8) *(rcx_u64_u*)(dst - t - 7) = __builtin_bswap64(*(const uint64_t*)(src + t));
+                    for (; t < len; t++) *(dst - t) = src[t];
+                    continue;
+                }
                 if (pass == 1 && s_len[m] <= cap) {                       // parked on the first chase: copy, no second chase
-                    const uint8_t* src = park + (size_t)m * cap;
+                    const uint8_t* src = park + (size_t)m * pitch;
                     const uint32_t len = s_len[m], dstp = n - s_rk[m];
                     uint32_t t = 0;
                     for (; t + 16 <= len && dstp + t + 16 <= n; t += 16)          // park slots are 16-byte aligned, `out` need not be
@@ -144,7 +167,7 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
                     continue;
                 }
                 live[q] = true; mid[q] = m; cur[q] = m < M0 ? m * stride : origin;
-                if (pass == 1) wr[q] = n - s_rk[m];
+                if (pass == 1) wr[q] = MIN ? s_tot[0] - s_rk[m] : n - s_rk[m];
                 break;
             }
         };
@@ -160,7 +183,12 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
             for (int q = 0; q < BWTI_SLOTS; q++) v[q] = live[q] ? table[cur[q]] : 0u;    // the jump-table loads, all in flight
 #pragma unroll
             for (int q = 0; q < BWTI_SLOTS; q++) {
-                if (packed) { ch[q] = (uint8_t)(v[q] >> 24); v[q] &= 0xffffffu; c2[q] = v[q] ? v[q] - 1u : origin; }
+                if (MIN) {                                                // the entry AT cur: LF(cur) and (packed) L[cur]
+                    if (packed) { ch[q] = (uint8_t)(v[q] >> 24); c2[q] = v[q] & 0xffffffu; }
+                    else { c2[q] = v[q]; ch[q] = live[q] ? L[cur[q]] : (uint8_t)0; }
+                    v[q] = 1u;                                            // no wrap slot on this path
+                }
+                else if (packed) { ch[q] = (uint8_t)(v[q] >> 24); v[q] &= 0xffffffu; c2[q] = v[q] ? v[q] - 1u : origin; }
                 else { c2[q] = v[q] ? v[q] - 1u : origin; ch[q] = live[q] ? L[c2[q]] : (uint8_t)0; }
             }
 #pragma unroll
@@ -175,12 +203,12 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
                     if (mk) nxt = (c2[q] == origin && !origin_marked) ? M0 : c2[q] / stride;
                     cur[q] = c2[q];
                 }
-                if (pass == 1) { if (wr[q] + cnt[q] < n) out[wr[q] + cnt[q]] = ch[q]; }
+                if (pass == 1) { if (wr[q] + cnt[q] < n) out[MIN ? n - 1u - (wr[q] + cnt[q]) : wr[q] + cnt[q]] = ch[q]; }
                 else {
                     // a byte store per step kept ~260 K partial-line writes per block on their way to HBM (the lines leave the L2
                     // long before a walker comes back to them): 8 bytes per store
                     pk[q] |= (uint64_t)ch[q] << (8u * (cnt[q] & 7u));
-                    if (((cnt[q] & 7u) == 7u || stop) && (cnt[q] & ~7u) < cap) { *(uint64_t*)(park + (size_t)mid[q] * cap + (cnt[q] & ~7u)) = pk[q]; pk[q] = 0; }
+                    if (((cnt[q] & 7u) == 7u || stop) && (cnt[q] & ~7u) < cap) { *(uint64_t*)(park + (size_t)mid[q] * pitch + (cnt[q] & ~7u)) = pk[q]; pk[q] = 0; }
                 }
                 cnt[q]++;
                 if (stop) {
@@ -193,6 +221,11 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
         if (pass == 0) {
             // rank the marked nodes: pointer jumping, s_rk[m] becomes the number of bytes emitted from m to the end of its chain
             constexpr int PER = (BWTI_MAXMARK + 1 + BWTI_THREADS - 1) / BWTI_THREADS;
+            const uint32_t mstart = origin_marked ? origin / stride : M0;
+            if (MIN) {                                                    // LF is a permutation: the list from origin's node comes back to it; cut it there
+                for (uint32_t m = tid; m < M; m += BWTI_THREADS) if (s_next[m] == mstart) s_next[m] = (uint16_t)NONE16;
+                __syncthreads();
+            }
             for (uint32_t span = 1; span < M; span <<= 1) {
                 uint32_t add[PER]; uint16_t nn[PER];
 #pragma unroll
@@ -210,11 +243,24 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
                 __syncthreads();
             }
             if (tid == 0) {                                               // origin's chain must end (no loop) and cover the block: else not a BWT
-                const uint32_t m = origin_marked ? origin / stride : M0;
-                s_ok = (s_next[m] == NONE16 && s_rk[m] == n) ? 1u : 0u;
+                const uint32_t m = mstart;
+                s_ok = (MIN || (s_next[m] == NONE16 && s_rk[m] == n)) ? 1u : 0u;
+                if (MIN) s_tot[0] = s_rk[m];                              // steps until the walk is back at origin
             }
             __syncthreads();
             if (!s_ok) break;
+        }
+    }
+    if (MIN) {
+        // a cycle of c < n steps: step j >= c repeats step j - c (mod.rs:309-314 just keeps walking).  Doubling copies down the block.
+        __threadfence_block();
+        __syncthreads();
+        for (uint32_t have = s_tot[0]; have < n;) {
+            const uint32_t cp = have < n - have ? have : n - have;
+            for (uint32_t t = tid; t < cp; t += BWTI_THREADS) out[n - 1u - (have + t)] = out[n - 1u - t];
+            have += cp;
+            __threadfence_block();
+            __syncthreads();
         }
     }
     if (tid == 0) {
@@ -225,9 +271,9 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
     }
 }
 
-static int launch_bwt_inverse(hipStream_t s, rcx_kargs& k, int variant, std::string& err)
+static int launch_bwt_inverse(hipStream_t s, rcx_kargs& k, int variant, std::string& err, bool minimal = false)
 {
-    (void)variant;
+    const uint32_t capx = variant == 1 ? 1u : BWTI_CAPX;
     const uint32_t nb = k.nblocks;
     std::vector<uint64_t> h_len(nb);
     if (hipMemcpyAsync(h_len.data(), k.in_len, nb * 8ull, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -240,7 +286,8 @@ static int launch_bwt_inverse(hipStream_t s, rcx_kargs& k, int variant, std::str
     if ((uint64_t)chunk * stride > k.scratch_bytes) { err = "bwt inverse: scratch too small"; return RCX_RC_BAD_ARG; }
     for (uint32_t b0 = 0; b0 < nb; b0 += BWTI_CHUNK) {
         const uint32_t cnt = nb - b0 < BWTI_CHUNK ? nb - b0 : BWTI_CHUNK;
-        hipLaunchKernelGGL(k_bwt_inverse, dim3(cnt), dim3(BWTI_THREADS), 0, s, k, b0, stride, tbytes);
+        if (minimal) hipLaunchKernelGGL(k_bwt_inverse<true>, dim3(cnt), dim3(BWTI_THREADS), 0, s, k, b0, stride, tbytes, capx);
+        else hipLaunchKernelGGL(k_bwt_inverse<false>, dim3(cnt), dim3(BWTI_THREADS), 0, s, k, b0, stride, tbytes, capx);
     }
     return RCX_RC_OK;
 }

@@ -138,7 +138,7 @@ extern "C" uint64_t rcx_scratch_bytes(int codec, uint32_t nblocks, uint64_t max_
     switch (codec) {
     case RCX_LZ4_ENCODE: return rcx_tu_lz4_encode_scratch(nblocks);
     case RCX_BWT_FORWARD: return rcx_tu_bwt_forward_scratch(nblocks, max_block);
-    case RCX_BWT_INVERSE: return rcx_tu_bwt_inverse_scratch(nblocks, max_block);
+    case RCX_BWT_INVERSE: case RCX_BWT_INVERSE_MINIMAL: return rcx_tu_bwt_inverse_scratch(nblocks, max_block);
     case RCX_INFLATE: case RCX_ZLIB_DECODE: return rcx_tu_inflate_scratch(nblocks);
     case RCX_GZIP_DECODE: return rcx_tu_gzip_scratch(nblocks) + rcx_tu_inflate_scratch(nblocks) + 512;   // + the carve's alignment slack
     default: return 0;
@@ -179,8 +179,8 @@ static int launch_codec(rcx_ctx* c, int codec, rcx_kargs& k)
         int rc = rcx_tu_bwt_forward(s, k, v, c->err);
         if (rc) return rc;
         break; }
-    case RCX_BWT_INVERSE: {
-        int rc = rcx_tu_bwt_inverse(s, k, v, c->err);
+    case RCX_BWT_INVERSE: case RCX_BWT_INVERSE_MINIMAL: {
+        int rc = rcx_tu_bwt_inverse(s, k, v, c->err, codec == RCX_BWT_INVERSE_MINIMAL);
         if (rc) return rc;
         break; }
     case RCX_ARI_APM_ENCODE: case RCX_ARI_APM_DECODE: {
@@ -334,6 +334,7 @@ extern "C" int rcx_crc32_batch(rcx_ctx* c, const rcx_batch* b, uint32_t* crc) { 
 extern "C" int rcx_gzip_decode_batch(rcx_ctx* c, const rcx_batch* b, uint32_t* flags) { return run_batch(c, RCX_GZIP_DECODE, b, nullptr, flags, nullptr, true); }
 extern "C" int rcx_bwt_forward_batch(rcx_ctx* c, const rcx_batch* b, uint32_t* origin) { return run_batch(c, RCX_BWT_FORWARD, b, nullptr, origin, nullptr, true); }
 extern "C" int rcx_bwt_inverse_batch(rcx_ctx* c, const rcx_batch* b, const uint32_t* origin) { return run_batch(c, RCX_BWT_INVERSE, b, origin, nullptr, nullptr, true); }
+extern "C" int rcx_bwt_inverse_minimal_batch(rcx_ctx* c, const rcx_batch* b, const uint32_t* origin) { return run_batch(c, RCX_BWT_INVERSE_MINIMAL, b, origin, nullptr, nullptr, true); }
 extern "C" int rcx_mtf_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_MTF_ENCODE, b, nullptr, nullptr, nullptr, true); }
 extern "C" int rcx_mtf_decode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_MTF_DECODE, b, nullptr, nullptr, nullptr, true); }
 extern "C" int rcx_dc_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_DC_ENCODE, b, nullptr, nullptr, nullptr, true); }

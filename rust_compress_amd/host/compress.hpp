@@ -373,12 +373,14 @@ public:
             Ls.emplace_back(d.begin() + p, d.begin() + p + bn); p += bn;
             if (n - p < 4) raise_status(RCX_E_EOF);
             origins.push_back(le32(&d[p])); p += 4;
-            if (bn == 0) raise_status(RCX_E_MALFORMED);                               // :230 panic
+            if (bn == 0 && extra_memory) raise_status(RCX_E_MALFORMED);               // :230 panic (decode_minimal: only if origin != 0, :300-302)
             caps.push_back(bn);
         }
         std::vector<uint8_t> out;
         if (Ls.empty()) return out;
-        auto r = run_batch(Ls, caps, [&](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_bwt_inverse_batch(c, b, origins.data()); });
+        // extra_mem = false is the reference's decode_minimal (:298-315, :397-399), reproduced as it computes (not an inverse in general)
+        auto r = run_batch(Ls, caps, [&](rcx_ctx* c, rcx_batch* b, uint32_t*) {
+            return extra_memory ? rcx_bwt_inverse_batch(c, b, origins.data()) : rcx_bwt_inverse_minimal_batch(c, b, origins.data()); });
         check(r);
         for (auto& o : r.out) out.insert(out.end(), o.begin(), o.end());
         return out;

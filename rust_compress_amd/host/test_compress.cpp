@@ -4,6 +4,7 @@
 //   g++ -std=c++17 test_compress.cpp -L../csrc -lrcx -Wl,-rpath,../csrc -o test_compress && ./test_compress <golden dir>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <random>
 #include "compress.hpp"
@@ -79,6 +80,14 @@ int main(int argc, char** argv)
         CHECK(bwt::mtf::decode(bwt::mtf::encode(data)) == data);
     }
     { auto e = bwt::encode_simple(B("abracadabra")); CHECK(e.first == B("rdarcaaaabb") && e.second == 2); }
+    for (const char* s : {"abracadabra", "banana", "test"}) {                         // extra_mem = false: decode_minimal, bwt/mod.rs:298-315, 549-551
+        bwt::Encoder<VecWriter> e(VecWriter(), 64);
+        e.write((const uint8_t*)s, strlen(s));
+        VecWriter w = e.finish();
+        bwt::Decoder<SliceReader> d(SliceReader(w.v), false);
+        const bool same = d.read_to_end() == B(s);
+        CHECK(same == (std::string(s) != "test"));                                    // the reference's function is not an inverse on "test" 
+    }
     for (const Bytes& data : {B("teeesst_dc"), B(""), txt}) {
         auto d = bwt::dc::encode_simple(data);
         CHECK(bwt::dc::decode_simple(data.size(), d) == data);

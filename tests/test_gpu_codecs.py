@@ -71,6 +71,34 @@ def test_bwt_forward_and_inverse(ctx, oracle):
     assert bad.status[0] == 3
 
 
+def test_bwt_inverse_minimal(ctx, oracle):
+    """decode_minimal (src/bwt/mod.rs:298-315), what bwt::Decoder runs with extra_mem = false: the reference's answer, which is
+    the text for some inputs ("abracadabra", its only test :549-551) and not for others ("test": SURVEY.md A.4)."""
+    from rust_compress_amd import synth
+    rng = np.random.default_rng(11)
+    raws = [b"abracadabra", b"banana", b"test", b"bab", b"some text"] + corpus.small_corpus(sizes=(17, 1000, 20000), with_empty=False)
+    raws += [synth.gen("text", 100000, 3).tobytes(), synth.gen("dna4", 70000, 4).tobytes()]         # stride 7 and 5: parked chains, reversed copies
+    pairs = [oracle.bwt_encode(r) for r in raws]
+    for n, alpha in ((1, 2), (2, 2), (9, 2), (64, 3), (1000, 4), (20000, 256), (40000, 7), (60000, 2)):   # not a BWT: short cycles, periodic output
+        L = rng.integers(0, alpha, n, dtype=np.uint8).tobytes()
+        pairs += [(L, int(rng.integers(0, n))), (L, n - 1), (L, 0)]
+    pairs += [(b"abc", 3), (b"abc", 7), (b"", 0), (b"", 1)]              # origin >= n is an error; n == 0 is Ok only with origin 0 (:300-302)
+    Ls, orgs = zip(*pairs)
+    exp = []
+    for L, og in pairs:
+        try:
+            exp.append((0, oracle.bwt_decode(L, og, minimal=True)))
+        except Exception as e:                                            # oracle_py.OracleError
+            exp.append((e.status, b""))
+    for variant in (0, 1):                                                # 1: park 8 bytes per walker at most, the rest by second chases
+        ctx.set_variant(N.BWT_INVERSE_MINIMAL, variant)
+        res = ctx.bwt_inverse_minimal(list(Ls), list(orgs))
+        for i, (est, eout) in enumerate(exp):
+            assert int(res.status[i]) == est and (est or res.outputs[i] == eout), (variant, i, len(Ls[i]), orgs[i])
+    ctx.set_variant(N.BWT_INVERSE_MINIMAL, 0)
+    assert exp[0][1] == raws[0] and exp[2][1] != raws[2]                  # the reference's function: right on its own test, wrong on "test"
+
+
 def test_bwt_forward_key_layouts(ctx, oracle):
     """The first sort key adapts to the batch (alphabet compaction, symbols per key) and big batches are sorted 1024 blocks
     at a time: every layout must give the reference's (L, origin)."""

@@ -189,10 +189,18 @@ def test_readers_are_left_exactly_after_the_stream(golden, oracle):
     assert C.gzip.Decoder(io.BytesIO(g)).read_to_end() == txt
 
 
-def test_bwt_decoder_extra_mem_flag(golden):
-    """`extra_mem = false` selects the reference's decode_minimal (bwt/mod.rs:298-315), which is wrong for general input; the flag is
-    accepted and both settings decode correctly here."""
+def test_bwt_decoder_extra_mem_flag(golden, oracle):
+    """`extra_mem = false` selects the reference's decode_minimal (bwt/mod.rs:298-315, :397-399), which is not an inverse in
+    general: the decoder returns what the reference's returns, block for block."""
+    import struct
     txt = golden("test.txt")
     w = io.BytesIO(); e = C.bwt.Encoder(w, 1 << 10); e.write(txt); e.finish()
-    for flag in (True, False):
-        assert C.bwt.Decoder(io.BytesIO(w.getvalue()), extra_mem=flag).read_to_end() == txt
+    assert C.bwt.Decoder(io.BytesIO(w.getvalue()), extra_mem=True).read_to_end() == txt
+    want = b"".join(oracle.bwt_decode(*oracle.bwt_encode(txt[i:i + 1024]), minimal=True) for i in range(0, len(txt), 1024))
+    assert C.bwt.Decoder(io.BytesIO(w.getvalue()), extra_mem=False).read_to_end() == want
+    w = io.BytesIO(); e = C.bwt.Encoder(w, 64); e.write(b"abracadabra"); e.finish()            # the reference's own case, :549-551
+    assert C.bwt.Decoder(io.BytesIO(w.getvalue()), extra_mem=False).read_to_end() == b"abracadabra"
+    empty = struct.pack("<III", 16, 0, 0)                                                       # an empty block: :230 panics, :300-302 does not
+    assert C.bwt.Decoder(io.BytesIO(empty), extra_mem=False).read_to_end() == b""
+    with pytest.raises(C.Malformed):
+        C.bwt.Decoder(io.BytesIO(empty), extra_mem=True).read_to_end()

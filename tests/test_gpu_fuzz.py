@@ -25,6 +25,7 @@ def test_dc_decode_fuzz(ctx):
 def test_bwt_inverse_fuzz(ctx):
     import fuzz_gpu_bwti
     assert fuzz_gpu_bwti.main(2000, 6, ctx) == 0
+    assert fuzz_gpu_bwti.main(1200, 7, ctx, minimal=True) == 0          # decode_minimal, src/bwt/mod.rs:298-315
 
 
 @pytest.mark.gpu

@@ -160,6 +160,37 @@ def test_bwt_inverse(oracle):
     outs, _, _, st, _ = simrun.run(N.BWT_INVERSE, 0, list(Ls), [len(r) for r in raws], aux=np.array(orgs, dtype=np.uint32),
                                    scratch_bytes=len(raws) * (24 * maxn + 70000) + 256)     # jump table (4n) + parked first-chase bytes (16n + slack)
     assert not st.any() and outs == raws
+    # variant 1 parks at most 8 bytes per walker, so most chains of the larger blocks take the second chase
+    outs, _, _, st, _ = simrun.run(N.BWT_INVERSE, 1, list(Ls), [len(r) for r in raws], aux=np.array(orgs, dtype=np.uint32),
+                                   scratch_bytes=len(raws) * (24 * maxn + 70000) + 256)
+    assert not st.any() and outs == raws
+
+
+def test_bwt_inverse_minimal(oracle):
+    """decode_minimal (src/bwt/mod.rs:298-315) as the reference computes it: on real BWT outputs (where it is sometimes not the
+    inverse), and on arbitrary (L, origin) pairs, where the LF walk closes cycles shorter than n and the output is periodic."""
+    import simrun
+    rng = np.random.default_rng(5)
+    raws = corpus.small_corpus(sizes=(17, 1000, 20000), with_empty=False) + [b"abracadabra", b"test", b"bab", b"some text", b"banana"]
+    pairs = [oracle.bwt_encode(r) for r in raws]
+    for n, alpha in ((1, 2), (2, 2), (9, 2), (64, 3), (1000, 4), (5000, 256), (20000, 2), (20000, 256), (40000, 7)):
+        L = rng.integers(0, alpha, n, dtype=np.uint8).tobytes()
+        pairs += [(L, int(rng.integers(0, n))), (L, n - 1), (L, 0)]
+    pairs += [(b"abc", 3), (b"abc", 7), (b"", 0), (b"", 1)]              # origin >= n -> error; n == 0 is Ok only with origin 0
+    Ls, orgs = zip(*pairs)
+    maxn = max(len(L) for L in Ls)
+    wrong = 0
+    for variant in (0, 1):                                                # 1: park at most 8 bytes per walker (second chases)
+        outs, olen, _, st, _ = simrun.run(N.BWT_INVERSE_MINIMAL, variant, list(Ls), [len(L) for L in Ls], aux=np.array(orgs, dtype=np.uint32),
+                                          scratch_bytes=len(Ls) * (24 * maxn + 70000) + 256)
+        for i, (L, og) in enumerate(pairs):
+            try:
+                exp, est = oracle.bwt_decode(L, og, minimal=True), 0
+            except Exception as e:                                        # oracle_py.OracleError
+                exp, est = b"", e.status
+            assert int(st[i]) == est and (est or outs[i] == exp), (variant, i, len(L), og)
+            wrong += i < len(raws) and exp != raws[i]
+    assert wrong >= 2                                                     # "test", "bab", "some text": the reference's function is not an inverse there
 
 
 def test_bwt_forward(oracle):
