@@ -245,8 +245,12 @@ __global__ void k_bwtf_finish(rcx_kargs a)
 static inline uint32_t bits_for(uint64_t v) { uint32_t b = 1; while ((1ull << b) <= v && b < 63) b++; return b; }
 
 // Suffixes per sorting pass: a suffix index shares its SA word with three flags, so a pass takes < 2^28 suffixes (1024 blocks of
-// 256 KiB); larger batches are sorted pass after pass.
+// 256 KiB); larger batches are sorted pass after pass.  A pass of 2^27 suffixes is the default: the random accesses of a round
+// then range over half the address space, which is worth more than the second pass's fixed cost (~1.7 ms of launches and counter
+// reads): 1024 x 256 KiB take 38.5 instead of 39.1 ms (text), 18.4 instead of 20.6 ms (DNA); 2^26 is slower again
+// (benchmarks/bwt_pass_size.py).  A single block may still use the whole range.
 #define BWTF_MAXN 0x0fffffffu
+#define BWTF_PASSN 0x08000000u
 
 static uint64_t bwt_forward_scratch_bytes(uint32_t nblocks, uint64_t max_block)
 {
@@ -258,7 +262,7 @@ static uint64_t bwt_forward_scratch_bytes(uint32_t nblocks, uint64_t max_block)
 
 static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::string& err)
 {
-    (void)variant;
+    const uint32_t pass_blocks = variant > 0 ? (uint32_t)variant : 0xffffffffu;      // A/B knob: at most `variant` blocks per sorting pass
     const uint32_t nb_all = k.nblocks;
     std::vector<uint64_t> h_len(nb_all);
     if (nb_all && (hipMemcpyAsync(h_len.data(), k.in_len, nb_all * 8ull, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -266,7 +270,7 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
     for (uint32_t lo = 0; lo < nb_all;) {
         // the next pass: as many blocks as stay below BWTF_MAXN suffixes
         uint32_t nb = 0; uint64_t N64 = 0, maxn = 0;
-        while (lo + nb < nb_all && N64 + h_len[lo + nb] <= (uint64_t)BWTF_MAXN) { N64 += h_len[lo + nb]; if (h_len[lo + nb] > maxn) maxn = h_len[lo + nb]; nb++; }
+        while (lo + nb < nb_all && nb < pass_blocks && N64 + h_len[lo + nb] <= (uint64_t)(nb ? BWTF_PASSN : BWTF_MAXN)) { N64 += h_len[lo + nb]; if (h_len[lo + nb] > maxn) maxn = h_len[lo + nb]; nb++; }
         if (nb == 0) { err = "bwt forward: a block of 2^28 bytes or more"; return RCX_RC_BAD_ARG; }
         rcx_kargs kk = k;
         kk.in_off += lo; kk.in_len += lo; kk.out_off += lo; kk.out_cap += lo; kk.out_len += lo; kk.status += lo;

@@ -116,7 +116,10 @@ def test_bwt_forward_key_layouts(ctx, oracle):
     check([bytes(rng.integers(0, 255, 40000, dtype=np.uint8))])                                           # 255 symbols, high entropy: plain bytes
     check([bytes(rng.choice(200, 30000, p=np.r_[[0.5], np.full(199, 0.5 / 199)]).astype(np.uint8))])      # 200 symbols, 8-bit codes
     small = [synth.gen(("text", "runs", "dna4", "rand")[i % 4], int(rng.integers(1, 400)), 100 + i).tobytes() for i in range(2500)]
-    check(small)                                                                                          # > 1024 blocks: three passes
+    ctx.set_variant(N.BWT_FORWARD, 700)                                                                   # at most 700 blocks per sorting pass: four passes
+    check(small)
+    ctx.set_variant(N.BWT_FORWARD, 0)
+    check(small)
 
 
 def test_mtf_dc_ari_rle(ctx, oracle):
