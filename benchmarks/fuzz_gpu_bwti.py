@@ -10,7 +10,7 @@ from rust_compress_amd import _native as N, synth, batch as B
 import oracle_py as O
 
 
-def main(count=6000, seed=4, ctx=None, minimal=False):
+def main(count=6000, seed=4, ctx=None, minimal=False, variant=0):
     """minimal: the reference's decode_minimal (src/bwt/mod.rs:298-315) instead -- every pair with origin < n has an answer there,
     mostly a periodic one (the walk closes a short cycle); the oracle's restatement is O(n^2), so the blocks are smaller."""
     rng = np.random.default_rng(seed)
@@ -35,7 +35,9 @@ def main(count=6000, seed=4, ctx=None, minimal=False):
     out = np.zeros(total + 64, np.uint8)
     aux = np.asarray(origins, np.uint32)
     _, olen, used, st = O.batch_run(N.BWT_INVERSE_MINIMAL if minimal else N.BWT_INVERSE, base, off, lens, out, ooff, ocap, aux=aux.copy(), threads=64)
+    ctx.set_variant(N.BWT_INVERSE_MINIMAL if minimal else N.BWT_INVERSE, variant)       # bit 0: short parking, bit 1: the scattered-table kernel
     res = ctx.bwt_inverse_minimal(Ls, origins) if minimal else ctx.bwt_inverse(Ls, origins)
+    ctx.set_variant(N.BWT_INVERSE_MINIMAL if minimal else N.BWT_INVERSE, 0)
     bad = 0
     for i in range(len(Ls)):
         ok = int(res.status[i]) == int(st[i])
@@ -50,4 +52,4 @@ def main(count=6000, seed=4, ctx=None, minimal=False):
 
 if __name__ == "__main__":
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-    sys.exit(1 if main(6000, seed) + main(3000, seed + 1, minimal=True) else 0)
+    sys.exit(1 if main(6000, seed) + main(3000, seed + 2, variant=1) + main(3000, seed + 3, variant=2) + main(3000, seed + 1, minimal=True) else 0)

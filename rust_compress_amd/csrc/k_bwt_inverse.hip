@@ -35,16 +35,23 @@ static uint64_t bwt_inverse_scratch_bytes(uint32_t nblocks, uint64_t max_block)
 // stride x ln(marked nodes)): 16384 marked nodes instead of 4096 cut it from ~530 to ~150 steps, and a thread keeps 8 chains in
 // flight and starts its next marked node the moment one of them ends.
 //
-// MIN = true is the reference's OTHER inverse, decode_minimal (src/bwt/mod.rs:298-315): i = origin; n times { ch = L[i]; the text is
+// MODE 1 (MIN) is the reference's OTHER inverse, decode_minimal (src/bwt/mod.rs:298-315): i = origin; n times { ch = L[i]; the text is
 // written BACKWARDS from its end; i = C[ch] + #{k < i : L[k] == ch} }.  That is a walk of n steps along the LF permutation
 // (table[i] = LF(i), a coalesced store here), with no special slot for origin -- which is why the reference's function returns a
 // wrong text whenever T[n-1] also occurs in L[..origin], and why the walk can close a cycle shorter than n (the output is then
 // periodic).  Both are reproduced: the marked-node list is cut where it returns to origin's node, ranked the same way, the parked
 // chains are copied in reverse, and a short cycle is replicated down the block.  The reference has no "not a BWT" check on this
 // path: every (L, origin < n) has an answer.
-template <bool MIN>
+//
+// MODE 2 is the table inverse again, computed along the same backward walk: the jump table is the inverse of the permutation
+// place(i) = slot of L[i] in the reference's placement order (origin first in its symbol), so the chain origin -> table[origin]-1 -> ...
+// read backwards is y_0 = origin, y_{j+1} = place(y_j), with out[n-1-j] = L[y_j]; origin has no predecessor in the table, so the
+// reference's chain always ends at the wrap slot, and "it covers the block" is "the cycle of place through origin has length n".
+// place(i) is stored at i -- coalesced, where MODE 0 scatters 4-byte entries -- which is what makes it the default (1024 x 256 KiB: 8.2 -> 7.6 ms; MODE 0 stays as variant 2).
+template <int MODE>
 __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint32_t block0, uint64_t table_stride, uint64_t table_bytes, uint32_t capx)
 {
+    constexpr bool MIN = MODE == 1, LF = MODE != 0;
     __shared__ uint32_t s_rk[BWTI_MAXMARK + 16];      // walker's emissions, then (pointer jumping) emissions from this node to the chain's end
     __shared__ uint16_t s_next[BWTI_MAXMARK + 16];    // marked node -> next marked node id (or NONE16)
     __shared__ uint16_t s_len[BWTI_MAXMARK + 16];     // min(emissions, 0xffff): parked chains are shorter than that
@@ -95,7 +102,8 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
     __syncthreads();
     // the origin element itself was counted in its wave's slice: take it out of that slice's budget
     if (!MIN && tid == 0) {
-        table[s_tot[osym]] = packed ? (osym << 24) : 0u;          // table[place(L[origin])] = 0 (+ the byte there, see below)
+        if (LF) table[origin] = packed ? s_tot[osym] | (osym << 24) : s_tot[osym];   // place(origin): the first slot of its symbol
+        else table[s_tot[osym]] = packed ? (osym << 24) : 0u;     // table[place(L[origin])] = 0 (+ the byte there, see below)
         const uint32_t ow = origin / per;
         for (int ww = (int)ow + 1; ww < BWTI_WAVES; ww++) s_cnt[ww][osym] -= 1u;
     }
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
         if (valid) {
             // the entry carries the byte the walker will emit from there (L[i]) in its top 8 bits when the block is shorter
             // than 2^24: the chase then costs ONE random load per step instead of two (the kernel is bound by random accesses)
-            if (MIN) table[i] = packed ? (basec + before) | (c << 24) : basec + before;   // LF(i), and the byte emitted AT i
+            if (LF) table[i] = packed ? (basec + before) | (c << 24) : basec + before;    // LF(i) / place(i), and the byte emitted AT i
             else table[basec + before] = packed ? (i + 1u) | (c << 24) : i + 1u;
             if (before == 0) s_cnt[w][c] = basec + (uint32_t)__popcll(peers);   // group leader advances the counter
         }
@@ -147,8 +155,8 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
             live[q] = false; wr[q] = NONE; cnt[q] = 0; cur[q] = 0; mid[q] = 0; pk[q] = 0;
             while (nextm < M) {
                 const uint32_t m = nextm; nextm += BWTI_THREADS;
-                if (MIN && pass == 1 && s_next[m] != NONE16) continue;    // not on origin's cycle: the walk never comes here
-                if (MIN && pass == 1 && s_len[m] <= cap) {                // step j of the walk writes out[n - 1 - j] (mod.rs:312)
+                if (LF && pass == 1 && s_next[m] != NONE16) continue;     // not on origin's cycle: the walk never comes here
+                if (LF && pass == 1 && s_len[m] <= cap) {                // step j of the walk writes out[n - 1 - j] (mod.rs:312)
                     const uint8_t* src = park + (size_t)m * pitch;
                     const uint32_t len = s_len[m];
                     uint8_t* dst = out + (n - 1u - (s_tot[0] - s_rk[m]));
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
                     continue;
                 }
                 live[q] = true; mid[q] = m; cur[q] = m < M0 ? m * stride : origin;
-                if (pass == 1) wr[q] = MIN ? s_tot[0] - s_rk[m] : n - s_rk[m];
+                if (pass == 1) wr[q] = LF ? s_tot[0] - s_rk[m] : n - s_rk[m];
                 break;
             }
         };
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
             for (int q = 0; q < BWTI_SLOTS; q++) v[q] = live[q] ? table[cur[q]] : 0u;    // the jump-table loads, all in flight
 #pragma unroll
             for (int q = 0; q < BWTI_SLOTS; q++) {
-                if (MIN) {                                                // the entry AT cur: LF(cur) and (packed) L[cur]
+                if (LF) {                                                 // the entry AT cur: LF(cur) and (packed) L[cur]
                     if (packed) { ch[q] = (uint8_t)(v[q] >> 24); c2[q] = v[q] & 0xffffffu; }
                     else { c2[q] = v[q]; ch[q] = live[q] ? L[cur[q]] : (uint8_t)0; }
                     v[q] = 1u;                                            // no wrap slot on this path
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
                     if (mk) nxt = (c2[q] == origin && !origin_marked) ? M0 : c2[q] / stride;
                     cur[q] = c2[q];
                 }
-                if (pass == 1) { if (wr[q] + cnt[q] < n) out[MIN ? n - 1u - (wr[q] + cnt[q]) : wr[q] + cnt[q]] = ch[q]; }
+                if (pass == 1) { if (wr[q] + cnt[q] < n) out[LF ? n - 1u - (wr[q] + cnt[q]) : wr[q] + cnt[q]] = ch[q]; }
                 else {
                     // a byte store per step kept ~260 K partial-line writes per block on their way to HBM (the lines leave the L2
                     // long before a walker comes back to them): 8 bytes per store
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
             // rank the marked nodes: pointer jumping, s_rk[m] becomes the number of bytes emitted from m to the end of its chain
             constexpr int PER = (BWTI_MAXMARK + 1 + BWTI_THREADS - 1) / BWTI_THREADS;
             const uint32_t mstart = origin_marked ? origin / stride : M0;
-            if (MIN) {                                                    // LF is a permutation: the list from origin's node comes back to it; cut it there
+            if (LF) {                                                     // a permutation: the list from origin's node comes back to it; cut it there
                 for (uint32_t m = tid; m < M; m += BWTI_THREADS) if (s_next[m] == mstart) s_next[m] = (uint16_t)NONE16;
                 __syncthreads();
             }
@@ -244,8 +252,8 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
             }
             if (tid == 0) {                                               // origin's chain must end (no loop) and cover the block: else not a BWT
                 const uint32_t m = mstart;
-                s_ok = (MIN || (s_next[m] == NONE16 && s_rk[m] == n)) ? 1u : 0u;
-                if (MIN) s_tot[0] = s_rk[m];                              // steps until the walk is back at origin
+                s_ok = (MIN || (s_next[m] == NONE16 && s_rk[m] == n)) ? 1u : 0u;    // (MODE 2: the cycle through origin is the whole block)
+                if (LF) s_tot[0] = s_rk[m];                               // steps until the walk is back at origin
             }
             __syncthreads();
             if (!s_ok) break;
@@ -273,7 +281,8 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
 
 static int launch_bwt_inverse(hipStream_t s, rcx_kargs& k, int variant, std::string& err, bool minimal = false)
 {
-    const uint32_t capx = variant == 1 ? 1u : BWTI_CAPX;
+    const uint32_t capx = (variant & 1) ? 1u : BWTI_CAPX;        // variant bit 0: park 8 bytes per walker at most (tests: second chases)
+    const bool scatter = (variant & 2) != 0;                     // variant bit 1: the forward chase over the scattered jump table (A/B)
     const uint32_t nb = k.nblocks;
     std::vector<uint64_t> h_len(nb);
     if (hipMemcpyAsync(h_len.data(), k.in_len, nb * 8ull, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -286,8 +295,9 @@ static int launch_bwt_inverse(hipStream_t s, rcx_kargs& k, int variant, std::str
     if ((uint64_t)chunk * stride > k.scratch_bytes) { err = "bwt inverse: scratch too small"; return RCX_RC_BAD_ARG; }
     for (uint32_t b0 = 0; b0 < nb; b0 += BWTI_CHUNK) {
         const uint32_t cnt = nb - b0 < BWTI_CHUNK ? nb - b0 : BWTI_CHUNK;
-        if (minimal) hipLaunchKernelGGL(k_bwt_inverse<true>, dim3(cnt), dim3(BWTI_THREADS), 0, s, k, b0, stride, tbytes, capx);
-        else hipLaunchKernelGGL(k_bwt_inverse<false>, dim3(cnt), dim3(BWTI_THREADS), 0, s, k, b0, stride, tbytes, capx);
+        if (minimal) hipLaunchKernelGGL(k_bwt_inverse<1>, dim3(cnt), dim3(BWTI_THREADS), 0, s, k, b0, stride, tbytes, capx);
+        else if (scatter) hipLaunchKernelGGL(k_bwt_inverse<0>, dim3(cnt), dim3(BWTI_THREADS), 0, s, k, b0, stride, tbytes, capx);
+        else hipLaunchKernelGGL(k_bwt_inverse<2>, dim3(cnt), dim3(BWTI_THREADS), 0, s, k, b0, stride, tbytes, capx);
     }
     return RCX_RC_OK;
 }

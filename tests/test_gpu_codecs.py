@@ -65,8 +65,11 @@ def test_bwt_forward_and_inverse(ctx, oracle):
         eL, eo = oracle.bwt_encode(r)
         assert L == eL and (not r or og == eo)
     nz = [i for i, r in enumerate(raws) if r]
-    inv = ctx.bwt_inverse([fw.outputs[i] for i in nz], [int(fw.aux[i]) for i in nz]).check()
-    assert inv.outputs == [raws[i] for i in nz]
+    for variant in (0, 1, 2, 3):                            # bit 0: short parking (second chases), bit 1: the scattered-table kernel
+        ctx.set_variant(N.BWT_INVERSE, variant)
+        inv = ctx.bwt_inverse([fw.outputs[i] for i in nz], [int(fw.aux[i]) for i in nz]).check()
+        assert inv.outputs == [raws[i] for i in nz]
+    ctx.set_variant(N.BWT_INVERSE, 0)
     bad = ctx.bwt_inverse([b"abc"], [3])                    # origin >= n: bwt/mod.rs:230 panics
     assert bad.status[0] == 3
 

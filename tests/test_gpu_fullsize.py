@@ -77,6 +77,15 @@ def test_config4_bwt_1024x256k(ctx, oracle):
     for i in (0, 511, 512, 1023):
         eL, eo = oracle.bwt_encode(raw_np[i * BLOCK:(i + 1) * BLOCK].tobytes())
         assert L[i * BLOCK:(i + 1) * BLOCK].tobytes() == eL and int(og[i]) == eo
+    # decode_minimal (bwt/mod.rs:298-315) over the same 1024 blocks; two of them against the O(n^2) restatement (7 s of CPU each)
+    inv.out_base.zero_()
+    ctx.launch_dev(N.BWT_INVERSE_MINIMAL, inv, sc)
+    torch.cuda.synchronize()
+    assert int(inv.status[:nb].abs().max()) == 0 and bool((inv.out_len[:nb] == BLOCK).all())
+    mn = inv.out_base.cpu().numpy()
+    for i in (3, 1020):
+        want = oracle.bwt_decode(L[i * BLOCK:(i + 1) * BLOCK].tobytes(), int(og[i]), minimal=True)
+        assert mn[i * BLOCK:(i + 1) * BLOCK].tobytes() == want
     ctx.set_stream(0)
 
 

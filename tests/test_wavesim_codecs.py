@@ -157,13 +157,16 @@ def test_bwt_inverse(oracle):
     raws = corpus.small_corpus(sizes=(17, 1000, 20000, 70000), with_empty=False)
     Ls, orgs = zip(*[oracle.bwt_encode(r) for r in raws])
     maxn = max(len(r) for r in raws)
-    outs, _, _, st, _ = simrun.run(N.BWT_INVERSE, 0, list(Ls), [len(r) for r in raws], aux=np.array(orgs, dtype=np.uint32),
-                                   scratch_bytes=len(raws) * (24 * maxn + 70000) + 256)     # jump table (4n) + parked first-chase bytes (16n + slack)
-    assert not st.any() and outs == raws
-    # variant 1 parks at most 8 bytes per walker, so most chains of the larger blocks take the second chase
-    outs, _, _, st, _ = simrun.run(N.BWT_INVERSE, 1, list(Ls), [len(r) for r in raws], aux=np.array(orgs, dtype=np.uint32),
-                                   scratch_bytes=len(raws) * (24 * maxn + 70000) + 256)
-    assert not st.any() and outs == raws
+    # variant bit 0: walkers park at most 8 bytes, so most chains of the larger blocks take the second chase; bit 1: the forward chase
+    # over the scattered jump table instead of the backward walk over place()
+    rng = np.random.default_rng(8)
+    bad = [(bytes(rng.integers(0, 4, 3000, dtype=np.uint8)), 17), (Ls[2], (orgs[2] + 1) % len(Ls[2])), (b"abc", 3)]     # not a BWT / wrong origin / origin >= n
+    for variant in (0, 1, 2, 3):
+        outs, _, _, st, _ = simrun.run(N.BWT_INVERSE, variant, list(Ls) + [b[0] for b in bad], [len(r) for r in raws] + [len(b[0]) for b in bad],
+                                       aux=np.array(list(orgs) + [b[1] for b in bad], dtype=np.uint32),
+                                       scratch_bytes=(len(raws) + len(bad)) * (24 * maxn + 70000) + 256)     # jump table (4n) + parked first-chase bytes (16n + slack)
+        assert not st[: len(raws)].any() and outs[: len(raws)] == raws, variant
+        assert list(st[len(raws):]) == [_oracle_status(oracle.bwt_decode, *b) for b in bad], variant
 
 
 def test_bwt_inverse_minimal(oracle):
