@@ -78,11 +78,59 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
         }
         return;
     }
-    // ---- 1. histogram per wave slice (each wave owns a contiguous slice of L), mod.rs:226-228
     for (unsigned i = tid; i < BWTI_WAVES * 256; i += BWTI_THREADS) (&s_cnt[0][0])[i] = 0;
     __syncthreads();
     const uint32_t per = ((n + BWTI_WAVES - 1) / BWTI_WAVES + 63u) & ~63u;
     const uint32_t w0 = w * per < n ? w * per : n, w1 = w0 + per < n ? w0 + per : n;
+    if constexpr (LF) {
+        // ---- 1+2 (backward walk).  Two passes over the wave's slice of L, 64 positions per step, equal bytes found by the sorter's
+        // hand-written match-any ballots: the first only counts (one LDS update per distinct byte of a step: the LDS-atomic
+        // histogram it replaces serialised on the text's frequent bytes and cost as much as the ranking itself), the second, after
+        // the prefix sums, stores place(i) = base + rank AT i.  Origin is left out of the counts: its place is the first slot of its
+        // symbol (mod.rs:230).
+        for (uint32_t i0 = w0; i0 < w1; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const bool valid = i < w1 && (MIN || i != origin);
+            const uint32_t c = i < w1 ? L[i] : 0u;
+            const unsigned long long peers = BWS_PEERS(valid, c);
+            if (valid && (peers & ((1ull << lane) - 1ull)) == 0) s_cnt[w][c] += (uint32_t)__popcll(peers);   // one lane per distinct byte
+        }
+        __syncthreads();
+        const uint32_t osym = L[origin];
+        if (tid < 256) {
+            uint32_t tot = (!MIN && tid == osym) ? 1u : 0u;
+            for (int ww = 0; ww < BWTI_WAVES; ww++) tot += s_cnt[ww][tid];
+            s_tot[tid] = tot;
+        }
+        __syncthreads();
+        if (tid == 0) { uint32_t acc = 0; for (int c = 0; c < 256; c++) { const uint32_t t = s_tot[c]; s_tot[c] = acc; acc += t; } }
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t acc = s_tot[tid] + ((!MIN && tid == osym) ? 1u : 0u);
+            for (int ww = 0; ww < BWTI_WAVES; ww++) { const uint32_t t = s_cnt[ww][tid]; s_cnt[ww][tid] = acc; acc += t; }
+        }
+        __syncthreads();
+        // the entry carries the byte the walker emits there (L[i]) in its top 8 bits when the block is shorter than 2^24: the
+        // chase then costs ONE random load per step instead of two
+        for (uint32_t i0 = w0; i0 < w1; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const bool valid = i < w1 && (MIN || i != origin);
+            const uint32_t c = i < w1 ? L[i] : 0u;
+            const unsigned long long peers = BWS_PEERS(valid, c);
+            const uint32_t before = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+            uint32_t basec = 0;
+            if (valid) basec = s_cnt[w][c];
+            rcx_wave_sync();
+            if (valid) {
+                table[i] = packed ? (basec + before) | (c << 24) : basec + before;
+                if (before == 0) s_cnt[w][c] = basec + (uint32_t)__popcll(peers);   // group leader advances the counter
+            }
+            else if (i < w1 && i == origin) table[i] = packed ? s_tot[osym] | (c << 24) : s_tot[osym];
+            rcx_wave_sync();
+        }
+    }
+    else {
+    // ---- 1. histogram per wave slice (each wave owns a contiguous slice of L), mod.rs:226-228
     for (uint32_t i = w0 + lane; i < w1; i += 64) atomicAdd(&s_cnt[w][L[i]], 1u);
     __syncthreads();
     // exclusive prefix over (symbol major, wave minor); the `origin` element goes first in its symbol (mod.rs:230)
@@ -131,6 +179,7 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
             if (before == 0) s_cnt[w][c] = basec + (uint32_t)__popcll(peers);   // group leader advances the counter
         }
         rcx_wave_sync();
+    }
     }
     __threadfence_block();
     __syncthreads();
