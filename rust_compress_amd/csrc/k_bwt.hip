@@ -218,16 +218,26 @@ __global__ __launch_bounds__(512) void k_bws_first(BwsState s, BwtfArgs a, const
 // L[j] = T[SA[j]-1], or T[n-1] where SA[j] == 0 (that j is `origin`), mod.rs:193-203
 __global__ void k_bwtf_emit(BwtfArgs a, const uint32_t* sa, uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap, uint32_t* origin)
 {
-    const uint32_t b = blockIdx.y;
+    uint32_t bx, b;
+    bws_xcd_grid(bx, b);                                    // T[] is read at random: a block's text stays in one XCD's L2
     const uint32_t n = (uint32_t)a.in_len[b];
     if (out_cap[b] < n) return;
     const uint32_t g0 = a.bstart[b];
     const uint8_t* T = a.in_base + a.in_off[b];
     uint8_t* out = out_base + out_off[b];
-    for (uint32_t jl = blockIdx.x * blockDim.x + threadIdx.x; jl < n; jl += gridDim.x * blockDim.x) {
-        const uint32_t i = (sa[g0 + jl] & BWS_IDX) - g0;
-        if (i == 0) { out[jl] = T[n - 1]; if (origin) origin[b] = jl; }
-        else out[jl] = T[i - 1];
+    for (uint32_t base = bx * BWS_GCHUNK; base < n; base += gridDim.x * BWS_GCHUNK) {      // eight per thread: see k_bws_gather
+        uint32_t i[BWS_GEPT]; uint8_t c[BWS_GEPT];
+#pragma unroll
+        for (int q = 0; q < BWS_GEPT; q++) { const uint32_t jl = base + (uint32_t)q * 256u + threadIdx.x; i[q] = jl < n ? (sa[g0 + jl] & BWS_IDX) - g0 : 1u; }
+#pragma unroll
+        for (int q = 0; q < BWS_GEPT; q++) c[q] = T[i[q] == 0 ? n - 1 : i[q] - 1];
+#pragma unroll
+        for (int q = 0; q < BWS_GEPT; q++) {
+            const uint32_t jl = base + (uint32_t)q * 256u + threadIdx.x;
+            if (jl >= n) continue;
+            out[jl] = c[q];
+            if (i[q] == 0 && origin) origin[b] = jl;
+        }
     }
 }
 __global__ void k_bwtf_finish(rcx_kargs a)
@@ -257,7 +267,7 @@ static uint64_t bwt_forward_scratch_bytes(uint32_t nblocks, uint64_t max_block)
     uint64_t N = (uint64_t)nblocks * max_block;
     if (N > (uint64_t)BWTF_MAXN) N = BWTF_MAXN;
     // keys 2 x 8N, SA 2 x 4N, rank 4N, group lists, bstart, counters, histogram
-    return 28 * N + 5 * (N / BWS_WAVE + nblocks + 1024) * sizeof(BwsSeg) + 2 * (N / 16 + 4096) * sizeof(BwsSeg) + 2 * (N / BWS_LWAVE + nblocks + 1024) * sizeof(BwsSeg) + (uint64_t)(nblocks + 2) * 4 + 4 * (N / 64 + 512) + (1ull << 20);
+    return 28 * N + 5 * (N / BWS_WAVE + nblocks + 1024) * sizeof(BwsSeg) + 2 * (N / 16 + 4096) * sizeof(BwsSeg) + 2 * (N / BWS_LWAVE + nblocks + 1024) * sizeof(BwsSeg) + (uint64_t)(nblocks + 2) * 4 + 4 * (N / 64 + 512) + (N / 256 + nblocks + 1024) + (1ull << 20);
 }
 
 static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::string& err)
@@ -297,13 +307,16 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
             st.cnt = (uint32_t*)carve(4 * (64 + BWS_NFLAG));
             uint32_t* hist = (uint32_t*)carve(1056); uint8_t* symmap = (uint8_t*)carve(256);
             const size_t nact = ((size_t)N / 64 + 64 + 7) & ~(size_t)7;
-            uint8_t* act0 = (uint8_t*)carve(4 * nact);
+            const size_t ndone = (size_t)N / 256 + nb + 64;                    // k_bws_gather's chunk flags (blockDim 256), cleared with act[]
+            uint8_t* act0 = (uint8_t*)carve(4 * nact + ndone);
             for (int q = 0; q < 4; q++) st.act[q] = act0 + q * nact;
+            st.gdone = act0 + 4 * nact;
             st.n = N; st.par = 0; st.rs = 0;
             if ((uint64_t)(p - (uint8_t*)k.scratch) > k.scratch_bytes) { err = "bwt forward: scratch too small"; return RCX_RC_BAD_ARG; }
             if (hipMemcpyAsync(bstart, h_bstart.data(), 4ull * (nb + 1), hipMemcpyHostToDevice, s) != hipSuccess) { err = "bwt forward: H2D"; return RCX_RC_HIP_ERROR; }
             BwtfArgs fa{kk.in_base, kk.in_off, kk.in_len, bstart, nb};
             const uint32_t gx = (uint32_t)((maxn + 255) / 256 < 1024 ? (maxn + 255) / 256 : 1024);
+            const uint32_t gxg = (uint32_t)((maxn + BWS_GCHUNK - 1) / BWS_GCHUNK < 1024 ? (maxn + BWS_GCHUNK - 1) / BWS_GCHUNK : 1024) + (maxn ? 0u : 1u);   // gather / emit: 2048 suffixes per workgroup
             // Alphabet compaction: the bytes that occur get dense, order-preserving codes, so that more symbols fit the first
             // key when the alphabet is small and skewed (text: 10 symbols of 6 bits instead of 7 of 9; DNA: 16).
             uint32_t nsym = 7, sbits = 9; bool plain_bytes = true;
@@ -323,7 +336,7 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                 if (hipMemcpyAsync(symmap, h_map, 256, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
                     err = "bwt forward: symbol map"; return RCX_RC_HIP_ERROR; }
             }
-            if (hipMemsetAsync(st.cnt, 0, 4 * (64 + BWS_NFLAG), s) != hipSuccess || hipMemsetAsync(act0, 0, 4 * nact, s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
+            if (hipMemsetAsync(st.cnt, 0, 4 * (64 + BWS_NFLAG), s) != hipSuccess || hipMemsetAsync(act0, 0, 4 * nact + ndone, s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
             const uint32_t kbits0 = nsym * sbits, top0 = kbits0 > 8 ? kbits0 - 8 : 0;
             const uint32_t kbits1 = bits_for(maxn), top1 = kbits1 > 8 ? kbits1 - 8 : 0;           // later keys: local rank + 1 <= maxn
             const bool fused_first = top0 > 0;                    // keys of more than 8 bits: the first level is built straight from the text
@@ -343,7 +356,7 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                 const uint32_t top = round == 0 ? top0 : top1, topn = top1;
                 // (the 32-bit key path packs the group id above a 24-bit rank in the wave sorts: blocks of 2^24 bytes and more take the 64-bit one)
                 const bool wide = round == 0 || kbits1 > 24;
-                if (round) { if (wide) hipLaunchKernelGGL(k_bws_gather<uint64_t>, dim3(gx ? gx : 1, nb), dim3(256), 0, s, st, bstart, nb, h); else hipLaunchKernelGGL(k_bws_gather<uint32_t>, dim3(gx ? gx : 1, nb), dim3(256), 0, s, st, bstart, nb, h); }
+                if (round) { if (wide) hipLaunchKernelGGL(k_bws_gather<uint64_t>, dim3(gxg, nb), dim3(256), 0, s, st, bstart, nb, h); else hipLaunchKernelGGL(k_bws_gather<uint32_t>, dim3(gxg, nb), dim3(256), 0, s, st, bstart, nb, h); }
                 const int levels = (int)((top + 7) / 8) + 1;
                 for (int lv = (round == 0 && fused_first) ? 1 : 0; lv < levels; lv++) {
                     if (hipMemsetAsync(&st.cnt[(lv + 1) & 1], 0, 4, s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
@@ -369,7 +382,7 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                 h = round == 0 ? nsym : 2 * h;
             }
             if (!converged) { err = "bwt forward: did not converge"; return RCX_RC_HIP_ERROR; }
-            hipLaunchKernelGGL(k_bwtf_emit, dim3(gx ? gx : 1, nb), dim3(256), 0, s, fa, st.saA, kk.out_base, kk.out_off, kk.out_cap, kk.aux);
+            hipLaunchKernelGGL(k_bwtf_emit, dim3(gxg, nb), dim3(256), 0, s, fa, st.saA, kk.out_base, kk.out_off, kk.out_cap, kk.aux);
         }
         hipLaunchKernelGGL(k_bwtf_finish, dim3((nb + 255) / 256), dim3(256), 0, s, kk);
         lo += nb;

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
             if (!any) break;
             uint32_t v[BWTI_SLOTS], c2[BWTI_SLOTS]; uint8_t ch[BWTI_SLOTS];
 #pragma unroll
-            for (int q = 0; q < BWTI_SLOTS; q++) v[q] = live[q] ? table[cur[q]] : 0u;    // the jump-table loads, all in flight
+            for (int q = 0; q < BWTI_SLOTS; q++) v[q] = live[q] ? table[cur[q]] : 0u;    // the jump-table loads, all in flight (non-temporal loads: 7.4 -> 10 ms)
 #pragma unroll
             for (int q = 0; q < BWTI_SLOTS; q++) {
                 if (LF) {                                                 // the entry AT cur: LF(cur) and (packed) L[cur]

@@ -43,6 +43,7 @@ struct BwsState {
     uint32_t par;                             // parity bit groups made in THIS round carry (BWS_PAR or 0)
     uint8_t* act[4];                          // "a group for the dense passes lies in this window": [round parity * 2 + grid], one byte
     uint32_t rs;                              // per 64-suffix window (grid 0: aligned, grid 1: shifted by 32); rs = round & 1
+    uint8_t* gdone;                           // k_bws_gather: "every suffix of this workgroup's chunk is FINAL" (it stays so)
 };
 
 template <class K> __device__ __forceinline__ K* bws_keys(const BwsState& s, int buf) { return (K*)(buf ? s.keyB : s.keyA); }
@@ -149,19 +150,63 @@ __device__ __forceinline__ void bws_wave_runs(uint32_t lane, uint32_t c0, uint32
     re = ra ? (uint32_t)__ffsll(ra) - 1u : 64u;
 }
 
+// A (chunk, block) grid whose workgroups read or write at random inside their block's arrays: workgroups go to the 8 XCDs round-robin in
+// dispatch order (x fastest), so dispatched as they are every XCD pulls every block's lines into its own L2 -- up to eight fetches of
+// each line.  XCD x takes the x-th eighth of the grid instead: the workgroups resident on it sit in one or two blocks.
+#ifndef BWS_XCD_GRID
+#define BWS_XCD_GRID 1
+#endif
+#define BWS_GEPT 8                       /* suffixes per thread and step of k_bws_gather / k_bwtf_emit */
+#define BWS_GCHUNK (256u * BWS_GEPT)
+__device__ __forceinline__ void bws_xcd_grid(uint32_t& bx, uint32_t& by)
+{
+    const uint32_t gx = gridDim.x, total = gx * gridDim.y;
+    uint32_t f = blockIdx.y * gx + blockIdx.x;
+    if (BWS_XCD_GRID && (total & 7u) == 0) f = (f & 7u) * (total >> 3) + (f >> 3);
+    bx = f % gx; by = f / gx;
+}
+
 // ---- keys of a doubling round: key[j] = local rank + 1 of (suffix at j) + h, 0 = past the end of its block ------------------
 template <class K>
 __global__ __launch_bounds__(256) void k_bws_gather(BwsState s, const uint32_t* bstart, uint32_t nblocks, uint32_t h)
 {
-    const uint32_t b = blockIdx.y;
+    __shared__ uint32_t s_open;
+    uint32_t bx, b;
+    bws_xcd_grid(bx, b);
     const uint32_t g0 = bstart[b], e = bstart[b + 1];
+    const uint32_t j0 = g0 + bx * BWS_GCHUNK;
+    if (j0 >= e) return;
+    // A text is mostly sorted after two or three rounds, and what is left lies in runs of the suffix array: a chunk all of whose
+    // suffixes are FINAL says so once, and later rounds read one byte of it instead of its SA words.  The chunks of a block, and of
+    // consecutive blocks, get consecutive distinct slots.
+    uint8_t* done = s.gdone + j0 / BWS_GCHUNK + b;
+    if (*done) return;
+    if (threadIdx.x == 0) s_open = 0;
+    __syncthreads();
     K* key = (K*)s.keyA;
-    for (uint32_t j = g0 + blockIdx.x * blockDim.x + threadIdx.x; j < e; j += gridDim.x * blockDim.x) {
-        const uint32_t v = s.saA[j];
-        if (v & BWS_FINAL) continue;
-        const uint32_t g = v & BWS_IDX;
-        key[j] = (g + h < e) ? s.rank[g + h] - g0 + 1u : 0u;
+    bool open = false;
+    // eight suffixes per thread, their loads in flight together: with one per thread a launch was a million workgroups of one dependent
+    // load -> load -> store chain each, and the 2048 workgroup slots of the GPU turned over no faster than that chain's latency
+    for (uint32_t base = j0; base < e; base += gridDim.x * BWS_GCHUNK) {
+        uint32_t v[BWS_GEPT], r[BWS_GEPT];
+#pragma unroll
+        for (int q = 0; q < BWS_GEPT; q++) { const uint32_t j = base + (uint32_t)q * 256u + threadIdx.x; v[q] = j < e ? s.saA[j] : BWS_FINAL; }
+#pragma unroll
+        for (int q = 0; q < BWS_GEPT; q++) {
+            const uint32_t g = (v[q] & BWS_IDX) + h;
+            const bool in = !(v[q] & BWS_FINAL) && g < e;
+            r[q] = in ? s.rank[g] - g0 + 1u : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < BWS_GEPT; q++) {
+            if (v[q] & BWS_FINAL) continue;
+            open = true;
+            key[base + (uint32_t)q * 256u + threadIdx.x] = r[q];
+        }
     }
+    if (open) s_open = 1u;
+    __syncthreads();
+    if (threadIdx.x == 0 && !s_open) *done = 1;
 }
 
 // ---- round 0 seed: every block is one group, identity order -----------------------------------------------------------------
