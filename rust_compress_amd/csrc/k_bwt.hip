@@ -96,13 +96,17 @@ __global__ __launch_bounds__(256) void k_bwtf_init(BwtfArgs a, uint64_t* keys, u
 // the generic level (which reads the 8-byte keys twice and the 4-byte suffixes once, writes 12 bytes and reads them again to mark
 // the small bins) a suffix costs two reads of its text byte and ONE 12-byte write: a bin of one is final, a bin of <= BWS_WAVE is
 // written to saA / keyA marked for the dense passes, a larger bin goes to the other buffer and on the list its size asks for.
-#define BWS_FT 2048u            /* suffixes per LDS tile of k_bws_first */
-__global__ __launch_bounds__(512) void k_bws_first(BwsState s, BwtfArgs a, const uint8_t* map, uint32_t nsym, uint32_t bits, uint32_t plus1,
+#define BWS_FTHREADS 1024u      /* threads of k_bws_first: one workgroup per block, so its waves are all the latency hiding a CU gets */
+#define BWS_FT 8192u            /* suffixes per LDS tile of k_bws_first */
+__global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs a, const uint8_t* map, uint32_t nsym, uint32_t bits, uint32_t plus1,
                                                    uint32_t top_shift, uint32_t topn)
 {
     __shared__ uint32_t s_map[256];
     __shared__ uint16_t s_sym[BWS_FT + 16];
-    __shared__ uint32_t s_hist[8][256], s_tot[256], s_beg[256];
+    __shared__ uint32_t s_hist[BWS_FTHREADS / 64][256], s_tot[256], s_beg[256];
+    __shared__ uint32_t s_th[256], s_ts[256], s_tc[256], s_gcur[256];      // the tile's digit counts, their scan, its cursors; the block's cursors
+    __shared__ uint16_t s_perm[BWS_FT];
+    __shared__ uint8_t s_dig[BWS_FT];
     __shared__ uint32_t s_one;
     const uint32_t b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const uint32_t n = (uint32_t)a.in_len[b];
@@ -110,12 +114,12 @@ __global__ __launch_bounds__(512) void k_bws_first(BwsState s, BwtfArgs a, const
     const uint8_t* T = a.in_base + a.in_off[b];
     const uint32_t g0 = a.bstart[b];
     if (tid < 256) s_map[tid] = (uint32_t)map[tid] + plus1;
-    for (uint32_t i = tid; i < 8 * 256; i += 512) ((uint32_t*)s_hist)[i] = 0;
+    for (uint32_t i = tid; i < (BWS_FTHREADS / 64) * 256; i += BWS_FTHREADS) ((uint32_t*)s_hist)[i] = 0;
     if (tid == 0) s_one = 0;
     __syncthreads();
     auto tile = [&](uint32_t i0) {                             // symbols of suffixes i0 .. i0+BWS_FT-1 and the 16 that follow (0 = past the end)
         __syncthreads();
-        for (uint32_t t = tid; t < BWS_FT + 16u; t += 512u) s_sym[t] = (i0 + t < n) ? (uint16_t)s_map[T[i0 + t]] : (uint16_t)0;
+        for (uint32_t t = tid; t < BWS_FT + 16u; t += BWS_FTHREADS) s_sym[t] = (i0 + t < n) ? (uint16_t)s_map[T[i0 + t]] : (uint16_t)0;
         __syncthreads();
     };
     auto key_at = [&](uint32_t t) {
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(512) void k_bws_first(BwsState s, BwtfArgs a, const
     if (n <= BWS_LMAX) {                                       // a small block: keys and identity order, listed as one group (what k_bws_seed did)
         for (uint32_t i0 = 0; i0 < n; i0 += BWS_FT) {
             tile(i0);
-            for (uint32_t t = tid; t < BWS_FT; t += 512u) {
+            for (uint32_t t = tid; t < BWS_FT; t += BWS_FTHREADS) {
                 const uint32_t i = i0 + t;
                 if (i < n) { s.keyA[g0 + i] = key_at(t); s.saA[g0 + i] = (g0 + i) | (i == 0 ? (BWS_HEAD | (s.par ^ BWS_PAR)) : 0u); }
             }
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(512) void k_bws_first(BwsState s, BwtfArgs a, const
     // ---- count
     for (uint32_t i0 = 0; i0 < n; i0 += BWS_FT) {
         tile(i0);
-        for (uint32_t t = tid; t < BWS_FT; t += 512u) {
+        for (uint32_t t = tid; t < BWS_FT; t += BWS_FTHREADS) {
             const uint32_t i = i0 + t; const bool ok = i < n;
             const uint32_t d = ok ? (uint32_t)(key_at(t) >> top_shift) & 0xffu : 0x100u;
             const unsigned long long peers = BWS_PEERS(ok, d);
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(512) void k_bws_first(BwsState s, BwtfArgs a, const
     if (tid < 256) {
         uint32_t t = 0;
 #pragma unroll
-        for (int w = 0; w < 8; w++) t += s_hist[w][tid];
+        for (int w = 0; w < (int)(BWS_FTHREADS / 64); w++) t += s_hist[w][tid];
         s_tot[tid] = t;
         if (t == n) s_one = 1;
     }
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(512) void k_bws_first(BwsState s, BwtfArgs a, const
     if (s_one) {                                               // every suffix starts with the same digit: the generic levels go on from the next one
         for (uint32_t i0 = 0; i0 < n; i0 += BWS_FT) {
             tile(i0);
-            for (uint32_t t = tid; t < BWS_FT; t += 512u) {
+            for (uint32_t t = tid; t < BWS_FT; t += BWS_FTHREADS) {
                 const uint32_t i = i0 + t;
                 if (i < n) { s.keyA[g0 + i] = key_at(t); s.saA[g0 + i] = (g0 + i) | (i == 0 ? (BWS_HEAD | (s.par ^ BWS_PAR)) : 0u); }
             }
@@ -180,22 +184,47 @@ __global__ __launch_bounds__(512) void k_bws_first(BwsState s, BwtfArgs a, const
     if (tid < 256) {
         uint32_t o = s_beg[tid];
 #pragma unroll
-        for (int w = 0; w < 8; w++) { const uint32_t c = s_hist[w][tid]; s_hist[w][tid] = o; o += c; }
+        for (int w = 0; w < (int)(BWS_FTHREADS / 64); w++) { const uint32_t c = s_hist[w][tid]; s_hist[w][tid] = o; o += c; }
     }
-    // ---- place (tile() synchronises)
+    // ---- place.  The suffixes of a tile are first ordered by digit INSIDE the tile (a permutation of tile positions in LDS: the keys
+    // are rebuilt from the symbols), then written out in that order: a wave's stores are runs of consecutive addresses, one run per
+    // digit present in the tile, instead of 64 stores scattered over the block's bins.  Scattered 8- and 4-byte stores reached HBM
+    // as partial-line writes: 8.7 GB written per 1024 blocks for 3.2 GB of keys and suffixes.  (The order inside a bin is whatever the
+    // LDS atomics make it: the levels below sort every bin to the end of its key anyway.)
+    if (tid < 256) { s_gcur[tid] = s_beg[tid]; s_th[tid] = 0; }
     for (uint32_t i0 = 0; i0 < n; i0 += BWS_FT) {
         tile(i0);
-        for (uint32_t t = tid; t < BWS_FT; t += 512u) {
-        const uint32_t i = i0 + t; const bool ok = i < n;
-        const uint64_t k = ok ? key_at(t) : 0ull;
-        const uint32_t d = ok ? (uint32_t)(k >> top_shift) & 0xffu : 0x100u;
-        const unsigned long long peers = BWS_PEERS(ok, d);
-        const uint32_t leader = (uint32_t)__ffsll(peers) - 1u;
-        uint32_t bse = 0;
-        if (ok && leader == lane) bse = atomicAdd(&s_hist[wave][d], (uint32_t)__popcll(peers));
-        bse = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((leader & 63u) << 2), (int)bse);
-        if (ok) {
-            const uint32_t p = bse + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull)), g = g0 + i;
+        const uint32_t tn = n - i0 < BWS_FT ? n - i0 : BWS_FT;
+        for (uint32_t t = tid; t < BWS_FT; t += BWS_FTHREADS) {         // digits of the tile + their counts
+            const bool ok = t < tn;
+            const uint32_t d = ok ? (uint32_t)(key_at(t) >> top_shift) & 0xffu : 0x100u;
+            if (ok) s_dig[t] = (uint8_t)d;
+            const unsigned long long peers = BWS_PEERS(ok, d);
+            if (ok && (uint32_t)__ffsll(peers) - 1u == lane) atomicAdd(&s_th[d], (uint32_t)__popcll(peers));
+        }
+        __syncthreads();
+        if (tid < 64) {                                        // exclusive scan of the tile's counts
+            const uint32_t t0 = s_th[4 * tid], t1 = s_th[4 * tid + 1], t2 = s_th[4 * tid + 2], t3 = s_th[4 * tid + 3];
+            const uint32_t ex = rcx_wave_incl_scan(t0 + t1 + t2 + t3) - (t0 + t1 + t2 + t3);
+            s_ts[4 * tid] = ex; s_ts[4 * tid + 1] = ex + t0; s_ts[4 * tid + 2] = ex + t0 + t1; s_ts[4 * tid + 3] = ex + t0 + t1 + t2;
+            s_tc[4 * tid] = ex; s_tc[4 * tid + 1] = ex + t0; s_tc[4 * tid + 2] = ex + t0 + t1; s_tc[4 * tid + 3] = ex + t0 + t1 + t2;
+        }
+        __syncthreads();
+        for (uint32_t t = tid; t < BWS_FT; t += BWS_FTHREADS) {         // tile position -> place in the tile's digit order
+            const bool ok = t < tn;
+            const uint32_t d = ok ? (uint32_t)s_dig[t] : 0x100u;
+            const unsigned long long peers = BWS_PEERS(ok, d);
+            const uint32_t leader = (uint32_t)__ffsll(peers) - 1u;
+            uint32_t bse = 0;
+            if (ok && leader == lane) bse = atomicAdd(&s_tc[d], (uint32_t)__popcll(peers));
+            bse = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((leader & 63u) << 2), (int)bse);
+            if (ok) s_perm[bse + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull))] = (uint16_t)t;
+        }
+        __syncthreads();
+        for (uint32_t q = tid; q < tn; q += BWS_FTHREADS) {
+            const uint32_t t = s_perm[q], d = s_dig[t];
+            const uint64_t k = key_at(t);
+            const uint32_t p = s_gcur[d] + (q - s_ts[d]), g = g0 + i0 + t;
             const uint32_t c = s_tot[d], b0 = s_beg[d], at = g0 + p;
             if (c == 1u) { s.saA[at] = g | BWS_HEAD | BWS_FINAL; s.rank[g] = at; }
             else if (c <= BWS_WAVE) {
@@ -203,7 +232,8 @@ __global__ __launch_bounds__(512) void k_bws_first(BwsState s, BwtfArgs a, const
                 if (p == b0 && bws_dense_ok(at, c)) bws_flag_dense(s, s.rs, at, c);
             } else { s.keyB[at] = k; s.saB[at] = g; }
         }
-        }
+        __syncthreads();
+        if (tid < 256) { s_gcur[tid] += s_th[tid]; s_th[tid] = 0; }
     }
     __syncthreads();
     if (tid < 256) {                                           // where each bin goes (waves 0-3 whole: wave-uniform calls)
@@ -340,7 +370,7 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
             const uint32_t kbits0 = nsym * sbits, top0 = kbits0 > 8 ? kbits0 - 8 : 0;
             const uint32_t kbits1 = bits_for(maxn), top1 = kbits1 > 8 ? kbits1 - 8 : 0;           // later keys: local rank + 1 <= maxn
             const bool fused_first = top0 > 0;                    // keys of more than 8 bits: the first level is built straight from the text
-            if (fused_first) hipLaunchKernelGGL(k_bws_first, dim3(nb), dim3(512), 0, s, st, fa, symmap, nsym, sbits, plain_bytes ? 1u : 0u, top0, top1);
+            if (fused_first) hipLaunchKernelGGL(k_bws_first, dim3(nb), dim3(BWS_FTHREADS), 0, s, st, fa, symmap, nsym, sbits, plain_bytes ? 1u : 0u, top0, top1);
             else {
                 hipLaunchKernelGGL(k_bwtf_init, dim3(gx ? gx : 1, nb), dim3(256), 0, s, fa, st.keyA, st.saA, symmap, nsym, sbits, plain_bytes ? 1u : 0u);
                 hipLaunchKernelGGL(k_bws_seed, dim3((nb + 255) / 256), dim3(256), 0, s, st, bstart, nb, top0);
