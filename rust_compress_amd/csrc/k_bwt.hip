@@ -103,7 +103,8 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
 {
     __shared__ uint32_t s_map[256];
     __shared__ uint16_t s_sym[BWS_FT + 16];
-    __shared__ uint32_t s_hist[BWS_FTHREADS / 64][256], s_tot[256], s_beg[256];
+    __shared__ uint32_t s_h12[4096], s_tot[256], s_beg[256], s_ws[BWS_FTHREADS / 64];
+    __shared__ uint8_t s_lut[4096];
     __shared__ uint32_t s_th[256], s_ts[256], s_tc[256], s_gcur[256];      // the tile's digit counts, their scan, its cursors; the block's cursors
     __shared__ uint16_t s_perm[BWS_FT];
     __shared__ uint8_t s_dig[BWS_FT];
@@ -114,7 +115,8 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
     const uint8_t* T = a.in_base + a.in_off[b];
     const uint32_t g0 = a.bstart[b];
     if (tid < 256) s_map[tid] = (uint32_t)map[tid] + plus1;
-    for (uint32_t i = tid; i < (BWS_FTHREADS / 64) * 256; i += BWS_FTHREADS) ((uint32_t*)s_hist)[i] = 0;
+    for (uint32_t i = tid; i < 4096u; i += BWS_FTHREADS) s_h12[i] = 0;
+    if (tid < 256) s_tot[tid] = 0;
     if (tid == 0) s_one = 0;
     __syncthreads();
     auto tile = [&](uint32_t i0) {                             // symbols of suffixes i0 .. i0+BWS_FT-1 and the 16 that follow (0 = past the end)
@@ -128,6 +130,12 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
         return k;
     };
     const uint32_t nshift = top_shift > 8u ? top_shift - 8u : 0u;
+    // The first level does not split by the key's top 8 bits (a text's first symbol and a quarter: ~160 bins of very unequal size, most
+    // of them above BWS_LMAX and through one or two more radix levels), but into 256 RANGES of its top 12 bits that hold about n / 256
+    // suffixes each: bin(v) = 256 * (suffixes with a smaller top-12 value) / n, from the block's own histogram.  Any monotone map
+    // of a key prefix keeps the bins in key order; what changes is that the levels below may take no key bit for sorted (the bins
+    // are listed with the first level's own shift), and that nearly every bin of a text goes straight to the LDS sorts.
+    const uint32_t kbits = top_shift + 8u, b12 = kbits < 12u ? kbits : 12u, sh12 = kbits - b12, m12 = (1u << b12) - 1u;
     if (n <= BWS_LMAX) {                                       // a small block: keys and identity order, listed as one group (what k_bws_seed did)
         for (uint32_t i0 = 0; i0 < n; i0 += BWS_FT) {
             tile(i0);
@@ -148,20 +156,25 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
     // ---- count
     for (uint32_t i0 = 0; i0 < n; i0 += BWS_FT) {
         tile(i0);
-        for (uint32_t t = tid; t < BWS_FT; t += BWS_FTHREADS) {
-            const uint32_t i = i0 + t; const bool ok = i < n;
-            const uint32_t d = ok ? (uint32_t)(key_at(t) >> top_shift) & 0xffu : 0x100u;
-            const unsigned long long peers = BWS_PEERS(ok, d);
-            if (ok && (uint32_t)__ffsll(peers) - 1u == lane) atomicAdd(&s_hist[wave][d], (uint32_t)__popcll(peers));
-        }
+        for (uint32_t t = tid; t < BWS_FT; t += BWS_FTHREADS)
+            if (i0 + t < n) atomicAdd(&s_h12[(uint32_t)(key_at(t) >> sh12) & m12], 1u);
     }
     __syncthreads();
-    if (tid < 256) {
-        uint32_t t = 0;
+    static_assert(BWS_FTHREADS * 4u == 4096u, "four top-12 values per thread");
+    {   // exclusive scan of the 4096 counts (4 per thread, wave scans, the waves' totals), then the bin of every top-12 value
+        const uint32_t c0 = s_h12[4 * tid], c1 = s_h12[4 * tid + 1], c2 = s_h12[4 * tid + 2], c3 = s_h12[4 * tid + 3], c = c0 + c1 + c2 + c3;
+        const uint32_t inc = rcx_wave_incl_scan(c);
+        if (lane == 63) s_ws[wave] = inc;
+        __syncthreads();
+        uint32_t before = inc - c;
+        for (uint32_t w = 0; w < wave; w++) before += s_ws[w];
+        const uint32_t e[4] = {before, before + c0, before + c0 + c1, before + c0 + c1 + c2}, cc[4] = {c0, c1, c2, c3};
 #pragma unroll
-        for (int w = 0; w < (int)(BWS_FTHREADS / 64); w++) t += s_hist[w][tid];
-        s_tot[tid] = t;
-        if (t == n) s_one = 1;
+        for (int q = 0; q < 4; q++) {
+            const uint32_t d = (uint32_t)(((uint64_t)e[q] << 8) / n);
+            s_lut[4 * tid + q] = (uint8_t)(d < 255u ? d : 255u);
+            if (cc[q]) { atomicAdd(&s_tot[d < 255u ? d : 255u], cc[q]); if (cc[q] == n) s_one = 1; }
+        }
     }
     __syncthreads();
     if (s_one) {                                               // every suffix starts with the same digit: the generic levels go on from the next one
@@ -181,11 +194,6 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
         s_beg[4 * tid] = ex; s_beg[4 * tid + 1] = ex + t0; s_beg[4 * tid + 2] = ex + t0 + t1; s_beg[4 * tid + 3] = ex + t0 + t1 + t2;
     }
     __syncthreads();
-    if (tid < 256) {
-        uint32_t o = s_beg[tid];
-#pragma unroll
-        for (int w = 0; w < (int)(BWS_FTHREADS / 64); w++) { const uint32_t c = s_hist[w][tid]; s_hist[w][tid] = o; o += c; }
-    }
     // ---- place.  The suffixes of a tile are first ordered by digit INSIDE the tile (a permutation of tile positions in LDS: the keys
     // are rebuilt from the symbols), then written out in that order: a wave's stores are runs of consecutive addresses, one run per
     // digit present in the tile, instead of 64 stores scattered over the block's bins.  Scattered 8- and 4-byte stores reached HBM
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
         const uint32_t tn = n - i0 < BWS_FT ? n - i0 : BWS_FT;
         for (uint32_t t = tid; t < BWS_FT; t += BWS_FTHREADS) {         // digits of the tile + their counts
             const bool ok = t < tn;
-            const uint32_t d = ok ? (uint32_t)(key_at(t) >> top_shift) & 0xffu : 0x100u;
+            const uint32_t d = ok ? (uint32_t)s_lut[(uint32_t)(key_at(t) >> sh12) & m12] : 0x100u;
             if (ok) s_dig[t] = (uint8_t)d;
             const unsigned long long peers = BWS_PEERS(ok, d);
             if (ok && (uint32_t)__ffsll(peers) - 1u == lane) atomicAdd(&s_th[d], (uint32_t)__popcll(peers));
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
     __syncthreads();
     if (tid < 256) {                                           // where each bin goes (waves 0-3 whole: wave-uniform calls)
         const uint32_t c = s_tot[tid], at = g0 + s_beg[tid];
-        const BwsSeg nx{at, c, nshift | (1u << 8)};
+        const BwsSeg nx{at, c, top_shift | (1u << 8)};           // no key bit is sorted yet inside a bin (see above)
         bws_append(s.large[1], &s.cnt[1], c > BWS_LMAX, nx);
         bws_append(s.local, &s.cnt[6], c > BWS_WAVE && c <= BWS_LWAVE, nx);
         bws_append(s.localw, &s.cnt[9], c > BWS_LWAVE && c <= BWS_LMAX, nx);
@@ -387,7 +395,7 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                 // (the 32-bit key path packs the group id above a 24-bit rank in the wave sorts: blocks of 2^24 bytes and more take the 64-bit one)
                 const bool wide = round == 0 || kbits1 > 24;
                 if (round) { if (wide) hipLaunchKernelGGL(k_bws_gather<uint64_t>, dim3(gxg, nb), dim3(256), 0, s, st, bstart, nb, h); else hipLaunchKernelGGL(k_bws_gather<uint32_t>, dim3(gxg, nb), dim3(256), 0, s, st, bstart, nb, h); }
-                const int levels = (int)((top + 7) / 8) + 1;
+                const int levels = (int)((top + 7) / 8) + 1 + ((round == 0 && fused_first) ? 1 : 0);   // (k_bws_first's bins start from the top digit again)
                 for (int lv = (round == 0 && fused_first) ? 1 : 0; lv < levels; lv++) {
                     if (hipMemsetAsync(&st.cnt[(lv + 1) & 1], 0, 4, s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
                     if (wide) hipLaunchKernelGGL(k_bws_partition<uint64_t>, dim3(gpart), dim3(512), 0, s, st, lv, topn);
