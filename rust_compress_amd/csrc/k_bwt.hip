@@ -105,6 +105,7 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
     __shared__ uint16_t s_sym[BWS_FT + 16];
     __shared__ uint32_t s_h12[4096], s_tot[256], s_beg[256], s_ws[BWS_FTHREADS / 64];
     __shared__ uint8_t s_lut[4096];
+    __shared__ uint32_t s_nv[256];                                        // top-12 values present in a bin
     __shared__ uint32_t s_th[256], s_ts[256], s_tc[256], s_gcur[256];      // the tile's digit counts, their scan, its cursors; the block's cursors
     __shared__ uint16_t s_perm[BWS_FT];
     __shared__ uint8_t s_dig[BWS_FT];
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
     const uint32_t g0 = a.bstart[b];
     if (tid < 256) s_map[tid] = (uint32_t)map[tid] + plus1;
     for (uint32_t i = tid; i < 4096u; i += BWS_FTHREADS) s_h12[i] = 0;
-    if (tid < 256) s_tot[tid] = 0;
+    if (tid < 256) { s_tot[tid] = 0; s_nv[tid] = 0; }
     if (tid == 0) s_one = 0;
     __syncthreads();
     auto tile = [&](uint32_t i0) {                             // symbols of suffixes i0 .. i0+BWS_FT-1 and the 16 that follow (0 = past the end)
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
         for (int q = 0; q < 4; q++) {
             const uint32_t d = (uint32_t)(((uint64_t)e[q] << 8) / n);
             s_lut[4 * tid + q] = (uint8_t)(d < 255u ? d : 255u);
-            if (cc[q]) { atomicAdd(&s_tot[d < 255u ? d : 255u], cc[q]); if (cc[q] == n) s_one = 1; }
+            if (cc[q]) { atomicAdd(&s_tot[d < 255u ? d : 255u], cc[q]); atomicAdd(&s_nv[d < 255u ? d : 255u], 1u); if (cc[q] == n) s_one = 1; }
         }
     }
     __syncthreads();
@@ -246,7 +247,8 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
     __syncthreads();
     if (tid < 256) {                                           // where each bin goes (waves 0-3 whole: wave-uniform calls)
         const uint32_t c = s_tot[tid], at = g0 + s_beg[tid];
-        const BwsSeg nx{at, c, top_shift | (1u << 8)};           // no key bit is sorted yet inside a bin (see above)
+        // no key bit is sorted yet inside a bin (see above) -- unless it holds ONE top-12 value (a frequent pair of symbols): its 12 bits are done
+        const BwsSeg nx{at, c, (s_nv[tid] == 1u ? (sh12 > 8u ? sh12 - 8u : 0u) : top_shift) | (1u << 8)};
         bws_append(s.large[1], &s.cnt[1], c > BWS_LMAX, nx);
         bws_append(s.local, &s.cnt[6], c > BWS_WAVE && c <= BWS_LWAVE, nx);
         bws_append(s.localw, &s.cnt[9], c > BWS_LWAVE && c <= BWS_LMAX, nx);
