@@ -95,7 +95,8 @@ void launch(dim3_ grid, dim3_ block, const std::function<void()>& body)
             }
             if (B.progress == last_progress) {
                 if (++idle_passes > 2) {
-                    fprintf(stderr, "wavesim: deadlock in block (%u,%u,%u): divergent collective or barrier\n", bx, by, bz);
+                    fprintf(stderr, "wavesim: deadlock in block (%u,%u,%u): divergent collective or barrier (block of %u threads, %d live, at the barrier: %d / %d)\n", bx, by, bz, nthreads, B.live, B.barrier_arrived[0], B.barrier_arrived[1]);
+                    for (size_t w = 0; w < B.waves.size(); w++) fprintf(stderr, "  wave %zu: %d live, in a collective: %d / %d\n", w, B.waves[w].live, B.waves[w].arrived[0], B.waves[w].arrived[1]);
                     abort();
                 }
             } else { idle_passes = 0; last_progress = B.progress; }
