@@ -22,6 +22,7 @@
 #define BWS_FINAL 0x80000000u
 #define BWS_HEAD  0x40000000u
 #define BWS_PAR   0x20000000u
+#define BWS_RV    0x10000000u            /* on a HEAD word: every member's rank[] is this group's first position (a finished sort wrote them) */
 #define BWS_IDX   0x0fffffffu            /* suffix index: batches of < 2^28 suffixes per pass */
 #define BWS_WAVE  32u                    /* the largest group left to the wave-level sorts: it always lies inside a 64-suffix window, aligned or shifted by 32 */
 #define BWS_LMAX  2048u                  /* the largest group sorted to the end of its key inside LDS (k_bws_local), by a workgroup ... */
@@ -248,7 +249,7 @@ __device__ __forceinline__ void bws_mark(const BwsState& s, const BwsSeg& sg, ui
     if (c > BWS_WAVE && !done) return;
     const uint32_t a = sg.start + p;
     if (c == 1u) { s.saA[a] = g | BWS_HEAD | BWS_FINAL; s.rank[g] = a; }
-    else if (done) { s.saA[a] = g | (p == beg ? (BWS_HEAD | s.par) : 0u); s.rank[g] = sg.start + beg; }
+    else if (done) { s.saA[a] = g | (p == beg ? (BWS_HEAD | BWS_RV | s.par) : 0u); s.rank[g] = sg.start + beg; }
     else {
         s.saA[a] = g | (p == beg ? (BWS_HEAD | (s.par ^ BWS_PAR)) : 0u);
         bws_keys<K>(s, 0)[a] = k;
@@ -442,6 +443,7 @@ struct BwsLocal {
         const int src = (int)((sg.info >> 8) & 1u);
         const K* ks = bws_keys<K>(s, src) + sg.start;
         const uint32_t* ss = bws_sa(s, src) + sg.start;
+        const bool whole = (ss[0] & BWS_RV) != 0;                            // a group an earlier round's sort made (not a bin of this round's radix levels)
         for (uint32_t i = t; i < len; i += T) { key[i] = ks[i]; val[i] = ss[i] & BWS_IDX; pa[i] = (uint16_t)i; }
         const uint32_t cs = (((len + NW - 1u) / NW) + 63u) & ~63u;           // a wave's contiguous share
         const uint32_t w0 = w * cs, w1 = (w0 + cs < len) ? w0 + cs : len;
@@ -555,8 +557,8 @@ struct BwsLocal {
                 else { const uint32_t nx = wi + 1u < nwords ? hist[64u + wi + 1u] : 0xffffffffu; re = nx < len ? nx : len; }
                 g = val[pa[p]];
                 const bool single = re - rs == 1u;
-                s.saA[sg.start + p] = g | (rs == p ? (BWS_HEAD | s.par) : 0u) | (single ? BWS_FINAL : 0u);
-                s.rank[g] = sg.start + rs;
+                s.saA[sg.start + p] = g | (rs == p ? (BWS_HEAD | BWS_RV | s.par) : 0u) | (single ? BWS_FINAL : 0u);
+                if (!(whole && rs == 0u)) s.rank[g] = sg.start + rs;             // the run at the start of a group whose ranks stand keeps its rank
             }
             Q->push(s, in && rs == p && re - rs >= 2u, sg.start + rs, re - rs, top_shift);
         }
@@ -626,7 +628,7 @@ __global__ __launch_bounds__(256) void k_bws_small(BwsState s, uint32_t top_shif
         bws_wave_runs<K>(lane, c0, klo, khi, rhead, rs, re);
         if (was) {
             const bool single = re - rs == 1u;
-            s.saA[sg.start + lane] = val | (rhead ? (BWS_HEAD | s.par) : 0u) | (single ? BWS_FINAL : 0u);
+            s.saA[sg.start + lane] = val | (rhead ? (BWS_HEAD | BWS_RV | s.par) : 0u) | (single ? BWS_FINAL : 0u);
             s.rank[val] = sg.start + rs;
         }
         bws_new_group(s, was && rhead && re - rs >= 2u, sg.start + rs, re - rs, top_shift);
@@ -676,8 +678,9 @@ __device__ __forceinline__ void bws_dense_window(const BwsState& s, uint32_t j0,
         }
         if (mine) {
             const bool single = eq == 1u;
-            s.saA[j0 + gs + less] = val | (less == lt ? (BWS_HEAD | s.par) : 0u) | (single ? BWS_FINAL : 0u);
-            s.rank[val] = j0 + gs + lt;
+            s.saA[j0 + gs + less] = val | (less == lt ? (BWS_HEAD | BWS_RV | s.par) : 0u) | (single ? BWS_FINAL : 0u);
+            if (!((hv & BWS_RV) && lt == 0u)) s.rank[val] = j0 + gs + lt;       // the run at the start of a group whose ranks stand keeps its rank:
+                                                                                  // these scattered 4-byte stores are what the dense passes wait for
         }
         rhead = less == lt; rs = 0; re = eq; gpos = j0 + gs + lt;
     } else {
@@ -688,8 +691,8 @@ __device__ __forceinline__ void bws_dense_window(const BwsState& s, uint32_t j0,
         bws_wave_runs<K>(lane, c0, klo, khi, rhead, rs, re);
         if (was) {
             const bool single = re - rs == 1u;
-            s.saA[j] = val | (rhead ? (BWS_HEAD | s.par) : 0u) | (single ? BWS_FINAL : 0u);
-            s.rank[val] = j0 + rs;
+            s.saA[j] = val | (rhead ? (BWS_HEAD | BWS_RV | s.par) : 0u) | (single ? BWS_FINAL : 0u);
+            if (!((hv & BWS_RV) && rs == gs)) s.rank[val] = j0 + rs;
         }
         gpos = j0 + rs;
     }
