@@ -669,11 +669,10 @@ __device__ __forceinline__ void bws_dense_window(const BwsState& s, uint32_t j0,
             const int pa = (int)((srcl & 63u) << 2);
             const uint32_t ol = (uint32_t)__builtin_amdgcn_ds_bpermute(pa, (int)klo);
             const uint32_t oh = sizeof(K) == 8 ? (uint32_t)__builtin_amdgcn_ds_bpermute(pa, (int)khi) : 0u;
-            const uint32_t ov = (uint32_t)__builtin_amdgcn_ds_bpermute(pa, (int)val);
             if (mine && srcl < ge) {
                 const bool l = oh < khi || (oh == khi && ol < klo), e = oh == khi && ol == klo;
                 lt += l ? 1u : 0u; eq += e ? 1u : 0u;
-                less += (l || (e && ov < val)) ? 1u : 0u;
+                less += (l || (e && srcl < lane)) ? 1u : 0u;       // equal keys keep the order they stand in (one ds_bpermute less per step)
             }
         }
         if (mine) {
