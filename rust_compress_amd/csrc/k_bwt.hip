@@ -305,6 +305,8 @@ static inline uint32_t bits_for(uint64_t v) { uint32_t b = 1; while ((1ull << b)
 static uint64_t bwt_forward_scratch_bytes(uint32_t nblocks, uint64_t max_block)
 {
     uint64_t N = (uint64_t)nblocks * max_block;
+    const uint64_t pass = max_block > (uint64_t)BWTF_PASSN ? max_block : (uint64_t)BWTF_PASSN;     // a pass: at most BWTF_PASSN suffixes, or one longer block
+    if (N > pass) N = pass;
     if (N > (uint64_t)BWTF_MAXN) N = BWTF_MAXN;
     // keys 2 x 8N, SA 2 x 4N, rank 4N, group lists, bstart, counters, histogram
     return 28 * N + 5 * (N / BWS_WAVE + nblocks + 1024) * sizeof(BwsSeg) + 2 * (N / 16 + 4096) * sizeof(BwsSeg) + 2 * (N / BWS_LWAVE + nblocks + 1024) * sizeof(BwsSeg) + (uint64_t)(nblocks + 2) * 4 + 4 * (N / 64 + 512) + (N / 256 + nblocks + 1024) + (1ull << 20);

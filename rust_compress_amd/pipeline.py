@@ -65,7 +65,7 @@ class BwtDcAri:
         # 1. BWT
         bw = DeviceBatch(raw, self._i64(off), self._i64(lens), torch.empty(int(lens.sum()) + 64, dtype=torch.uint8, device=self.dev),
                          self._i64(off), self._i64(lens))
-        sc = self._scratch(N.BWT_FORWARD, nb, maxn)          # the library sorts at most 2^27 suffixes per pass (scratch is sized for 2^28: 7.5 GB)
+        sc = self._scratch(N.BWT_FORWARD, nb, maxn)          # the library sorts at most 2^27 suffixes per pass (3.9 GB of scratch for 256 KiB blocks)
         self.ctx.launch_dev(N.BWT_FORWARD, bw, sc)
         # 2. DC into the record slot, 12 bytes in (n, origin, k go in front)
         slot = (4 * (HDR_WORDS + 256 + maxn) + 63) // 64 * 64
