@@ -46,8 +46,8 @@ class BwtDcAri:
         return self.torch.as_tensor(np.asarray(a, dtype=np.int64), device=self.dev)
 
     def _scratch(self, codec, nb, maxn):
-        """One scratch buffer per pipeline object, grown on demand: the suffix sort wants 48 B per input byte of the (at
-        most 1024) blocks it sorts at a time, 13 GB for 256 KiB blocks, and a fresh hipMalloc of that size per call is slow."""
+        """One scratch buffer per pipeline object, grown on demand: the suffix sort wants ~29 B per suffix of a pass (at
+        most 2^27 suffixes), 3.9 GB for 256 KiB blocks, and a fresh hipMalloc of that size per call is slow."""
         need = self.ctx.scratch_bytes(codec, nb, maxn) + 256
         if getattr(self, "_sc", None) is None or self._sc.numel() < need:
             self._sc = None
