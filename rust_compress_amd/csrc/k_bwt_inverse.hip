@@ -194,14 +194,14 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
     // nodes are ranked, a parked chain is COPIED to its place -- only a chain longer than `cap` is chased a second time.
     // (`capx` < BWTI_CAPX is the test knob, variant 1: it parks less, so that second chases happen on ordinary inputs)
     const uint32_t pitch = (uint32_t)bwti_cap(stride);
-    const uint32_t cap = capx >= BWTI_CAPX ? pitch : (((capx * stride + 7u) & ~7u) < pitch ? ((capx * stride + 7u) & ~7u) : pitch);
+    const uint32_t cap = capx >= BWTI_CAPX ? pitch : (((capx * stride + 15u) & ~15u) < pitch ? ((capx * stride + 15u) & ~15u) : pitch);
     // a thread owns the marked nodes tid, tid + 1024, ...; it chases BWTI_SLOTS of them at once and refills a slot when its chain ends
     for (int pass = 0; pass < 2; pass++) {
         uint32_t cur[BWTI_SLOTS], cnt[BWTI_SLOTS], wr[BWTI_SLOTS], mid[BWTI_SLOTS]; bool live[BWTI_SLOTS];
-        uint64_t pk[BWTI_SLOTS];                                          // pass 0: the chain's bytes, parked eight at a time
+        uint64_t pk[BWTI_SLOTS], pk2[BWTI_SLOTS];                         // pass 0: the chain's bytes, parked sixteen at a time
         uint32_t nextm = tid;
         auto start = [&](int q) {                                         // the thread's next marked node -> slot q
-            live[q] = false; wr[q] = NONE; cnt[q] = 0; cur[q] = 0; mid[q] = 0; pk[q] = 0;
+            live[q] = false; wr[q] = NONE; cnt[q] = 0; cur[q] = 0; mid[q] = 0; pk[q] = 0; pk2[q] = 0;
             while (nextm < M) {
                 const uint32_t m = nextm; nextm += BWTI_THREADS;
                 if (LF && pass == 1 && s_next[m] != NONE16) continue;     // not on origin's cycle: the walk never comes here
@@ -264,8 +264,11 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inverse(rcx_kargs a, uint3
                 else {
                     // a byte store per step kept ~260 K partial-line writes per block on their way to HBM (the lines leave the L2
                     // long before a walker comes back to them): 8 bytes per store
-                    pk[q] |= (uint64_t)ch[q] << (8u * (cnt[q] & 7u));
-                    if (((cnt[q] & 7u) == 7u || stop) && (cnt[q] & ~7u) < cap) { *(uint64_t*)(park + (size_t)mid[q] * pitch + (cnt[q] & ~7u)) = pk[q]; pk[q] = 0; }
+                    if (cnt[q] & 8u) pk2[q] |= (uint64_t)ch[q] << (8u * (cnt[q] & 7u)); else pk[q] |= (uint64_t)ch[q] << (8u * (cnt[q] & 7u));
+                    if (((cnt[q] & 15u) == 15u || stop) && (cnt[q] & ~15u) < cap) {
+                        *(rcx_u32x4*)(park + (size_t)mid[q] * pitch + (cnt[q] & ~15u)) = rcx_u32x4{(uint32_t)pk[q], (uint32_t)(pk[q] >> 32), (uint32_t)pk2[q], (uint32_t)(pk2[q] >> 32)};
+                        pk[q] = 0; pk2[q] = 0;
+                    }
                 }
                 cnt[q]++;
                 if (stop) {
