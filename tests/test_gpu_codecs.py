@@ -93,7 +93,7 @@ def test_bwt_inverse_minimal(ctx, oracle):
             exp.append((0, oracle.bwt_decode(L, og, minimal=True)))
         except Exception as e:                                            # oracle_py.OracleError
             exp.append((e.status, b""))
-    for variant in (0, 1):                                                # 1: park 8 bytes per walker at most, the rest by second chases
+    for variant in (0, 1):                                                # 1: park 16 bytes per walker at most, the rest by second chases
         ctx.set_variant(N.BWT_INVERSE_MINIMAL, variant)
         res = ctx.bwt_inverse_minimal(list(Ls), list(orgs))
         for i, (est, eout) in enumerate(exp):

@@ -25,7 +25,7 @@ def test_dc_decode_fuzz(ctx):
 def test_bwt_inverse_fuzz(ctx):
     import fuzz_gpu_bwti
     assert fuzz_gpu_bwti.main(2000, 6, ctx) == 0
-    assert fuzz_gpu_bwti.main(1000, 8, ctx, variant=1) == 0             # walkers park 8 bytes at most: second chases
+    assert fuzz_gpu_bwti.main(1000, 8, ctx, variant=1) == 0             # walkers park 16 bytes at most: second chases
     assert fuzz_gpu_bwti.main(1000, 9, ctx, variant=2) == 0             # the forward chase over the scattered jump table (A/B kernel)
     assert fuzz_gpu_bwti.main(1200, 7, ctx, minimal=True) == 0          # decode_minimal, src/bwt/mod.rs:298-315
 

@@ -157,7 +157,7 @@ def test_bwt_inverse(oracle):
     raws = corpus.small_corpus(sizes=(17, 1000, 20000, 70000), with_empty=False)
     Ls, orgs = zip(*[oracle.bwt_encode(r) for r in raws])
     maxn = max(len(r) for r in raws)
-    # variant bit 0: walkers park at most 8 bytes, so most chains of the larger blocks take the second chase; bit 1: the forward chase
+    # variant bit 0: walkers park at most 16 bytes, so most chains of the larger blocks take the second chase; bit 1: the forward chase
     # over the scattered jump table instead of the backward walk over place()
     rng = np.random.default_rng(8)
     bad = [(bytes(rng.integers(0, 4, 3000, dtype=np.uint8)), 17), (Ls[2], (orgs[2] + 1) % len(Ls[2])), (b"abc", 3)]     # not a BWT / wrong origin / origin >= n
@@ -183,7 +183,7 @@ def test_bwt_inverse_minimal(oracle):
     Ls, orgs = zip(*pairs)
     maxn = max(len(L) for L in Ls)
     wrong = 0
-    for variant in (0, 1):                                                # 1: park at most 8 bytes per walker (second chases)
+    for variant in (0, 1):                                                # 1: park at most 16 bytes per walker (second chases)
         outs, olen, _, st, _ = simrun.run(N.BWT_INVERSE_MINIMAL, variant, list(Ls), [len(L) for L in Ls], aux=np.array(orgs, dtype=np.uint32),
                                           scratch_bytes=len(Ls) * (24 * maxn + 70000) + 256)
         for i, (L, og) in enumerate(pairs):
