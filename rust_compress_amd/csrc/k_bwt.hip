@@ -105,7 +105,7 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
     __shared__ uint16_t s_sym[BWS_FT + 16];
     __shared__ uint32_t s_h12[4096], s_tot[256], s_beg[256], s_ws[BWS_FTHREADS / 64];
     __shared__ uint8_t s_lut[4096];
-    __shared__ uint32_t s_nv[256];                                        // top-12 values present in a bin
+    __shared__ uint32_t s_vlo[256], s_vhi[256];                           // smallest and largest top-12 value of a bin
     __shared__ uint32_t s_th[256], s_ts[256], s_tc[256], s_gcur[256];      // the tile's digit counts, their scan, its cursors; the block's cursors
     __shared__ uint16_t s_perm[BWS_FT];
     __shared__ uint8_t s_dig[BWS_FT];
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
     const uint32_t g0 = a.bstart[b];
     if (tid < 256) s_map[tid] = (uint32_t)map[tid] + plus1;
     for (uint32_t i = tid; i < 4096u; i += BWS_FTHREADS) s_h12[i] = 0;
-    if (tid < 256) { s_tot[tid] = 0; s_nv[tid] = 0; }
+    if (tid < 256) { s_tot[tid] = 0; s_vlo[tid] = 0xffffffffu; s_vhi[tid] = 0; }
     if (tid == 0) s_one = 0;
     __syncthreads();
     auto tile = [&](uint32_t i0) {                             // symbols of suffixes i0 .. i0+BWS_FT-1 and the 16 that follow (0 = past the end)
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
         for (int q = 0; q < 4; q++) {
             const uint32_t d = (uint32_t)(((uint64_t)e[q] << 8) / n);
             s_lut[4 * tid + q] = (uint8_t)(d < 255u ? d : 255u);
-            if (cc[q]) { atomicAdd(&s_tot[d < 255u ? d : 255u], cc[q]); atomicAdd(&s_nv[d < 255u ? d : 255u], 1u); if (cc[q] == n) s_one = 1; }
+            if (cc[q]) { atomicAdd(&s_tot[d < 255u ? d : 255u], cc[q]); atomicMin(&s_vlo[d < 255u ? d : 255u], 4u * tid + (uint32_t)q); atomicMax(&s_vhi[d < 255u ? d : 255u], 4u * tid + (uint32_t)q); if (cc[q] == n) s_one = 1; }
         }
     }
     __syncthreads();
@@ -247,8 +247,13 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
     __syncthreads();
     if (tid < 256) {                                           // where each bin goes (waves 0-3 whole: wave-uniform calls)
         const uint32_t c = s_tot[tid], at = g0 + s_beg[tid];
-        // no key bit is sorted yet inside a bin (see above) -- unless it holds ONE top-12 value (a frequent pair of symbols): its 12 bits are done
-        const BwsSeg nx{at, c, (s_nv[tid] == 1u ? (sh12 > 8u ? sh12 - 8u : 0u) : top_shift) | (1u << 8)};
+        // the key bits a bin's values share are sorted inside it (all twelve when it holds ONE value, a frequent pair of symbols): the
+        // levels below start at the first digit that is not wholly inside that common prefix
+        const uint32_t dv = c ? s_vlo[tid] ^ s_vhi[tid] : 0u;
+        const uint32_t unsorted = sh12 + (dv ? 32u - (uint32_t)__clz((int)dv) : 0u);      // bits [0, unsorted) may differ inside the bin
+        uint32_t shift = top_shift;
+        while (shift >= 8u && shift >= unsorted) shift -= 8u;
+        const BwsSeg nx{at, c, shift | (1u << 8)};
         bws_append(s.large[1], &s.cnt[1], c > BWS_LMAX, nx);
         bws_append(s.local, &s.cnt[6], c > BWS_WAVE && c <= BWS_LWAVE, nx);
         bws_append(s.localw, &s.cnt[9], c > BWS_LWAVE && c <= BWS_LMAX, nx);
