@@ -248,11 +248,10 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
     if (tid < 256) {                                           // where each bin goes (waves 0-3 whole: wave-uniform calls)
         const uint32_t c = s_tot[tid], at = g0 + s_beg[tid];
         // the key bits a bin's values share are sorted inside it (all twelve when it holds ONE value, a frequent pair of symbols): the
-        // levels below start at the first digit that is not wholly inside that common prefix
+        // levels below start right under that common prefix
         const uint32_t dv = c ? s_vlo[tid] ^ s_vhi[tid] : 0u;
         const uint32_t unsorted = sh12 + (dv ? 32u - (uint32_t)__clz((int)dv) : 0u);      // bits [0, unsorted) may differ inside the bin
-        uint32_t shift = top_shift;
-        while (shift >= 8u && shift >= unsorted) shift -= 8u;
+        const uint32_t shift = unsorted > 8u ? unsorted - 8u : 0u;                        // the first digit: the eight highest bits that may differ
         const BwsSeg nx{at, c, shift | (1u << 8)};
         bws_append(s.large[1], &s.cnt[1], c > BWS_LMAX, nx);
         bws_append(s.local, &s.cnt[6], c > BWS_WAVE && c <= BWS_LWAVE, nx);
