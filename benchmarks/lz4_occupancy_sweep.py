@@ -10,12 +10,13 @@ import rust_compress_amd as R
 from rust_compress_amd import _native as N
 import bench
 kind = sys.argv[1] if len(sys.argv) > 1 else "text"
+variants = tuple(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else (0, 10)
 dev = torch.device("cuda", 0)
 ctx = R.Context(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 names = ["parse", "room", "head", "far+lit", "dep", "copy", "flush", "stage", "solo", "wide"]
 for nb in (256, 1024, 2048, 4096, 8192, 16384):
     dec, raw, cb, ob = bench.make_workload(R, ctx, torch, dev, kind, nb, 0x4C5A3401)
-    for variant in (0, 10):
+    for variant in variants:
         ctx.set_variant(N.LZ4_DECODE, variant)
         sc = torch.zeros(nb * 16 * 8 + 64, dtype=torch.uint8, device=dev)
         for _ in range(2):

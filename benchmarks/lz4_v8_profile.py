@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Phase timers of the segment-parallel parser wave (k_lz4_decode_v8, A/B variant 24): RCX_AB=1 python benchmarks/lz4_v8_profile.py [kind] [nblocks]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import rust_compress_amd as R
+from rust_compress_amd import _native as N
+import bench
+kind = sys.argv[1] if len(sys.argv) > 1 else "text"
+nb = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+dev = torch.device("cuda", 0)
+ctx = R.Context(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+dec, raw, cb, ob = bench.make_workload(R, ctx, torch, dev, kind, nb, 0x4C5A3401)
+ctx.set_variant(N.LZ4_DECODE, 24)
+sc = torch.zeros(nb * 256 + 64, dtype=torch.uint8, device=dev)
+for _ in range(2):
+    ctx.launch_dev(N.LZ4_DECODE, dec, sc); torch.cuda.synchronize()
+p = sc[: nb * 256].view(torch.int64).view(nb, 32).cpu().numpy().astype(np.float64).mean(axis=0)
+names = ["walk", "link", "list", "fields", "post(wait)", "-", "tiles", "walk steps", "repairs", "batches"]
+print("kind %s, %d blocks: parser total %.0fK cycles, executor total %.0fK" % (kind, nb, p[10] / 1e3, p[11] / 1e3))
+print("  cycles: " + "  ".join("%s %.0fK" % (names[i], p[i] / 1e3) for i in range(5)))
+print("  counts: " + "  ".join("%s %.1f" % (names[i], p[i]) for i in range(6, 10)))
+e = p[16:28]
+print("  executor: waiting for a batch %.0fK | scan+validate %.0fK  loads+chains %.0fK  lit/gather stores %.0fK  copy rounds %.0fK  flush %.0fK | rounds %.1f  emit calls %.1f  batches %.1f" % (e[0] / 1e3, e[4] / 1e3, e[5] / 1e3, e[6] / 1e3, e[7] / 1e3, e[8] / 1e3, e[9], e[10], e[2]))

@@ -48,7 +48,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
     static constexpr int STAGE5 = B::LIN + 64;         // 64 lanes x 32 bytes of old-match staging (bytes 32.. of a longer
     static constexpr int WBUF5 = STAGE5 + 64 * SB;     // gathered match go straight to their place): 16 blocks per CU fit
     RCX_LDS_AS Ring* ring;                         // address space 3: the volatile head / tail accesses must be ds_read / ds_write, not flat
-    uint64_t pw[4] = {0, 0, 0, 0};                 // PROF5: cycles waiting on the ring, cycles working, batches, -
+    uint64_t pw[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // PROF5: [0] cycles waiting on the ring, [2] batches; executor phases [4] scan+validate [5] loads+chains [6] literal/gather stores [7] copy rounds [8] flush [9] rounds [10] emit calls
 
     // ------------------------------------------------------------------------------------------ parser wave
     __device__ void run_parser()
@@ -118,6 +118,8 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
         const unsigned lane = this->lane;
         const uint8_t* in = this->in; uint8_t* out = this->out; uint8_t* wb_ = this->wb_;
         const uint32_t cap = this->cap, n = this->n;
+        uint64_t tq_ = PROF5 ? (uint64_t)__builtin_readcyclecounter() : 0;
+#define V5P_ADD(slot) do { if (PROF5) { const uint64_t t1_ = (uint64_t)__builtin_readcyclecounter(); pw[slot] += t1_ - tq_; tq_ = t1_; } } while (0)
         this->make_room(B::TCAP);
         bool act = (int)lane >= lo && (int)lane < ns;
         uint32_t L = act ? w1 & 0xffu : 0u, M = act ? (w1 >> 8) & 0xffu : 0u, off = act ? w1 >> 16 : 0u;
@@ -144,6 +146,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
         }
         const unsigned long long bad = __ballot(err != 0);
         if (bad) return __builtin_amdgcn_readlane(err, __ffsll(bad) - 1);
+        V5P_ADD(4);
 
         const int32_t lbase = this->lbase;
         const uint32_t re = this->rlo_eff();
@@ -207,6 +210,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
             }
         }
 
+        V5P_ADD(5);
         // ---- literals, then gathered matches: registers -> their place in the window
         if (__ballot(L != 0)) {
             RCX_LDS_STORE16(wb_ + li_o, g0[0], g0[1], g0[2], g0[3], lit16 ? (L < 16u ? L : 16u) : 0u);
@@ -226,6 +230,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
                 if (farb && i < M) d[i] = out[slo + i];
         }
         rcx_wave_sync();
+        V5P_ADD(6);
 
         // ---- window matches: copy rounds (16 bytes per ready lane), see Lz4V4::emit.  A short-period match (off < 16, off < M)
         // reads its periodic source 8 bytes a pass; once 16 bytes stand it copies from off * ceil(16 / off) >= 16 bytes
@@ -244,6 +249,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
                 for (;;) {
                     const unsigned long long pm = __ballot(pending);
                     if (!pm) break;
+                    if (PROF5) pw[9] += 1;
                     const bool ready = pending && (pm & dep) == 0;
                     const bool rn = ready && !ovl;
                     uint32_t v0, v1, v2 = 0, v3 = 0, nv;
@@ -276,9 +282,13 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
             if (__ballot(ovl0 && M > 16u)) rounds(std::true_type{}); else rounds(std::false_type{});
             if (!LITLDS) __builtin_amdgcn_s_setprio(RCX_FLUSH_PRIO); else if (RCX_INF_ROUNDS_PRIO) __builtin_amdgcn_s_setprio(0);
         }
+        V5P_ADD(7);
         this->oend = RCX_U(oend0 + T);
         this->flush(this->oend, false);
         if (!LITLDS && RCX_FLUSH_PRIO != RCX_EXEC_PRIO) __builtin_amdgcn_s_setprio(RCX_EXEC_PRIO);
+        V5P_ADD(8);
+        if (PROF5) pw[10] += 1;
+#undef V5P_ADD
         return 0;
     }
 
@@ -317,10 +327,10 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
     }
 };
 
-template <int CB, int TC = 2560, int HH = 2048, bool PROF5 = false>
+template <int CB, int TC = 2560, int HH = 2048, bool PROF5 = false, int SB = 32>
 __global__ __launch_bounds__(128, 8) void k_lz4_decode_v5(rcx_kargs a, int only_status = 0)
 {
-    typedef Lz4V5<CB, TC, HH, PROF5> S;
+    typedef Lz4V5<CB, TC, HH, PROF5, SB> S;
     const uint64_t tk0 = PROF5 ? (uint64_t)__builtin_readcyclecounter() : 0;
     __shared__ __align__(16) uint8_t s_cbuf[CB + 96];
     __shared__ __align__(16) uint8_t s_wbuf[S::WBUF5 + 16];     // + 16: the last staging slot is read one dword past its end

@@ -1,0 +1,517 @@
+// k_lz4_decode_v8.hip -- LZ4 block decode, two waves per block as in v5, with a SEGMENT-PARALLEL parser wave
+// (reference: BlockDecoder::decode, src/lz4.rs:67-140; the executor wave is Lz4V5's, unchanged).
+//
+// Why: with the executor switched off the v5 kernel still takes 0.44 of its 0.67 ms (4096 x 64 KiB of text, A/B variant 21):
+// the token walk -- v_readlane + s_bitset + s_add per token, one window of 64 input bytes at a time, ~95 scalar instructions
+// per window -- keeps the CU's one scalar port 80 % busy on its own.  A walk is serial, but WHERE a walk starts hardly matters:
+// two walks over the same bytes that ever meet stay together, and on real streams they meet after ~33 bytes (p90 85, measured
+// on every synthetic distribution).
+//
+// So the parser wave stages 4 KiB of input in LDS (coalesced 16-byte loads, as v4/v5 do), cuts it into 64 SEGMENTS of 64 bytes
+// and walks them all at once, a LANE per segment: each lane starts PRE = 128 bytes BEFORE its segment -- a guess -- and marks
+// the token starts it visits inside its segment in a 64-bit register; the lane that holds the true cursor starts there.  Then
+// the segments are LINKED in order (scalar code over registers, no memory): the true walk enters segment k where the last
+// true segment's walk left; if that byte is marked in k's map the two walks have met, the marks below it are dropped and k's
+// exit is the true one; if not (a few per cent) the true walk is followed by hand until it meets the map or leaves the
+// segment.  A segment the true walk jumps over (a long literal run) is cleared.  What is left is the exact set of token
+// starts, and from there on everything is a lane per TOKEN: the maps are unpacked into a list of positions, 64 list entries
+// make a batch, and each lane reads its token's fields from 16 bytes of the staged input (token, <= 12 literals, offset and
+// the first length extension fit; the few others, and the last 20 bytes of a block, take a bounds-checked byte path through
+// global memory that reproduces the reference's error cases, as collect()'s general path does).
+//
+// (Two earlier forms of the same idea, measured and dropped: a lane per 256..384-byte segment reading global memory -- 64 lanes,
+// 64 cache lines per load instruction: a step of the walk took 3600 cycles with sixteen blocks on a CU, 0.25 ms before the first
+// batch -- and linking by "is the entry byte marked" without the head start: 68 of 94 segments needed the hand walk.)
+#include "rcx_dev.h"
+
+#define V8P_T0() uint64_t t0_ = PROF8 ? (uint64_t)__builtin_readcyclecounter() : 0
+#define V8P_ADD(slot) do { if (PROF8) { const uint64_t t1_ = (uint64_t)__builtin_readcyclecounter(); pp[slot] += t1_ - t0_; t0_ = t1_; } } while (0)
+
+template <int TC = 1024, int HH = 1024, int SB = 16, bool PROF8 = false, int PRE_ = 128, int SPLIT_ = 32>
+struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
+    // A match longer than SPLIT bytes is handed over as TWO entries -- (L, SPLIT, offset) and (0, M - SPLIT, offset): the same
+    // bytes -- so that the executor's copy rounds, 16 bytes a lane and round, are paced by SPLIT and not by the 64-byte cap
+    // (3.8 of its 4.6 rounds per batch of text were the long matches').  0: off.
+    static constexpr int SPLIT = SPLIT_;
+    static_assert(SPLIT_ == 0 || 2 * SPLIT_ >= 64, "two entries cover the 64-byte cap");
+    typedef Lz4V5<1024, TC, HH, PROF8, SB> P5;
+    typedef typename P5::B B;
+    static constexpr int SEGB = 64, NSEG = 64, CH = SEGB * NSEG;      // a chunk: 64 segments of 64 bytes, a lane each
+    static constexpr int PRE = PRE_;                                  // head start of a guessing lane (staged in front of the chunk)
+    static constexpr int CSLACK = 32;                                 // staged beyond the chunk: a token's fields are read 16 bytes at a time
+    static constexpr int CBUF8 = PRE + CH + CSLACK;
+    static constexpr int LWIN = 8;                                    // segments unpacked into the list at a time (512 bytes of input)
+    static constexpr int LISTN = LWIN * 22 + 64;                      // a token is >= 3 bytes (the last one apart): <= 22 per segment
+    static_assert((PRE % 16) == 0 && (CBUF8 % 16) == 0, "staging is 16 bytes a lane");
+    int16_t* list;                                                    // LDS: LISTN token positions, relative to the chunk
+    // The ring between the two waves: EIGHT batches deep -- between the last batch of a chunk and the first of the next the parser
+    // stages, walks and links (~55K cycles alone; the executor takes ~10K a batch) -- and a batch entry is ONE word,
+    // L | M << 8 | offset << 16: where the literals lie follows from the token's position, and that from the position of the
+    // batch's first token (hdr[7]) and the sizes of the tokens in front (3 + L bytes, + 1 from L = 15 on, + 1 from M = 19 on:
+    // up to the per-lane caps each extension is a single byte), a wave scan on the executor's side.
+    static constexpr int NSLOT8 = 8;
+    struct Slot8 { uint32_t hdr[8]; uint32_t d[64]; };
+    struct Ring8 { Slot8 slot[NSLOT8]; volatile uint32_t head, tail, abort_, pad; };
+    RCX_LDS_AS Ring8* ring8;
+    uint64_t pp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};          // PROF8 (A/B builds): cycles per parser phase, counts
+
+    // byte q of the input (q < n): from the staged bytes when it is among them (two loads kept apart: a select between the
+    // two POINTERS would be a flat load)
+    __device__ __forceinline__ uint32_t gb(uint32_t q) const
+    {
+        const int32_t i = (int32_t)q - this->cbase;
+        uint32_t v;
+        if (i >= 0 && i < CBUF8) v = ((const RCX_LDS_AS uint8_t*)this->cbuf)[i]; else v = ((const RCX_GLOBAL_AS uint8_t*)this->in)[q];
+        return v;
+    }
+    // four bytes at q (q + 4 <= n), same sources
+    __device__ __forceinline__ uint32_t gd(uint32_t q) const
+    {
+        const int32_t i = (int32_t)q - this->cbase;
+        uint32_t v;
+        if (i >= 0 && i + 8 <= CBUF8) v = B::lds_load4u(this->cbuf, i); else v = *(const uint32_t __attribute__((aligned(1)))*)(this->in + q);
+        return v;
+    }
+    // A run of 255s in a length extension, four bytes a step (a 64 KiB literal run has 257 extension bytes): advances q over
+    // whole words of 0xff and returns how many bytes that were.
+    __device__ __forceinline__ uint32_t skip_ff(uint32_t& q) const
+    {
+        const uint32_t n = this->n;
+        uint32_t k = 0;
+        while (q + 4u <= n && q + 4u > q && gd(q) == 0xffffffffu) { q += 4; k += 4; }
+        return k;
+    }
+    // Where the token after the one at p starts (n: there is none).  Bounds-checked; never faults on garbage.  The slow path of
+    // next_tok_c (a guessing lane walks garbage: on incompressible data one token in sixteen has a length extension).
+    __device__ uint32_t next_tok(uint32_t p) const
+    {
+        const uint32_t n = this->n;
+        uint32_t q = p + 1;
+        const uint32_t t = gb(p);
+        uint32_t L = t >> 4;
+        if (L == 15) {
+            L += 255u * skip_ff(q);
+            for (;;) { if (q >= n) return n; const uint32_t x = gb(q++); L += x; if (x != 255) break; }
+        }
+        if (L >= n - q) return n;                                    // the literals reach the end: the last token
+        q += L;
+        if (n - q < 2) return n;
+        q += 2;
+        if ((t & 15u) == 15u) {
+            skip_ff(q);
+            for (;;) { if (q >= n) return n; const uint32_t x = gb(q++); if (x != 255) break; }
+        }
+        return q;
+    }
+    // The same from the staged bytes: p lies in [cbase, chunk end) (the walk never leaves them), so token and extension byte are
+    // staged; long literal runs, longer extension chains and the last 20 bytes of the block go through next_tok.
+    __device__ __forceinline__ uint32_t next_tok_c(uint32_t p) const
+    {
+        const uint32_t n = this->n;
+        const RCX_LDS_AS uint8_t* cb = (const RCX_LDS_AS uint8_t*)this->cbuf;
+        uint32_t q = 0;
+        bool slow = n < 20u || p > n - 20u;
+        if (!slow) {
+            const int32_t i = (int32_t)p - this->cbase;
+            const uint32_t t = cb[i];
+            const uint32_t L = t >> 4;
+            q = p + 3u + L;
+            if (L == 15u) slow = true;
+            else if ((t & 15u) == 15u) {
+                const uint32_t x = cb[i + 3 + (int32_t)L];
+                if (x == 255u) slow = true; else q++;
+            }
+        }
+        return slow ? next_tok(p) : q;
+    }
+
+    // Stage [cs - PRE, cs + CH + CSLACK) of the input (what exists of it); (cs + the input's misalignment) is a multiple of 16.
+    __device__ void stage8(int32_t cs)
+    {
+        const uint8_t* in = this->in; const uint32_t n = this->n; uint8_t* cbuf = this->cbuf;
+        const unsigned lane = this->lane;
+        this->cbase = cs - PRE;
+        constexpr int NR = (CBUF8 / 16 + 63) / 64;
+        rcx_u32x4 v[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int j = r * 64 + (int)lane;
+            const int32_t pos = this->cbase + 16 * j;
+            v[r] = rcx_u32x4{0, 0, 0, 0};
+            if (j < CBUF8 / 16 && pos >= 0 && (uint32_t)pos + 16 <= n) v[r] = *(const rcx_u32x4*)(in + pos);
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int j = r * 64 + (int)lane;
+            const int32_t pos = this->cbase + 16 * j;
+            if (j < CBUF8 / 16) {
+                if (pos >= 0 && (uint32_t)pos + 16 <= n) *(rcx_u32x4*)(cbuf + 16 * j) = v[r];
+                else {
+                    for (int t = 0; t < 16; t++) {
+                        const int32_t q = pos + t;
+                        cbuf[16 * j + t] = (q >= 0 && (uint32_t)q < n) ? in[q] : (uint8_t)0;
+                    }
+                }
+            }
+        }
+        rcx_wave_sync();
+    }
+
+    // Fields of the token at p, lane by lane (collect()'s general path, restated per lane): perr 0, RCX_E_MALFORMED, or -1 with
+    // gL = L ("the literals are copied, then the offset read fails", lz4.rs:96-111).
+    __device__ __forceinline__ void fields(uint32_t p, bool on, uint32_t& L, uint32_t& M, uint32_t& off, uint32_t& src, int& perr)
+    {
+        const uint8_t* in = this->in; const uint32_t n = this->n;
+        L = 0; M = 0; off = 0; src = p + 1; perr = 0;
+        bool slow = on;
+        const int32_t ci = (int32_t)p - this->cbase;
+        const bool fast = on && (uint64_t)p + 20u <= (uint64_t)n && ci >= 0 && ci + 20 <= CBUF8;
+        if (__ballot(fast)) {
+            uint32_t v0, v1, v2, v3;
+            B::lds_load16u(this->cbuf, fast ? ci : 0, v0, v1, v2, v3);
+            const uint32_t t = v0 & 0xffu, Ln = t >> 4;
+            if (fast && Ln <= 12u) {
+                const uint32_t i = 1u + Ln, q = i >> 2;
+                const uint32_t lo = q == 0 ? v0 : q == 1 ? v1 : q == 2 ? v2 : v3;
+                const uint32_t hi = q == 0 ? v1 : q == 1 ? v2 : v3;
+                const uint32_t w = RCX_ALIGNBYTE(hi, lo, i & 3u);            // offset lo, hi, first extension byte
+                const uint32_t x = (w >> 16) & 0xffu;
+                if ((t & 15u) != 15u || x != 255u) {
+                    L = Ln; off = w & 0xffffu; M = (t & 15u) + 4u + ((t & 15u) == 15u ? x : 0u);
+                    slow = false;
+                }
+            }
+        }
+        if (__ballot(slow)) {
+            if (slow) {                                              // (bytes through gb(): staged ones come from LDS)
+                uint32_t q = p + 1;
+                const uint32_t t = gb(p);
+                L = t >> 4;
+                if (L == 15) {
+                    L += 255u * skip_ff(q);
+                    for (;;) { if (q >= n) { perr = RCX_E_MALFORMED; break; } const uint32_t x = gb(q++); L += x; if (x != 255) break; }
+                }
+                src = q;
+                if (!perr && L > n - q) perr = RCX_E_MALFORMED;
+                if (!perr) {
+                    q += L;
+                    if (q != n) {
+                        if (n - q < 2) perr = -1;
+                        else {
+                            off = gb(q) | (gb(q + 1) << 8);
+                            q += 2;
+                            M = t & 15u;
+                            if (M == 15) {
+                                M += 255u * skip_ff(q);
+                                for (;;) { if (q >= n) { perr = -1; break; } const uint32_t x = gb(q++); M += x; if (x != 255) break; }
+                            }
+                            M += 4;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // post one batch (p0: where its first token starts); returns false when the executor has given up
+    // lane's token becomes entry `idx` (and idx + 1 when w1b != 0) of the batch, if `put`
+    __device__ __forceinline__ bool post(uint32_t& head, int ns, int why, int perr, uint32_t gL, uint32_t gM, uint32_t goff, uint32_t gsrc, uint32_t p0, bool put, uint32_t idx, uint32_t w1, uint32_t w1b)
+    {
+        const unsigned lane = this->lane;
+        auto ring = this->ring8;
+        for (;;) {
+            const uint32_t t = RCX_U(ring->tail);
+            if (RCX_U(ring->abort_)) return false;
+            if (head - t < (uint32_t)NSLOT8) break;
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_sleep(16);
+        }
+        __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO);
+        rcx_wave_sync();
+        RCX_LDS_AS Slot8* sl = &ring->slot[head % NSLOT8];
+        if (put) { sl->d[idx] = w1; if (w1b) sl->d[idx + 1] = w1b; }
+        if (lane == 0) {
+            sl->hdr[0] = (uint32_t)ns; sl->hdr[1] = (uint32_t)why; sl->hdr[2] = (uint32_t)perr;
+            sl->hdr[3] = gL; sl->hdr[4] = gM; sl->hdr[5] = goff; sl->hdr[6] = gsrc; sl->hdr[7] = p0;
+        }
+        rcx_wave_sync();
+        head++;
+        if (lane == 0) ring->head = head;
+        return true;
+    }
+
+    // Up to 64 list entries from `pos` on -> one batch (cut at the first entry the executor takes alone: a long sequence, or
+    // an error).  Returns the entries used up, or -1 when the parser is done (error posted / executor gone).
+    __device__ __forceinline__ int batch8(uint32_t& head, int32_t cs, uint32_t pos, uint32_t m)
+    {
+        const unsigned lane = this->lane;
+        const bool on = lane < m;
+        const uint32_t tp = (uint32_t)(cs + (on ? (int32_t)list[pos + lane] : 0));
+        uint32_t L, M, off, src; int perr;
+        V8P_T0();
+        fields(tp, on, L, M, off, src, perr);
+        V8P_ADD(3);
+        const unsigned long long stop = __ballot(on && (perr != 0 || L > (uint32_t)B::LCAP || M > (uint32_t)B::MCAP));
+        int nt = (int)m, why = B::GO, gerr = 0;                          // nt: tokens that become entries
+        uint32_t gL = 0, gM = 0, goff = 0, gsrc = 0;
+        int g = -1;
+        if (stop) { g = __ffsll(stop) - 1; nt = g; }
+        // entries: one per token, two for a match longer than SPLIT; at most 64 a batch
+        const bool two = SPLIT && (int)lane < nt && M > (uint32_t)SPLIT && off >= 16u;      // (a short period copies itself: its halves would only wait for each other)
+        const uint32_t ecnt = (int)lane < nt ? (two ? 2u : 1u) : 0u;
+        const uint32_t eincl = SPLIT ? rcx_wave_incl_scan(ecnt) : (uint32_t)lane + ecnt;
+        uint32_t ne = (uint32_t)nt;
+        if (SPLIT) {
+            ne = nt ? RCX_U(__builtin_amdgcn_readlane(eincl, nt - 1)) : 0u;
+            if (ne > 64u) {                                          // the tokens whose entries fit; the rest (and a stop) come next time
+                nt = (int)__popcll(__ballot((int)lane < nt && eincl <= 64u));
+                ne = RCX_U(__builtin_amdgcn_readlane(eincl, nt - 1));
+                g = -1;
+            }
+        }
+        if (g >= 0) {
+            gerr = __builtin_amdgcn_readlane(perr, g);
+            gL = RCX_U(__builtin_amdgcn_readlane(L, g)); gM = RCX_U(__builtin_amdgcn_readlane(M, g));
+            goff = RCX_U(__builtin_amdgcn_readlane(off, g)); gsrc = RCX_U(__builtin_amdgcn_readlane(src, g));
+            if (gerr) { why = B::ERR_; if (gerr > 0) gL = 0; }
+            else why = (gL + gM <= (uint32_t)B::SOLO) ? B::SOLO_ : B::WIDE_;
+        }
+        const bool put = (int)lane < nt;
+        const uint32_t M1 = two ? (uint32_t)SPLIT : M;
+        if (!post(head, (int)ne, why, gerr, gL, gM, goff, gsrc, RCX_U(tp), put, eincl - ecnt, L | (M1 << 8) | (off << 16),
+                  (put && two) ? (0x80u | ((M - (uint32_t)SPLIT) << 8) | (off << 16)) : 0u)) return -1;
+        V8P_ADD(4);
+        if (PROF8) pp[9] += 1;
+        if (why == B::ERR_) return -1;
+        return nt + (g >= 0 ? 1 : 0);
+    }
+
+    __device__ void run_executor8(int32_t* st_out, uint32_t* len_out)
+    {
+        this->lane = rcx_lane();
+        const unsigned lane = this->lane;
+        this->init_window();
+        int st = RCX_OK;
+        uint32_t tail = 0;
+        auto ring = this->ring8;
+        for (;;) {
+            uint64_t te0 = PROF8 ? (uint64_t)__builtin_readcyclecounter() : 0;
+            while (RCX_U(ring->head) == tail) __builtin_amdgcn_s_sleep(4);
+            if (PROF8) { this->pw[0] += (uint64_t)__builtin_readcyclecounter() - te0; this->pw[2] += 1; }
+            rcx_wave_sync();
+            const RCX_LDS_AS Slot8* sl = &ring->slot[tail % NSLOT8];
+            typename B::Batch bt;
+            bt.ns = (int)RCX_U(sl->hdr[0]); bt.why = (int)RCX_U(sl->hdr[1]); bt.perr = (int)RCX_U(sl->hdr[2]);
+            bt.gL = RCX_U(sl->hdr[3]); bt.gM = RCX_U(sl->hdr[4]); bt.goff = RCX_U(sl->hdr[5]); bt.gsrc = RCX_U(sl->hdr[6]);
+            bt.gnext = 0;
+            const uint32_t p0 = RCX_U(sl->hdr[7]);
+            uint32_t w1 = sl->d[lane];
+            rcx_wave_sync();
+            tail++;
+            if (lane == 0) ring->tail = tail;             // the slot is in registers: hand it back
+            // where each entry's literals lie: behind its token, and the tokens follow one another (the second half of a split
+            // match, flagged 0x80, is no token)
+            const bool cont = (w1 & 0x80u) != 0;
+            if (cont) w1 &= ~0xffu;
+            const uint32_t L = w1 & 0xffu, M = (w1 >> 8) & 0xffu;
+            const uint32_t hop = ((int)lane < bt.ns && !cont) ? 3u + L + (L >= 15u ? 1u : 0u) + (M >= 19u ? 1u : 0u) : 0u;
+            const uint32_t w0 = p0 + rcx_wave_incl_scan(hop) - hop + 1u + (L >= 15u ? 1u : 0u);
+            int lo = 0, e = 0;
+            while (lo < bt.ns && !e) e = this->emit5(bt.ns, lo, w0, w1);
+            if (e) { st = e; break; }
+            if (this->after_batch(bt, st)) break;
+        }
+        if (st && lane == 0) ring->abort_ = 1;
+        if (!st) this->flush(this->oend, true);
+        *st_out = st;
+        *len_out = st ? 0u : this->oend;
+    }
+
+    __device__ void run_parser8()
+    {
+        this->lane = rcx_lane();
+        const unsigned lane = this->lane;
+        const uint32_t n = this->n;
+        const uint32_t inmis = (uint32_t)((uintptr_t)this->in & 15u);
+        uint32_t head = 0;
+        uint32_t c = 0;                                              // the true walk's cursor
+        int32_t cs = -(int32_t)inmis;                                // chunk start (cs + inmis is a multiple of 16)
+        uint32_t lcnt = 0;                                           // list entries carried over from the last chunk
+        while (c < n) {
+            V8P_T0();
+            __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO);             // (the ring drains while a chunk is staged, walked and linked)
+            stage8(cs);
+            const int nseg = ((int64_t)n - cs >= CH) ? NSEG : (int)(((int64_t)n - cs + SEGB - 1) / SEGB);
+            const int k0 = (int)(((int32_t)c - cs) / SEGB);
+            // ---- 1. every segment walked at once (a lane each)
+            const int32_t s = cs + SEGB * (int32_t)lane;
+            const uint32_t e = ((int64_t)s + SEGB < (int64_t)n) ? (uint32_t)(s + SEGB) : n;
+            const bool mine = (int)lane >= k0 && (int)lane < nseg;
+            int32_t p0 = s - PRE; p0 = p0 < 0 ? 0 : p0;
+            uint32_t p = ((int)lane == k0) ? c : (uint32_t)p0;
+            uint64_t map = 0;
+            for (;;) {
+                const bool go = mine && p < e;
+                if (!__ballot(go)) break;
+                if (PROF8) pp[7] += 1;
+                if (go) {
+                    if ((int32_t)p >= s) map |= 1ull << (p - (uint32_t)s);
+                    p = next_tok_c(p);
+                }
+            }
+            const uint32_t ex = p;                                   // where the segment's walk left it
+            V8P_ADD(0);
+            // ---- 2. link the segments.  Every lane first checks the usual case by itself: the walk of the segment before mine left
+            // it at a byte my map has marked.  What is left -- a jump over a segment, walks that have not met -- is settled in
+            // order by scalar code over the lanes' registers (and whatever that changes is checked again downstream).
+            uint32_t lowv = 0; bool clr = false;
+            {
+                const uint32_t eprev = (uint32_t)__shfl_up((int)ex, 1);
+                const bool chk = mine && (int)lane > k0;
+                bool ok = false;
+                if (chk && eprev < e) { lowv = eprev - (uint32_t)s; ok = (map >> lowv) & 1ull; }
+                if (!ok) lowv = 0;
+                unsigned long long bad = __ballot(chk && !ok);
+                c = RCX_U(__builtin_amdgcn_readlane(ex, nseg - 1));
+                int k = 0; uint32_t cin = 0; bool forced = false;
+                for (;;) {
+                    if (!forced) {
+                        if (!bad) break;
+                        k = __ffsll(bad) - 1;
+                        cin = RCX_U(__builtin_amdgcn_readlane(ex, k - 1));
+                    }
+                    bad &= ~(1ull << k);
+                    const uint32_t sk = (uint32_t)(cs + SEGB * k);
+                    const uint32_t ek = (sk + SEGB < n) ? sk + SEGB : n;
+                    const uint32_t exk = RCX_U(__builtin_amdgcn_readlane(ex, k));
+                    uint32_t X;
+                    if (cin >= ek) { if ((int)lane == k) { clr = true; lowv = 0; } X = cin; }          // jumped over
+                    else {
+                        const uint64_t mk = (uint64_t)RCX_U(__builtin_amdgcn_readlane((uint32_t)map, k)) | ((uint64_t)RCX_U(__builtin_amdgcn_readlane((uint32_t)(map >> 32), k)) << 32);
+                        if ((mk >> (cin - sk)) & 1ull) { if ((int)lane == k) { lowv = cin - sk; clr = false; } X = exk; }
+                        else {                                       // follow the true walk until it meets k's map or leaves k
+                            if (PROF8) pp[8] += 1;
+                            uint64_t tm = 0;
+                            uint32_t q = cin;
+                            while (q < ek && !((mk >> (q - sk)) & 1ull)) { tm |= 1ull << (q - sk); q = RCX_U(next_tok_c(q)); }
+                            const bool merged = q < ek;
+                            const uint64_t nm = (merged ? mk & ~((1ull << (q - sk)) - 1ull) : 0ull) | tm;
+                            if ((int)lane == k) { map = nm; lowv = 0; clr = false; }
+                            X = merged ? exk : q;
+                        }
+                    }
+                    if (k == nseg - 1) c = X;
+                    forced = X != exk && k + 1 < nseg;
+                    if (forced) { k++; cin = X; }
+                }
+            }
+            if (clr) map = 0;
+            map &= ~((1ull << lowv) - 1ull);
+            if (!mine) map = 0;
+            V8P_ADD(1);
+            if (PROF8) pp[6] += 1;
+            // ---- 3. a lane per token: the maps unpacked into a position list (eight input bytes a lane), 64 entries a batch
+            const int nwin = (nseg + LWIN - 1) / LWIN;
+            for (int w = k0 / LWIN; w < nwin; w++) {
+                const int sl = LWIN * w + (int)(lane >> 3);                   // the segment whose map byte (lane & 7) this lane unpacks
+                const uint32_t mlo = (uint32_t)__builtin_amdgcn_ds_bpermute(sl << 2, (int)(uint32_t)map);
+                const uint32_t mhi = (uint32_t)__builtin_amdgcn_ds_bpermute(sl << 2, (int)(uint32_t)(map >> 32));
+                uint32_t bits = (((lane & 4u) ? mhi : mlo) >> (8u * (lane & 3u))) & 0xffu;
+                if (sl >= nseg) bits = 0;
+                const uint32_t cnt = (uint32_t)__popc(bits);
+                const uint32_t incl = rcx_wave_incl_scan(cnt);
+                uint32_t at = lcnt + incl - cnt;
+                const int32_t bpos = SEGB * sl + 8 * (int32_t)(lane & 7u);
+                for (;;) {
+                    if (!__ballot(bits != 0)) break;
+                    if (bits) { const uint32_t b = (uint32_t)__ffs(bits) - 1u; bits &= bits - 1u; list[at++] = (int16_t)(bpos + (int32_t)b); }
+                }
+                lcnt += RCX_U(__builtin_amdgcn_readlane(incl, 63));
+                rcx_wave_sync();
+                V8P_ADD(2);
+                const bool last = (w + 1 == nwin) && c >= n;                  // the end of the block: nothing is carried over
+                uint32_t pos = 0;
+                while (lcnt - pos >= 64u || (last && lcnt > pos)) {
+                    const int used = batch8(head, cs, pos, lcnt - pos < 64u ? lcnt - pos : 64u);
+                    if (used < 0) return;
+                    pos += (uint32_t)used;
+                    if (PROF8) t0_ = (uint64_t)__builtin_readcyclecounter();
+                }
+                if (pos) {                                           // the entries left over move to the front
+                    const uint32_t left = lcnt - pos;
+                    const int16_t v = lane < left ? list[pos + lane] : (int16_t)0;
+                    rcx_wave_sync();
+                    if (lane < left) list[lane] = v;
+                    lcnt = left;
+                    rcx_wave_sync();
+                }
+            }
+            // ---- the next chunk: right behind this one, or where the cursor is if a long literal run jumped further
+            int32_t ncs = cs + CH;
+            if (c < n && (int64_t)c >= (int64_t)ncs + CH) ncs = (int32_t)((c + inmis) & ~15u) - (int32_t)inmis;
+            if (lcnt) {                                              // carried entries are relative to the chunk
+                if ((int32_t)(int16_t)RCX_U((uint32_t)(uint16_t)list[0]) - (ncs - cs) < -30000) {     // (too far back for 16 bits: hand them over as a short batch)
+                    uint32_t pos = 0;
+                    while (lcnt > pos) { const int used = batch8(head, cs, pos, lcnt - pos); if (used < 0) return; pos += (uint32_t)used; }
+                    lcnt = 0;
+                } else {
+                    if (lane < lcnt) list[lane] = (int16_t)(list[lane] - (int16_t)(ncs - cs));
+                    rcx_wave_sync();
+                }
+            }
+            cs = ncs;
+        }
+        post(head, 0, B::END_, 0, 0, 0, 0, 0, 0, false, 0, 0, 0);
+    }
+};
+
+template <int TC = 1024, int HH = 1024, bool PROF8 = false, int PRE_ = 128, int SPLIT_ = 32>
+__global__ __launch_bounds__(128, 8) void k_lz4_decode_v8(rcx_kargs a, int only_status = 0)
+{
+    typedef Lz4V8<TC, HH, 16, PROF8, PRE_, SPLIT_> S;
+    const uint64_t tk0 = PROF8 ? (uint64_t)__builtin_readcyclecounter() : 0;
+    __shared__ __align__(16) uint8_t s_wbuf[S::WBUF5 + 16];
+    __shared__ __align__(16) typename S::Ring8 s_ring;
+    __shared__ __align__(16) uint8_t s_cbuf[S::CBUF8 + 16];
+    __shared__ int16_t s_list[S::LISTN];
+    const uint32_t b = blockIdx.x;
+    if (b >= a.nblocks) return;
+    if (only_status && a.status[b] != only_status) return;
+    if (threadIdx.x == 0) { RCX_LDS_AS typename S::Ring8* r0 = (RCX_LDS_AS typename S::Ring8*)&s_ring; r0->head = 0; r0->tail = 0; r0->abort_ = 0; }
+    __syncthreads();
+    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    S s;
+    s.in = a.in_base + a.in_off[b];
+    s.n = (uint32_t)a.in_len[b];
+    s.out = a.out_base + a.out_off[b];
+    const uint64_t cap64 = a.out_cap[b];
+    s.cap = cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)cap64;
+    s.cbuf = s_cbuf;
+    s.wb_ = s_wbuf;
+    s.epos = nullptr;
+    s.ring = nullptr;
+    s.ring8 = (RCX_LDS_AS typename S::Ring8*)&s_ring;
+    s.list = s_list;
+    if (role == 0) {
+        s.run_parser8();
+        if (PROF8 && a.scratch && (threadIdx.x & 63u) == 0) {          // [0..9] parser phases, [10] parser total
+            uint64_t* q = (uint64_t*)a.scratch + (size_t)b * 32;
+            for (int i = 0; i < 10; i++) q[i] = s.pp[i];
+            q[10] = (uint64_t)__builtin_readcyclecounter() - tk0;
+        }
+        return;
+    }
+    int32_t st; uint32_t olen;
+    __builtin_amdgcn_s_setprio(RCX_EXEC_PRIO);
+    s.run_executor8(&st, &olen);
+    if (PROF8 && a.scratch && (threadIdx.x & 63u) == 0) {              // [11] executor total, [16..] executor phases (Lz4V5::pw)
+        uint64_t* q = (uint64_t*)a.scratch + (size_t)b * 32;
+        q[11] = (uint64_t)__builtin_readcyclecounter() - tk0;
+        for (int i = 0; i < 12; i++) q[16 + i] = s.pw[i];
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        a.status[b] = st;
+        a.out_len[b] = olen;
+        if (a.in_used) a.in_used[b] = s.n;
+    }
+}

@@ -8,6 +8,8 @@
 #endif
 #include "k_lz4_decode_v4.hip"
 #include "k_lz4_decode_v5.hip"
+#include "k_lz4_decode_v7.hip"
+#include "k_lz4_decode_v8.hip"
 #ifdef RCX_AB_VARIANTS
 #include "k_lz4_decode_v6.hip"
 #endif
@@ -24,6 +26,8 @@ int rcx_tu_lz4_decode(hipStream_t s, rcx_kargs& k, int v, std::string& err)
     const uint32_t n = k.nblocks;
     if (v == 0 || v == 15) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1536, 2048>), dim3(n), dim3(128), 0, s, k, 0);
     else if (v == 11) hipLaunchKernelGGL((k_lz4_decode_v4<1024, 1>), dim3(n), dim3(64), 0, s, k);
+    else if (v == 23) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 1024>), dim3(n), dim3(128), 0, s, k, 0);
+    else if (v == 20) hipLaunchKernelGGL((k_lz4_decode_v7<1024, 1008, 2048, 2048>), dim3(n), dim3(128), 0, s, k, 0);
 #ifdef RCX_AB_VARIANTS
     else if (v == 1) hipLaunchKernelGGL(k_lz4_decode_v1, dim3(n), dim3(64), 0, s, k);
     else if (v == 2) hipLaunchKernelGGL((k_lz4_decode_v3<2048, 2048, 64, 64, 4>), dim3((n + 3) / 4), dim3(256), 0, s, k);
@@ -44,6 +48,15 @@ int rcx_tu_lz4_decode(hipStream_t s, rcx_kargs& k, int v, std::string& err)
         hipLaunchKernelGGL((k_lz4_decode_v6<8>), dim3(n), dim3(512), 0, s, k);
         hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1536, 2048>), dim3(n), dim3(128), 0, s, k, (int)RCX_ST_BAIL6);
     }
+    else if (v == 21) hipLaunchKernelGGL((k_lz4_decode_v7<1024, 1008, 2048, 2048, 2, true>), dim3(n), dim3(128), 0, s, k, 0);     // parser wave alone (wrong output on purpose)
+    else if (v == 22) hipLaunchKernelGGL((k_lz4_decode_v7<2048, 1008, 1536, 2048, 2, true>), dim3(n), dim3(128), 0, s, k, 0);
+    else if (v == 24) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 1024, true>), dim3(n), dim3(128), 0, s, k, 0);     // parser phase timers -> scratch
+    else if (v == 29) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 1024, false, 128, 0>), dim3(n), dim3(128), 0, s, k, 0);    // no split of long matches
+    else if (v == 31) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 1024, false, 96, 32>), dim3(n), dim3(128), 0, s, k, 0);    // shorter head start
+    else if (v == 25) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1024, 1024, false, 32>), dim3(n), dim3(128), 0, s, k, 0);   // LDS trade-offs of the executor
+    else if (v == 26) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1024, 1024, false, 16>), dim3(n), dim3(128), 0, s, k, 0);
+    else if (v == 27) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1280, 1024, false, 0>), dim3(n), dim3(128), 0, s, k, 0);
+    else if (v == 28) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1536, 2048, false, 16>), dim3(n), dim3(128), 0, s, k, 0);
     else if (v == 19) hipLaunchKernelGGL((k_lz4_decode_v6<8, true>), dim3(n), dim3(512), 0, s, k);      // phase timers -> scratch, no second pass
 #endif
     else { err = "lz4 decode: unknown kernel variant (A/B variants need a -DRCX_AB_VARIANTS build)"; return RCX_RC_BAD_ARG; }

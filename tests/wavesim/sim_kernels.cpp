@@ -4,6 +4,8 @@
 #include "../../rust_compress_amd/csrc/k_lz4_decode.hip"
 #include "../../rust_compress_amd/csrc/k_lz4_decode_v4.hip"
 #include "../../rust_compress_amd/csrc/k_lz4_decode_v5.hip"
+#include "../../rust_compress_amd/csrc/k_lz4_decode_v7.hip"
+#include "../../rust_compress_amd/csrc/k_lz4_decode_v8.hip"
 #include "../../rust_compress_amd/csrc/k_lz4_decode_v6.hip"
 #include "../../rust_compress_amd/csrc/k_lz4_encode.hip"
 #define hipStream_t int
@@ -41,6 +43,8 @@ extern "C" int sim_launch(int codec, int variant, const rcx_kargs* a)
             ws::launch(dim3(k.nblocks), dim3(512), [&] { k_lz4_decode_v6<8>(k); });
             ws::launch(dim3(k.nblocks), dim3(128), [&] { k_lz4_decode_v5<2048, 1536, 2048>(k, (int)RCX_ST_BAIL6); });
         }
+        else if (variant == 23) ws::launch(dim3(k.nblocks), dim3(128), [&] { k_lz4_decode_v8<1024, 1024>(k); });
+        else if (variant == 20) ws::launch(dim3(k.nblocks), dim3(128), [&] { k_lz4_decode_v7<1024, 1008, 2048, 2048>(k); });
         else if (variant == 18) ws::launch(dim3(k.nblocks), dim3(512), [&] { k_lz4_decode_v6<8>(k); });      // no second pass: which blocks bail
         else if (variant == 0 || variant == 15) ws::launch(dim3(k.nblocks), dim3(128), [&] { k_lz4_decode_v5<2048, 1536, 2048>(k); });
         else ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_decode_v4<1024, 1>(k); });
@@ -67,3 +71,5 @@ extern "C" int sim_launch(int codec, int variant, const rcx_kargs* a)
         return -1;
     }
 }
+
+extern "C" unsigned long long* sim_stats() { return ws::g_stat; }

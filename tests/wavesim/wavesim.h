@@ -231,6 +231,8 @@ static inline unsigned __byte_perm_(unsigned a, unsigned b, unsigned s) { (void)
 #define __builtin_amdgcn_mbcnt_hi(m, b) ((int)(ws::cur->tid & 63) < 32 ? (b) : (int)(ws::cur->tid & 63) - 32 + (b))
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
+namespace ws { extern unsigned long long g_stat[16]; }
+#define RCX_V7_STAT(slot, v) (ws::g_stat[slot] += (unsigned long long)(v))
 // portable version of rcx_dev.h's hand-scheduled LZ4 token walk (the product uses inline gfx950 asm)
 static inline void ws_hop_walk(uint32_t dv, uint32_t& rel, uint64_t& vis)
 {
