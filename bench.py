@@ -107,6 +107,19 @@ class GpuEngine:
         assert nblk == 0 or int(db.status[:nblk].abs().max()) == 0
         return self._e2e_out, ar * BLOCK, db.out_len[:nblk].cpu().numpy()
 
+    def block_crcs(self, base, offs, lens):
+        """CRC-32 of every block (the product's k_crc32): what the end-to-end leg compares, block by block"""
+        torch, R = self.torch, self.R
+        n = len(lens)
+        if n == 0:
+            return np.zeros(0, np.uint32)
+        i64 = lambda a: torch.tensor(np.asarray(a, dtype=np.int64), dtype=torch.int64, device=self.dev)
+        dummy = torch.zeros(64, dtype=torch.uint8, device=self.dev)
+        db = R.DeviceBatch(base, i64(offs), i64(lens), dummy, i64(np.zeros(n)), i64(np.zeros(n)))
+        self.ctx.launch_dev(self.N.CRC32, db)
+        torch.cuda.synchronize()
+        return db.aux[:n].cpu().numpy().astype(np.uint32)
+
     def close(self):
         self.ctx.close()
 
@@ -153,6 +166,11 @@ class DryEngine:
         lens = np.array([len(o) for o in outs], dtype=np.int64)
         out = self.torch.from_numpy(np.frombuffer(b"".join(outs) + b"\0", dtype=np.uint8).copy())
         return out, np.concatenate([[0], np.cumsum(lens)[:-1]]) if nblk else np.zeros(0, np.int64), lens
+
+    def block_crcs(self, base, offs, lens):
+        import zlib
+        buf = base.numpy()
+        return np.array([zlib.crc32(buf[int(o):int(o) + int(l)].tobytes()) for o, l in zip(offs, lens)], dtype=np.uint32)
 
     def close(self):
         pass
@@ -243,12 +261,15 @@ def end_to_end(eng, wl, dist, rank, world, reps=3):
     nb = wl["nblocks"]
     # untimed set-up: collect every rank's compressed blocks on the root, packed
     packed, clens = D.gather_blocks(base, off, lens, np.arange(world + 1, dtype=np.int64) * nb, root=0)
-    raw_sum = torch.zeros(1, dtype=torch.float64, device=eng.dev)
+    # what must come back, block by block: CRC-32 of every rank's source blocks, in global block order (all_gather of small arrays)
     if eng.name == "gpu":
-        raw_sum[0] = wl["raw"][: nb * BLOCK].to(torch.float64).sum()
+        mine = eng.block_crcs(wl["raw"], np.arange(nb, dtype=np.int64) * BLOCK, np.full(nb, BLOCK, dtype=np.int64))
     else:
-        raw_sum[0] = float(sum(sum(r) for r in wl["raws"]))
-    dist.all_reduce(raw_sum, op=dist.ReduceOp.SUM)
+        import zlib
+        mine = np.array([zlib.crc32(r) for r in wl["raws"]], dtype=np.uint32)
+    crc_all = [torch.zeros(nb, dtype=torch.int64, device=eng.dev) for _ in range(world)]
+    dist.all_gather(crc_all, torch.from_numpy(mine.astype(np.int64)).to(eng.dev))
+    want = torch.cat(crc_all).cpu().numpy().astype(np.uint32)
     roff = bounds = None
     if rank == 0:
         roff = np.concatenate([[0], np.cumsum(clens)[:-1]])
@@ -271,7 +292,8 @@ def end_to_end(eng, wl, dist, rank, world, reps=3):
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     res = None
     if rank == 0:
-        ok = bool(int(glens.sum()) == world * nb * BLOCK and abs(float(got.to(torch.float64).sum()) - float(raw_sum[0])) < 0.5)
+        goff = np.concatenate([[0], np.cumsum(glens)[:-1]]).astype(np.int64)
+        ok = bool(len(glens) == world * nb and (glens == BLOCK).all() and np.array_equal(eng.block_crcs(got, goff, glens), want))   # every block, in its place
         sc, de, ga = [float(x) for x in tt.tolist()]
         res = {"scatter_ms": round(sc * 1e3, 3), "decode_ms": round(de * 1e3, 3), "gather_ms": round(ga * 1e3, 3),
                "value": round(float(glens.sum()) / (sc + de + ga) / 2**30, 3), "unit": "GiB/s decoded, root scatter + decode + root gather",
@@ -310,6 +332,55 @@ def hbm_ceiling(torch, dev, nbytes=1 << 30, reps=10):
     return {"GB/s": round(2 * nbytes / t / 1e9, 1), "what": "device-to-device copy of 1 GiB (read + write bytes / time)", "spec_peak_GB/s": HBM_PEAK_GBS}
 
 
+def dry_sharded_pipeline(eng, dist, rank, world, nblocks=11, block=4096):
+    """BASELINE config 5's sharding on CPU ranks (--dry-gloo): ONE stream, its RCXQ container split by block ranges
+    (dist.partition + pipeline.split_container), the shards scattered, decoded per rank, the decoded ranges gathered and
+    compared with the source byte for byte; and the other way round -- raw ranges scattered, encoded per rank, the shards'
+    containers gathered and joined: byte for byte the container one device writes.  The block codec is the test suite's."""
+    import rust_compress_amd.dist as D
+    from rust_compress_amd import pipeline as P, synth
+    torch = eng.torch
+    codec = eng.codec
+    total = nblocks * block - 1234                              # a ragged last block
+    lens = np.array([min(block, total - i) for i in range(0, total, block)], dtype=np.int64)
+    bounds = D.partition(lens, world)
+    data = whole = None
+    t8 = lambda b: torch.from_numpy(np.frombuffer(bytes(b) + b"\0", dtype=np.uint8).copy())
+    if dist is None:                                            # (one rank, no process group: the same calls without transport)
+        data = synth.gen("text", total, 0xC5).tobytes()
+        whole = codec.pipe_encode(data, block)
+        ok = P.join_containers(P.split_container(whole, bounds)) == whole and codec.pipe_decode(whole) == data
+        return {"config": 5, "n_gpus": 1, "sharded_container_verified": bool(ok), "joined_equals_single_device": bool(ok), "blocks": int(len(lens))}
+    # 1. decode side: container shards root -> ranks, decoded ranges ranks -> root
+    shards, slen = None, None
+    if rank == 0:
+        data = synth.gen("text", total, 0xC5).tobytes()
+        whole = codec.pipe_encode(data, block)
+        parts = P.split_container(whole, bounds)
+        slen = np.array([len(x) for x in parts], dtype=np.int64)
+        shards = t8(b"".join(parts))
+    sb = np.arange(world + 1, dtype=np.int64)                   # one "block" per rank: its shard
+    soff = None if slen is None else np.concatenate([[0], np.cumsum(slen)[:-1]])
+    local, loff, llen, _ = D.scatter_blocks(shards, soff, slen, sb, root=0, device=eng.dev)
+    mine = local.numpy()[: int(llen[0])].tobytes() if len(llen) else P.build_container(block, 16, [], [], [], b"")
+    dec = codec.pipe_decode(mine)
+    a, b = int(bounds[rank]), int(bounds[rank + 1])
+    got, glens = D.gather_blocks(t8(dec), np.concatenate([[0], np.cumsum(lens[a:b])[:-1]]) if b > a else np.zeros(0, np.int64), lens[a:b], bounds, root=0)
+    # 2. encode side: raw ranges root -> ranks, containers ranks -> root, joined
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    lraw, lo_, ll_, _ = D.scatter_blocks(t8(data) if rank == 0 else None, offs, lens, bounds, root=0, device=eng.dev)
+    myc = codec.pipe_encode(lraw.numpy()[: int(ll_.sum())].tobytes(), block) if len(ll_) else P.build_container(block, 16, [], [], [], b"")
+    cg, clens = D.gather_blocks(t8(myc), np.zeros(1, np.int64), np.array([len(myc)], dtype=np.int64), sb, root=0)
+    if rank != 0:
+        return None
+    ok_dec = bool(np.array_equal(glens, lens) and got.numpy()[: total].tobytes() == data)
+    buf = cg.numpy()
+    co = np.concatenate([[0], np.cumsum(clens)[:-1]])
+    joined = P.join_containers([buf[int(o):int(o) + int(l)].tobytes() for o, l in zip(co, clens)])
+    return {"config": 5, "n_gpus": world, "sharded_container_verified": ok_dec, "joined_equals_single_device": bool(joined == whole),
+            "blocks": int(len(lens)), "block_ranges": np.diff(bounds).tolist(), "container_bytes": len(whole)}
+
+
 # ------------------------------------------------------------------------------------------------ launcher
 def self_spawn(args):
     """`python bench.py --gpus N` outside torch.distributed.run: start one rank per GPU and pass their output through."""
@@ -333,6 +404,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the scatter / decode / gather leg")
     ap.add_argument("--no-others", action="store_true", help="skip BASELINE configs 3-5 and the HBM ceiling")
+    ap.add_argument("--no-dists", action="store_true", help="skip config 2's other distributions (G-runs, G-rand)")
     ap.add_argument("--others-scale", type=float, default=1.0, help="fraction of the full size of configs 3-5")
     ap.add_argument("--extras", action="store_true", help="also time the other distributions / variants")
     ap.add_argument("--dry-gloo", action="store_true", help="CPU test of the multi-rank plumbing (see the module docstring)")
@@ -383,11 +455,63 @@ def main():
     wall = float(t.item())
     total_out = float(tot[0].item())
 
+    # ---- config 2's other distributions (reported separately), same timing discipline, every rank
+    per_dist = {}
+    if not args.no_dists and not args.dry_gloo:
+        for kind in ("runs", "rand"):
+            w2 = eng.make_workload(kind, args.nblocks, 0x4C5A3401 + 7919 * rank + len(kind))
+            eng.check(w2)
+            wall2, km2, _ = time_steps(eng, w2, max(5, args.steps // 2), 2, dist if world > 1 else None)
+            tt2 = torch.tensor([wall2, float(w2["out_bytes"]), float(w2["comp_bytes"])], dtype=torch.float64, device=eng.dev)
+            if dist is not None:
+                mx = tt2.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+                sm = tt2.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+                wall2, tot_out2 = float(mx[0]), float(sm[1])
+            else:
+                tot_out2 = float(w2["out_bytes"])
+            st2 = max(5, args.steps // 2)
+            alg2 = w2["comp_bytes"] + w2["out_bytes"]
+            per_dist["G-" + kind] = {"GiB/s": round(tot_out2 * st2 / wall2 / 2**30, 2), "ms_per_step": round(wall2 / st2 * 1e3, 4), "kernel_ms_avg": round(km2, 4),
+                                     "lz4_ratio": round(w2["out_bytes"] / w2["comp_bytes"], 3),
+                                     "roofline_frac": round(alg2 / (km2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": alg2}
+            del w2
+            torch.cuda.empty_cache()
+
     e2e = selfp2p = None
     if dist is not None and not args.no_e2e:
         e2e = end_to_end(eng, wl, dist, rank, world)
         if eng.backend == "nccl":
             selfp2p = rccl_self_sendrecv(eng, dist, rank)
+
+    cpu_base = None
+    if rank == 0 and world == 1 and not args.no_cpu and not args.dry_gloo:
+        cpu_base = cpu_baseline(wl["dec"], wl["raw"], torch, args.nblocks)
+    # ---- BASELINE configs 3, 4, 5 on the same ranks: 3 and 4 weak (every rank its own members / blocks), 5 ONE stream sharded
+    others = None
+    if not args.no_others:
+        others = []
+        if args.dry_gloo:
+            r5 = dry_sharded_pipeline(eng, dist, rank, world)
+            if r5 is not None:
+                others.append(r5)
+        else:
+            sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
+            import bench_configs as BC
+            del wl
+            torch.cuda.empty_cache()
+            cpu_legs = world == 1 and not args.no_cpu
+            kw = dict(rank=rank, world=world, dist=dist if world > 1 else None)
+            for fn in (lambda: [BC.config3(eng.ctx, torch, eng.dev, args.others_scale, cpu=cpu_legs, **kw)],
+                       lambda: BC.config4(eng.ctx, torch, eng.dev, args.others_scale, cpu=cpu_legs, **kw),
+                       lambda: [BC.config5(eng.ctx, torch, eng.dev, args.others_scale, reps=3, cpu=cpu_legs, **kw)]):
+                try:
+                    others += [r for r in fn() if r is not None]
+                except Exception as e:                          # a failing side config must not lose the headline line
+                    if world > 1:
+                        raise                                   # (but with peers in a collective there is no carrying on)
+                    others.append({"error": "%s: %s" % (type(e).__name__, str(e)[:200])})
+                torch.cuda.empty_cache()
+            wl = None
 
     if rank == 0:
         alg_bytes = comp_bytes + out_bytes                     # per launch on this rank
@@ -422,29 +546,23 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": round(kern_ms, 4),
                          "kernel_ms_median": round(kern_med, 4)},
+            "per_distribution": None,
             "end_to_end": e2e,
         }
+        pd = {"G-" + args.kind: {"GiB/s": res["value"], "ms_per_step": res["ms_per_step"], "kernel_ms_avg": round(kern_ms, 4),
+                                 "lz4_ratio": round(out_bytes / comp_bytes, 3), "roofline_frac": res["roofline"]["frac"], "algorithmic_bytes_per_launch": alg_bytes}}
+        pd.update(per_dist)
+        res["per_distribution"] = pd
+        if others is not None:
+            res["other_configs"] = others
         if selfp2p is not None:
             res["rccl_self_sendrecv"] = selfp2p
         if args.dry_gloo:
             res["data"] = "synthetic (dry run on CPU: plumbing test, not a measurement)"
-        if world == 1 and not args.no_cpu and not args.dry_gloo:
-            res["cpu_baseline"] = cpu_baseline(wl["dec"], wl["raw"], torch, args.nblocks)
+        if cpu_base is not None:
+            res["cpu_baseline"] = cpu_base
         if world == 1 and not args.no_others and not args.dry_gloo:
-            sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
-            import bench_configs as BC
             res["hbm_ceiling_measured"] = hbm_ceiling(torch, eng.dev)
-            del wl
-            others = []
-            for fn in (lambda: [BC.config3(eng.ctx, torch, eng.dev, args.others_scale, cpu=not args.no_cpu)],
-                       lambda: BC.config4(eng.ctx, torch, eng.dev, args.others_scale),
-                       lambda: [BC.config5(eng.ctx, torch, eng.dev, args.others_scale, reps=3)]):
-                try:
-                    others += fn()
-                except Exception as e:                          # a failing side config must not lose the headline line
-                    others.append({"error": "%s: %s" % (type(e).__name__, str(e)[:200])})
-                torch.cuda.empty_cache()
-            res["other_configs"] = others
         if args.extras and world == 1 and not args.dry_gloo:
             N = eng.N
             extras = {}

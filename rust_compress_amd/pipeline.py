@@ -146,49 +146,83 @@ class BwtDcAri:
         return inv.out_base[:total]
 
 
+# ---------------------------------------------------------------------------------------------- container (host side, no device)
+def parse_container(blob):
+    """-> (block_size, parts, lens[nb], praw[nb, parts], clen[nb, parts], payload offset).  Raises ContainerError."""
+    _need(len(blob) >= 16 and bytes(blob[:4]) == MAGIC, "not an RCXQ container")
+    block_size, nb, parts = struct.unpack_from("<III", blob, 4)
+    _need(parts >= 1 and block_size >= 1, "container header: bad block size / piece count")
+    _need(16 + nb * (4 + 8 * parts) <= len(blob), "container descriptor table is truncated")
+    tab = np.frombuffer(blob, dtype="<u4", count=nb * (1 + 2 * parts), offset=16).reshape(nb, 1 + 2 * parts).astype(np.int64)
+    lens = tab[:, 0]
+    _need(bool((lens <= block_size).all()), "container block longer than the block size")
+    praw, clen = tab[:, 1::2], tab[:, 2::2]
+    p = 16 + nb * (4 + 8 * parts)
+    _need(p + int(clen.sum()) <= len(blob), "container payload is truncated")
+    return block_size, parts, lens, praw, clen, p
+
+
+def build_container(block_size, parts, lens, praw, clen, payload):
+    """The container of blocks with the given descriptors; `payload` = the coded pieces back to back (bytes)."""
+    lens = np.asarray(lens, dtype=np.int64)
+    nb = len(lens)
+    tab = np.zeros((nb, 1 + 2 * parts), dtype="<u4")
+    if nb:
+        tab[:, 0] = lens
+        tab[:, 1::2] = np.asarray(praw).reshape(nb, parts)
+        tab[:, 2::2] = np.asarray(clen).reshape(nb, parts)
+    return b"".join([MAGIC, struct.pack("<III", block_size, nb, parts), tab.tobytes(), bytes(payload)])
+
+
+def split_container(blob, bounds):
+    """One container per block range [bounds[g], bounds[g + 1]) -- each a valid container on its own: blocks are independent
+    in every stage (bwt/mod.rs:373-401), so a stream shards across GPUs by block ranges (dist.partition over the decoded sizes)."""
+    block_size, parts, lens, praw, clen, p = parse_container(blob)
+    ends = p + np.concatenate([[0], np.cumsum(clen.sum(axis=1))]).astype(np.int64)
+    out = []
+    for g in range(len(bounds) - 1):
+        a, b = int(bounds[g]), int(bounds[g + 1])
+        out.append(build_container(block_size, parts, lens[a:b], praw[a:b], clen[a:b], blob[int(ends[a]):int(ends[b])]))
+    return out
+
+
+def join_containers(blobs):
+    """Inverse of split_container: the shards' containers, in rank order, as one stream (byte for byte what one device writes)."""
+    metas = [parse_container(b) for b in blobs]
+    _need(len(metas) > 0, "nothing to join")
+    bs, parts = metas[0][0], metas[0][1]
+    _need(all(m[0] == bs and m[1] == parts for m in metas), "shards disagree on block size / piece count")
+    lens = np.concatenate([m[2] for m in metas])
+    praw = np.concatenate([m[3].reshape(-1, parts) for m in metas])
+    clen = np.concatenate([m[4].reshape(-1, parts) for m in metas])
+    payload = b"".join(bytes(b[m[5]: m[5] + int(m[4].sum())]) for b, m in zip(blobs, metas))
+    return build_container(bs, parts, lens, praw, clen, payload)
+
+
 def encode_stream(ctx, data, block_size=256 * 1024, device=None, parts=PARTS):
     """bytes -> container bytes"""
     import torch
     dev = device or torch.device("cuda", torch.cuda.current_device())
     data = bytes(data)
     lens = [min(block_size, len(data) - i) for i in range(0, len(data), block_size)]
-    out = [MAGIC, struct.pack("<III", block_size, len(lens), parts)]
-    if lens:
-        raw = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
-        comp, coff, clen, praw, _ = BwtDcAri(ctx, dev, parts).encode(raw, lens)
-        comp = comp.cpu().numpy()
-        for b, n in enumerate(lens):
-            out.append(struct.pack("<I", n))
-            for s_ in range(parts):
-                out.append(struct.pack("<II", int(praw[b, s_]), int(clen[b, s_])))
-        for o, cl in zip(coff.reshape(-1), clen.reshape(-1)):
-            out.append(comp[int(o):int(o) + int(cl)].tobytes())
-    return b"".join(out)
+    if not lens:
+        return build_container(block_size, parts, [], [], [], b"")
+    raw = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+    comp, coff, clen, praw, _ = BwtDcAri(ctx, dev, parts).encode(raw, lens)
+    comp = comp.cpu().numpy()
+    payload = b"".join(comp[int(o):int(o) + int(cl)].tobytes() for o, cl in zip(coff.reshape(-1), clen.reshape(-1)))
+    return build_container(block_size, parts, lens, praw, clen, payload)
 
 
 def decode_stream(ctx, blob, device=None):
     import torch
     dev = device or torch.device("cuda", torch.cuda.current_device())
-    _need(len(blob) >= 16 and blob[:4] == MAGIC, "not an RCXQ container")
-    block_size, nb, parts = struct.unpack_from("<III", blob, 4)
-    _need(parts >= 1 and block_size >= 1, "container header: bad block size / piece count")
-    _need(16 + nb * (4 + 8 * parts) <= len(blob), "container descriptor table is truncated")
-    p = 16
-    lens, clen, praw = [], [], []
-    for _ in range(nb):
-        (n,) = struct.unpack_from("<I", blob, p)
-        p += 4
-        _need(n <= block_size, "container block longer than the block size")
-        lens.append(n)
-        for _s in range(parts):
-            rl, cl = struct.unpack_from("<II", blob, p)
-            p += 8
-            praw.append(rl); clen.append(cl)
-    _need(p + sum(clen) <= len(blob), "container payload is truncated")
+    block_size, parts, lens, praw, clen, p = parse_container(blob)
+    nb = len(lens)
     if not nb:
         return b""
-    clen = np.asarray(clen, dtype=np.int64)
+    clen = clen.reshape(-1)
     coff = np.concatenate([[0], np.cumsum(clen)[:-1]]).astype(np.int64)
     comp = torch.frombuffer(bytearray(blob[p:p + int(clen.sum())] + b"\0" * 64), dtype=torch.uint8).to(dev)
-    out = BwtDcAri(ctx, dev, parts).decode(comp, coff.reshape(nb, parts), clen.reshape(nb, parts), np.asarray(praw).reshape(nb, parts), lens)
+    out = BwtDcAri(ctx, dev, parts).decode(comp, coff.reshape(nb, parts), clen.reshape(nb, parts), praw.reshape(nb, parts), lens)
     return out.cpu().numpy().tobytes()

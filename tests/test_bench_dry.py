@@ -25,6 +25,11 @@ def test_bench_gpus_n_spawns_n_ranks(gpus, oracle):
     e = res["end_to_end"]
     assert e["verified"] is True and e["bytes_gathered"] == (gpus - 1) * 5 * 65536 and e["bytes_scattered"] > 0
     assert e["scatter_ms"] > 0 and e["gather_ms"] > 0 and "gloo" in e["transport"]
+    # BASELINE config 5's sharding: ONE stream's RCXQ container split by block ranges, scattered, decoded per rank, gathered ==
+    # the source; and raw ranges scattered, encoded per rank, the containers gathered and joined == what one device writes
+    c5 = [o for o in res["other_configs"] if o.get("config") == 5][0]
+    assert c5["n_gpus"] == gpus and c5["sharded_container_verified"] is True and c5["joined_equals_single_device"] is True
+    assert sum(c5["block_ranges"]) == c5["blocks"] == 11 and len(c5["block_ranges"]) == gpus and min(c5["block_ranges"]) >= 1
 
 
 def test_bench_single_rank_dry(oracle):
@@ -36,3 +41,26 @@ def test_bench_single_rank_dry(oracle):
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     res = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert res["n_gpus"] == 1 and res["end_to_end"]["verified"] is True and res["end_to_end"]["bytes_gathered"] == 0
+    assert res["other_configs"][0]["sharded_container_verified"] is True
+
+
+def test_container_split_join(oracle):
+    """pipeline.split_container / join_containers: every shard is a valid container of its block range, and the shards joined
+    in rank order are the stream again, byte for byte (the container one device writes)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import _dry_codec as D
+    from rust_compress_amd import pipeline as P, dist, synth
+    data = synth.gen("text", 9 * 2048 + 77, 3).tobytes()
+    whole = D.pipe_encode(data, 2048)
+    bs, parts, lens, praw, clen, p = P.parse_container(whole)
+    assert bs == 2048 and parts == 16 and lens.tolist() == [2048] * 9 + [77]
+    for world in (1, 2, 3, 7, 12):
+        bounds = dist.partition(lens, world)
+        shards = P.split_container(whole, bounds)
+        assert len(shards) == world and P.join_containers(shards) == whole
+        assert b"".join(D.pipe_decode(x) for x in shards) == data
+    with pytest.raises(P.ContainerError):
+        P.parse_container(whole[:40])
+    with pytest.raises(P.ContainerError):
+        P.join_containers([whole, D.pipe_encode(data[:100], 1024)])

@@ -140,6 +140,30 @@ def test_config5_pipeline_roundtrip_and_stage_parity(ctx, oracle):
     ctx.set_stream(0)
 
 
+def test_config5_sharded_container_on_the_device(ctx, oracle):
+    """BASELINE config 5's sharding on the GPU: the container the device writes for a stream is, byte for byte, the one the
+    oracle's stages write on the CPU; split by block ranges (dist.partition) every shard decodes on its own, the decoded ranges
+    in rank order are the stream, and the shards encoded separately and joined are the single-device container again."""
+    import os, sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _dry_codec as D
+    from rust_compress_amd import pipeline as P, dist
+    BS = 8192
+    data = synth.gen("text", 13 * BS + 4321, 0x5EA).tobytes()
+    whole = P.encode_stream(ctx, data, block_size=BS)
+    assert whole == D.pipe_encode(data, BS)
+    _, _, lens, _, _, _ = P.parse_container(whole)
+    for world in (2, 3, 8):
+        bounds = dist.partition(lens, world)
+        shards = P.split_container(whole, bounds)
+        assert b"".join(P.decode_stream(ctx, x) for x in shards) == data
+        cuts = np.concatenate([[0], np.cumsum(lens)])[bounds]
+        enc = [P.encode_stream(ctx, data[int(cuts[g]):int(cuts[g + 1])], block_size=BS) for g in range(world)]
+        assert P.join_containers(enc) == whole
+    ctx.set_stream(0)
+
+
 def test_config5_pipeline_1e9_bytes(ctx, oracle):
     """BASELINE configs[4] at its full size: 10^9 bytes of G-text in 3815 blocks of 256 KiB through BWT -> DC -> Ari and back,
     decode(encode(x)) == x over the whole gigabyte, and three sampled blocks compared with the oracle stage by stage."""
