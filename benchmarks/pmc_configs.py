@@ -54,7 +54,7 @@ def group(per, pred):
     f = sum(d["f"] for k, d in per.items() if pred(k))
     w = sum(d["w"] for k, d in per.items() if pred(k))
     g = bytes_of(f, w)
-    g["kernels"] = sorted(k for k in per if pred(k))
+    g["kernel_names"] = sorted(k for k in per if pred(k))
     return g
 
 
@@ -72,10 +72,10 @@ def main():
             per, _, _ = table(fdb, wdb)
             res["forward_" + label] = group(per, fwd)
             res["inverse_" + label] = group(per, inv)
-            res["kernels_" + label] = {k: dict(dispatches=d["dispatches"], **bytes_of(d["f"], d["w"])) for k, d in sorted(per.items(), key=lambda kv: -(kv[1]["f"] + kv[1]["w"]))}
+            res["per_kernel_" + label] = {k: dict(dispatches=d["dispatches"], **bytes_of(d["f"], d["w"])) for k, d in sorted(per.items(), key=lambda kv: -(kv[1]["f"] + kv[1]["w"]))}
     else:
         per, seq, wseq = table(sys.argv[2], sys.argv[3])
-        res["kernels"] = {k: dict(dispatches=d["dispatches"], **bytes_of(d["f"], d["w"])) for k, d in sorted(per.items(), key=lambda kv: -(kv[1]["f"] + kv[1]["w"]))}
+        res["per_kernel"] = {k: dict(dispatches=d["dispatches"], **bytes_of(d["f"], d["w"])) for k, d in sorted(per.items(), key=lambda kv: -(kv[1]["f"] + kv[1]["w"]))}
         res.update(group(per, lambda k: True))
         if cfg == "5":
             # the range coder's kernel runs once per direction: its first dispatch is the encoder's
@@ -88,10 +88,10 @@ def main():
                     b = bytes_of(ari_f[i], ari_w[i])
                     for key in ("hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "hbm_bytes_per_launch"):
                         g[key] += b[key]
-                    g["kernels"].append("k_ari_byte (dispatch %d of 2)" % (i + 1))
+                    g["kernel_names"].append("k_ari_byte (dispatch %d of 2)" % (i + 1))
             res["encode"], res["decode"] = enc, dec
     json.dump(res, open(out, "w"), indent=1)
-    print(json.dumps({k: v for k, v in res.items() if not k.startswith("kernels")})[:1500])
+    print(json.dumps({k: v for k, v in res.items() if not k.startswith("per_kernel")})[:1500])
 
 
 if __name__ == "__main__":
