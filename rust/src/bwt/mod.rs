@@ -34,22 +34,27 @@ impl<W: Write> Encoder<W> {
     pub fn new(w: W, block_size: usize) -> Encoder<W> {
         Encoder { w, buf: Vec::new(), block_size, wrote_header: false }
     }
-    /// :485-489.  ONE batch call for all blocks of the stream.
+    /// Everything buffered since the last flush, cut into blocks of `block_size` (the last one may be shorter), in ONE batch
+    /// call -- the blocks the reference writes one by one as its buffer fills (:497-505) plus the partial block its `flush`
+    /// encodes (:511-516).
+    fn encode_pending(&mut self) -> io::Result<()> {
+        if self.buf.is_empty() {
+            return Ok(());
+        }
+        let buf = std::mem::take(&mut self.buf);
+        let blocks: Vec<&[u8]> = buf.chunks(self.block_size.max(1)).collect();
+        let caps: Vec<u64> = blocks.iter().map(|b| b.len() as u64).collect();
+        let r = run_batch(&blocks, &caps, |c, b, o| unsafe { rcx_bwt_forward_batch(c, b, o) }).check()?;
+        for i in 0..blocks.len() {
+            self.w.write_all(&(blocks[i].len() as u32).to_le_bytes())?;
+            self.w.write_all(&r.out[i])?;
+            self.w.write_all(&r.aux[i].to_le_bytes())?;
+        }
+        Ok(())
+    }
+    /// :485-489: `flush`, then the writer back.
     pub fn finish(mut self) -> (W, io::Result<()>) {
-        let res = (|| {
-            let blocks: Vec<&[u8]> = self.buf.chunks(self.block_size).collect();
-            if blocks.is_empty() {
-                return Ok(());
-            }
-            let caps: Vec<u64> = blocks.iter().map(|b| b.len() as u64).collect();
-            let r = run_batch(&blocks, &caps, |c, b, o| unsafe { rcx_bwt_forward_batch(c, b, o) }).check()?;
-            for i in 0..blocks.len() {
-                self.w.write_all(&(blocks[i].len() as u32).to_le_bytes())?;
-                self.w.write_all(&r.out[i])?;
-                self.w.write_all(&r.aux[i].to_le_bytes())?;
-            }
-            Ok(())
-        })();
+        let res = self.flush();
         (self.w, res)
     }
 }
@@ -63,8 +68,11 @@ impl<W: Write> Write for Encoder<W> {
         self.buf.extend_from_slice(buf);
         Ok(0) // the reference's Ok(0) quirk (:507): callers use write_all-free loops, kept for byte-for-byte behaviour
     }
+    /// :511-518: the pending (partial) block is encoded as a block of its own, then the writer is flushed -- a caller that
+    /// flushes mid-stream gets the block boundary the reference gives it.
     fn flush(&mut self) -> io::Result<()> {
-        self.w.flush()
+        let ret = self.encode_pending();
+        ret.and(self.w.flush())
     }
 }
 

@@ -111,11 +111,14 @@ pub(crate) fn grow_decode<F>(d: &[u8], first_cap: u64, call: F) -> io::Result<Ba
 where
     F: Fn(*mut rcx_ctx, *const rcx_batch, *mut u32) -> i32,
 {
-    let mut cap = first_cap.max(1 << 16);
+    // the last attempt is the largest slot a block may have (the kernels index a block with 32 bits; run_batch rejects a
+    // larger slot with RCX_RC_BAD_ARG): past it the block's own RCX_E_OUTPUT_TOO_SMALL is the answer, not a batch-level failure
+    const MAX_BLOCK: u64 = 0xFFFF_FFFF;
+    let mut cap = first_cap.max(1 << 16).min(MAX_BLOCK);
     loop {
         let r = run_batch(&[d], &[cap], &call);
-        if r.status[0] == RCX_E_OUTPUT_TOO_SMALL && cap < (1u64 << 33) {
-            cap *= 8;
+        if r.status[0] == RCX_E_OUTPUT_TOO_SMALL && cap < MAX_BLOCK {
+            cap = (cap * 8).min(MAX_BLOCK);
             continue;
         }
         return r.check();

@@ -109,14 +109,19 @@ class TailReader:
             self._tail = bytes(data) + self._tail
 
 
-def _grow_caps(call, first_cap, limit=1 << 33):
+MAX_BLOCK = 0xFFFFFFFF          # the kernels index a block with 32 bits (run_batch rejects a larger slot with RCX_RC_BAD_ARG)
+
+
+def _grow_caps(call, first_cap, limit=MAX_BLOCK):
     """Run `call(cap)` with growing output slots until the block fits.  A kernel stops at a full slot, so a failed attempt
-    costs its (8x smaller) slot: all the retries together cost a seventh of the decode that fits."""
-    cap = first_cap
+    costs its (8x smaller) slot: all the retries together cost a seventh of the decode that fits.  The last attempt is the
+    largest slot a block may have (2^32 - 1 bytes); past that the answer is the block's own RCX_E_OUTPUT_TOO_SMALL status,
+    not a batch-level error."""
+    cap = min(first_cap, limit)
     while True:
         res = call(cap)
         if res.status[0] == N.E_OUTPUT_TOO_SMALL and cap < limit:
-            cap *= 8
+            cap = min(cap * 8, limit)
             continue
         return res
 
@@ -424,14 +429,21 @@ class bwt:
             self._buf += bytes(buf)
             return 0                                   # same Ok(0) quirk as lz4 (:507)
 
-        def finish(self):
-            data, bs = bytes(self._buf), self.block_size
+        def flush(self):
+            """bwt/mod.rs:511-518: what is buffered -- whole blocks and the partial one -- is encoded (ONE batch call), then the
+            writer is flushed: a caller that flushes mid-stream gets the block boundary the reference gives it."""
+            data, bs = bytes(self._buf), max(self.block_size, 1)
             blocks = [data[i:i + bs] for i in range(0, len(data), bs)]
-            if blocks:                                 # ONE batch call for all blocks of the stream
+            if blocks:
                 res = _check(context().bwt_forward(blocks))
                 for blk, L, origin in zip(blocks, res.outputs, res.aux):
                     self.w.write(struct.pack("<I", len(blk)) + L + struct.pack("<I", int(origin)))
             self._buf.clear()
+            if hasattr(self.w, "flush"):
+                self.w.flush()
+
+        def finish(self):                              # :485-489: flush, then the writer back
+            self.flush()
             return self.w
 
     class Decoder(_BufferedDecoder):                   # bwt/mod.rs:321-432
@@ -513,7 +525,7 @@ class rle:
 
     class Decoder(_BufferedDecoder):                   # rle.rs:176-281
         def _decode_all(self, data):
-            res = _grow_caps(lambda cap: context().rle_decode([data], [cap]), max(1 << 12, 16 * len(data)), limit=1 << 36)
+            res = _grow_caps(lambda cap: context().rle_decode([data], [cap]), max(1 << 12, 16 * len(data)))
             if res.status[0] == 30:
                 raise CompressError(30)                # io::ErrorKind::Other "Overly long run"
             return _check(res).outputs[0]

@@ -26,16 +26,25 @@ def build(force=False, verbose=False, ab=None):
     deps = [os.path.join(HERE, f) for f in sorted(os.listdir(HERE)) if f.endswith((".hip", ".h"))]
     deps.append(os.path.join(HERE, "..", "..", "include", "rcx.h"))
     newest = max(os.path.getmtime(d) for d in deps)
-    if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
-        return out
-    objdir = os.path.join(HERE, "build", "ab" if ab else "ship")
-    os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
     if ab:
         flags.append("-DRCX_AB_VARIANTS")
     if verbose:
         flags.append("-Rpass-analysis=kernel-resource-usage")
     flags += os.environ.get("RCX_EXTRA_FLAGS", "").split()        # A/B experiments with compiler options
+    # objects are cached per flag list: a rebuild with other RCX_EXTRA_FLAGS must not link objects compiled with the old ones
+    import hashlib
+    tag = hashlib.sha256(" ".join(flags).encode()).hexdigest()[:8]
+    objdir = os.path.join(HERE, "build", ("ab" if ab else "ship") + "-" + tag)
+    os.makedirs(objdir, exist_ok=True)
+    stamp = out + ".flags"
+    if not force and os.path.exists(out) and (not os.path.exists(stamp) or open(stamp).read() != tag):
+        force_link = True
+    else:
+        force_link = False
+
+    if not force and not force_link and os.path.exists(out) and os.path.getmtime(out) >= newest:
+        return out
 
     def compile_tu(tu):
         obj = os.path.join(objdir, tu + ".o")
@@ -47,6 +56,8 @@ def build(force=False, verbose=False, ab=None):
     with ThreadPoolExecutor(len(TUS)) as ex:
         objs = list(ex.map(compile_tu, TUS))
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-Wl,-rpath,/opt/rocm/lib", "-o", out] + objs)
+    with open(stamp, "w") as fh:
+        fh.write(tag)
     return out
 
 

@@ -69,7 +69,7 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
     {
         const int32_t i = (int32_t)q - this->cbase;
         uint32_t v;
-        if (i >= 0 && i + 8 <= CBUF8) v = B::lds_load4u(this->cbuf, i); else v = *(const uint32_t __attribute__((aligned(1)))*)(this->in + q);
+        if (i >= 0 && i + 8 <= CBUF8) v = B::lds_load4u(this->cbuf, i); else v = *(const rcx_u32_u*)(this->in + q);
         return v;
     }
     // A run of 255s in a length extension, four bytes a step (a 64 KiB literal run has 257 extension bytes): advances q over

@@ -27,6 +27,7 @@ struct rcx_kargs {
 typedef unsigned int rcx_u32x4 __attribute__((vector_size(16)));
 typedef rcx_u32x4 __attribute__((aligned(1))) rcx_u32x4_u;
 typedef uint64_t __attribute__((aligned(1))) rcx_u64_u;
+typedef uint32_t __attribute__((aligned(1))) rcx_u32_u;
 
 __device__ __forceinline__ unsigned rcx_lane() { return threadIdx.x & 63u; }
 

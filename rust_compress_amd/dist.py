@@ -71,6 +71,8 @@ def scatter_blocks(base, off, lens, bounds, root=0, device=None):
     ops = []
     if rank == root:
         keep = []                                                            # tensors a pending isend reads
+        if base.device != dev:                                               # (a host-resident stream on a device backend: the sends
+            base = base.to(dev)                                              # and the root's own share live where the peers receive)
         for g in range(world):
             ga, gb = int(bounds[g]), int(bounds[g + 1])
             d = torch.from_numpy(np.concatenate([off[ga:gb] - int(spans[g][0]), lens[ga:gb]])).to(dev)
@@ -95,7 +97,8 @@ def scatter_blocks(base, off, lens, bounds, root=0, device=None):
 
 def gather_blocks(local_out, local_off, local_len, bounds, root=0):
     """Inverse of scatter for the outputs.  Root returns (packed uint8 tensor of every block's bytes in global order,
-    int64 numpy lengths per block); the other ranks return (None, None).  Two grouped exchanges: lengths, then bytes."""
+    int64 numpy lengths per block); the other ranks return (None, None).  The root receives in two groups (it needs the lengths
+    to size the byte buffer); a peer posts its two sends as one group."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -113,11 +116,13 @@ def gather_blocks(local_out, local_off, local_len, bounds, root=0):
     else:
         packed = torch.cat([local_out[int(o):int(o) + int(l)] for o, l in zip(local_off, local_len)])
     mylens = torch.from_numpy(local_len).to(dev)
-    if rank != root:
+    if rank != root:                                                         # lengths and bytes: ONE group (the root posts its
+        ops = []                                                             # receives for both before it waits for either)
         if n_local:
-            _group([dist.P2POp(dist.isend, mylens, root)])
+            ops.append(dist.P2POp(dist.isend, mylens, root))
         if packed.numel():
-            _group([dist.P2POp(dist.isend, packed.contiguous(), root)])
+            ops.append(dist.P2POp(dist.isend, packed.contiguous(), root))
+        _group(ops)
         return None, None
     counts = np.diff(bounds)
     lens_all = torch.empty(int(bounds[-1]), dtype=torch.int64, device=dev)

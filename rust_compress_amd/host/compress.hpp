@@ -26,6 +26,7 @@
 #include "../../include/rcx.h"
 
 namespace compress {
+namespace detail { constexpr uint64_t MAX_BLOCK = 0xFFFFFFFFull; }    // the kernels index a block with 32 bits (run_batch rejects a larger slot)
 
 enum class ErrorKind { InvalidInput, UnexpectedEof, Other, Panic };
 
@@ -179,9 +180,10 @@ inline size_t decode_block(const std::vector<uint8_t>& input, std::vector<uint8_
 {
     // the reference grows its Vec as the block decodes (:148-161): slots grow 8x until the block fits (a kernel stops at a full
     // slot, so the failed attempts together cost a seventh of the one that fits)
-    for (uint64_t cap = std::max<uint64_t>(1u << 16, 8 * input.size());; cap *= 8) {
+    // (the last attempt is the largest slot a block may have, 2^32 - 1 bytes: past it the block's own status is the answer)
+    for (uint64_t cap = std::min<uint64_t>(detail::MAX_BLOCK, std::max<uint64_t>(1u << 16, 8 * input.size()));; cap = std::min<uint64_t>(cap * 8, detail::MAX_BLOCK)) {
         auto r = run_batch({input}, {cap}, [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_lz4_decode_batch(c, b); });
-        if (r.status[0] == RCX_E_OUTPUT_TOO_SMALL && cap < (1ull << 33)) continue;
+        if (r.status[0] == RCX_E_OUTPUT_TOO_SMALL && cap < detail::MAX_BLOCK) continue;
         check(r);
         output.insert(output.end(), r.out[0].begin(), r.out[0].end());
         return r.out[0].size();
@@ -270,9 +272,9 @@ private:
 namespace detail {
 template <class Fn> std::vector<uint8_t> grow_decode(const std::vector<uint8_t>& d, size_t& consumed, Fn fn, uint32_t* flags = nullptr)
 {
-    for (uint64_t cap = std::max<uint64_t>(1u << 16, 4 * d.size());; cap *= 8) {
+    for (uint64_t cap = std::min<uint64_t>(MAX_BLOCK, std::max<uint64_t>(1u << 16, 4 * d.size()));; cap = std::min<uint64_t>(cap * 8, MAX_BLOCK)) {
         auto r = run_batch({d}, {cap}, fn);
-        if (r.status[0] == RCX_E_OUTPUT_TOO_SMALL && cap < (1ull << 33)) continue;
+        if (r.status[0] == RCX_E_OUTPUT_TOO_SMALL && cap < MAX_BLOCK) continue;
         check(r);
         consumed = r.in_used[0];
         if (flags) *flags = r.aux[0];
@@ -338,11 +340,12 @@ public:
         buf_.insert(buf_.end(), buf, buf + n);
         return 0;                                                                     // Ok(0) quirk, :507
     }
-    W finish()
+    void flush()                                                                      // :511-518: the buffered blocks and the partial one, ONE batch call
     {
         std::vector<std::vector<uint8_t>> blocks; std::vector<uint64_t> caps;
-        for (size_t i = 0; i < buf_.size(); i += bs_) { blocks.emplace_back(buf_.begin() + i, buf_.begin() + std::min(buf_.size(), i + bs_)); caps.push_back(blocks.back().size()); }
-        if (!blocks.empty()) {                                                        // ONE batch call for the whole stream
+        const size_t bs = std::max<size_t>(bs_, 1);
+        for (size_t i = 0; i < buf_.size(); i += bs) { blocks.emplace_back(buf_.begin() + i, buf_.begin() + std::min(buf_.size(), i + bs)); caps.push_back(blocks.back().size()); }
+        if (!blocks.empty()) {
             auto r = run_batch(blocks, caps, [](rcx_ctx* c, rcx_batch* b, uint32_t* o) { return rcx_bwt_forward_batch(c, b, o); });
             check(r);
             for (size_t i = 0; i < blocks.size(); i++) {
@@ -351,8 +354,9 @@ public:
                 h.clear(); put32(h, r.aux[i]); w_.write(h.data(), 4);
             }
         }
-        return std::move(w_);
+        buf_.clear();
     }
+    W finish() { flush(); return std::move(w_); }                                     // :485-489
 private:
     W w_; size_t bs_; std::vector<uint8_t> buf_; bool wrote_header_ = false;
 };

@@ -204,3 +204,17 @@ def test_bwt_decoder_extra_mem_flag(golden, oracle):
     assert C.bwt.Decoder(io.BytesIO(empty), extra_mem=False).read_to_end() == b""
     with pytest.raises(C.Malformed):
         C.bwt.Decoder(io.BytesIO(empty), extra_mem=True).read_to_end()
+
+
+def test_bwt_encoder_flush_makes_the_reference_block_boundary(golden, oracle):
+    """bwt/mod.rs:511-518: flush() encodes the pending partial block as a block of its own; a stream flushed mid-way has that
+    boundary (and still decodes to the text)."""
+    import struct
+    txt = golden("test.txt")[:3000]
+    w = io.BytesIO(); e = C.bwt.Encoder(w, 1024); e.write(txt[:1500]); e.flush(); e.write(txt[1500:]); e.finish()
+    want = struct.pack("<I", 1024)
+    for part in (txt[:1024], txt[1024:1500], txt[1500:2524], txt[2524:]):                      # the reference's blocks for this call sequence
+        L, origin = oracle.bwt_encode(part)
+        want += struct.pack("<I", len(part)) + L + struct.pack("<I", origin)
+    assert w.getvalue() == want
+    assert C.bwt.Decoder(io.BytesIO(w.getvalue()), extra_mem=True).read_to_end() == txt
