@@ -156,18 +156,32 @@ def config3(ctx, torch, dev, scale=1.0, gzip_framing=False, cpu=True, rank=0, wo
     ar = np.arange(nb, dtype=np.int64)
     db = R.DeviceBatch.from_host(base, off, lens, nb * BLOCK, (ar * BLOCK).astype(np.uint64), np.full(nb, BLOCK, dtype=np.uint64), dev)
     codec = N.GZIP_DECODE if gzip_framing else N.ZLIB_DECODE
+    if os.environ.get("RCX_INFLATE_VARIANT"):                  # A/B of the DEFLATE kernels (see launch_inflate)
+        ctx.set_variant(codec, int(os.environ["RCX_INFLATE_VARIANT"]))
     sc = torch.empty(ctx.scratch_bytes(codec, nb, BLOCK) + 256, dtype=torch.uint8, device=dev)
     t = timeit_ranks(lambda: ctx.launch_dev(codec, db, sc), torch, dist if world > 1 else None, reps=1 if once else 5, warm=0 if once else 1)
     assert int(db.status[:nb].abs().max()) == 0 and torch.equal(db.out_base[: nb * BLOCK].cpu(), torch.from_numpy(raw_np))
     if gzip_framing:
         assert bool((db.in_used[:nb].cpu() == torch.from_numpy(lens.astype(np.int64))).all())
     alg = int(lens.sum()) + nb * BLOCK                       # per rank and launch
+    cliff = None
+    if not gzip_framing and not once and rank == 0 and world == 1 and not os.environ.get("RCX_INFLATE_VARIANT"):
+        # what a batch costs when EVERY member is handed to the exact lane-per-stream kernel (k_inflate2, the second pass of
+        # the default path: statuses, odd codes, overruns): the same members with that kernel alone (variant 9)
+        ctx.set_variant(codec, 9)
+        t9 = timeit(lambda: ctx.launch_dev(codec, db, sc), torch, reps=3)
+        ctx.set_variant(codec, 0)
+        assert int(db.status[:nb].abs().max()) == 0 and torch.equal(db.out_base[: nb * BLOCK].cpu(), torch.from_numpy(raw_np))
+        cliff = {"ms": round(t9 * 1e3, 3), "GiB/s": round(nb * BLOCK / t9 / 2**30, 2), "times_the_default_path": round(t9 / t, 2),
+                 "what": "every member decoded by the fallback kernel k_inflate2 (lane per stream) instead of k_inflate3 (wave per stream)"}
     res = {"config": "3g" if gzip_framing else 3, "n_gpus": world, "scaling": "weak",
            "workload": "%s decode, %d members x 16 KiB per GPU (G-text; %s)" % (
                "gzip (header + DEFLATE + CRC-32/ISIZE check)" if gzip_framing else "zlib", nb,
                "levels 1/6/9" if gzip_framing else "levels 1/6/9 and Z_FIXED, a quarter each"),
            "GiB/s": round(world * nb * BLOCK / t / 2**30, 2), "ms": round(t * 1e3, 3), "ratio": round(nb * BLOCK / lens.sum(), 2),
            "roofline": _roof(alg, t, None if gzip_framing else pmc_traffic(3))}
+    if cliff is not None:
+        res["fallback_cliff"] = cliff
     if cpu and not gzip_framing and rank == 0 and world == 1:
         res["cpu_baseline_libz"] = _libz_rate(members, nb * BLOCK)
         ns = min(nb, 4096)                                  # the oracle walks its Huffman trees bit by bit: a bounded sample

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_adler32(rcx_kargs a)
 #define INF3_OCC 6
 #endif
 template <int SPW, int LG, int MINW> __global__ __launch_bounds__(64, MINW) void k_inflate2(rcx_kargs a, int zlib);
-template <int CB> __global__ __launch_bounds__(64, INF3_OCC) void k_inflate3(rcx_kargs a, int zlib);
+template <int CB, bool SPEC = false> __global__ __launch_bounds__(64, INF3_OCC) void k_inflate3(rcx_kargs a, int zlib);
 __global__ void k_zlib_tail3(rcx_kargs a, const uint32_t* adler);
 template <int WAVES> __global__ void k_adler32(rcx_kargs a);
 
@@ -389,12 +389,16 @@ static void launch_inflate(hipStream_t s, rcx_kargs& k, bool zlib, int v)
 #endif
     // one wave per stream (16 waves per CU) against one lane per stream: 65536 streams of 16 KiB 28 vs 34 ms, 4096 streams
     // 2.2 vs 20.7 ms (benchmarks/inflate_spw_sweep.py); variant 10 forces it, 9 forces k_inflate2
-    const bool wave_per_stream = v == 10 || (v == 0 && n < INF3_MAX_STREAMS);
-    if (!wave_per_stream || k.scratch == nullptr || k.scratch_bytes < inflate_scratch_bytes(n)) { launch_inflate2(s, k, zlib ? 1 : 0, (v == 9 || v == 10) ? 0 : v); return; }
+    // The wave-per-stream kernel's symbol pass is the speculative one (Inf3::pass4: a lane per 128-bit segment, 11.7 against
+    // 12.4 ms for config 3); 11 / 10: the window pass (Inf3::pass) with / without the second pass, 12: pass4 without it
+    const bool spec = v == 0 || v == 12;
+    const bool wave_per_stream = v == 10 || v == 11 || v == 12 || (v == 0 && n < INF3_MAX_STREAMS);
+    if (!wave_per_stream || k.scratch == nullptr || k.scratch_bytes < inflate_scratch_bytes(n)) { launch_inflate2(s, k, zlib ? 1 : 0, (v >= 9 && v <= 12) ? 0 : v); return; }
     rcx_kargs k3 = k;
     uint32_t* adler = (uint32_t*)k.scratch;
     if (!k3.in_used) k3.in_used = (uint64_t*)((uint8_t*)k.scratch + ((4ull * n + 63) & ~63ull));
-    hipLaunchKernelGGL((k_inflate3<1024>), dim3(n), dim3(64), 0, s, k3, zlib ? 1 : 0);
+    if (spec) hipLaunchKernelGGL((k_inflate3<1024, true>), dim3(n), dim3(64), 0, s, k3, zlib ? 1 : 0);
+    else hipLaunchKernelGGL((k_inflate3<1024, false>), dim3(n), dim3(64), 0, s, k3, zlib ? 1 : 0);
     if (zlib) {
         rcx_kargs ka = k3;
         ka.in_base = k3.out_base; ka.in_off = k3.out_off; ka.in_len = k3.out_len; ka.out_len = nullptr; ka.in_used = nullptr;
@@ -402,7 +406,7 @@ static void launch_inflate(hipStream_t s, rcx_kargs& k, bool zlib, int v)
         hipLaunchKernelGGL((k_adler32<4>), dim3((n + 3) / 4), dim3(256), 0, s, ka);
         hipLaunchKernelGGL(k_zlib_tail3, dim3((n + 255) / 256), dim3(256), 0, s, k3, adler);
     }
-    if (v != 10) launch_inflate2(s, k, (zlib ? 1 : 0) | 2, 0);                      // 10: A/B, shows what the first pass handed back
+    if (v != 10 && v != 12) launch_inflate2(s, k, (zlib ? 1 : 0) | 2, 0);                      // 10: A/B, shows what the first pass handed back
 }
 static void launch_adler32(hipStream_t s, rcx_kargs& k)
 {

@@ -148,7 +148,7 @@ __device__ __forceinline__ uint32_t rcx_inf_walk(uint32_t pk1, uint32_t pk2, uin
 #ifndef INF3_OCC
 #define INF3_OCC 6
 #endif
-template <int CB>
+template <int CB, bool SPEC = false>
 struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
     // The kernel is bound by the latency of its dependent phases, so what it needs is waves: 12 / 16 / 18 / 20 / 24 waves per CU take
     // 18.5 / 14.3 / 13.1 / 12.4 / 11.6 ms for config 3.  24 waves = 6400 bytes of LDS each (handed out in 1280-byte granules) and
@@ -395,6 +395,323 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
         return status;
     }
 
+    // ---- the SPECULATIVE symbol pass (SPEC) ---------------------------------------------------------------------------
+    // pass() above decodes a candidate symbol at EVERY bit of a 64-bit window (75 vector instructions) to find the 6-7 real ones
+    // and walks them with scalar code: ~44 instructions per symbol.  A Huffman stream resynchronises by itself -- a decoder
+    // started at an arbitrary bit is on the true symbol boundaries after ~90 bits (p90 207, measured on zlib level 1/6/9
+    // members of text) -- so here the next 4096 staged bits are cut into 64 SEGMENTS of 64 bits and decoded all at once, a LANE
+    // per segment, each lane starting PRE4 = 256 bits before its segment and marking the symbol starts it sees inside it in a
+    // 64-bit register; lane 0 starts at the true position.  The segments are linked as in k_lz4_decode_v8 (the walk of the
+    // segment before mine left it at a bit my map has marked: the walks have met; else the true walk is followed by hand), and
+    // what is left is the exact set of symbol starts of the tile.  Then a lane per SYMBOL: 64 symbols at a time are decoded in
+    // full, literals go to the literal buffer by prefix sum, matches and full 32-literal runs become descriptors, the limits
+    // (literal buffer, 64 descriptors, distance beyond the output) cut the batch where they bite, and the first symbol the fast
+    // path does not take (end of block, a code without table entry, a match longer than 64) stops it.  The tile survives the
+    // flushes in between (two registers).
+    // a segment's map: symbol starts inside my 128 bits of the tile (two registers a lane)
+    struct Map { uint64_t lo, hi; };
+    static __device__ __forceinline__ void mset(Map& m, uint32_t r) { if (r < 64u) m.lo |= 1ull << r; else m.hi |= 1ull << (r - 64u); }
+    static __device__ __forceinline__ bool mtest(const Map& m, uint32_t r) { return ((r < 64u ? m.lo >> r : m.hi >> (r - 64u)) & 1ull) != 0; }
+    static __device__ __forceinline__ void mbelow(Map& m, uint32_t r)            // drop the marks below bit r (r <= 128)
+    {
+        if (r >= 128u) { m.lo = 0; m.hi = 0; }
+        else if (r >= 64u) { m.lo = 0; m.hi &= ~((1ull << (r - 64u)) - 1ull); }
+        else m.lo &= ~((1ull << r) - 1ull);
+    }
+    Map tmap = {0, 0};
+    uint32_t tb_ = 0, tns_ = 0; int32_t tcb_ = 0;    // tile: first bit (relative to cbuf[0]), segments (0: none), the staging it was built on
+    static constexpr uint32_t SEGB4 = 128, PRE4 = 256, XEOB = 0xfffffffeu, XGEN = 0xffffffffu;
+
+    __device__ __forceinline__ uint64_t bits64(uint32_t b) const                 // 64 bits from bit b of the staged bytes
+    {
+        const uint32_t* q = (const uint32_t*)(this->cbuf + ((b >> 3) & ~3u));
+        const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], sh = b & 31u;
+        const uint32_t lo = (uint32_t)((((uint64_t)w1 << 32) | w0) >> sh), hi = (uint32_t)((((uint64_t)w2 << 32) | w1) >> sh);
+        return (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+    // One symbol from the bits w, lane by lane.  kind 0: literal `val`; 1: end of block; 2: match of val <= 64 bytes at `dist`;
+    // 3: a longer match; 4: no code / symbols 286, 287, 30, 31 (the general path decides).  nb: the bits it takes (a match:
+    // with its extra bits and its distance symbol).  Codes longer than the tables are decoded canonically (flate.rs:129-146).
+    __device__ __forceinline__ void sym4(uint64_t w, uint32_t& kind, uint32_t& nb, uint32_t& val, uint32_t& dist) const
+    {
+        const uint32_t w32 = (uint32_t)w;
+        const uint32_t eL = lutL[w32 & (uint32_t)(LUTN - 1)];
+        kind = 4; nb = 0; val = 0; dist = 0;
+        uint32_t tot = 0; bool isLen = false;
+        if (eL & 0x8000u) {
+            tot = eL & 15u;
+            const uint32_t xb = (eL >> 4) & 7u;
+            val = ((eL >> 7) & 0xffu) + 3u + ((w32 >> (tot - xb)) & ((1u << xb) - 1u));
+            isLen = true;
+        } else {
+            const uint32_t sp = eL >> 12;
+            if (sp == 0u) { kind = 0; val = (eL >> 4) & 0xffu; nb = eL & 15u; }
+            else if (sp == 1u) { kind = 1; nb = eL & 15u; }
+            else if (sp == 2u) {
+                const uint32_t rev = __brev(w32) >> 17;
+                uint32_t sym = 0x7fffu, l = 0;
+#pragma unroll 1
+                for (uint32_t k = LUTBITS + 1; k <= 15; k++)
+                    if (l == 0 && rev < tab[k]) { l = k; sym = symL[(rev >> (15u - k)) + tab[16 + k]]; }
+                if (l) {
+                    if (sym < 256u) { kind = 0; val = sym; nb = l; }
+                    else if (sym == 256u) { kind = 1; nb = l; }
+                    else {
+                        const uint32_t nn = sym - 257u;
+                        if (nn < 29u) {
+                            const uint32_t lb = nn < 8 ? 0u : (nn == 28 ? 0u : (nn - 4u) >> 2);
+                            const uint32_t lbase = nn < 8 ? 3u + nn : (nn == 28 ? 258u : 3u + ((4u + (nn & 3u)) << lb));
+                            val = lbase + ((w32 >> l) & ((1u << lb) - 1u));
+                            tot = l + lb; isLen = true;
+                        }
+                    }
+                }
+            }
+        }
+        if (isLen) {
+            const uint32_t wd = (uint32_t)(w >> tot);
+            const uint32_t eD = lutD[wd & (uint32_t)(DLUTN - 1)];
+            uint32_t nbD = eD & 15u, dsy = (eD >> 4) & 31u;
+            if (nbD == 0u) {
+                const uint32_t rev = __brev(wd) >> 17;
+#pragma unroll 1
+                for (uint32_t k = DBITS + 1; k <= 15; k++)
+                    if (nbD == 0u && rev < tab[32 + k]) { nbD = k; dsy = symD[(rev >> (15u - k)) + tab[48 + k]]; }
+            }
+            if (nbD != 0u && dsy < 30u) {
+                const uint32_t xbD = dsy < 4u ? 0u : (dsy - 2u) >> 1;                        // EXTRADIST / EXTRADBITS (flate.rs:275-284)
+                const uint32_t dbase = dsy < 4u ? 1u + dsy : 1u + ((2u + (dsy & 1u)) << xbD);
+                dist = dbase + ((wd >> nbD) & ((1u << xbD) - 1u));
+                nb = tot + nbD + xbD;
+                kind = val <= (uint32_t)B::MCAP ? 2u : 3u;
+            }
+        }
+    }
+    // sym4 for the walk: only what kind of symbol it is (1 end of block, 4 the general path, 0 anything else) and the bits it takes
+    __device__ __forceinline__ void hop4(uint64_t w, uint32_t& kind, uint32_t& nb) const
+    {
+        const uint32_t w32 = (uint32_t)w;
+        const uint32_t eL = lutL[w32 & (uint32_t)(LUTN - 1)];
+        kind = 0; nb = eL & 15u;
+        bool isLen = (eL & 0x8000u) != 0;
+        if (!isLen && (eL >> 12)) {
+            const uint32_t sp = eL >> 12;
+            kind = sp == 1u ? 1u : 4u;
+            if (sp == 2u) {                                          // a code longer than the table
+                const uint32_t rev = __brev(w32) >> 17;
+                uint32_t sym = 0x7fffu, l = 0;
+#pragma unroll 1
+                for (uint32_t k = LUTBITS + 1; k <= 15; k++)
+                    if (l == 0 && rev < tab[k]) { l = k; sym = symL[(rev >> (15u - k)) + tab[16 + k]]; }
+                if (l && sym <= 256u) { kind = sym == 256u ? 1u : 0u; nb = l; }
+                else if (l && sym - 257u < 29u) {
+                    const uint32_t nn = sym - 257u;
+                    nb = l + (nn < 8 ? 0u : (nn == 28 ? 0u : (nn - 4u) >> 2));
+                    isLen = true; kind = 0;
+                }
+            }
+        }
+        if (isLen) {
+            const uint32_t wd = (uint32_t)(w >> nb);
+            const uint32_t eD = lutD[wd & (uint32_t)(DLUTN - 1)];
+            uint32_t nbD = eD & 15u, dsy = (eD >> 4) & 31u;
+            if (nbD == 0u) {
+                const uint32_t rev = __brev(wd) >> 17;
+#pragma unroll 1
+                for (uint32_t k = DBITS + 1; k <= 15; k++)
+                    if (nbD == 0u && rev < tab[32 + k]) { nbD = k; dsy = symD[(rev >> (15u - k)) + tab[48 + k]]; }
+            }
+            if (nbD != 0u && dsy < 30u) nb += nbD + (dsy < 4u ? 0u : (dsy - 2u) >> 1);
+            else kind = 4;
+        }
+    }
+    __device__ __forceinline__ Map lanemap(const Map& v, int k) const
+    {
+        Map r;
+        r.lo = (uint64_t)RCX_U(__builtin_amdgcn_readlane((uint32_t)v.lo, k)) | ((uint64_t)RCX_U(__builtin_amdgcn_readlane((uint32_t)(v.lo >> 32), k)) << 32);
+        r.hi = (uint64_t)RCX_U(__builtin_amdgcn_readlane((uint32_t)v.hi, k)) | ((uint64_t)RCX_U(__builtin_amdgcn_readlane((uint32_t)(v.hi >> 32), k)) << 32);
+        return r;
+    }
+    // Build the tile at bit bp: every segment decoded at once, then linked.
+    __device__ __forceinline__ void tile4(uint32_t bp, uint32_t nseg)
+    {
+        const unsigned lane = this->lane;
+        tb_ = bp; tcb_ = this->cbase; tns_ = nseg;
+        const uint32_t s = bp + SEGB4 * lane, e = s + SEGB4;
+        const bool mine = lane < nseg;
+        uint32_t q = lane == 0 ? bp : (s >= PRE4 ? s - PRE4 : 0u);
+        Map map = {0, 0};
+        uint32_t ex = 0;
+        bool live = mine;
+        for (;;) {
+            const bool go = live && q < e;
+            if (!__ballot(go)) break;
+            if (go) {
+                uint32_t kind, nb;
+                hop4(bits64(q), kind, nb);
+                if (q >= s) mset(map, q - s);                        // (an end of block or a symbol for the general path is marked too: the consumer stops on it)
+                if (kind == 1u) { ex = XEOB; live = false; }
+                else if (kind == 4u) { ex = XGEN; live = false; }
+                else q += nb;
+            }
+        }
+        if (live) ex = q;
+        // link (see k_lz4_decode_v8.hip): the usual case lane by lane, the rest in order by scalar code over the lanes' registers
+        uint32_t lowv = 0; bool clr = false;
+        const uint32_t eprev = (uint32_t)__shfl_up((int)ex, 1);
+        const bool chk = mine && lane > 0;
+        bool ok = false;
+        if (chk && eprev >= s && eprev < e) { lowv = eprev - s; ok = mtest(map, lowv); }
+        if (!ok) lowv = 0;
+        unsigned long long bad = __ballot(chk && !ok);
+        int k = 0; uint32_t cin = 0; bool forced = false;
+        for (;;) {
+            if (!forced) {
+                if (!bad) break;
+                k = __ffsll(bad) - 1;
+                cin = RCX_U(__builtin_amdgcn_readlane(ex, k - 1));
+            }
+            bad &= ~(1ull << k);
+            const uint32_t sk = bp + SEGB4 * (uint32_t)k, ek = sk + SEGB4;
+            const uint32_t exk = RCX_U(__builtin_amdgcn_readlane(ex, k));
+            uint32_t X;
+            if (cin >= ek) { if ((int)lane == k) { clr = true; lowv = 0; } X = cin; }            // the stream ended (or left for the general path) before this segment
+            else {
+                const Map mk = lanemap(map, k);
+                if (mtest(mk, cin - sk)) { if ((int)lane == k) { lowv = cin - sk; clr = false; } X = exk; }
+                else {                                               // follow the true walk until it meets k's map, leaves k or stops
+                    Map tm = {0, 0};
+                    uint32_t q2 = cin, stop = 0;
+                    while (q2 < ek && !mtest(mk, q2 - sk)) {
+                        uint32_t kind, nb;
+                        hop4(bits64(q2), kind, nb);
+                        kind = RCX_U(kind); nb = RCX_U(nb);
+                        mset(tm, q2 - sk);
+                        if (kind == 1u) { stop = XEOB; break; }
+                        if (kind == 4u) { stop = XGEN; break; }
+                        q2 += nb;
+                    }
+                    const bool merged = !stop && q2 < ek;
+                    Map nm = mk;
+                    if (merged) mbelow(nm, q2 - sk); else { nm.lo = 0; nm.hi = 0; }
+                    nm.lo |= tm.lo; nm.hi |= tm.hi;
+                    if ((int)lane == k) { map = nm; lowv = 0; clr = false; }
+                    X = stop ? stop : merged ? exk : q2;
+                }
+            }
+            forced = X != exk && k + 1 < (int)nseg;
+            if (forced) { k++; cin = X; }
+        }
+        if (clr || !mine) { map.lo = 0; map.hi = 0; }
+        mbelow(map, lowv);
+        tmap = map;
+    }
+
+    __device__ __forceinline__ uint32_t pass4(uint32_t& flen, uint32_t& fdist)
+    {
+        const unsigned lane = this->lane;
+        const uint32_t LIMB = 8u * (uint32_t)CB - 64u;               // a symbol that starts below this bit is staged in full (<= 48 bits)
+        flen = 0; fdist = 0;
+        for (;;) {
+            uint32_t bp = RCX_U(8u * (uint32_t)((int32_t)p - this->cbase) - bc);   // the next unread bit, relative to cbuf[0]
+            // ---- the tile: the one left from the last call if the stream is still on it, else a new one
+            bool have = tns_ != 0 && tcb_ == this->cbase && bp >= tb_ && bp < tb_ + SEGB4 * tns_;
+            if (have) have = mtest(lanemap(tmap, (int)((bp - tb_) / SEGB4)), (bp - tb_) % SEGB4);
+            if (!have) {
+                tns_ = 0;
+                if (bp + 2u * SEGB4 > LIMB) return pass(flen, fdist);               // too few staged bits for a tile: the window pass (it knows when to restage)
+                const uint32_t nseg = (LIMB - bp) / SEGB4 < 64u ? (LIMB - bp) / SEGB4 : 64u;
+                tile4(bp, nseg);
+            }
+            {                                                        // marks below the stream's position are history
+                const int32_t rel = (int32_t)bp - (int32_t)(tb_ + SEGB4 * lane);
+                if (rel > 0) mbelow(tmap, (uint32_t)rel);
+            }
+            // ---- the next 64 symbols, a lane each
+            const uint32_t cnt = (uint32_t)__popcll(tmap.lo) + (uint32_t)__popcll(tmap.hi);
+            const uint32_t incl = rcx_wave_incl_scan(cnt);
+            const uint32_t total = RCX_U(__builtin_amdgcn_readlane(incl, 63));
+            if (total == 0u) { tns_ = 0; continue; }                // (cannot happen right after a build: bp itself is marked)
+            const uint32_t nv = total < 64u ? total : 64u;
+            uint32_t j = 0;                                          // the lane whose map holds symbol `lane`: the number of lanes with incl <= lane
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((j + (uint32_t)step - 1u) << 2), (int)incl);
+                j = v <= lane ? j + (uint32_t)step : j;
+            }
+            const uint32_t jj = j < 63u ? j : 63u;
+            uint32_t r = lane - (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jj << 2), (int)(incl - cnt));
+            const uint32_t m0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jj << 2), (int)(uint32_t)tmap.lo);
+            const uint32_t m1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jj << 2), (int)(uint32_t)(tmap.lo >> 32));
+            const uint32_t m2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jj << 2), (int)(uint32_t)tmap.hi);
+            const uint32_t m3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jj << 2), (int)(uint32_t)(tmap.hi >> 32));
+            const bool valid = lane < nv;
+            uint32_t w = m0, base = 0;                               // the r-th set bit of the 128-bit map
+            { const uint32_t c = (uint32_t)__popc(m0); if (r >= c) { r -= c; w = m1; base = 32; const uint32_t c1 = (uint32_t)__popc(m1);
+                if (r >= c1) { r -= c1; w = m2; base = 64; const uint32_t c2 = (uint32_t)__popc(m2); if (r >= c2) { r -= c2; w = m3; base = 96; } } } }
+            { const uint32_t c = (uint32_t)__popc(w & 0xffffu); if (r >= c) { r -= c; w >>= 16; base += 16; } }
+            { const uint32_t c = (uint32_t)__popc(w & 0xffu); if (r >= c) { r -= c; w >>= 8; base += 8; } }
+            { const uint32_t c = (uint32_t)__popc(w & 0xfu); if (r >= c) { r -= c; w >>= 4; base += 4; } }
+            { const uint32_t c = (uint32_t)__popc(w & 0x3u); if (r >= c) { r -= c; w >>= 2; base += 2; } }
+            { const uint32_t c = w & 1u; if (r >= c) { base += 1; } }
+            const uint32_t b = valid ? tb_ + SEGB4 * jj + base : tb_;
+            uint32_t kind, nb, val, dist;
+            sym4(bits64(b), kind, nb, val, dist);
+            // ---- what gets booked: symbols before the first one the fast path does not take, within the limits
+            const unsigned long long stopm = __ballot(valid && (kind == 1u || kind >= 3u));
+            const uint32_t g = stopm ? (uint32_t)__ffsll(stopm) - 1u : nv;
+            const bool isL = lane < g && kind == 0u, isM = lane < g && kind == 2u;
+            const uint32_t litn0 = RCX_U(litn), ns0 = RCX_U((uint32_t)ns), runL0 = RCX_U(runL), otot0 = RCX_U(otot);
+            const uint32_t ob = isL ? 1u : isM ? val : 0u;
+            const uint32_t obefore = otot0 + rcx_wave_incl_scan(ob) - ob;
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const unsigned long long litm = __ballot(isL), matm = __ballot(isM);
+            const uint32_t lbefore = (uint32_t)__popcll(litm & below);             // literals in front of this lane
+            const unsigned long long mb = matm & below;
+            const uint32_t lastM = mb ? 64u - (uint32_t)__clzll(mb) : 0u;          // (index + 1) of the last match in front of this lane
+            const uint32_t lbM = lastM ? (uint32_t)__popcll(litm & ((1ull << (lastM - 1u)) - 1ull)) : 0u;
+            const uint32_t R = lastM ? lbefore - lbM : lbefore + runL0;          // literals since the last match (a run closes every 32)
+            const bool closes = isL && ((R + 1u) & 31u) == 0u;
+            const bool emit = isM || closes;
+            const uint32_t eidx = ns0 + (uint32_t)__popcll(__ballot(emit) & below);
+            const bool over = (isL && litn0 + lbefore >= (uint32_t)LITCAP) || eidx >= 64u;       // (nothing is booked behind the 64th descriptor: an open run would be the 65th)
+            const bool badd = isM && dist > obefore;
+            const unsigned long long cutm = __ballot(over || badd);
+            const uint32_t c = cutm ? (uint32_t)__ffsll(cutm) - 1u : g;           // symbols [0, c) are booked
+            if (isL && lane < c) litbuf[litn0 + lbefore] = (uint8_t)val;
+            if (emit && lane < c) {
+                desc[2 * eidx] = closes ? litn0 + lbefore + 1u - 32u : litn0 + lbefore - (R & 31u);
+                desc[2 * eidx + 1] = closes ? 32u : ((R & 31u) | (val << 8) | (dist << 16));
+            }
+            // the state behind symbol c - 1
+            if (c) {
+                const int cl = (int)c - 1;
+                const uint32_t e1 = emit ? 1u : 0u, l1 = isL ? 1u : 0u;
+                litn = RCX_U(__builtin_amdgcn_readlane(litn0 + lbefore + l1, cl));
+                ns = (int)RCX_U(__builtin_amdgcn_readlane(eidx + e1, cl));
+                otot = RCX_U(__builtin_amdgcn_readlane(obefore + ob, cl));
+                runL = RCX_U(__builtin_amdgcn_readlane(emit ? 0u : (R + 1u) & 31u, cl));
+                runsrc = litn - runL;
+            }
+            rcx_wave_sync();
+            // ---- where the stream stands now, and why the pass stopped (if it did)
+            uint32_t status = 0xffu, nbp;
+            if (c < nv) {
+                const uint32_t kc = RCX_U(__builtin_amdgcn_readlane(kind, (int)c));
+                nbp = RCX_U(__builtin_amdgcn_readlane(b, (int)c));
+                if ((cutm >> c) & 1ull) status = RCX_U(__builtin_amdgcn_readlane(badd ? 1u : 0u, (int)c)) ? 4u : 0u;
+                else if (kc == 1u) { nbp += RCX_U(__builtin_amdgcn_readlane(nb, (int)c)); status = 2u; }
+                else status = 3u;
+            } else nbp = RCX_U(__builtin_amdgcn_readlane(b + nb, (int)nv - 1));
+            // the bit reader resumes at bit nbp
+            const uint32_t pa = (nbp >> 3) & ~3u, drop = nbp - 8u * pa;
+            p = (uint32_t)(this->cbase + (int32_t)pa); bb = 0; bc = 0;
+            refill();
+            bb >>= drop; bc -= drop;
+            if (status != 0xffu) return status;
+        }
+    }
+
     // Decoder::block to BFINAL (flate.rs:195-206) after an optional zlib header (zlib.rs:55-86): the engine loop
     __device__ void run(int zlib, int32_t* st_out, uint32_t* len_out, uint32_t* used_out, uint32_t* flags_out)
     {
@@ -430,6 +747,10 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
                     const uint32_t w0 = (int)lane < ns ? desc[2 * lane] : 0u, w1 = (int)lane < ns ? desc[2 * lane + 1] : 0u;
                     int lo = 0, e = 0;
                     while (lo < ns && !e) e = this->template emit5<true>(ns, lo, w0, w1, litbuf);
+#ifdef RCX_SIM_TRACE
+                    if (e && this->lane == 0) { fprintf(stderr, "SPEC%d emit5 -> %d ns %d litn %u otot %u oend %u\n", (int)SPEC, e, ns, litn, otot, this->oend);
+                        for (int i = 0; i < ns; i++) fprintf(stderr, "  d%d src %u L %u M %u off %u\n", i, desc[2*i], desc[2*i+1] & 255, (desc[2*i+1] >> 8) & 255, desc[2*i+1] >> 16); }
+#endif
                     if (e) { st = RCX_ST_FALLBACK; break; }
                 }
                 ns = 0; litn = 0; runL = 0; runsrc = 0;
@@ -555,7 +876,10 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
                 for (;;) {
                     // The fast path: symbols with table-length codes are decoded AND booked by pass(); the rest comes back as a status.
                     uint32_t flen = 0, fdist = 0;
-                    const uint32_t fs = pass(flen, fdist);
+                    const uint32_t fs = SPEC ? pass4(flen, fdist) : pass(flen, fdist);
+#ifdef RCX_SIM_TRACE
+                    if (fs >= 3u && this->lane == 0) fprintf(stderr, "SPEC%d pass -> %u at bit %u otot %u ns %d litn %u runL %u\n", (int)SPEC, fs, 8u * (uint32_t)((int32_t)p - this->cbase) - bc, otot, ns, litn, runL);
+#endif
                     if (fs == 4u) { st = RCX_ST_FALLBACK; break; }      // :314 distance beyond the output
                     if (fs == 1u) {                                    // a match longer than 64 bytes: flush, then the wave-wide copy
                         otot = RCX_U(otot + flen);
@@ -626,13 +950,13 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
 
 #define INF3_LDS_EXTRA (2 * 1024 + 2 * 288 + 2 * 32 + 352 + 4 * 80 + (1024 + 64) + 4 * 128)
 
-template <int CB>
+template <int CB, bool SPEC>
 #ifndef INF3_VGPR
 #define INF3_VGPR 96
 #endif
 __global__ __launch_bounds__(64, INF3_OCC) void k_inflate3(rcx_kargs a, int zlib)
 {
-    typedef Inf3<CB> S;
+    typedef Inf3<CB, SPEC> S;
     __shared__ __align__(16) uint8_t s_cbuf[CB + 96];
     __shared__ __align__(16) uint8_t s_wbuf[S::WBUF5 + 16];     // + 16: lds_load16u reads one dword past the last staging slot
     __shared__ __align__(16) uint16_t s_lutL[512];

@@ -132,7 +132,7 @@ def test_inflate_zlib_adler(oracle, golden):
     for i in range(10):
         zs.append(golden("test.z.%d" % i)); exp.append(txt)
     sb = 12 * (len(zs) + 1) + 256                  # variant 0 = wave-per-stream kernel + exact fallback: wants scratch
-    for variant in (0, 9, 2, 3, 4, 1):              # ..., lane-per-stream auto (8 streams per wave here), 64, 32, 16, first kernel
+    for variant in (0, 11, 9, 2, 3, 4, 1):          # ..., speculative pass, lane-per-stream auto (8 streams per wave here), 64, 32, 16, first kernel
         outs, _, used, st, _ = simrun.run(N.ZLIB_DECODE, variant, zs, [len(e) for e in exp], scratch_bytes=sb)
         assert not st.any() and outs == exp and list(used) == [len(z) for z in zs], variant
     raw = [z[2:-4] for z in zs] + [golden("test.z.go")]
