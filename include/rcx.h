@@ -170,6 +170,15 @@ int rcx_dc_encode_batch(rcx_ctx*, const rcx_batch*);
 /* reference: src/bwt/dc.rs:162-252 decode_simple; in = the words above,
  * n_out[i] = decoded length n (dc carries no length itself) */
 int rcx_dc_decode_batch(rcx_ctx*, const rcx_batch*, const uint64_t* n_out);
+/* The same two with the coding CONTEXT of every distance (reference: src/bwt/dc.rs:40-58 `Context`; yielded next to each
+ * distance by EncodeIterator :88-103, handed to decode's distance callback :199-229; the reference's test :268-289 checks
+ * that the two sides see the same contexts).  A context is 8 bytes: u32 LE symbol | last_rank << 8, u32 LE distance_limit.
+ *   encode: block i's slot must hold 4*(256+n) + 8*n bytes (n = in_len[i]); words as above in its first 4*(256+k) bytes,
+ *           the k contexts from byte 4*(256+n) on; out_len[i] = 4*(256+n) + 8*k.
+ *   decode: the slot must be 8-byte aligned and hold ((n+7)&~7) + 8*(in_len[i]/4 - 256) bytes; the n decoded bytes first,
+ *           one context per distance consumed from byte (n+7)&~7 on; out_len[i] = that offset + 8 * (distances consumed). */
+int rcx_dc_encode_ctx_batch(rcx_ctx*, const rcx_batch*);
+int rcx_dc_decode_ctx_batch(rcx_ctx*, const rcx_batch*, const uint64_t* n_out);
 
 /* ---- adaptive byte range coder ---------------------------------------------- */
 /* reference: src/entropy/ari/table.rs:185-224 ByteEncoder::write + finish

@@ -22,6 +22,49 @@ pub fn decode_simple(input: &[u8], origin: usize) -> Vec<u8> {
     r.out[0].clone()
 }
 
+/// bwt/mod.rs:136-210 in batch-backed form: `encode(input, suf)` returns an iterator over the transformed bytes with the
+/// origin behind it; here the block is transformed by ONE kernel call and the iterator serves the result (there is no suffix
+/// array on the host to hand in: the device sorts in its own scratch).
+pub struct TransformIterator {
+    bytes: std::vec::IntoIter<u8>,
+    origin: usize,
+}
+
+impl TransformIterator {
+    /// :192-195
+    pub fn get_origin(&self) -> usize {
+        self.origin
+    }
+}
+
+impl Iterator for TransformIterator {
+    type Item = u8;
+    fn next(&mut self) -> Option<u8> {
+        self.bytes.next()
+    }
+}
+
+pub fn encode(input: &[u8]) -> TransformIterator {
+    let (l, origin) = encode_simple(input);
+    TransformIterator { bytes: l.into_iter(), origin }
+}
+
+/// bwt/mod.rs:223-288 in batch-backed form: `decode(input, origin, table)` returns an iterator over the original bytes.
+pub struct InverseIterator {
+    bytes: std::vec::IntoIter<u8>,
+}
+
+impl Iterator for InverseIterator {
+    type Item = u8;
+    fn next(&mut self) -> Option<u8> {
+        self.bytes.next()
+    }
+}
+
+pub fn decode(input: &[u8], origin: usize) -> InverseIterator {
+    InverseIterator { bytes: decode_simple(input, origin).into_iter() }
+}
+
 /// bwt/mod.rs:437-518: `u32 LE block_size`, then per block `u32 LE n`, n bytes of L, `u32 LE origin`.
 pub struct Encoder<W: Write> {
     w: W,

@@ -31,7 +31,7 @@ impl<W: Write> Write for Encoder<W> {
 }
 
 pub struct Decoder<R: Read> {
-    r: TailReader<R>,
+    pub r: TailReader<R>,
     buf: Buffered,
 }
 
@@ -52,5 +52,18 @@ impl<R: Read> Read for Decoder<R> {
             Ok((r.out[0].clone(), None))
         })?;
         Ok(self.buf.serve(dst))
+    }
+}
+
+/// mtf.rs:44-91 in batch-backed form.  The crate's `MTF` moves one symbol per call (`encode(sym) -> rank`, `decode(rank) ->
+/// sym`); a whole block through the same list, started as the stream codecs start it (identity, :103-104), is one kernel call.
+pub struct MTF;
+
+impl MTF {
+    pub fn encode_block(input: &[u8]) -> Vec<u8> {
+        run_batch(&[input], &[input.len() as u64], |c, b, _| unsafe { rcx_mtf_encode_batch(c, b) }).check().unwrap().out[0].clone()
+    }
+    pub fn decode_block(ranks: &[u8]) -> Vec<u8> {
+        run_batch(&[ranks], &[ranks.len() as u64], |c, b, _| unsafe { rcx_mtf_decode_batch(c, b) }).check().unwrap().out[0].clone()
     }
 }

@@ -1,7 +1,21 @@
 //! Adaptive order-0 byte range coder (reference: src/entropy/ari/table.rs:185-273 over mod.rs:67-293, table.rs:20-122).
+pub mod apm;
+pub mod bin;
+pub mod table;
+
 use crate::rcx_sys::*;
 use crate::{grow_decode, run_batch, Buffered, TailReader};
 use std::io::{self, Read, Write};
+
+// What is NOT here, and why: `RangeEncoder` (mod.rs:67-165), the `Model<V>` trait (:170-196) and the generic `Encoder<W>` /
+// `Decoder<R>` (:200-293) code ONE symbol per call against a caller-supplied model -- host-side control flow that cannot
+// cross an FFI made of batch calls.  A port keeps using the crate's own host code for those; the device offers every model
+// the crate ships as whole-stream codecs: `table::Model` through `ByteEncoder` / `ByteDecoder` below, `bin::Model`,
+// `table::SumProxy` + `bin::SumProxy`, `apm::Bit` + `apm::Gate` through the `encode_bytes` / `decode_bytes` of their modules.
+
+/// The stream coder over `table::Model` is the crate's `ari::Encoder<W>` / `ari::Decoder<R>` as its byte codecs use them.
+pub type Encoder<W> = ByteEncoder<W>;
+pub type Decoder<R> = ByteDecoder<R>;
 
 /// table.rs:185-224
 pub struct ByteEncoder<W: Write> {
@@ -37,7 +51,7 @@ impl<W: Write> Write for ByteEncoder<W> {
 /// table.rs:229-273.  Stops exactly at the stream's end: `finish()` returns the reader positioned after it
 /// (mod.rs:289-292; test.rs:52-89 decodes two streams back to back from one reader).
 pub struct ByteDecoder<R: Read> {
-    r: TailReader<R>,
+    pub r: TailReader<R>,
     buf: Buffered,
 }
 

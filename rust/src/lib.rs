@@ -136,9 +136,31 @@ pub struct TailReader<R: Read> {
     tpos: usize,
 }
 
+/// `decoder.r` is a `TailReader<R>` where the reference has an `R` (flate.rs:166, lz4.rs:320, bwt/mod.rs:325): it derefs to
+/// the `R`, so call sites that use the reader's own methods (`decoder.r.get_ref()`, `decoder.r.position()`) keep compiling;
+/// code that READS from it must go through the `TailReader` (its `Read` impl serves the handed-back bytes first), and
+/// `into_inner()` gives the `R` back once those are used up.
+impl<R: Read> std::ops::Deref for TailReader<R> {
+    type Target = R;
+    fn deref(&self) -> &R {
+        &self.inner
+    }
+}
+
+impl<R: Read> std::ops::DerefMut for TailReader<R> {
+    fn deref_mut(&mut self) -> &mut R {
+        &mut self.inner
+    }
+}
+
 impl<R: Read> TailReader<R> {
     pub fn new(r: R) -> TailReader<R> {
         TailReader { inner: r, tail: Vec::new(), tpos: 0 }
+    }
+    /// The wrapped reader and the bytes handed back but not yet read again (empty once the caller has drained them).
+    pub fn into_inner(self) -> (R, Vec<u8>) {
+        let rest = self.tail[self.tpos..].to_vec();
+        (self.inner, rest)
     }
     pub fn unread(&mut self, data: &[u8]) {
         if data.is_empty() {

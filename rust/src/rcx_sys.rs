@@ -132,6 +132,8 @@ extern "C" {
     pub fn rcx_mtf_decode_batch(ctx: *mut rcx_ctx, b: *const rcx_batch) -> c_int;
     pub fn rcx_dc_encode_batch(ctx: *mut rcx_ctx, b: *const rcx_batch) -> c_int;
     pub fn rcx_dc_decode_batch(ctx: *mut rcx_ctx, b: *const rcx_batch, n_out: *const u64) -> c_int;
+    pub fn rcx_dc_encode_ctx_batch(ctx: *mut rcx_ctx, b: *const rcx_batch) -> c_int;
+    pub fn rcx_dc_decode_ctx_batch(ctx: *mut rcx_ctx, b: *const rcx_batch, n_out: *const u64) -> c_int;
     // ---- range coders (src/entropy/ari/*.rs)
     pub fn rcx_ari_byte_encode_batch(ctx: *mut rcx_ctx, b: *const rcx_batch) -> c_int;
     pub fn rcx_ari_byte_decode_batch(ctx: *mut rcx_ctx, b: *const rcx_batch) -> c_int;

@@ -31,7 +31,7 @@ EXPORTS = [
     "rcx_status_string", "rcx_lz4_decode_batch", "rcx_lz4_encode_batch", "rcx_lz4_compression_bound",
     "rcx_inflate_batch", "rcx_zlib_decode_batch", "rcx_adler32_batch", "rcx_crc32_batch", "rcx_gzip_decode_batch",
     "rcx_bwt_forward_batch", "rcx_bwt_inverse_batch", "rcx_mtf_encode_batch", "rcx_mtf_decode_batch", "rcx_dc_encode_batch",
-    "rcx_dc_decode_batch", "rcx_ari_byte_encode_batch", "rcx_ari_byte_decode_batch", "rcx_ari_byte_encode_bound",
+    "rcx_dc_decode_batch", "rcx_dc_encode_ctx_batch", "rcx_dc_decode_ctx_batch", "rcx_ari_byte_encode_batch", "rcx_ari_byte_decode_batch", "rcx_ari_byte_encode_bound",
     "rcx_rle_encode_batch", "rcx_rle_decode_batch", "rcx_rle_encode_bound", "rcx_scratch_bytes", "rcx_launch_dev",
     "rcx_ari_binary_encode_batch", "rcx_ari_binary_decode_batch", "rcx_ari_proxy_encode_batch", "rcx_ari_proxy_decode_batch",
     "rcx_ctx_set_param", "rcx_ari_apm_encode_batch", "rcx_ari_apm_decode_batch", "rcx_bwt_inverse_minimal_batch",
@@ -79,7 +79,7 @@ def lib():
         L.rcx_scratch_bytes.restype = C.c_uint64
         L.rcx_launch_dev.argtypes = [C.c_void_p, C.c_int, C.POINTER(DevBatch), C.c_void_p, C.c_uint64]
         for name in ("rcx_lz4_decode_batch", "rcx_lz4_encode_batch", "rcx_mtf_encode_batch", "rcx_mtf_decode_batch",
-                     "rcx_dc_encode_batch", "rcx_ari_byte_encode_batch", "rcx_ari_byte_decode_batch",
+                     "rcx_dc_encode_batch", "rcx_dc_encode_ctx_batch", "rcx_ari_byte_encode_batch", "rcx_ari_byte_decode_batch",
                      "rcx_rle_encode_batch", "rcx_rle_decode_batch", "rcx_ari_proxy_encode_batch", "rcx_ari_proxy_decode_batch",
                      "rcx_ari_apm_encode_batch", "rcx_ari_apm_decode_batch"):
             getattr(L, name).argtypes = [C.c_void_p, C.POINTER(Batch)]
@@ -88,7 +88,7 @@ def lib():
         L.rcx_ctx_set_param.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
         for name in ("rcx_inflate_batch", "rcx_zlib_decode_batch", "rcx_adler32_batch", "rcx_crc32_batch",
                      "rcx_gzip_decode_batch", "rcx_bwt_forward_batch",
-                     "rcx_bwt_inverse_batch", "rcx_bwt_inverse_minimal_batch", "rcx_dc_decode_batch"):
+                     "rcx_bwt_inverse_batch", "rcx_bwt_inverse_minimal_batch", "rcx_dc_decode_batch", "rcx_dc_decode_ctx_batch"):
             getattr(L, name).argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p]
         _lib = L
     return _lib

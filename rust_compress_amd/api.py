@@ -141,6 +141,14 @@ class Context:
     def dc_decode(self, blobs, n_out):
         return self._run_host("rcx_dc_decode_batch", blobs, list(n_out), n_out=n_out)
 
+    def dc_encode_ctx(self, blobs):
+        """-> result whose outputs[i] = the words (first 4 * (256 + k) bytes), a gap, then k 8-byte contexts from byte
+        4 * (256 + n) on (include/rcx.h); `dc_split_ctx` cuts it up"""
+        return self._run_host("rcx_dc_encode_ctx_batch", blobs, [4 * (256 + len(b)) + 8 * len(b) for b in blobs])
+
+    def dc_decode_ctx(self, blobs, n_out):
+        return self._run_host("rcx_dc_decode_ctx_batch", blobs, [((n + 7) & ~7) + 8 * max(0, len(b) // 4 - 256) for b, n in zip(blobs, n_out)], n_out=n_out)
+
     def ari_byte_encode(self, blobs):
         return self._run_host("rcx_ari_byte_encode_batch", blobs, [int(N.lib().rcx_ari_byte_encode_bound(len(b))) for b in blobs])
 

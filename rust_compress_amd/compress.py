@@ -402,6 +402,28 @@ class _dc:
         blob = struct.pack("<%dI" % len(distances), *distances)
         return _check(context().dc_decode([blob], [n])).outputs[0]
 
+    @staticmethod
+    def encode(input):
+        """dc.rs:110-149 in batch-backed form -> (init[256], [(distance, (symbol, last_rank, distance_limit)), ...]): the
+        initial positions and the (distance, Context) pairs the reference's EncodeIterator yields (:88-103), from ONE kernel call"""
+        input = bytes(input)
+        n = len(input)
+        out = _check(context().dc_encode_ctx([input])).outputs[0]
+        k = (len(out) - 4 * (256 + n)) // 8
+        words = struct.unpack("<%dI" % (256 + k), out[: 4 * (256 + k)])
+        cw = struct.unpack("<%dI" % (2 * k), out[4 * (256 + n): 4 * (256 + n) + 8 * k])
+        return list(words[:256]), [(words[256 + j], (cw[2 * j] & 255, (cw[2 * j] >> 8) & 255, cw[2 * j + 1])) for j in range(k)]
+
+    @staticmethod
+    def decode(init, distances, n):
+        """dc.rs:162-233 in batch-backed form -> (bytes, contexts): the Context handed to the distance callback before each
+        distance is read (:208), in call order"""
+        blob = struct.pack("<%dI" % (256 + len(distances)), *(list(init) + list(distances)))
+        out = _check(context().dc_decode_ctx([blob], [n])).outputs[0]
+        co = (n + 7) & ~7
+        cw = struct.unpack("<%dI" % ((len(out) - co) // 4), out[co:])
+        return out[:n], [(cw[2 * j] & 255, (cw[2 * j] >> 8) & 255, cw[2 * j + 1]) for j in range(len(cw) // 2)]
+
 
 class bwt:
     mtf = _mtf

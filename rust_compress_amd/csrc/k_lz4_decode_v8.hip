@@ -346,10 +346,14 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
             // ---- 1. every segment walked at once (a lane each)
             const int32_t s = cs + SEGB * (int32_t)lane;
             const uint32_t e = ((int64_t)s + SEGB < (int64_t)n) ? (uint32_t)(s + SEGB) : n;
-            const bool mine = (int)lane >= k0 && (int)lane < nseg;
+            // (a token whose literal run reaches past the chunk -- incompressible data is ONE such token -- is the chunk's only
+            // token: nothing to guess at, the 63 other lanes would walk garbage)
+            const uint32_t nx = RCX_U(next_tok_c(c));
+            const bool giant = nx >= n || (int64_t)nx >= (int64_t)cs + CH;
+            const bool mine = !giant && (int)lane >= k0 && (int)lane < nseg;
             int32_t p0 = s - PRE; p0 = p0 < 0 ? 0 : p0;
             uint32_t p = ((int)lane == k0) ? c : (uint32_t)p0;
-            uint64_t map = 0;
+            uint64_t map = (giant && (int)lane == k0) ? 1ull << (c - (uint32_t)s) : 0ull;
             for (;;) {
                 const bool go = mine && p < e;
                 if (!__ballot(go)) break;
@@ -365,7 +369,8 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
             // it at a byte my map has marked.  What is left -- a jump over a segment, walks that have not met -- is settled in
             // order by scalar code over the lanes' registers (and whatever that changes is checked again downstream).
             uint32_t lowv = 0; bool clr = false;
-            {
+            if (giant) c = nx;
+            else {
                 const uint32_t eprev = (uint32_t)__shfl_up((int)ex, 1);
                 const bool chk = mine && (int)lane > k0;
                 bool ok = false;
@@ -407,7 +412,7 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
             }
             if (clr) map = 0;
             map &= ~((1ull << lowv) - 1ull);
-            if (!mine) map = 0;
+            if (!mine && !giant) map = 0;
             V8P_ADD(1);
             if (PROF8) pp[6] += 1;
             // ---- 3. a lane per token: the maps unpacked into a position list (eight input bytes a lane), 64 entries a batch

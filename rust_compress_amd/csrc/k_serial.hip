@@ -348,9 +348,13 @@ __device__ __forceinline__ uint32_t dc_encode_steps(LT& L, SeqWin<uint8_t>& win,
     return i;
 }
 
+// withctx: also writes the coding CONTEXT of every distance (dc.rs:40-58; yielded with it by EncodeIterator, :88-103) -- eight
+// bytes each, {symbol | last_rank << 8, distance_limit}, from byte 4 * (256 + n) of the block's slot on; out_len is then
+// 4 * (256 + n) + 8 * k (k distances; the words are the first 4 * (256 + k) bytes as always).
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a)
+__global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a, int withctx)
 {
+    __shared__ uint32_t s_pos[WAVES][256];                  // (withctx) where each symbol's next occurrence was predicted, :94
     const unsigned w = threadIdx.x >> 6, lane = rcx_lane();
     const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + w));   // wave-uniform: keeps descriptors in SGPRs
     if (b >= a.nblocks) return;
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a)
     const uint32_t n = (uint32_t)a.in_len[b];
     uint32_t* words = (uint32_t*)(a.out_base + a.out_off[b]);
     // the out slot doubles as the dist[] work array (dc.rs:112 `distances`), so it must hold 256+n words
-    if (a.out_cap[b] < 4ull * (256ull + n) || ((uintptr_t)words & 3u)) {
+    if (a.out_cap[b] < 4ull * (256ull + n) + (withctx ? 8ull * n : 0ull) || ((uintptr_t)words & 3u)) {
         if (lane == 0) { a.status[b] = RCX_E_OUTPUT_TOO_SMALL; a.out_len[b] = 0; if (a.in_used) a.in_used[b] = 0; }
         return;
     }
@@ -384,21 +388,51 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a)
     rcx_wave_sync();
     // compact the non-filler distances in position order (EncodeIterator :88-104): ballot + prefix popcount
     uint32_t k = 0;
+    uint32_t last_active = 0;                                // (withctx) :97, one past the position of the last distance yielded
+    uint32_t* const posn = s_pos[w];
+    uint32_t* const ctxo = dist + n;                         // byte 4 * (256 + n) of the slot
+    if (withctx) { for (int q = 0; q < 4; q++) posn[lane + 64 * q] = words[lane + 64 * q]; rcx_wave_sync(); }
     for (uint32_t j = 0; j < n; j += 64) {
         const uint32_t p = j + lane;
         const uint32_t d = p < n ? dist[p] : n;
         const bool keep = d != n;
         const unsigned long long m = __ballot(keep);
+        if (withctx && m) {                                  // Context::new(sym, last_active - pos[sym], size - i), :94-102
+            const uint32_t sym = keep ? in[p] : 0u;
+            unsigned long long same = m;                     // the kept lanes that hold my symbol
+#pragma unroll
+            for (int bit = 0; bit < 8; bit++) {
+                const unsigned long long bbm = __ballot(keep && ((sym >> bit) & 1u));
+                same &= ((sym >> bit) & 1u) ? bbm : ~bbm;
+            }
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const unsigned long long pk = m & below, ps = same & below;
+            const uint32_t la = pk ? j + (63u - (uint32_t)__clzll(pk)) + 1u : last_active;
+            const uint32_t ql = ps ? 63u - (uint32_t)__clzll(ps) : lane;
+            const uint32_t dq = (uint32_t)__shfl((int)d, (int)ql);
+            const uint32_t tabv = posn[sym];
+            const uint32_t posv = ps ? j + ql + 1u + dq : tabv;
+            if (keep) {
+                const uint32_t at = k + (uint32_t)__popcll(pk);
+                ctxo[2 * at] = sym | (((la - posv) & 0xffu) << 8);
+                ctxo[2 * at + 1] = n - p;
+            }
+            rcx_wave_sync();
+            if (keep && (same >> lane) == 1ull) posn[sym] = p + 1u + d;          // the last of its symbol in this window
+            last_active = RCX_UNI(j + (63u - (uint32_t)__clzll(m)) + 1u);
+            rcx_wave_sync();
+        }
         rcx_wave_sync();                                     // all reads of this 64-slot window precede the writes
         if (keep) dist[k + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = d;
         k += (uint32_t)__popcll(m);
     }
-    if (lane == 0) { a.status[b] = RCX_OK; a.out_len[b] = 4ull * (256ull + k); if (a.in_used) a.in_used[b] = n; }
+    if (lane == 0) { a.status[b] = RCX_OK; a.out_len[b] = withctx ? 4ull * (256ull + n) + 8ull * k : 4ull * (256ull + k); if (a.in_used) a.in_used[b] = n; }
 }
 
 // dc.rs:199-229 driven as decode_simple :236-252; returns the status
 template <class LT>
-__device__ __forceinline__ int dc_decode_steps(LT& L, SeqWin<uint32_t>& wwin, uint32_t& i, uint32_t n, uint32_t A, uint32_t& di, uint32_t nwords, uint8_t* out, unsigned lane)
+__device__ __forceinline__ int dc_decode_steps(LT& L, SeqWin<uint32_t>& wwin, uint32_t& i, uint32_t n, uint32_t A, uint32_t& di, uint32_t nwords, uint8_t* out, unsigned lane,
+                                               uint32_t* ctxo = nullptr, uint8_t* ranks = nullptr)
 {
     while (i < n) {
         const uint32_t sym = L.sym_at(0);
@@ -406,6 +440,10 @@ __device__ __forceinline__ int dc_decode_steps(LT& L, SeqWin<uint32_t>& wwin, ui
         if (stop > n) return RCX_E_MALFORMED;                  // output[i] index panic
         for (uint32_t t = i + lane; t < stop; t += 64) out[t] = (uint8_t)sym;
         if (stop > i) i = stop;
+        if (ctxo && lane == 0) {                               // Context::new(sym, ranks[sym], n + 1 - i), :208: what the distance callback is handed
+            ctxo[2 * (di - 256u)] = sym | ((uint32_t)ranks[sym] << 8);
+            ctxo[2 * (di - 256u) + 1] = n + 1u - i;
+        }
         di++;                                                  // decode_simple closure :243-249
         if (di > nwords) return RCX_E_EOF;
         const uint32_t d = wwin.get(di - 1);
@@ -414,15 +452,19 @@ __device__ __forceinline__ int dc_decode_steps(LT& L, SeqWin<uint32_t>& wwin, ui
         const uint32_t future = (uint32_t)future64;
         const uint32_t rank = L.first_fit(future, A);          // :214-218
         L.back_v(rank, sym, future + rank - 1);                // lst[0..rank-2] = lst[1..rank-1]; lst[rank-1] = sym, :225-227
+        if (ctxo && lane == 0) ranks[sym] = (uint8_t)(rank - 1u);                  // :228
     }
     return RCX_OK;
 }
 
+// withctx: also writes the Context handed to the distance callback at every step (dc.rs:199-229), eight bytes each as in
+// k_dc_encode, from byte (n + 7) & ~7 of the block's slot on; out_len is then that offset + 8 * (distances consumed).
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void k_dc_decode(rcx_kargs a)
+__global__ __launch_bounds__(64 * WAVES) void k_dc_decode(rcx_kargs a, int withctx)
 {
     __shared__ __align__(16) uint8_t s_lst[WAVES][256];    // only to order the alphabet once; the loop keeps the list in registers
     __shared__ uint32_t s_next[WAVES][256];
+    __shared__ uint8_t s_ranks[WAVES][256];                // (withctx) :190-196, 228
     const unsigned w = threadIdx.x >> 6, lane = rcx_lane();
     const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + w));   // wave-uniform: keeps descriptors in SGPRs
     if (b >= a.nblocks) return;
@@ -434,9 +476,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_decode(rcx_kargs a)
     uint8_t* out = a.out_base + a.out_off[b];
     int st = RCX_OK;
     uint32_t di = 256, i = 0, A = 0;
+    const uint64_t coff = ((uint64_t)n + 7ull) & ~7ull;
+    uint32_t* const ctxo = withctx ? (uint32_t*)(out + coff) : nullptr;
+    uint8_t* const ranks = s_ranks[w];
     if (nwords < 256 || ((uintptr_t)words & 3u)) st = RCX_E_MALFORMED;          // :239-241
-    else if (a.out_cap[b] < n) st = RCX_E_OUTPUT_TOO_SMALL;
+    else if (a.out_cap[b] < (withctx ? coff + 8ull * (nwords - 256u) : (uint64_t)n) || (withctx && ((uintptr_t)out & 7u))) st = RCX_E_OUTPUT_TOO_SMALL;
     if (!st) {
+        if (withctx) { for (int k = 0; k < 4; k++) ranks[lane + 64 * k] = 0; }
         for (int k = 0; k < 4; k++) { next[lane + 64 * k] = words[lane + 64 * k]; lst[lane + 64 * k] = 0; }
         rcx_wave_sync();
         // :168-179 order the present symbols by first position: rank(sym) = #present symbols with a smaller
@@ -469,18 +515,18 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_decode(rcx_kargs a)
         auto check = [&](uint32_t, uint32_t, uint32_t x) { bad = bad || x < n || x >= n + A; };           // :230 assert, listed symbols
         if (A <= 64) {                                         // one entry per lane (v = the symbol's next occurrence)
             DcRegs1 L; L.lane = lane; L.sy = lst[lane]; L.v = lane < A ? next[lst[lane]] : 0xffffffffu;
-            st = dc_decode_steps(L, wwin, i, n, A, di, nwords, out, lane);
+            st = dc_decode_steps(L, wwin, i, n, A, di, nwords, out, lane, ctxo, ranks);
             L.each(A, check);
         } else {
             DcRegs4 L; L.lane = lane; L.w = *(const uint32_t*)(lst + 4 * lane);
             for (int k = 0; k < 4; k++) L.v[k] = (4u * lane + (uint32_t)k < A) ? next[lst[4 * lane + k]] : 0xffffffffu;
-            st = dc_decode_steps(L, wwin, i, n, A, di, nwords, out, lane);
+            st = dc_decode_steps(L, wwin, i, n, A, di, nwords, out, lane, ctxo, ranks);
             L.each(A, check);
         }
         if (!st && A > 1 && __ballot(bad)) st = RCX_E_MALFORMED;
     }
     if (lane == 0) {
-        a.status[b] = st; a.out_len[b] = st ? 0 : n;
+        a.status[b] = st; a.out_len[b] = st ? 0 : withctx ? coff + 8ull * (di - 256u) : (uint64_t)n;
         if (a.in_used) a.in_used[b] = st ? 0 : 4ull * di;
     }
 }
@@ -1184,8 +1230,8 @@ static void launch_serial(hipStream_t s, int codec, rcx_kargs& k, int v, uint32_
     switch (codec) {
     case RCX_MTF_ENCODE: hipLaunchKernelGGL((k_mtf<4>), dim3((n + 3) / 4), dim3(256), 0, s, k, 0); break;
     case RCX_MTF_DECODE: hipLaunchKernelGGL((k_mtf<4>), dim3((n + 3) / 4), dim3(256), 0, s, k, 1); break;
-    case RCX_DC_ENCODE: hipLaunchKernelGGL((k_dc_encode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k); break;
-    case RCX_DC_DECODE: hipLaunchKernelGGL((k_dc_decode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k); break;
+    case RCX_DC_ENCODE: hipLaunchKernelGGL((k_dc_encode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k, (int)(param & 1u)); break;    // param 1: with contexts
+    case RCX_DC_DECODE: hipLaunchKernelGGL((k_dc_decode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k, (int)(param & 1u)); break;
     case RCX_RLE_ENCODE: hipLaunchKernelGGL((k_rle_encode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k); break;
     case RCX_RLE_DECODE: hipLaunchKernelGGL((k_rle_decode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k); break;
     case RCX_ARI_BYTE_ENCODE: case RCX_ARI_BYTE_DECODE: {

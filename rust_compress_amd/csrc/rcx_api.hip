@@ -339,6 +339,23 @@ extern "C" int rcx_mtf_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run
 extern "C" int rcx_mtf_decode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_MTF_DECODE, b, nullptr, nullptr, nullptr, true); }
 extern "C" int rcx_dc_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_DC_ENCODE, b, nullptr, nullptr, nullptr, true); }
 extern "C" int rcx_dc_decode_batch(rcx_ctx* c, const rcx_batch* b, const uint64_t* n_out) { return run_batch(c, RCX_DC_DECODE, b, nullptr, nullptr, n_out, true); }
+// the same with the coding contexts behind the payload (include/rcx.h): the kernels' `withctx` rides in the codec's parameter
+extern "C" int rcx_dc_encode_ctx_batch(rcx_ctx* c, const rcx_batch* b)
+{
+    if (!c) return RCX_RC_BAD_ARG;
+    c->param[RCX_DC_ENCODE] = 1;
+    const int rc = run_batch(c, RCX_DC_ENCODE, b, nullptr, nullptr, nullptr, true);
+    c->param[RCX_DC_ENCODE] = 0;
+    return rc;
+}
+extern "C" int rcx_dc_decode_ctx_batch(rcx_ctx* c, const rcx_batch* b, const uint64_t* n_out)
+{
+    if (!c) return RCX_RC_BAD_ARG;
+    c->param[RCX_DC_DECODE] = 1;
+    const int rc = run_batch(c, RCX_DC_DECODE, b, nullptr, nullptr, n_out, true);
+    c->param[RCX_DC_DECODE] = 0;
+    return rc;
+}
 extern "C" int rcx_ari_byte_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_ARI_BYTE_ENCODE, b, nullptr, nullptr, nullptr, true); }
 extern "C" int rcx_ari_byte_decode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_ARI_BYTE_DECODE, b, nullptr, nullptr, nullptr, true); }
 extern "C" int rcx_ari_binary_encode_batch(rcx_ctx* c, const rcx_batch* b, uint32_t rate)

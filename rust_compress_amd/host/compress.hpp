@@ -413,6 +413,35 @@ inline std::vector<uint8_t> decode_simple(size_t n, const std::vector<uint32_t>&
     check(r);
     return r.out[0];
 }
+struct Context { uint8_t symbol, last_rank; size_t distance_limit;                  // dc.rs:40-58
+                 bool operator==(const Context& o) const { return symbol == o.symbol && last_rank == o.last_rank && distance_limit == o.distance_limit; } };
+struct Encoded { std::vector<uint32_t> init; std::vector<std::pair<uint32_t, Context>> pairs; };
+// dc.rs:110-149 in batch-backed form: the initial positions (:83-86) and the (distance, Context) pairs the iterator yields (:88-103)
+inline Encoded encode(const std::vector<uint8_t>& in)
+{
+    const size_t n = in.size();
+    auto r = run_batch({in}, {4 * (256 + n) + 8 * n}, [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_dc_encode_ctx_batch(c, b); });
+    check(r);
+    const auto& o = r.out[0];
+    const size_t k = (o.size() - 4 * (256 + n)) / 8, cb = 4 * (256 + n);
+    Encoded e;
+    for (size_t s = 0; s < 256; s++) e.init.push_back(le32(&o[4 * s]));
+    for (size_t j = 0; j < k; j++) e.pairs.push_back({le32(&o[4 * (256 + j)]), Context{o[cb + 8 * j], o[cb + 8 * j + 1], le32(&o[cb + 8 * j + 4])}});
+    return e;
+}
+// dc.rs:162-233 in batch-backed form: the decoded block and the Context handed to the distance callback before each read (:208)
+inline std::pair<std::vector<uint8_t>, std::vector<Context>> decode(const std::vector<uint32_t>& init, const std::vector<uint32_t>& distances, size_t n)
+{
+    std::vector<uint8_t> blob; for (uint32_t x : init) put32(blob, x); for (uint32_t x : distances) put32(blob, x);
+    uint64_t nn = n;
+    const size_t co = (n + 7) & ~(size_t)7;
+    auto r = run_batch({blob}, {co + 8 * distances.size()}, [&](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_dc_decode_ctx_batch(c, b, &nn); });
+    check(r);
+    const auto& o = r.out[0];
+    std::vector<Context> cx;
+    for (size_t p = co; p + 8 <= o.size(); p += 8) cx.push_back(Context{o[p], o[p + 1], le32(&o[p + 4])});
+    return {std::vector<uint8_t>(o.begin(), o.begin() + n), cx};
+}
 }  // namespace dc
 }  // namespace bwt
 

@@ -141,6 +141,20 @@ def test_mtf_dc_ari_rle(ctx, oracle):
     e = ctx.dc_encode(raws).check()
     assert e.outputs == [oracle.dc_encode(r).tobytes() for r in raws]
     assert ctx.dc_decode(e.outputs, lens).check().outputs == raws
+    # dc::Context (dc.rs:40-58) from the device: next to every distance the encoder yields (:88-103) and for every call of
+    # the decoder's distance callback (:199-229); both == the oracle's, and == each other wherever the reference's test says so
+    ex = ctx.dc_encode_ctx(raws).check()
+    dx = ctx.dc_decode_ctx(e.outputs, lens).check()
+    for r, w, x, y in zip(raws, e.outputs, ex.outputs, dx.outputs):
+        n, k = len(r), len(w) // 4 - 256
+        assert len(x) == 4 * (256 + n) + 8 * k and x[: len(w)] == w
+        got = np.frombuffer(x[4 * (256 + n):], dtype="<u4").reshape(-1, 2)
+        assert [(int(a) & 255, (int(a) >> 8) & 255, int(b_)) for a, b_ in got] == oracle.dc_encode(r, with_ctx=True)[1]
+        co = (n + 7) & ~7
+        want = oracle.dc_decode(np.frombuffer(w, dtype="<u4"), n, with_ctx=True)[2]
+        assert y[:n] == r and len(y) == co + 8 * len(want)
+        gotd = np.frombuffer(y[co:], dtype="<u4").reshape(-1, 2)
+        assert [(int(a) & 255, (int(a) >> 8) & 255, int(b_)) for a, b_ in gotd] == want
 
 
 def test_ari_binary_and_proxy_models(ctx, oracle):

@@ -63,6 +63,21 @@ def test_mtf_rle_ari_dc(oracle):
     assert not st.any() and enc == [oracle.dc_encode(r).tobytes() for r in raws]
     dec, _, _, st, _ = simrun.run(N.DC_DECODE, 0, enc, lens, n_out=np.array(lens, dtype=np.uint64))
     assert not st.any() and dec == raws
+    # the same with the coding contexts (dc.rs:40-58): encoder and decoder see the same ones, and the oracle's (dc.rs:268-289)
+    encx, _, _, st, _ = simrun.run(N.DC_ENCODE, 1, raws, [4 * (256 + n) + 8 * n for n in lens])
+    assert not st.any()
+    decx, _, _, st, _ = simrun.run(N.DC_DECODE, 1, enc, [((n + 7) & ~7) + 8 * (len(e) // 4 - 256) for n, e in zip(lens, enc)], n_out=np.array(lens, dtype=np.uint64))
+    assert not st.any()
+    for r, e, x, y in zip(raws, enc, encx, decx):
+        n, k = len(r), len(e) // 4 - 256
+        want = [(s_, rk, dl) for s_, rk, dl in oracle.dc_encode(r, with_ctx=True)[1]]
+        assert len(x) == 4 * (256 + n) + 8 * k and x[: len(e)] == e
+        got = np.frombuffer(x[4 * (256 + n):], dtype="<u4").reshape(-1, 2)
+        assert [(int(a) & 255, (int(a) >> 8) & 255, int(b_)) for a, b_ in got] == want
+        co = (n + 7) & ~7
+        assert y[:n] == r and len(y) == co + 8 * len(oracle.dc_decode(np.frombuffer(e, dtype="<u4"), n, with_ctx=True)[2])
+        gotd = np.frombuffer(y[co:], dtype="<u4").reshape(-1, 2)
+        assert [(int(a) & 255, (int(a) >> 8) & 255, int(b_)) for a, b_ in gotd] == oracle.dc_decode(np.frombuffer(e, dtype="<u4"), n, with_ctx=True)[2]
 
 
 def _oracle_status(fn, *args):
