@@ -531,18 +531,35 @@ class entropy:
 
 # ------------------------------------------------------------------------------------------------ rle
 class rle:
-    class Encoder:                                     # rle.rs:40-123 (one-shot semantics)
+    class Encoder:
+        """rle.rs:40-143.  Buffers, and codes on flush / finish with one batch call; writes what the reference's streaming
+        `write` (:100-114) and `flush` (:116-143) write for the same calls, including their two oddities: every write after
+        the first drops its first byte (the loop starts at buf[1..]; only the very first call seeds the run with buf[0]),
+        and a flush in the middle of a run writes the run without closing it, so it is written again, with its full count,
+        when it ends."""
+
         def __init__(self, w):
-            self.w, self._buf = w, bytearray()
+            self.w, self._buf, self._in_run = w, bytearray(), False
 
         def write(self, buf):
-            self._buf += bytes(buf)
+            buf = bytes(buf)
+            if not self._in_run and buf:
+                self._buf.append(buf[0])
+                self._in_run = True
+            self._buf += buf[1:]
             return len(buf)
 
         write_all = write
 
-        def finish(self):
-            self.w.write(_check(context().rle_encode([bytes(self._buf)])).outputs[0])
+        def flush(self):
+            if self._buf:
+                self.w.write(_check(context().rle_encode([bytes(self._buf)])).outputs[0])
+                last = self._buf[-1]
+                run = len(self._buf) - len(self._buf.rstrip(bytes([last])))
+                del self._buf[: len(self._buf) - run]      # the open run stays open (:116-143 never reset it)
+
+        def finish(self):                              # :62-66
+            self.flush()
             return self.w
 
     class Decoder(_BufferedDecoder):                   # rle.rs:176-281

@@ -218,3 +218,58 @@ def test_bwt_encoder_flush_makes_the_reference_block_boundary(golden, oracle):
         want += struct.pack("<I", len(part)) + L + struct.pack("<I", origin)
     assert w.getvalue() == want
     assert C.bwt.Decoder(io.BytesIO(w.getvalue()), extra_mem=True).read_to_end() == txt
+
+
+def _ref_rle_stream(calls):
+    """The reference's streaming rle::Encoder (rle.rs:82-143) restated as a state machine (TEST INFRASTRUCTURE): `calls` is a
+    list of ("w", bytes) / ("f",) ; returns what its writer receives, finish() included."""
+    out = bytearray()
+    st = {"byte": 0, "reps": 0, "in_run": False}
+
+    def flush():
+        if st["reps"] == 1:
+            out.append(st["byte"])
+        elif st["reps"] > 1:
+            out.extend([st["byte"], st["byte"]])
+            v = st["reps"] - 2
+            while True:
+                x = v & 0x7F
+                v >>= 7
+                if v == 0:
+                    out.append(x | 0x80)
+                    break
+                out.append(x)
+
+    for c in calls + [("f",)]:
+        if c[0] == "f":
+            flush()
+            continue
+        buf = c[1]
+        if not st["in_run"] and buf:
+            st["byte"], st["reps"], st["in_run"] = buf[0], 1, True
+        for b in buf[1:]:
+            if st["byte"] == b:
+                st["reps"] += 1
+            else:
+                flush()
+                st["reps"], st["byte"] = 1, b
+    return bytes(out)
+
+
+def test_rle_encoder_streaming_writes_like_the_reference():
+    """rle.rs:100-143: several write() calls and flushes in between come out as the reference writes them, oddities included
+    (a later write loses its first byte; a flush inside a run writes the run again when it ends)."""
+    rng = random.Random(5)
+    for trial in range(30):
+        calls = []
+        for _ in range(rng.randrange(1, 6)):
+            n = rng.randrange(0, 40)
+            calls.append(("w", bytes(rng.choice(b"ab") if rng.random() < 0.8 else rng.randrange(256) for _ in range(n))))
+            if rng.random() < 0.4:
+                calls.append(("f",))
+        w = io.BytesIO()
+        e = C.rle.Encoder(w)
+        for c in calls:
+            e.write(c[1]) if c[0] == "w" else e.flush()
+        e.finish()
+        assert w.getvalue() == _ref_rle_stream(calls), (trial, calls)
