@@ -20,6 +20,7 @@
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -94,6 +95,72 @@ BatchResult run_batch(const std::vector<std::vector<uint8_t>>& blobs, const std:
     return r;
 }
 inline void check(const BatchResult& r) { for (int st : r.status) raise_status(st); }
+
+// ---- more than one GPU from a host that is not Python -----------------------------------------------------------------
+// Blocks are independent in every codec (lz4.rs:445-456, bwt/mod.rs:373-401, ari/test.rs:52-89), so a batch shards by
+// contiguous block ranges balanced by output bytes -- the partition of rust_compress_amd/dist.py -- and needs no collective:
+// one rcx_ctx per device (a context binds one device, include/rcx.h), one host thread per context (a context is
+// thread-compatible, not thread-safe), every range staged to and from its own GPU by the library's host-memory path.
+// `devices` may name a device more than once (two ranges on one GPU); the result is block for block what run_batch returns.
+inline std::vector<size_t> partition(const std::vector<uint64_t>& weights, size_t parts)
+{
+    std::vector<size_t> bounds(parts + 1, weights.size());
+    bounds[0] = 0;
+    long double total = 0, run = 0;
+    for (uint64_t w : weights) total += (long double)w;
+    size_t g = 1;
+    for (size_t i = 0; i < weights.size() && g < parts; i++) {
+        while (g < parts && run >= total * g / parts) bounds[g++] = i;
+        run += (long double)weights[i];
+    }
+    return bounds;
+}
+template <class Call>
+BatchResult run_batch_devices(const std::vector<int>& devices, const std::vector<std::vector<uint8_t>>& blobs, const std::vector<uint64_t>& caps, Call call)
+{
+    const size_t G = devices.size(), n = blobs.size();
+    if (G == 0) throw std::runtime_error("run_batch_devices: no device");
+    const std::vector<size_t> bounds = partition(caps, G);
+    std::vector<BatchResult> part(G);
+    std::vector<std::string> err(G);
+    std::vector<std::thread> th;
+    for (size_t g = 0; g < G; g++)
+        th.emplace_back([&, g] {
+            try {
+                const size_t a = bounds[g], b = bounds[g + 1];
+                if (a == b) return;
+                Context ctx(devices[g]);
+                const uint32_t m = (uint32_t)(b - a);
+                std::vector<uint64_t> in_off(m), in_len(m), out_off(m), out_cap(m), out_len(m), in_used(m);
+                std::vector<int32_t> status(m);
+                uint64_t it = 0, ot = 0;
+                for (uint32_t i = 0; i < m; i++) {
+                    in_off[i] = it; in_len[i] = blobs[a + i].size(); it += (blobs[a + i].size() + 15) & ~15ull;
+                    out_off[i] = ot; out_cap[i] = caps[a + i]; ot += (caps[a + i] + 15) & ~15ull;
+                }
+                std::vector<uint8_t> in(it + 16), out(ot + 16);
+                for (uint32_t i = 0; i < m; i++) if (!blobs[a + i].empty()) std::memcpy(in.data() + in_off[i], blobs[a + i].data(), blobs[a + i].size());
+                rcx_batch bt{in.data(), in_off.data(), in_len.data(), out.data(), out_off.data(), out_cap.data(), out_len.data(), in_used.data(), status.data(), m, RCX_MEM_HOST};
+                BatchResult& r = part[g];
+                r.aux.assign(m, 0);
+                if (call(ctx.get(), &bt, r.aux.data()) != RCX_RC_OK) { err[g] = std::string("rcx batch call failed: ") + rcx_last_error(ctx.get()); return; }
+                r.out.resize(m);
+                for (uint32_t i = 0; i < m; i++) r.out[i].assign(out.begin() + out_off[i], out.begin() + out_off[i] + out_len[i]);
+                r.in_used = in_used; r.status = status;
+            } catch (const std::exception& e) { err[g] = e.what(); }
+        });
+    for (auto& t : th) t.join();
+    BatchResult all;
+    for (size_t g = 0; g < G; g++) {
+        if (!err[g].empty()) throw std::runtime_error("device " + std::to_string(devices[g]) + ": " + err[g]);
+        all.out.insert(all.out.end(), part[g].out.begin(), part[g].out.end());
+        all.in_used.insert(all.in_used.end(), part[g].in_used.begin(), part[g].in_used.end());
+        all.status.insert(all.status.end(), part[g].status.begin(), part[g].status.end());
+        all.aux.insert(all.aux.end(), part[g].aux.begin(), part[g].aux.end());
+    }
+    if (all.out.size() != n) throw std::runtime_error("run_batch_devices: lost blocks");
+    return all;
+}
 
 struct SliceReader {                              // BufReader::new(&[u8])
     const uint8_t* p; size_t n, pos = 0;

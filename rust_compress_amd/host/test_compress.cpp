@@ -55,6 +55,25 @@ int main(int argc, char** argv)
     CHECK(!lz4::compression_bound(0x7e000001u).has_value() && *lz4::compression_bound(100) == 120);
     try { Bytes bad = B("\x01\x02\x03\x04zzzz"); lz4::Decoder<SliceReader> d{SliceReader(bad)}; d.read_to_end(); CHECK(false); }
     catch (const io_error& e) { CHECK(e.kind == ErrorKind::InvalidInput && std::string(e.what()).empty()); }
+    // ---- a batch sharded over several contexts (here: the one GPU, named three times): block for block what one context returns
+    {
+        std::vector<Bytes> raws, encs; std::vector<uint64_t> caps;
+        for (int i = 0; i < 23; i++) { Bytes r(txt.begin(), txt.begin() + (txt.size() * (i + 1)) / 23); raws.push_back(r); caps.push_back(*lz4::compression_bound((uint32_t)r.size())); }
+        auto call_e = [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_lz4_encode_batch(c, b); };
+        BatchResult one = run_batch(raws, caps, call_e), many = run_batch_devices({0, 0, 0}, raws, caps, call_e);
+        CHECK(one.out == many.out && one.status == many.status && one.in_used == many.in_used);
+        std::vector<uint64_t> dcaps; for (auto& r : raws) dcaps.push_back(r.size());
+        BatchResult dec = run_batch_devices({0, 0}, many.out, dcaps, [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_lz4_decode_batch(c, b); });
+        CHECK(dec.out == raws);
+        std::vector<size_t> bd = partition(dcaps, 3);
+        CHECK(bd.size() == 4 && bd[0] == 0 && bd[3] == raws.size() && bd[1] > 0 && bd[2] > bd[1] && bd[2] < raws.size());
+        // dc::Context from both sides (dc.rs:268-289: the decoder is handed the contexts the encoder yields)
+        bwt::dc::Encoded e = bwt::dc::encode(txt);
+        std::vector<uint32_t> ds; for (auto& p : e.pairs) ds.push_back(p.first);
+        auto back = bwt::dc::decode(e.init, ds, txt.size());
+        CHECK(back.first == txt && back.second.size() == e.pairs.size());
+        for (size_t j = 0; j < e.pairs.size(); j++) CHECK(back.second[j] == e.pairs[j].second);
+    }
     // ---- flate / zlib (flate.rs:528-582, zlib.rs:151-203)
     for (int i = 0; i <= 9; i++) {
         Bytes z = file("test.z." + std::to_string(i));
