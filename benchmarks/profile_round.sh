@@ -11,6 +11,6 @@ cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $REPO/gpurun_out/lz4_deco
 rocprofv3 --pmc FETCH_SIZE -d /tmp/pf -- python $REPO/bench.py --steps 5 --warmup 1 --no-cpu --no-e2e --no-others > /tmp/pf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d /tmp/pw -- python $REPO/bench.py --steps 5 --warmup 1 --no-cpu --no-e2e --no-others > /tmp/pw.log 2>&1
 ALG=$(python -c "import json,sys; print(json.loads(open('$REPO/gpurun_out/bench_line_profiled.json').read())['roofline']['algorithmic_bytes_per_launch'])")
-python $REPO/benchmarks/pmc_traffic.py $(find /tmp/pf -name "*.db" | head -1) $(find /tmp/pw -name "*.db" | head -1) lz4_decode_v5 $ALG $REPO/gpurun_out/pmc_lz4_decode.json
+python $REPO/benchmarks/pmc_traffic.py $(find /tmp/pf -name "*.db" | head -1) $(find /tmp/pw -name "*.db" | head -1) lz4_decode_v8 $ALG $REPO/gpurun_out/pmc_lz4_decode.json
 head -4 $REPO/gpurun_out/lz4_decode_kernel_stats.csv | cut -c1-200
 cd $REPO && python bench.py 2>&1 | tail -1 | tee gpurun_out/bench_line.json

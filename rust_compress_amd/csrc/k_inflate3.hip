@@ -977,6 +977,7 @@ __global__ __launch_bounds__(64, INF3_OCC) void k_inflate3(rcx_kargs a, int zlib
     s.cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;
     s.cbuf = s_cbuf; s.wb_ = s_wbuf; s.epos = nullptr; s.ring = nullptr;
     s.lutL = s_lutL; s.lutD = s_lutD; s.symL = s_symL; s.symD = s_symD; s.lens = s_lit; s.tab = s_tab; s.litbuf = s_lit; s.desc = s_desc;
+    s.lmap = s_desc;                                             // (the descriptors are in registers while emit5 runs: its scratch)
     int32_t st; uint32_t olen, used, flags;
     s.run(zlib, &st, &olen, &used, &flags);
     if ((threadIdx.x & 63u) == 0) {

@@ -48,6 +48,12 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
     static constexpr int STAGE5 = B::LIN + 64;         // 64 lanes x 32 bytes of old-match staging (bytes 32.. of a longer
     static constexpr int WBUF5 = STAGE5 + 64 * SB;     // gathered match go straight to their place): 16 blocks per CU fit
     RCX_LDS_AS Ring* ring;                         // address space 3: the volatile head / tail accesses must be ds_read / ds_write, not flat
+    // 256 bytes of LDS scratch (or null): "which entry produces output byte x" as a bitmap of the entries' first bytes + a
+    // running count per word, two LDS reads and a popcount, instead of a binary search over the lanes (Lz4V4::lane_of: six
+    // DEPENDENT ds_bpermute round trips, twice per batch: ~1500 cycles of the executor's ~11 000 per batch)
+    uint32_t* lmap = nullptr;
+    static constexpr int LMW = (B::TCAP + 31) / 32 + 1;              // bitmap words; the counts (a byte each) follow them
+    static constexpr bool LMOK = LMW <= 50;                          // 4 * LMW + LMW <= 256
     uint64_t pw[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // PROF5: [0] cycles waiting on the ring, [2] batches; executor phases [4] scan+validate [5] loads+chains [6] literal/gather stores [7] copy rounds [8] flush [9] rounds [10] emit calls
 
     // ------------------------------------------------------------------------------------------ parser wave
@@ -121,6 +127,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
         uint64_t tq_ = PROF5 ? (uint64_t)__builtin_readcyclecounter() : 0;
 #define V5P_ADD(slot) do { if (PROF5) { const uint64_t t1_ = (uint64_t)__builtin_readcyclecounter(); pw[slot] += t1_ - tq_; tq_ = t1_; } } while (0)
         this->make_room(B::TCAP);
+        const int lo0 = lo;
         bool act = (int)lane >= lo && (int)lane < ns;
         uint32_t L = act ? w1 & 0xffu : 0u, M = act ? (w1 >> 8) & 0xffu : 0u, off = act ? w1 >> 16 : 0u;
         const uint32_t src = w0;
@@ -188,8 +195,30 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
         bool inb = M && !isfar && shi > oend0;
         uint32_t S = off;
         if (__ballot(inb)) {
-            uint32_t ka = this->lane_of(ostart, slo > oend0 ? slo : oend0);
-            uint32_t kb = this->lane_of(ostart, shi > oend0 ? shi - 1 : oend0);
+            uint32_t ka, kb;
+            if (LMOK && lmap != nullptr && !__ballot(act && len == 0u)) {       // (an empty entry shares its first byte with the next one: the search handles that)
+                uint8_t* const lcnt = (uint8_t*)(lmap + LMW);
+                if (lane < (unsigned)LMW) lmap[lane] = 0;
+                rcx_wave_sync();
+                const uint32_t rel = ostart - oend0;
+                if (act) atomicOr(&lmap[rel >> 5], 1u << (rel & 31u));
+                rcx_wave_sync();
+                const uint32_t pc = (uint32_t)__popc(lane < (unsigned)LMW ? lmap[lane] : 0u);
+                const uint32_t ex = rcx_wave_incl_scan(pc) - pc;
+                if (lane < (unsigned)LMW) lcnt[lane] = (uint8_t)ex;
+                rcx_wave_sync();
+                auto entry_of = [&](uint32_t x) -> uint32_t {                    // the active entry whose first byte is the last one <= x
+                    uint32_t r = x - oend0;
+                    r = r < (uint32_t)B::TCAP ? r : (uint32_t)B::TCAP;
+                    const uint32_t w = r >> 5;
+                    return (uint32_t)lo0 + (uint32_t)lcnt[w] + (uint32_t)__popc(lmap[w] & (0xffffffffu >> (31u - (r & 31u)))) - 1u;
+                };
+                ka = entry_of(slo > oend0 ? slo : oend0) & 63u;
+                kb = entry_of(shi > oend0 ? shi - 1 : oend0) & 63u;
+            } else {
+                ka = this->lane_of(ostart, slo > oend0 ? slo : oend0);
+                kb = this->lane_of(ostart, shi > oend0 ? shi - 1 : oend0);
+            }
             const uint32_t pmd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ka << 2), (int)((isfar || off < M) ? 0xffffffffu : mdst));
             uint32_t prod = (inb && ka == kb && slo >= pmd && off >= M) ? ka : 64u;
 #pragma unroll
@@ -336,6 +365,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_decode_v5(rcx_kargs a, int only_
     __shared__ __align__(16) uint8_t s_wbuf[S::WBUF5 + 16];     // + 16: the last staging slot is read one dword past its end
     __shared__ uint32_t s_epos[64];
     __shared__ __align__(16) typename S::Ring s_ring;
+    __shared__ uint32_t s_lmap[64];
     const uint32_t b = blockIdx.x;
     if (b >= a.nblocks) return;
     if (only_status && a.status[b] != only_status) return;       // second pass over the blocks another kernel handed back
@@ -352,6 +382,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_decode_v5(rcx_kargs a, int only_
     s.wb_ = s_wbuf;
     s.epos = s_epos;
     s.ring = (RCX_LDS_AS typename S::Ring*)&s_ring;
+    s.lmap = s_lmap;
     if (role == 0) {
         s.run_parser();
         if (PROF5 && a.scratch && (threadIdx.x & 63u) == 0) {          // [0..3] parser: ring-full wait, total, posts

@@ -470,7 +470,7 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
     }
 };
 
-template <int TC = 1024, int HH = 1024, bool PROF8 = false, int PRE_ = 128, int SPLIT_ = 32>
+template <int TC = 1024, int HH = 768, bool PROF8 = false, int PRE_ = 128, int SPLIT_ = 32>
 __global__ __launch_bounds__(128, 8) void k_lz4_decode_v8(rcx_kargs a, int only_status = 0)
 {
     typedef Lz4V8<TC, HH, 16, PROF8, PRE_, SPLIT_> S;
@@ -479,6 +479,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_decode_v8(rcx_kargs a, int only_
     __shared__ __align__(16) typename S::Ring8 s_ring;
     __shared__ __align__(16) uint8_t s_cbuf[S::CBUF8 + 16];
     __shared__ int16_t s_list[S::LISTN];
+    __shared__ uint32_t s_lmap[64];
     const uint32_t b = blockIdx.x;
     if (b >= a.nblocks) return;
     if (only_status && a.status[b] != only_status) return;
@@ -497,6 +498,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_decode_v8(rcx_kargs a, int only_
     s.ring = nullptr;
     s.ring8 = (RCX_LDS_AS typename S::Ring8*)&s_ring;
     s.list = s_list;
+    s.lmap = s_lmap;
     if (role == 0) {
         s.run_parser8();
         if (PROF8 && a.scratch && (threadIdx.x & 63u) == 0) {          // [0..9] parser phases, [10] parser total

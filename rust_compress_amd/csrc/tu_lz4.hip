@@ -1,6 +1,6 @@
 // tu_lz4.hip -- LZ4 block decode / encode kernels + their launch code (one translation unit).
-// Shipped variants of the decoder: 0 = two waves per block (parser || executor, k_lz4_decode_v5), 11 = one wave per block
-// (k_lz4_decode_v4, the fallback).  Everything else -- the earlier kernel generations, profiling instantiations and the
+// Shipped variants of the decoder: 0 = two waves per block with the segment-parallel parser (k_lz4_decode_v8), 15 = with the
+// serial-walk parser (k_lz4_decode_v5), 11 = one wave per block (k_lz4_decode_v4), 20 = the chunk-centric executor experiment (v7).  Everything else -- the earlier kernel generations, profiling instantiations and the
 // workgroup-per-block experiment (k_lz4_decode_v6) -- is compiled only with -DRCX_AB_VARIANTS (benchmarks/, A/B history).
 #include "rcx_tu.h"
 #ifdef RCX_AB_VARIANTS
@@ -19,14 +19,15 @@ static const uint32_t LZ4E_CHUNK = 8192;        // LZ4 blocks encoded per launch
 
 uint64_t rcx_tu_lz4_encode_scratch(uint32_t nblocks) { return (uint64_t)(nblocks < LZ4E_CHUNK ? nblocks : LZ4E_CHUNK) * LZ4E_TABLE * 4ull; }
 
-// Default: the two-wave kernel (parser || executor).  It is 1.2-1.4x faster than the single-wave kernel below ~12 blocks
-// per CU (latency bound) and still 5-7 % faster at 16 and more blocks per CU (benchmarks/lz4_occupancy_sweep.py).
+// Default (0): two waves per block with the SEGMENT-PARALLEL parser wave (k_lz4_decode_v8: the token walk no longer owns the
+// CU's scalar port; 4096 x 64 KiB: text 0.636 against 0.662 ms, words 0.80 / 0.84, rand 0.151 / 0.155, runs 1.19 / 1.17).
+// 15: the serial-walk parser wave (k_lz4_decode_v5, the default of rounds 1-2).  11: one wave per block (k_lz4_decode_v4).
 int rcx_tu_lz4_decode(hipStream_t s, rcx_kargs& k, int v, std::string& err)
 {
     const uint32_t n = k.nblocks;
-    if (v == 0 || v == 15) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1536, 2048>), dim3(n), dim3(128), 0, s, k, 0);
+    if (v == 0 || v == 23) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768>), dim3(n), dim3(128), 0, s, k, 0);
+    else if (v == 15) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1536, 2048>), dim3(n), dim3(128), 0, s, k, 0);
     else if (v == 11) hipLaunchKernelGGL((k_lz4_decode_v4<1024, 1>), dim3(n), dim3(64), 0, s, k);
-    else if (v == 23) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 1024>), dim3(n), dim3(128), 0, s, k, 0);
     else if (v == 20) hipLaunchKernelGGL((k_lz4_decode_v7<1024, 1008, 2048, 2048>), dim3(n), dim3(128), 0, s, k, 0);
 #ifdef RCX_AB_VARIANTS
     else if (v == 1) hipLaunchKernelGGL(k_lz4_decode_v1, dim3(n), dim3(64), 0, s, k);
@@ -50,9 +51,9 @@ int rcx_tu_lz4_decode(hipStream_t s, rcx_kargs& k, int v, std::string& err)
     }
     else if (v == 21) hipLaunchKernelGGL((k_lz4_decode_v7<1024, 1008, 2048, 2048, 2, true>), dim3(n), dim3(128), 0, s, k, 0);     // parser wave alone (wrong output on purpose)
     else if (v == 22) hipLaunchKernelGGL((k_lz4_decode_v7<2048, 1008, 1536, 2048, 2, true>), dim3(n), dim3(128), 0, s, k, 0);
-    else if (v == 24) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 1024, true>), dim3(n), dim3(128), 0, s, k, 0);     // parser phase timers -> scratch
-    else if (v == 29) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 1024, false, 128, 0>), dim3(n), dim3(128), 0, s, k, 0);    // no split of long matches
-    else if (v == 31) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 1024, false, 96, 32>), dim3(n), dim3(128), 0, s, k, 0);    // shorter head start
+    else if (v == 24) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, true>), dim3(n), dim3(128), 0, s, k, 0);     // parser phase timers -> scratch
+    else if (v == 29) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 0>), dim3(n), dim3(128), 0, s, k, 0);    // no split of long matches
+    else if (v == 31) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 96, 32>), dim3(n), dim3(128), 0, s, k, 0);    // shorter head start
     else if (v == 25) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1024, 1024, false, 32>), dim3(n), dim3(128), 0, s, k, 0);   // LDS trade-offs of the executor
     else if (v == 26) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1024, 1024, false, 16>), dim3(n), dim3(128), 0, s, k, 0);
     else if (v == 27) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1280, 1024, false, 0>), dim3(n), dim3(128), 0, s, k, 0);
