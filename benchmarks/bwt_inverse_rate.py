@@ -18,7 +18,9 @@ for kind in ("text", "dna4"):
     ctx.launch_dev(N.BWT_FORWARD, fw, sc); torch.cuda.synchronize(); del sc
     inv = R.DeviceBatch(fw.out_base, fw.out_off, fw.out_len, torch.zeros(nb * BLOCK + 64, dtype=torch.uint8, device=dev), i64(ar * BLOCK), i64(np.full(nb, BLOCK)), aux=fw.aux)
     sc = torch.empty(ctx.scratch_bytes(N.BWT_INVERSE, nb, BLOCK) + 256, dtype=torch.uint8, device=dev)
-    for codec, name, variant in ((N.BWT_INVERSE, "inverse", 0), (N.BWT_INVERSE, "inverse (scattered table)", 2), (N.BWT_INVERSE_MINIMAL, "decode_minimal", 0)):
+    extra = [(N.BWT_INVERSE, "chase geometry %d" % g, g << 4) for g in range(1, 10)] if "--sweep" in sys.argv else []
+    extra += [(N.BWT_INVERSE, "contract geometry %d" % g, g << 8) for g in range(1, 7)] if "--sweep2" in sys.argv else []
+    for codec, name, variant in [(N.BWT_INVERSE, "inverse", 0)] + extra + [(N.BWT_INVERSE, "inverse (one workgroup per block)", 4), (N.BWT_INVERSE, "inverse (scattered table)", 2), (N.BWT_INVERSE_MINIMAL, "decode_minimal", 0)]:
         ctx.set_variant(codec, variant)
         inv.out_base.zero_()
         ctx.launch_dev(codec, inv, sc); torch.cuda.synchronize()
@@ -27,4 +29,4 @@ for kind in ("text", "dna4"):
         for _ in range(5): ctx.launch_dev(codec, inv, sc)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 5
-        print("%-5s %-26s %.2f ms  %.1f GiB/s" % (kind, name, dt * 1e3, nb * BLOCK / dt / 2**30), flush=True)
+        print("%-5s %-34s %.2f ms  %.1f GiB/s" % (kind, name, dt * 1e3, nb * BLOCK / dt / 2**30), flush=True)

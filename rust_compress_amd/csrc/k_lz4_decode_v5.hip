@@ -118,7 +118,8 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
     // Entries [lo, hi) as in Lz4V4::emit (hi < ns only when the batch's output exceeds TCAP bytes); advances lo.
     // LITLDS: the literal bytes sit in an LDS buffer (`litbuf`, with 32 bytes of slack) instead of the input in HBM --
     // that is how the inflate front end (k_inflate3.hip) feeds this executor.
-    template <bool LITLDS = false>
+    // NORED: the parser has already shortened the chains (k_lz4_decode_v8.hip: the offsets ARE the shifts).
+    template <bool LITLDS = false, bool NORED = false>
     __device__ int emit5(int ns, int& lo, uint32_t w0, uint32_t w1, const uint8_t* litbuf = nullptr)
     {
         const unsigned lane = this->lane;
@@ -219,10 +220,13 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
                 ka = this->lane_of(ostart, slo > oend0 ? slo : oend0);
                 kb = this->lane_of(ostart, shi > oend0 ? shi - 1 : oend0);
             }
-            const uint32_t pmd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ka << 2), (int)((isfar || off < M) ? 0xffffffffu : mdst));
-            uint32_t prod = (inb && ka == kb && slo >= pmd && off >= M) ? ka : 64u;
+            uint32_t prod = 64u;
+            if (!NORED) {
+                const uint32_t pmd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ka << 2), (int)((isfar || off < M) ? 0xffffffffu : mdst));
+                prod = (inb && ka == kb && slo >= pmd && off >= M) ? ka : 64u;
+            }
 #pragma unroll
-            for (int rr = 0; rr < B::RR; rr++) {
+            for (int rr = 0; rr < (NORED ? 0 : B::RR); rr++) {
                 if (!__ballot(prod < 64u)) break;
                 const uint32_t j = prod < 64u ? prod : lane;
                 const uint32_t Sj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)S);

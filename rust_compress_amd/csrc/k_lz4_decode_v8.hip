@@ -27,7 +27,7 @@
 #define V8P_T0() uint64_t t0_ = PROF8 ? (uint64_t)__builtin_readcyclecounter() : 0
 #define V8P_ADD(slot) do { if (PROF8) { const uint64_t t1_ = (uint64_t)__builtin_readcyclecounter(); pp[slot] += t1_ - t0_; t0_ = t1_; } } while (0)
 
-template <int TC = 1024, int HH = 1024, int SB = 16, bool PROF8 = false, int PRE_ = 128, int SPLIT_ = 32>
+template <int TC = 1024, int HH = 1024, int SB = 16, bool PROF8 = false, int PRE_ = 128, int SPLIT_ = 32, bool PRED = false, int PRR = 2>
 struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
     // A match longer than SPLIT bytes is handed over as TWO entries -- (L, SPLIT, offset) and (0, M - SPLIT, offset): the same
     // bytes -- so that the executor's copy rounds, 16 bytes a lane and round, are paced by SPLIT and not by the 64-byte cap
@@ -44,6 +44,7 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
     static constexpr int LISTN = LWIN * 22 + 64;                      // a token is >= 3 bytes (the last one apart): <= 22 per segment
     static_assert((PRE % 16) == 0 && (CBUF8 % 16) == 0, "staging is 16 bytes a lane");
     int16_t* list;                                                    // LDS: LISTN token positions, relative to the chunk
+    uint32_t po = 0, prlo = 0;                                        // parser's view of the output position / window floor (PRED)
     // The ring between the two waves: EIGHT batches deep -- between the last batch of a chunk and the first of the next the parser
     // stages, walks and links (~55K cycles alone; the executor takes ~10K a batch) -- and a batch entry is ONE word,
     // L | M << 8 | offset << 16: where the literals lie follows from the token's position, and that from the position of the
@@ -230,6 +231,52 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
         rcx_wave_sync();
         RCX_LDS_AS Slot8* sl = &ring->slot[head % NSLOT8];
         if (put) { sl->d[idx] = w1; if (w1b) sl->d[idx + 1] = w1b; }
+        if (PRED) {
+            // Match chains are shortened HERE, by the wave that has the time: an entry whose whole source lies in the match
+            // bytes of ONE earlier entry of the batch copies from that entry's source instead (Lz4V4::emit's redirection),
+            // so that the executor need not wait for it.  The parser follows the output position itself (po; prlo: the
+            // oldest byte a window rebuilt after a wide sequence can hold) and uses a window bound that is never below the
+            // executor's: max(prlo, entry's first byte - H) -- the window base only moves in make_room(), to at most H
+            // bytes behind the output position of the emit call the entry belongs to.  The shift replaces the offset in
+            // the entry; the executor cannot tell (a redirected source is in the window, at least M bytes back).
+            uint32_t T = 0;
+            if (ns > 0) {
+                rcx_wave_sync();
+                const uint32_t e = (int)lane < ns ? sl->d[lane] : 0u;
+                const uint32_t eL = (e & 0x80u) ? 0u : e & 0x7fu, eM = (e >> 8) & 0xffu, eoff = e >> 16;
+                const uint32_t len = eL + eM;
+                const uint32_t incl = rcx_wave_incl_scan(len);
+                T = RCX_U(__builtin_amdgcn_readlane(incl, 63));
+                const uint32_t o0 = po;
+                const uint32_t ostart = o0 + incl - len, mdst = ostart + eL;
+                const uint32_t slo = mdst - eoff;
+                const uint32_t shi = (slo + eM < mdst) ? slo + eM : mdst;
+                const uint32_t lb = ostart > (uint32_t)B::H ? ostart - (uint32_t)B::H : 0u;
+                const uint32_t re = prlo > lb ? prlo : lb;
+                const bool ok = eM && eoff != 0 && eoff <= mdst && slo >= re;
+                const bool inb = ok && shi > o0;
+                if (__ballot(inb)) {
+                    const uint32_t ka = this->lane_of(ostart, slo > o0 ? slo : o0);
+                    const uint32_t kb = this->lane_of(ostart, shi > o0 ? shi - 1 : o0);
+                    const uint32_t pmd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ka << 2), (int)((!ok || eoff < eM) ? 0xffffffffu : mdst));
+                    uint32_t prod = (inb && ka == kb && slo >= pmd && eoff >= eM) ? ka : 64u;
+                    uint32_t S = eoff;
+#pragma unroll
+                    for (int rr = 0; rr < PRR; rr++) {
+                        if (!__ballot(prod < 64u)) break;
+                        const uint32_t j = prod < 64u ? prod : lane;
+                        const uint32_t Sj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)S);
+                        const uint32_t pj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)prod);
+                        if (prod < 64u) {
+                            if (mdst - S - Sj >= re && S + Sj <= mdst && S + Sj < 0x10000u) { S += Sj; prod = pj; } else prod = 64u;
+                        }
+                    }
+                    if (S != eoff) sl->d[lane] = (e & 0xffffu) | (S << 16);
+                }
+            }
+            po = RCX_U(po + T + ((why == B::SOLO_ || why == B::WIDE_) ? gL + gM : 0u));
+            if (why == B::SOLO_ || why == B::WIDE_) { const uint32_t r = po > (uint32_t)B::RH ? po - (uint32_t)B::RH : 0u; prlo = r > prlo ? r : prlo; }
+        }
         if (lane == 0) {
             sl->hdr[0] = (uint32_t)ns; sl->hdr[1] = (uint32_t)why; sl->hdr[2] = (uint32_t)perr;
             sl->hdr[3] = gL; sl->hdr[4] = gM; sl->hdr[5] = goff; sl->hdr[6] = gsrc; sl->hdr[7] = p0;
@@ -317,7 +364,7 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
             const uint32_t hop = ((int)lane < bt.ns && !cont) ? 3u + L + (L >= 15u ? 1u : 0u) + (M >= 19u ? 1u : 0u) : 0u;
             const uint32_t w0 = p0 + rcx_wave_incl_scan(hop) - hop + 1u + (L >= 15u ? 1u : 0u);
             int lo = 0, e = 0;
-            while (lo < bt.ns && !e) e = this->emit5(bt.ns, lo, w0, w1);
+            while (lo < bt.ns && !e) e = this->template emit5<false, PRED>(bt.ns, lo, w0, w1);
             if (e) { st = e; break; }
             if (this->after_batch(bt, st)) break;
         }
@@ -470,10 +517,10 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
     }
 };
 
-template <int TC = 1024, int HH = 768, bool PROF8 = false, int PRE_ = 128, int SPLIT_ = 32>
+template <int TC = 1024, int HH = 768, bool PROF8 = false, int PRE_ = 128, int SPLIT_ = 32, bool PRED = false, int PRR = 2>
 __global__ __launch_bounds__(128, 8) void k_lz4_decode_v8(rcx_kargs a, int only_status = 0)
 {
-    typedef Lz4V8<TC, HH, 16, PROF8, PRE_, SPLIT_> S;
+    typedef Lz4V8<TC, HH, 16, PROF8, PRE_, SPLIT_, PRED, PRR> S;
     const uint64_t tk0 = PROF8 ? (uint64_t)__builtin_readcyclecounter() : 0;
     __shared__ __align__(16) uint8_t s_wbuf[S::WBUF5 + 16];
     __shared__ __align__(16) typename S::Ring8 s_ring;

@@ -120,8 +120,7 @@ __device__ __forceinline__ void rcx_lds_store16(uint8_t* p, uint32_t v0, uint32_
         "v_cmpx_lt_u32_e32 vcc, " #O2 ", %[nv]\n\t"                       \
         "ds_write_b8_d16_hi %[a], %[" V "] offset:" #O2 "\n\t"             \
         "v_cmpx_lt_u32_e32 vcc, " #O3 ", %[nv]\n\t"                       \
-        "v_lshrrev_b32_e32 %[t], 24, %[" V "]\n\t"                        \
-        "ds_write_b8 %[a], %[t] offset:" #O3 "\n\t"
+        "ds_write_b8_d16_hi %[a], %[t] offset:" #O3 "\n\t"     /* t = V >> 8 from byte 1 (its lanes include these): bits 23:16 = byte 3 */
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
         RCX_ST4("v0", 0, 1, 2, 3) RCX_ST4("v1", 4, 5, 6, 7) RCX_ST4("v2", 8, 9, 10, 11) RCX_ST4("v3", 12, 13, 14, 15)

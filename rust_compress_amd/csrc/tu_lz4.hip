@@ -53,6 +53,8 @@ int rcx_tu_lz4_decode(hipStream_t s, rcx_kargs& k, int v, std::string& err)
     else if (v == 22) hipLaunchKernelGGL((k_lz4_decode_v7<2048, 1008, 1536, 2048, 2, true>), dim3(n), dim3(128), 0, s, k, 0);
     else if (v == 24) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, true>), dim3(n), dim3(128), 0, s, k, 0);     // parser phase timers -> scratch
     else if (v == 29) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 0>), dim3(n), dim3(128), 0, s, k, 0);    // no split of long matches
+    else if (v == 32) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, true, 2>), dim3(n), dim3(128), 0, s, k, 0);   // chains shortened by the parser (more instructions in total: slower)
+    else if (v == 33) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, true, 3>), dim3(n), dim3(128), 0, s, k, 0);  // three redirection rounds
     else if (v == 31) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 96, 32>), dim3(n), dim3(128), 0, s, k, 0);    // shorter head start
     else if (v == 25) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1024, 1024, false, 32>), dim3(n), dim3(128), 0, s, k, 0);   // LDS trade-offs of the executor
     else if (v == 26) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1024, 1024, false, 16>), dim3(n), dim3(128), 0, s, k, 0);

@@ -59,13 +59,15 @@ def test_adler32(ctx, oracle):
 
 
 def test_bwt_forward_and_inverse(ctx, oracle):
+    from rust_compress_amd import synth
     raws = corpus.small_corpus(sizes=(17, 1000, 20000, 262144))
+    raws.append(synth.gen("text", 1 << 20, 9).tobytes())                 # 16 slots per marked node: chains of several 16-byte groups
     fw = ctx.bwt_forward(raws).check()
     for r, L, og in zip(raws, fw.outputs, fw.aux):
         eL, eo = oracle.bwt_encode(r)
         assert L == eL and (not r or og == eo)
     nz = [i for i, r in enumerate(raws) if r]
-    for variant in (0, 1, 2, 3):                            # bit 0: short parking (second chases), bit 1: the scattered-table kernel
+    for variant in (0, 1, 2, 3, 4, 5, 0x10, 0x41, 0x60):    # bit 0: short parking (second chases), bit 1: the scattered-table kernel, bit 2: one workgroup per block, bits 4..7: chase geometry
         ctx.set_variant(N.BWT_INVERSE, variant)
         inv = ctx.bwt_inverse([fw.outputs[i] for i in nz], [int(fw.aux[i]) for i in nz]).check()
         assert inv.outputs == [raws[i] for i in nz]

@@ -169,17 +169,20 @@ def test_inflate_zlib_adler(oracle, golden):
 
 def test_bwt_inverse(oracle):
     import simrun
+    from rust_compress_amd import synth
     raws = corpus.small_corpus(sizes=(17, 1000, 20000, 70000), with_empty=False)
+    raws.append(synth.gen("text", 200000, 5).tobytes())                  # 4 slots per marked node: ~500 chains use the second park array, a few the long list
     Ls, orgs = zip(*[oracle.bwt_encode(r) for r in raws])
     maxn = max(len(r) for r in raws)
     # variant bit 0: walkers park at most 16 bytes, so most chains of the larger blocks take the second chase; bit 1: the forward chase
     # over the scattered jump table instead of the backward walk over place()
     rng = np.random.default_rng(8)
     bad = [(bytes(rng.integers(0, 4, 3000, dtype=np.uint8)), 17), (Ls[2], (orgs[2] + 1) % len(Ls[2])), (b"abc", 3)]     # not a BWT / wrong origin / origin >= n
-    for variant in (0, 1, 2, 3):
+    # bit 2: one workgroup per block from start to end (the default is three launches: table, chase by (block, slice), rank + copy); bits 4..7: chase geometry
+    for variant in (0, 1, 2, 3, 4, 5, 0x10, 0x41, 0x60):
         outs, _, _, st, _ = simrun.run(N.BWT_INVERSE, variant, list(Ls) + [b[0] for b in bad], [len(r) for r in raws] + [len(b[0]) for b in bad],
                                        aux=np.array(list(orgs) + [b[1] for b in bad], dtype=np.uint32),
-                                       scratch_bytes=(len(raws) + len(bad)) * (24 * maxn + 70000) + 256)     # jump table (4n) + parked first-chase bytes (16n + slack)
+                                       scratch_bytes=(len(raws) + len(bad)) * (24 * maxn + (4 << 20)) + 256)     # jump table (4n) + parked first-chase bytes (16n + slack) + node records
         assert not st[: len(raws)].any() and outs[: len(raws)] == raws, variant
         assert list(st[len(raws):]) == [_oracle_status(oracle.bwt_decode, *b) for b in bad], variant
 
@@ -200,7 +203,7 @@ def test_bwt_inverse_minimal(oracle):
     wrong = 0
     for variant in (0, 1):                                                # 1: park at most 16 bytes per walker (second chases)
         outs, olen, _, st, _ = simrun.run(N.BWT_INVERSE_MINIMAL, variant, list(Ls), [len(L) for L in Ls], aux=np.array(orgs, dtype=np.uint32),
-                                          scratch_bytes=len(Ls) * (24 * maxn + 70000) + 256)
+                                          scratch_bytes=len(Ls) * (24 * maxn + (4 << 20)) + 256)
         for i, (L, og) in enumerate(pairs):
             try:
                 exp, est = oracle.bwt_decode(L, og, minimal=True), 0
