@@ -19,6 +19,7 @@ def main(count=6000, seed=4, ctx=None, minimal=False, variant=0):
     big = 30000 if minimal else 70000
     for it in range(count):
         n = int(rng.integers(1, 40)) if it % 3 == 0 else int(rng.integers(1, 3000)) if it % 3 == 1 else int(rng.integers(1, big))
+        if not minimal and it % 40 == 7: n = int(rng.integers(70000, 700000))           # several table slots per marked node: chains of more than one step, park groups, the long list
         k = ("text", "runs", "dna4", "rand")[it % 4]
         src = synth.gen(k, n, int(rng.integers(1 << 30))).tobytes()
         L, og = O.bwt_encode(src)
@@ -35,7 +36,7 @@ def main(count=6000, seed=4, ctx=None, minimal=False, variant=0):
     out = np.zeros(total + 64, np.uint8)
     aux = np.asarray(origins, np.uint32)
     _, olen, used, st = O.batch_run(N.BWT_INVERSE_MINIMAL if minimal else N.BWT_INVERSE, base, off, lens, out, ooff, ocap, aux=aux.copy(), threads=64)
-    ctx.set_variant(N.BWT_INVERSE_MINIMAL if minimal else N.BWT_INVERSE, variant)       # bit 0: short parking, bit 1: the scattered-table kernel
+    ctx.set_variant(N.BWT_INVERSE_MINIMAL if minimal else N.BWT_INVERSE, variant)       # bit 0: short parking, bit 1: the scattered-table kernel, bit 2: one workgroup per block
     res = ctx.bwt_inverse_minimal(Ls, origins) if minimal else ctx.bwt_inverse(Ls, origins)
     ctx.set_variant(N.BWT_INVERSE_MINIMAL if minimal else N.BWT_INVERSE, 0)
     bad = 0
@@ -52,4 +53,4 @@ def main(count=6000, seed=4, ctx=None, minimal=False, variant=0):
 
 if __name__ == "__main__":
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-    sys.exit(1 if main(6000, seed) + main(3000, seed + 2, variant=1) + main(3000, seed + 3, variant=2) + main(3000, seed + 1, minimal=True) else 0)
+    sys.exit(1 if main(6000, seed) + main(3000, seed + 2, variant=1) + main(3000, seed + 3, variant=2) + main(3000, seed + 4, variant=4) + main(3000, seed + 1, minimal=True) else 0)

@@ -454,12 +454,22 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwti_table(rcx_kargs a, uint32
     __syncthreads();
     const uint32_t per = ((n + BWTI_WAVES - 1) / BWTI_WAVES + 63u) & ~63u;
     const uint32_t w0 = w * per < n ? w * per : n, w1 = w0 + per < n ? w0 + per : n;
-    for (uint32_t i0 = w0; i0 < w1; i0 += 64) {
-        const uint32_t i = i0 + lane;
-        const bool valid = i < w1 && i != origin;
-        const uint32_t c = i < w1 ? L[i] : 0u;
-        const unsigned long long peers = BWS_PEERS(valid, c);
-        if (valid && (peers & ((1ull << lane) - 1ull)) == 0) s_cnt[w][c] += (uint32_t)__popcll(peers);
+    // (a step is 64 bytes of L per wave: eight steps' loads are issued together, or the loop is one memory latency per 64 bytes)
+    constexpr int PF = 8;
+    for (uint32_t i0 = w0; i0 < w1; i0 += 64 * PF) {
+        uint32_t cc[PF];
+#pragma unroll
+        for (int k = 0; k < PF; k++) { const uint32_t i = i0 + 64u * (uint32_t)k + lane; cc[k] = i < w1 ? L[i] : 0u; }
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const uint32_t i = i0 + 64u * (uint32_t)k + lane;
+            if (i0 + 64u * (uint32_t)k >= w1) break;
+            const bool valid = i < w1 && i != origin;
+            const uint32_t c = cc[k];
+            const unsigned long long peers = BWS_PEERS(valid, c);
+            if (valid && (peers & ((1ull << lane) - 1ull)) == 0) s_cnt[w][c] += (uint32_t)__popcll(peers);
+            rcx_wave_sync();
+        }
     }
     __syncthreads();
     const uint32_t osym = L[origin];
@@ -476,21 +486,28 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwti_table(rcx_kargs a, uint32
         for (int ww = 0; ww < BWTI_WAVES; ww++) { const uint32_t t = s_cnt[ww][tid]; s_cnt[ww][tid] = acc; acc += t; }
     }
     __syncthreads();
-    for (uint32_t i0 = w0; i0 < w1; i0 += 64) {
-        const uint32_t i = i0 + lane;
-        const bool valid = i < w1 && i != origin;
-        const uint32_t c = i < w1 ? L[i] : 0u;
-        const unsigned long long peers = BWS_PEERS(valid, c);
-        const uint32_t before = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
-        uint32_t basec = 0;
-        if (valid) basec = s_cnt[w][c];
-        rcx_wave_sync();
-        if (valid) {
-            table[i] = packed ? (basec + before) | (c << 24) : basec + before;
-            if (before == 0) s_cnt[w][c] = basec + (uint32_t)__popcll(peers);
+    for (uint32_t i0 = w0; i0 < w1; i0 += 64 * PF) {
+        uint32_t cc[PF];
+#pragma unroll
+        for (int k = 0; k < PF; k++) { const uint32_t i = i0 + 64u * (uint32_t)k + lane; cc[k] = i < w1 ? L[i] : 0u; }
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const uint32_t i = i0 + 64u * (uint32_t)k + lane;
+            if (i0 + 64u * (uint32_t)k >= w1) break;
+            const bool valid = i < w1 && i != origin;
+            const uint32_t c = cc[k];
+            const unsigned long long peers = BWS_PEERS(valid, c);
+            const uint32_t before = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+            uint32_t basec = 0;
+            if (valid) basec = s_cnt[w][c];
+            rcx_wave_sync();
+            if (valid) {
+                table[i] = packed ? (basec + before) | (c << 24) : basec + before;
+                if (before == 0) s_cnt[w][c] = basec + (uint32_t)__popcll(peers);
+            }
+            else if (i < w1 && i == origin) table[i] = packed ? s_tot[osym] | (c << 24) : s_tot[osym];
+            rcx_wave_sync();
         }
-        else if (i < w1 && i == origin) table[i] = packed ? s_tot[osym] | (c << 24) : s_tot[osym];
-        rcx_wave_sync();
     }
 }
 
@@ -717,11 +734,19 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwti3_emit(rcx_kargs a, uint32
     // eight nodes a thread and step: the records, then the park slots of those that fall into the tile, are loaded together (one
     // node at a time this loop was two dependent loads per iteration and the kernel 1.7 ms)
     constexpr int U = 8;
+    bwti_node rn[U];                                                    // the NEXT step's records: in flight while this step's chains are stored
+#pragma unroll
+    for (int u = 0; u < U; u++) { const uint32_t m = tid + (uint32_t)u * BWTI_THREADS; rn[u].a = 0; rn[u].b = 0; if (m < g.M) rn[u] = nodes[m]; }
     for (uint32_t mb = 0; mb < g.M; mb += BWTI_THREADS * U) {          // (every thread makes every step: the stores below are wave-wide)
         const uint32_t m0 = mb + tid;
         bwti_node r[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) { const uint32_t m = m0 + (uint32_t)u * BWTI_THREADS; r[u].a = 0; r[u].b = 0; if (m < g.M) r[u] = nodes[m]; }
+        for (int u = 0; u < U; u++) {
+            r[u] = rn[u];
+            const uint32_t m = m0 + BWTI_THREADS * U + (uint32_t)u * BWTI_THREADS;
+            rn[u].a = 0; rn[u].b = 0;
+            if (m < g.M) rn[u] = nodes[m];
+        }
         uint32_t hi[U], len[U]; bool in[U]; rcx_u32x4 pv[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
