@@ -351,13 +351,26 @@ __device__ __forceinline__ uint32_t dc_encode_steps(LT& L, SeqWin<uint8_t>& win,
 // withctx: also writes the coding CONTEXT of every distance (dc.rs:40-58; yielded with it by EncodeIterator, :88-103) -- eight
 // bytes each, {symbol | last_rank << 8, distance_limit}, from byte 4 * (256 + n) of the block's slot on; out_len is then
 // 4 * (256 + n) + 8 * k (k distances; the words are the first 4 * (256 + k) bytes as always).
+// (the lane-per-chunk encoder's scratch slot, k_dcx_* below: its first word says whether it has taken the block)
+#define DCX_CHUNKS 64u
+#define DCX_MIN 8192u
+#define DCX_NONE 0xffffffffu
+#define DCX_O_MAP 64u                                   /* head: handled, alpha, ch, nchunks, ... */
+#define DCX_O_LAST 512u                                 /* u32 [64 symbols][64 chunks], laid out as DCX_AT says */
+#define DCX_AT(sym, chunk) (((((sym) >> 2) * DCX_CHUNKS + (chunk)) << 2) + ((sym) & 3u))
+#define DCX_O_LRUN (DCX_O_LAST + 16384u)
+#define DCX_O_RC (DCX_O_LRUN + 16384u)                  /* u32 [64 chunks] */
+#define DCX_SLOT (DCX_O_RC + 256u)                      /* 33 536 bytes a block */
+static uint64_t dc_encode_scratch_bytes(uint32_t nblocks) { return (uint64_t)nblocks * DCX_SLOT + 256; }
+
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a, int withctx)
+__global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a, int withctx, int skip_handled)
 {
     __shared__ uint32_t s_pos[WAVES][256];                  // (withctx) where each symbol's next occurrence was predicted, :94
     const unsigned w = threadIdx.x >> 6, lane = rcx_lane();
     const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + w));   // wave-uniform: keeps descriptors in SGPRs
     if (b >= a.nblocks) return;
+    if (skip_handled && *(const uint32_t*)((const uint8_t*)a.scratch + (size_t)b * DCX_SLOT) == 1u) return;       // k_dcx_main has encoded it
     const uint8_t* in = a.in_base + a.in_off[b];
     const uint32_t n = (uint32_t)a.in_len[b];
     uint32_t* words = (uint32_t*)(a.out_base + a.out_off[b]);
@@ -427,6 +440,201 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a, int withc
         k += (uint32_t)__popcll(m);
     }
     if (lane == 0) { a.status[b] = RCX_OK; a.out_len[b] = withctx ? 4ull * (256ull + n) + 8ull * k : 4ull * (256ull + k); if (a.in_used) a.in_used[b] = n; }
+}
+
+// -------------------------------------------------------------------------------------------------
+// DC encode, ONE LANE PER CHUNK (alphabets of at most 64 symbols: any text; blocks of 8 KiB and more; no contexts).
+// k_dc_encode above is one wave per block with the list in its registers: a wave64 instruction stream in which a few lanes work,
+// ~16 instructions per byte, and the kernel is bound by the CUs' issue slots (3815 blocks of 256 KiB: 26 ms).  The state the loop
+// carries is small and can be had for ANY position without running the loop: the list order is the order of the symbols' last
+// occurrences, a symbol's pending distance belongs to the end of its last run.  So a block is cut into 64 chunks:
+//   k_dcx_prep  (a workgroup per block) finds the alphabet, per chunk every symbol's last position and the number of runs, and
+//               from these the state at every chunk's start: list order, last positions, the run each of those ended in;
+//   k_dcx_main  (a wave per block) runs the reference's loop (dc.rs:117-138) for 64 chunks at once, a lane each, its lists and
+//               tables in LDS (entry-major: lane-contiguous, no bank conflicts).  A distance is stored straight at its place: the
+//               k-th word belongs to the k-th run's end (EncodeIterator :88-104 yields them in position order), and the lane that
+//               meets a symbol again knows the run its previous occurrence ended -- no dist[] array, no compaction pass.
+// ~1.4 wave instructions per byte instead of 16.  Blocks this path does not take (flag in the scratch slot) are left to k_dc_encode.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dcx_prep(rcx_kargs a)
+{
+    __shared__ uint32_t s_present[8];
+    __shared__ uint8_t s_map[256];
+    __shared__ uint32_t s_lp[DCX_CHUNKS][64];            // per chunk and symbol: its last position there,
+    __shared__ uint32_t s_lr[DCX_CHUNKS][64];            // the run (counted from the chunk's first run start; -1: the run the chunk begins in) it lies in
+    __shared__ uint32_t s_rs[DCX_CHUNKS];                // run starts in the chunk
+    __shared__ uint32_t s_alpha;
+    const uint32_t b = blockIdx.x;
+    if (b >= a.nblocks) return;
+    const unsigned tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    const uint8_t* in = a.in_base + a.in_off[b];
+    const uint32_t n = (uint32_t)a.in_len[b];
+    uint32_t* words = (uint32_t*)(a.out_base + a.out_off[b]);
+    uint8_t* slot = (uint8_t*)a.scratch + (size_t)b * DCX_SLOT;
+    uint32_t* head = (uint32_t*)slot;
+    // (what k_dc_encode refuses it refuses itself: the block is left to it)
+    if (n < DCX_MIN || a.in_len[b] >= 0x7fffffffull || a.out_cap[b] < 4ull * (256ull + n) || ((uintptr_t)words & 3u)) { if (tid == 0) head[0] = 0; return; }
+    if (tid < 8) s_present[tid] = 0;
+    __syncthreads();
+    {   // the alphabet: 256 presence bits per thread, ORed together
+        uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+        for (uint32_t p = tid * 16u; p < n; p += 256u * 16u) {
+            uint32_t q[4] = {0, 0, 0, 0};
+            uint32_t cnt = 16;
+            if (p + 16u <= n) { const rcx_u32x4 v = *(const rcx_u32x4_u*)(in + p); q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = v[3]; }
+            else { cnt = n - p; for (uint32_t t = 0; t < cnt; t++) q[t >> 2] |= (uint32_t)in[p + t] << (8u * (t & 3u)); }
+#pragma unroll
+            for (uint32_t t = 0; t < 16; t++) {
+                if (t < cnt) {
+                    const uint32_t c = (q[t >> 2] >> (8u * (t & 3u))) & 0xffu;
+                    const uint64_t bit = 1ull << (c & 63u);
+                    const uint32_t hi = c >> 6;
+                    m0 |= hi == 0 ? bit : 0ull; m1 |= hi == 1 ? bit : 0ull; m2 |= hi == 2 ? bit : 0ull; m3 |= hi == 3 ? bit : 0ull;
+                }
+            }
+        }
+        if ((uint32_t)m0) atomicOr(&s_present[0], (uint32_t)m0); if ((uint32_t)(m0 >> 32)) atomicOr(&s_present[1], (uint32_t)(m0 >> 32));
+        if ((uint32_t)m1) atomicOr(&s_present[2], (uint32_t)m1); if ((uint32_t)(m1 >> 32)) atomicOr(&s_present[3], (uint32_t)(m1 >> 32));
+        if ((uint32_t)m2) atomicOr(&s_present[4], (uint32_t)m2); if ((uint32_t)(m2 >> 32)) atomicOr(&s_present[5], (uint32_t)(m2 >> 32));
+        if ((uint32_t)m3) atomicOr(&s_present[6], (uint32_t)m3); if ((uint32_t)(m3 >> 32)) atomicOr(&s_present[7], (uint32_t)(m3 >> 32));
+    }
+    __syncthreads();
+    {
+        uint32_t below = 0;
+        for (uint32_t k = 0; k < (tid >> 5); k++) below += (uint32_t)__popc(s_present[k]);
+        below += (uint32_t)__popc(s_present[tid >> 5] & ((1u << (tid & 31u)) - 1u));
+        s_map[tid] = (uint8_t)(below & 63u);
+        if (tid == 255) s_alpha = below + ((s_present[7] >> 31) & 1u);
+    }
+    __syncthreads();
+    const uint32_t alpha = s_alpha;
+    if (alpha > 64u) { if (tid == 0) head[0] = 0; return; }
+    const uint32_t ch = (((n + DCX_CHUNKS - 1u) / DCX_CHUNKS) + 63u) & ~63u;      // a chunk: a multiple of 64 positions
+    const uint32_t nchunks = (n + ch - 1u) / ch;
+    for (uint32_t c = w; c < nchunks; c += 4) {
+        const uint32_t cs = c * ch, ce = cs + ch < n ? cs + ch : n;
+        s_lp[c][lane] = DCX_NONE; s_lr[c][lane] = 0;
+        rcx_wave_sync();
+        uint32_t runs = 0;
+        uint32_t carry = cs ? in[cs - 1] : 0x100u;               // the byte in front of the window
+        for (uint32_t p0 = cs; p0 < ce; p0 += 64) {
+            const uint32_t p = p0 + lane;
+            const bool valid = p < ce;
+            const uint32_t c8 = valid ? in[p] : 0u;
+            uint32_t pv = (uint32_t)__shfl_up((int)c8, 1);
+            if (lane == 0) pv = carry;
+            const bool rs = valid && c8 != pv;
+            const unsigned long long rsm = __ballot(rs);
+            const uint32_t id = s_map[c8];
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 6; bit++) {
+                const unsigned long long m = __ballot((id >> bit) & 1u);
+                peers &= ((id >> bit) & 1u) ? m : ~m;
+            }
+            if (valid && (peers >> lane) == 1ull) {               // the last of its symbol in this window
+                s_lp[c][id] = p;
+                s_lr[c][id] = runs + (uint32_t)__popcll(rsm & ((2ull << lane) - 1ull)) - 1u;
+            }
+            runs += (uint32_t)__popcll(rsm);
+            carry = (uint32_t)__shfl((int)c8, 63);
+            rcx_wave_sync();
+        }
+        if (lane == 0) s_rs[c] = runs;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < 256; i += 256) words[i] = n;       // init[]: n = absent (dc.rs:114-115); the main kernel fills in the first occurrences
+    if (w != 0) return;
+    // the state at every chunk's start, chunk after chunk: lane = symbol.  last1: position + 1 of the symbol's last occurrence so far (0: none)
+    uint32_t cur_last1 = 0, cur_lr = 0, basec = 0;
+    uint32_t* o_last = (uint32_t*)(slot + DCX_O_LAST);
+    uint32_t* o_lrun = (uint32_t*)(slot + DCX_O_LRUN);
+    uint32_t* o_rc = (uint32_t*)(slot + DCX_O_RC);
+    for (uint32_t c = 0; c < nchunks; c++) {
+        o_last[DCX_AT(lane, c)] = cur_last1;
+        o_lrun[DCX_AT(lane, c)] = cur_lr;
+        if (lane == 0) o_rc[c] = basec - 1u;                      // the run position cs - 1 lies in (-1 in front of the block)
+        const uint32_t lp = s_lp[c][lane];
+        if (lp != DCX_NONE) { cur_last1 = lp + 1u; cur_lr = basec + s_lr[c][lane]; }
+        basec += s_rs[c];
+    }
+    for (int k = 0; k < 4; k++) slot[DCX_O_MAP + lane + 64 * k] = s_map[lane + 64 * k];
+    if (lane == 0) { head[1] = alpha; head[2] = ch; head[3] = nchunks; head[0] = 1; }
+}
+
+__global__ __launch_bounds__(64) void k_dcx_main(rcx_kargs a)
+{
+    __shared__ __align__(16) uint32_t s_last[64 * DCX_CHUNKS];      // [symbol / 4][chunk][symbol % 4]: four symbols of a lane in one 16-byte read
+    __shared__ uint32_t s_lrun[64 * DCX_CHUNKS];
+    __shared__ uint8_t s_map[256];
+    const uint32_t b = blockIdx.x;
+    if (b >= a.nblocks) return;
+    const uint8_t* slot = (const uint8_t*)a.scratch + (size_t)b * DCX_SLOT;
+    const uint32_t* head = (const uint32_t*)slot;
+    if (head[0] != 1u) return;
+    const unsigned lane = rcx_lane();
+    const uint8_t* in = a.in_base + a.in_off[b];
+    const uint32_t n = (uint32_t)a.in_len[b];
+    uint32_t* words = (uint32_t*)(a.out_base + a.out_off[b]);
+    const uint32_t alpha = head[1], ch = head[2], nchunks = head[3];
+    for (uint32_t i = lane; i < 64 * DCX_CHUNKS; i += 64) { s_last[i] = ((const uint32_t*)(slot + DCX_O_LAST))[i]; s_lrun[i] = ((const uint32_t*)(slot + DCX_O_LRUN))[i]; }
+    for (int k = 0; k < 4; k++) s_map[lane + 64 * k] = slot[DCX_O_MAP + lane + 64 * k];
+    rcx_wave_sync();
+    const bool mine = lane < nchunks;
+    const uint32_t cs = lane * ch, ce = mine ? (cs + ch < n ? cs + ch : n) : 0u;
+    uint32_t rc = mine ? ((const uint32_t*)(slot + DCX_O_RC))[lane] : 0u;
+    uint32_t front = (mine && cs) ? (uint32_t)s_map[in[cs - 1u]] : 0xffu;      // the symbol whose run is open
+    const uint32_t quads = (alpha + 3u) >> 2;
+    for (uint32_t t0 = 0; t0 < ch; t0 += 16) {
+        uint32_t q[4] = {0, 0, 0, 0};                            // sixteen bytes of every chunk
+        {
+            const uint32_t p = cs + t0;
+            if (mine && p < ce) {
+                if (p + 16u <= n) { const rcx_u32x4 v = *(const rcx_u32x4_u*)(in + p); q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = v[3]; }
+                else for (uint32_t t = 0; p + t < n; t++) q[t >> 2] |= (uint32_t)in[p + t] << (8u * (t & 3u));
+            }
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < 16; t++) {
+            const uint32_t i = cs + t0 + t;
+            const bool act = mine && i < ce;
+            const uint32_t c8 = (q[t >> 2] >> (8u * (t & 3u))) & 0xffu;
+            const uint32_t id = s_map[c8];
+            const bool sw = act && id != front;                   // a run ends at i - 1, the run of `id` starts at i
+            if (!__ballot(sw)) continue;
+            if (sw && front != 0xffu) { s_last[DCX_AT(front, lane)] = i; s_lrun[DCX_AT(front, lane)] = rc; }      // (position i - 1, + 1)
+            rcx_wave_sync();
+            uint32_t base1 = 0, lr = 0;
+            if (sw) { base1 = s_last[DCX_AT(id, lane)]; lr = s_lrun[DCX_AT(id, lane)]; rc++; }
+            // the symbol's rank in the move-to-front list (mtf.rs:63-79) = the symbols seen since its last occurrence = the entries
+            // of the lane's table that are younger -- counted, no list is kept
+            uint32_t rank = 0;
+            const uint32_t key = sw ? base1 : 0xffffffffu;
+            for (uint32_t g = 0; g < quads; g++) {
+                const rcx_u32x4 v = *(const rcx_u32x4*)&s_last[(g * DCX_CHUNKS + lane) * 4u];
+                rank += (v[0] > key ? 1u : 0u) + (v[1] > key ? 1u : 0u) + (v[2] > key ? 1u : 0u) + (v[3] > key ? 1u : 0u);
+            }
+            if (sw) {
+                front = id;
+                if (base1) words[256u + lr] = i - (base1 - 1u) - rank - 1u;    // dc.rs:134, stored where EncodeIterator will yield it
+                else words[c8] = i;                                           // first occurrence: init[], dc.rs:126
+            }
+        }
+    }
+    // dc.rs:139-144: the distances still open at the end, one per symbol; lane = symbol, over the last chunk's table
+    const uint32_t lc = nchunks - 1u;
+    const uint32_t rcl = (uint32_t)__shfl((int)rc, (int)lc), frl = (uint32_t)__shfl((int)front, (int)lc);
+    rcx_wave_sync();
+    if (lane == lc && front != 0xffu) { s_last[DCX_AT(front, lane)] = n; s_lrun[DCX_AT(front, lane)] = rc; }
+    rcx_wave_sync();
+    {
+        const uint32_t my1 = s_last[DCX_AT(lane, lc)], mylr = s_lrun[DCX_AT(lane, lc)];
+        uint32_t rank = 0;
+        for (uint32_t d = 0; d < alpha; d++) rank += s_last[DCX_AT(d, lc)] > my1 ? 1u : 0u;
+        if (lane < alpha && my1) words[256u + mylr] = n - (my1 - 1u) - rank - 1u;
+    }
+    (void)frl;
+    if (lane == 0) { a.status[b] = RCX_OK; a.out_len[b] = 4ull * (256ull + rcl + 1u); if (a.in_used) a.in_used[b] = n; }
 }
 
 // dc.rs:199-229 driven as decode_simple :236-252; returns the status
@@ -1230,7 +1438,14 @@ static void launch_serial(hipStream_t s, int codec, rcx_kargs& k, int v, uint32_
     switch (codec) {
     case RCX_MTF_ENCODE: hipLaunchKernelGGL((k_mtf<4>), dim3((n + 3) / 4), dim3(256), 0, s, k, 0); break;
     case RCX_MTF_DECODE: hipLaunchKernelGGL((k_mtf<4>), dim3((n + 3) / 4), dim3(256), 0, s, k, 1); break;
-    case RCX_DC_ENCODE: hipLaunchKernelGGL((k_dc_encode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k, (int)(param & 1u)); break;    // param 1: with contexts
+    case RCX_DC_ENCODE: {                                       // param 1: with contexts; variant 1: the wave-per-block kernel only
+        const bool chunks = !(param & 1u) && v != 1 && k.scratch && k.scratch_bytes >= dc_encode_scratch_bytes(n);
+        if (chunks) {
+            hipLaunchKernelGGL(k_dcx_prep, dim3(n), dim3(256), 0, s, k);
+            hipLaunchKernelGGL(k_dcx_main, dim3(n), dim3(64), 0, s, k);
+        }
+        hipLaunchKernelGGL((k_dc_encode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k, (int)(param & 1u), chunks ? 1 : 0);
+        break; }
     case RCX_DC_DECODE: hipLaunchKernelGGL((k_dc_decode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k, (int)(param & 1u)); break;
     case RCX_RLE_ENCODE: hipLaunchKernelGGL((k_rle_encode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k); break;
     case RCX_RLE_DECODE: hipLaunchKernelGGL((k_rle_decode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k); break;

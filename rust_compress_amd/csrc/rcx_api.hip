@@ -138,6 +138,7 @@ extern "C" uint64_t rcx_scratch_bytes(int codec, uint32_t nblocks, uint64_t max_
     switch (codec) {
     case RCX_LZ4_ENCODE: return rcx_tu_lz4_encode_scratch(nblocks);
     case RCX_BWT_FORWARD: return rcx_tu_bwt_forward_scratch(nblocks, max_block);
+    case RCX_DC_ENCODE: return rcx_tu_dc_encode_scratch(nblocks);       // (optional: without it the wave-per-block kernel encodes every block)
     case RCX_BWT_INVERSE: case RCX_BWT_INVERSE_MINIMAL: return rcx_tu_bwt_inverse_scratch(nblocks, max_block);
     case RCX_INFLATE: case RCX_ZLIB_DECODE: return rcx_tu_inflate_scratch(nblocks);
     case RCX_GZIP_DECODE: return rcx_tu_gzip_scratch(nblocks) + rcx_tu_inflate_scratch(nblocks) + 512;   // + the carve's alignment slack

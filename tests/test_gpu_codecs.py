@@ -159,6 +159,26 @@ def test_mtf_dc_ari_rle(ctx, oracle):
         assert [(int(a) & 255, (int(a) >> 8) & 255, int(b_)) for a, b_ in gotd] == want
 
 
+def test_dc_encode_lane_per_chunk(ctx, oracle):
+    """The default DC encoder for blocks of >= 8 KiB over <= 64 symbols (k_dcx_prep + k_dcx_main, a lane per chunk) and the
+    wave-per-block kernel (variant 1; also what takes the blocks the first refuses): both == the oracle."""
+    from rust_compress_amd import synth
+    rng = np.random.default_rng(12)
+    srcs = [synth.gen("text", 262144, 1).tobytes(), synth.gen("dna4", 100000, 2).tobytes(), synth.gen("runs", 70000, 3).tobytes(),
+            synth.gen("words", 9000, 4).tobytes(), synth.gen("text", 1 << 20, 7).tobytes()]
+    raws = [oracle.bwt_encode(x)[0] for x in srcs] + srcs[:2]
+    raws += [b"a" * 10000, b"ab" * 5000, bytes(rng.integers(0, 64, 8192, dtype=np.uint8)), bytes(rng.integers(0, 64, 8193, dtype=np.uint8)),
+             bytes(rng.integers(0, 3, 12345, dtype=np.uint8)) + bytes(range(3, 64))]
+    raws += [bytes(rng.integers(0, 65, 9000, dtype=np.uint8)), synth.gen("rand", 10000, 5).tobytes(), synth.gen("text", 5000, 6).tobytes(), b""]
+    want = [oracle.dc_encode(r).tobytes() for r in raws]
+    for variant in (0, 1):
+        ctx.set_variant(N.DC_ENCODE, variant)
+        e = ctx.dc_encode(raws).check()
+        assert e.outputs == want, variant
+    ctx.set_variant(N.DC_ENCODE, 0)
+    assert ctx.dc_decode(want, [len(r) for r in raws]).check().outputs == raws
+
+
 def test_ari_binary_and_proxy_models(ctx, oracle):
     """bin::Model (every rate the reference's tests use, test.rs:52-89) and the SumProxy pair (test.rs:91-148)."""
     raws = [r[:20000] for r in corpus.small_corpus()] + [bytes(range(256)) * 8]

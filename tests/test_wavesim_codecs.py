@@ -80,6 +80,28 @@ def test_mtf_rle_ari_dc(oracle):
         assert [(int(a) & 255, (int(a) >> 8) & 255, int(b_)) for a, b_ in gotd] == oracle.dc_decode(np.frombuffer(e, dtype="<u4"), n, with_ctx=True)[2]
 
 
+def test_dc_encode_lane_per_chunk(oracle):
+    """k_dcx_prep + k_dcx_main (blocks of >= 8 KiB over <= 64 symbols, scratch given): the same words as the oracle; the blocks
+    that path refuses (short, or a larger alphabet) come from the wave-per-block kernel in the same launch."""
+    import simrun
+    from rust_compress_amd import synth
+    rng = np.random.default_rng(12)
+    srcs = [synth.gen("text", 70000, 1).tobytes(), synth.gen("dna4", 20000, 2).tobytes(), synth.gen("runs", 30000, 3).tobytes(),
+            synth.gen("words", 9000, 4).tobytes()]
+    raws = [oracle.bwt_encode(x)[0] for x in srcs] + srcs[:2]                  # after the BWT (the pipeline's input) and plain
+    raws += [b"a" * 10000, b"ab" * 5000, bytes(rng.integers(0, 64, 8192, dtype=np.uint8)), bytes(rng.integers(0, 64, 8193, dtype=np.uint8)),
+             bytes(rng.integers(0, 3, 12345, dtype=np.uint8)) + bytes(range(3, 64))]            # one run / two symbols / exactly 64 symbols / late first occurrences
+    raws += [bytes(rng.integers(0, 65, 9000, dtype=np.uint8)), synth.gen("rand", 10000, 5).tobytes(), synth.gen("text", 5000, 6).tobytes(), b""]   # refused: 65 symbols, 256, short, empty
+    lens = [len(r) for r in raws]
+    sc = []
+    enc, _, used, st, _ = simrun.run(N.DC_ENCODE, 0, raws, [4 * (256 + n) for n in lens], scratch_bytes=len(raws) * 33536 + 256, scratch_out=sc)
+    assert not st.any() and list(used) == lens
+    took = [int(sc[0][i * 33536: i * 33536 + 4].view("<u4")[0]) for i in range(len(raws))]           # the slot's first word: 1 = the chunk kernels encoded the block
+    assert took == [1] * (len(raws) - 4) + [0] * 4
+    for i, r in enumerate(raws):
+        assert enc[i] == oracle.dc_encode(r).tobytes(), (i, len(r))
+
+
 def _oracle_status(fn, *args):
     try:
         fn(*args)

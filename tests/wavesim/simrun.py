@@ -31,7 +31,7 @@ def lib():
     return _lib
 
 
-def run(codec, variant, blobs, caps, aux=None, n_out=None, in_misalign=0, out_misalign=0, scratch_bytes=0, scratch_init=None):
+def run(codec, variant, blobs, caps, aux=None, n_out=None, in_misalign=0, out_misalign=0, scratch_bytes=0, scratch_init=None, scratch_out=None):
     """-> (outputs list[bytes], out_len, in_used, status, aux)"""
     n = len(blobs)
     base, off, lens = B.pack(blobs)
@@ -52,6 +52,8 @@ def run(codec, variant, blobs, caps, aux=None, n_out=None, in_misalign=0, out_mi
               p(n_out) if n_out is not None else None, p(scratch), scratch.size, n)
     rc = lib().sim_launch(codec, variant, C.byref(k))
     assert rc == 0
+    if scratch_out is not None:
+        scratch_out.append(scratch)
     outs = [bytes(out[int(o):int(o) + int(l)]) for o, l in zip(ooff, out_len)]
     # guard: nothing outside [off, off+cap) may be touched
     mask = np.ones(out.size, bool)
