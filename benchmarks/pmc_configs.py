@@ -64,7 +64,7 @@ def main():
            "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, over `python benchmarks/bench_configs.py --configs %s --once` (every launch once)" % cfg,
            "correction": "MI355X_MICROARCH.md HBM section: KiB units; gfx950 FETCH_SIZE counts 64 B per 128-B request -> read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 as is"}
     fwd = lambda k: k.startswith("k_bws") or k.startswith("k_bwtf")
-    inv = lambda k: k.startswith("k_bwt_inverse")
+    inv = lambda k: k.startswith("k_bwt_inverse") or k.startswith("k_bwti")
     if cfg == "4":
         extra = sys.argv[5:]
         sets = [("text", sys.argv[2], sys.argv[3])] + [(extra[i], extra[i + 1], extra[i + 2]) for i in range(0, len(extra) - 2, 3)]
@@ -81,7 +81,7 @@ def main():
             # the range coder's kernel runs once per direction: its first dispatch is the encoder's
             ari_f = [v for k, v in seq if k.startswith("k_ari_byte")]
             ari_w = [v for k, v in wseq if k.startswith("k_ari_byte")]
-            enc = group(per, lambda k: fwd(k) or k.startswith("k_dc_encode"))
+            enc = group(per, lambda k: fwd(k) or k.startswith("k_dc_encode") or k.startswith("k_dcx"))
             dec = group(per, lambda k: inv(k) or k.startswith("k_dc_decode"))
             if len(ari_f) == 2 and len(ari_w) == 2:
                 for g, i in ((enc, 0), (dec, 1)):
