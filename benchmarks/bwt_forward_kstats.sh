@@ -3,7 +3,7 @@
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kf
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kf -- python $REPO/benchmarks/bwt_forward_profile.py ${1:-text} ${2:-1024} > /tmp/kf.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kf -- python $REPO/benchmarks/bwt_forward_profile.py ${1:-text} ${2:-1024} ${3:-262144} > /tmp/kf.log 2>&1
 f=$(find /tmp/kf -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys

@@ -8,7 +8,7 @@ import rust_compress_amd as R
 from rust_compress_amd import _native as N, synth
 kind = sys.argv[1] if len(sys.argv) > 1 else "text"
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-BLOCK = 262144
+BLOCK = int(sys.argv[3]) if len(sys.argv) > 3 else 262144
 dev = torch.device("cuda", 0); ctx = R.Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 i64 = lambda a: torch.tensor(a, dtype=torch.int64, device=dev)

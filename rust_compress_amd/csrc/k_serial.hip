@@ -360,7 +360,9 @@ __device__ __forceinline__ uint32_t dc_encode_steps(LT& L, SeqWin<uint8_t>& win,
 #define DCX_AT(sym, chunk) (((((sym) >> 2) * DCX_CHUNKS + (chunk)) << 2) + ((sym) & 3u))
 #define DCX_O_LRUN (DCX_O_LAST + 16384u)
 #define DCX_O_RC (DCX_O_LRUN + 16384u)                  /* u32 [64 chunks] */
-#define DCX_SLOT (DCX_O_RC + 256u)                      /* 33 536 bytes a block */
+#define DCX_O_RANK (DCX_O_RC + 256u)                    /* u8 [64 symbols][64 chunks]: the symbol's place in the move-to-front list (0xff: not seen), laid out as DCX_RK says */
+#define DCX_RK(sym, chunk) (((((sym) >> 4) * DCX_CHUNKS + (chunk)) << 4) + ((sym) & 15u))
+#define DCX_SLOT (DCX_O_RANK + 4096u)                   /* 37 632 bytes a block */
 static uint64_t dc_encode_scratch_bytes(uint32_t nblocks) { return (uint64_t)nblocks * DCX_SLOT + 256; }
 
 template <int WAVES>
@@ -459,6 +461,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_encode(rcx_kargs a, int withc
 __global__ __launch_bounds__(256) void k_dcx_prep(rcx_kargs a)
 {
     __shared__ uint32_t s_present[8];
+    __shared__ uint8_t s_flag[256];
     __shared__ uint8_t s_map[256];
     __shared__ uint32_t s_lp[DCX_CHUNKS][64];            // per chunk and symbol: its last position there,
     __shared__ uint32_t s_lr[DCX_CHUNKS][64];            // the run (counted from the chunk's first run start; -1: the run the chunk begins in) it lies in
@@ -474,37 +477,26 @@ __global__ __launch_bounds__(256) void k_dcx_prep(rcx_kargs a)
     uint32_t* head = (uint32_t*)slot;
     // (what k_dc_encode refuses it refuses itself: the block is left to it)
     if (n < DCX_MIN || a.in_len[b] >= 0x7fffffffull || a.out_cap[b] < 4ull * (256ull + n) || ((uintptr_t)words & 3u)) { if (tid == 0) head[0] = 0; return; }
-    if (tid < 8) s_present[tid] = 0;
+    s_flag[tid] = 0;
     __syncthreads();
-    {   // the alphabet: 256 presence bits per thread, ORed together
-        uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-        for (uint32_t p = tid * 16u; p < n; p += 256u * 16u) {
-            uint32_t q[4] = {0, 0, 0, 0};
-            uint32_t cnt = 16;
-            if (p + 16u <= n) { const rcx_u32x4 v = *(const rcx_u32x4_u*)(in + p); q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = v[3]; }
-            else { cnt = n - p; for (uint32_t t = 0; t < cnt; t++) q[t >> 2] |= (uint32_t)in[p + t] << (8u * (t & 3u)); }
+    // the alphabet: a flag byte per value (plain stores of 1: whoever wins writes the same)
+    for (uint32_t p = tid * 16u; p < n; p += 256u * 16u) {
+        if (p + 16u <= n) {
+            const rcx_u32x4 v = *(const rcx_u32x4_u*)(in + p);
 #pragma unroll
-            for (uint32_t t = 0; t < 16; t++) {
-                if (t < cnt) {
-                    const uint32_t c = (q[t >> 2] >> (8u * (t & 3u))) & 0xffu;
-                    const uint64_t bit = 1ull << (c & 63u);
-                    const uint32_t hi = c >> 6;
-                    m0 |= hi == 0 ? bit : 0ull; m1 |= hi == 1 ? bit : 0ull; m2 |= hi == 2 ? bit : 0ull; m3 |= hi == 3 ? bit : 0ull;
-                }
-            }
+            for (int k = 0; k < 4; k++) { s_flag[v[k] & 0xffu] = 1; s_flag[(v[k] >> 8) & 0xffu] = 1; s_flag[(v[k] >> 16) & 0xffu] = 1; s_flag[v[k] >> 24] = 1; }
         }
-        if ((uint32_t)m0) atomicOr(&s_present[0], (uint32_t)m0); if ((uint32_t)(m0 >> 32)) atomicOr(&s_present[1], (uint32_t)(m0 >> 32));
-        if ((uint32_t)m1) atomicOr(&s_present[2], (uint32_t)m1); if ((uint32_t)(m1 >> 32)) atomicOr(&s_present[3], (uint32_t)(m1 >> 32));
-        if ((uint32_t)m2) atomicOr(&s_present[4], (uint32_t)m2); if ((uint32_t)(m2 >> 32)) atomicOr(&s_present[5], (uint32_t)(m2 >> 32));
-        if ((uint32_t)m3) atomicOr(&s_present[6], (uint32_t)m3); if ((uint32_t)(m3 >> 32)) atomicOr(&s_present[7], (uint32_t)(m3 >> 32));
+        else for (uint32_t t = p; t < n; t++) s_flag[in[t]] = 1;
     }
     __syncthreads();
     {
-        uint32_t below = 0;
-        for (uint32_t k = 0; k < (tid >> 5); k++) below += (uint32_t)__popc(s_present[k]);
-        below += (uint32_t)__popc(s_present[tid >> 5] & ((1u << (tid & 31u)) - 1u));
+        const unsigned long long pm = __ballot(s_flag[tid] != 0);
+        if (lane == 0) s_present[w] = (uint32_t)__popcll(pm);
+        __syncthreads();
+        uint32_t below = (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+        for (uint32_t k = 0; k < w; k++) below += s_present[k];
         s_map[tid] = (uint8_t)(below & 63u);
-        if (tid == 255) s_alpha = below + ((s_present[7] >> 31) & 1u);
+        if (tid == 0) s_alpha = s_present[0] + s_present[1] + s_present[2] + s_present[3];
     }
     __syncthreads();
     const uint32_t alpha = s_alpha;
@@ -553,6 +545,11 @@ __global__ __launch_bounds__(256) void k_dcx_prep(rcx_kargs a)
     for (uint32_t c = 0; c < nchunks; c++) {
         o_last[DCX_AT(lane, c)] = cur_last1;
         o_lrun[DCX_AT(lane, c)] = cur_lr;
+        {   // list order: the later the last occurrence, the nearer the front
+            uint32_t rank = 0;
+            for (int d = 0; d < 64; d++) rank += (uint32_t)__shfl((int)cur_last1, d) > cur_last1 ? 1u : 0u;
+            slot[DCX_O_RANK + DCX_RK(lane, c)] = cur_last1 ? (uint8_t)rank : (uint8_t)0xff;
+        }
         if (lane == 0) o_rc[c] = basec - 1u;                      // the run position cs - 1 lies in (-1 in front of the block)
         const uint32_t lp = s_lp[c][lane];
         if (lp != DCX_NONE) { cur_last1 = lp + 1u; cur_lr = basec + s_lr[c][lane]; }
@@ -564,8 +561,9 @@ __global__ __launch_bounds__(256) void k_dcx_prep(rcx_kargs a)
 
 __global__ __launch_bounds__(64) void k_dcx_main(rcx_kargs a)
 {
-    __shared__ __align__(16) uint32_t s_last[64 * DCX_CHUNKS];      // [symbol / 4][chunk][symbol % 4]: four symbols of a lane in one 16-byte read
+    __shared__ __align__(16) uint32_t s_last[64 * DCX_CHUNKS];      // DCX_AT: [symbol / 4][chunk][symbol % 4]
     __shared__ uint32_t s_lrun[64 * DCX_CHUNKS];
+    __shared__ __align__(16) uint32_t s_rank[16 * DCX_CHUNKS];      // DCX_RK (bytes): sixteen symbols of a lane in one 16-byte access
     __shared__ uint8_t s_map[256];
     const uint32_t b = blockIdx.x;
     if (b >= a.nblocks) return;
@@ -578,13 +576,15 @@ __global__ __launch_bounds__(64) void k_dcx_main(rcx_kargs a)
     uint32_t* words = (uint32_t*)(a.out_base + a.out_off[b]);
     const uint32_t alpha = head[1], ch = head[2], nchunks = head[3];
     for (uint32_t i = lane; i < 64 * DCX_CHUNKS; i += 64) { s_last[i] = ((const uint32_t*)(slot + DCX_O_LAST))[i]; s_lrun[i] = ((const uint32_t*)(slot + DCX_O_LRUN))[i]; }
+    for (uint32_t i = lane; i < 16 * DCX_CHUNKS; i += 64) s_rank[i] = ((const uint32_t*)(slot + DCX_O_RANK))[i];
     for (int k = 0; k < 4; k++) s_map[lane + 64 * k] = slot[DCX_O_MAP + lane + 64 * k];
     rcx_wave_sync();
+    uint8_t* const rankb = (uint8_t*)s_rank;
     const bool mine = lane < nchunks;
     const uint32_t cs = lane * ch, ce = mine ? (cs + ch < n ? cs + ch : n) : 0u;
     uint32_t rc = mine ? ((const uint32_t*)(slot + DCX_O_RC))[lane] : 0u;
     uint32_t front = (mine && cs) ? (uint32_t)s_map[in[cs - 1u]] : 0xffu;      // the symbol whose run is open
-    const uint32_t quads = (alpha + 3u) >> 2;
+    const uint32_t quads = (alpha + 15u) >> 4;
     for (uint32_t t0 = 0; t0 < ch; t0 += 16) {
         uint32_t q[4] = {0, 0, 0, 0};                            // sixteen bytes of every chunk
         {
@@ -603,37 +603,39 @@ __global__ __launch_bounds__(64) void k_dcx_main(rcx_kargs a)
             const bool sw = act && id != front;                   // a run ends at i - 1, the run of `id` starts at i
             if (!__ballot(sw)) continue;
             if (sw && front != 0xffu) { s_last[DCX_AT(front, lane)] = i; s_lrun[DCX_AT(front, lane)] = rc; }      // (position i - 1, + 1)
-            rcx_wave_sync();
-            uint32_t base1 = 0, lr = 0;
-            if (sw) { base1 = s_last[DCX_AT(id, lane)]; lr = s_lrun[DCX_AT(id, lane)]; rc++; }
-            // the symbol's rank in the move-to-front list (mtf.rs:63-79) = the symbols seen since its last occurrence = the entries
-            // of the lane's table that are younger -- counted, no list is kept
-            uint32_t rank = 0;
-            const uint32_t key = sw ? base1 : 0xffffffffu;
+            uint32_t base1 = 0, lr = 0, r = 0;
+            if (sw) {
+                base1 = s_last[DCX_AT(id, lane)]; lr = s_lrun[DCX_AT(id, lane)]; rc++;
+                r = base1 ? (uint32_t)rankb[DCX_RK(id, lane)] : 64u;           // its place in the list (mtf.rs:63-79); a new symbol pushes the whole list (dc.rs:123-124)
+            }
+            // move to front without a list: every symbol in front of `id` moves one place down -- sixteen places per 16-byte access, four
+            // per instruction (a place is < 64 or 0xff: (x | 0x80) - r keeps its top bit exactly where x >= r, and no byte borrows)
+            const uint32_t rr = r * 0x01010101u;                  // (r = 0 for a lane that stays in its run: nothing moves)
             for (uint32_t g = 0; g < quads; g++) {
-                const rcx_u32x4 v = *(const rcx_u32x4*)&s_last[(g * DCX_CHUNKS + lane) * 4u];
-                rank += (v[0] > key ? 1u : 0u) + (v[1] > key ? 1u : 0u) + (v[2] > key ? 1u : 0u) + (v[3] > key ? 1u : 0u);
+                rcx_u32x4 v = *(const rcx_u32x4*)&s_rank[(g * DCX_CHUNKS + lane) * 4u];
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] += (~((v[k] | 0x80808080u) - rr) >> 7) & 0x01010101u;
+                *(rcx_u32x4*)&s_rank[(g * DCX_CHUNKS + lane) * 4u] = v;
             }
             if (sw) {
+                rankb[DCX_RK(id, lane)] = 0;
                 front = id;
-                if (base1) words[256u + lr] = i - (base1 - 1u) - rank - 1u;    // dc.rs:134, stored where EncodeIterator will yield it
+                if (base1) words[256u + lr] = i - (base1 - 1u) - r - 1u;       // dc.rs:134, stored where EncodeIterator will yield it
                 else words[c8] = i;                                           // first occurrence: init[], dc.rs:126
             }
+            rcx_wave_sync();
         }
     }
     // dc.rs:139-144: the distances still open at the end, one per symbol; lane = symbol, over the last chunk's table
     const uint32_t lc = nchunks - 1u;
-    const uint32_t rcl = (uint32_t)__shfl((int)rc, (int)lc), frl = (uint32_t)__shfl((int)front, (int)lc);
+    const uint32_t rcl = (uint32_t)__shfl((int)rc, (int)lc);
     rcx_wave_sync();
     if (lane == lc && front != 0xffu) { s_last[DCX_AT(front, lane)] = n; s_lrun[DCX_AT(front, lane)] = rc; }
     rcx_wave_sync();
     {
-        const uint32_t my1 = s_last[DCX_AT(lane, lc)], mylr = s_lrun[DCX_AT(lane, lc)];
-        uint32_t rank = 0;
-        for (uint32_t d = 0; d < alpha; d++) rank += s_last[DCX_AT(d, lc)] > my1 ? 1u : 0u;
+        const uint32_t my1 = s_last[DCX_AT(lane, lc)], mylr = s_lrun[DCX_AT(lane, lc)], rank = rankb[DCX_RK(lane, lc)];
         if (lane < alpha && my1) words[256u + mylr] = n - (my1 - 1u) - rank - 1u;
     }
-    (void)frl;
     if (lane == 0) { a.status[b] = RCX_OK; a.out_len[b] = 4ull * (256ull + rcl + 1u); if (a.in_used) a.in_used[b] = n; }
 }
 

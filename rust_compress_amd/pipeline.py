@@ -73,7 +73,7 @@ class BwtDcAri:
         roff = np.arange(nb, dtype=np.int64) * slot
         dc = DeviceBatch(bw.out_base, bw.out_off, bw.out_len, rec, self._i64(roff + 4 * HDR_WORDS),
                          self._i64(np.full(nb, slot - 4 * HDR_WORDS)))
-        self.ctx.launch_dev(N.DC_ENCODE, dc, self._scratch(N.DC_ENCODE, nb, maxn))       # (33 KiB a block: the lane-per-chunk encoder's chunk states)
+        self.ctx.launch_dev(N.DC_ENCODE, dc, self._scratch(N.DC_ENCODE, nb, maxn))       # (37 KiB a block: the lane-per-chunk encoder's chunk states)
         # 3. header words n, origin, k
         k = (dc.out_len[:nb] // 4 - 256).to(torch.int32)
         hdr = torch.stack([self._i64(lens).to(torch.int32), bw.aux[:nb].to(torch.int32), k], dim=1).contiguous()

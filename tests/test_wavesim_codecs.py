@@ -94,9 +94,9 @@ def test_dc_encode_lane_per_chunk(oracle):
     raws += [bytes(rng.integers(0, 65, 9000, dtype=np.uint8)), synth.gen("rand", 10000, 5).tobytes(), synth.gen("text", 5000, 6).tobytes(), b""]   # refused: 65 symbols, 256, short, empty
     lens = [len(r) for r in raws]
     sc = []
-    enc, _, used, st, _ = simrun.run(N.DC_ENCODE, 0, raws, [4 * (256 + n) for n in lens], scratch_bytes=len(raws) * 33536 + 256, scratch_out=sc)
+    enc, _, used, st, _ = simrun.run(N.DC_ENCODE, 0, raws, [4 * (256 + n) for n in lens], scratch_bytes=len(raws) * 37632 + 256, scratch_out=sc)
     assert not st.any() and list(used) == lens
-    took = [int(sc[0][i * 33536: i * 33536 + 4].view("<u4")[0]) for i in range(len(raws))]           # the slot's first word: 1 = the chunk kernels encoded the block
+    took = [int(sc[0][i * 37632: i * 37632 + 4].view("<u4")[0]) for i in range(len(raws))]           # the slot's first word: 1 = the chunk kernels encoded the block
     assert took == [1] * (len(raws) - 4) + [0] * 4
     for i, r in enumerate(raws):
         assert enc[i] == oracle.dc_encode(r).tobytes(), (i, len(r))
