@@ -509,28 +509,37 @@ __global__ __launch_bounds__(256) void k_dcx_prep(rcx_kargs a)
         rcx_wave_sync();
         uint32_t runs = 0;
         uint32_t carry = cs ? in[cs - 1] : 0x100u;               // the byte in front of the window
-        for (uint32_t p0 = cs; p0 < ce; p0 += 64) {
-            const uint32_t p = p0 + lane;
-            const bool valid = p < ce;
-            const uint32_t c8 = valid ? in[p] : 0u;
-            uint32_t pv = (uint32_t)__shfl_up((int)c8, 1);
-            if (lane == 0) pv = carry;
-            const bool rs = valid && c8 != pv;
-            const unsigned long long rsm = __ballot(rs);
-            const uint32_t id = s_map[c8];
-            unsigned long long peers = __ballot(valid);
+        constexpr int PF = 8;                                    // (a window is 64 bytes per wave: eight windows' loads are issued together)
+        for (uint32_t pb = cs; pb < ce; pb += 64 * PF) {
+            uint32_t cc[PF];
 #pragma unroll
-            for (int bit = 0; bit < 6; bit++) {
-                const unsigned long long m = __ballot((id >> bit) & 1u);
-                peers &= ((id >> bit) & 1u) ? m : ~m;
+            for (int k = 0; k < PF; k++) { const uint32_t p = pb + 64u * (uint32_t)k + lane; cc[k] = p < ce ? in[p] : 0u; }
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                const uint32_t p0 = pb + 64u * (uint32_t)k;
+                if (p0 >= ce) break;
+                const uint32_t p = p0 + lane;
+                const bool valid = p < ce;
+                const uint32_t c8 = cc[k];
+                uint32_t pv = (uint32_t)__shfl_up((int)c8, 1);
+                if (lane == 0) pv = carry;
+                const bool rs = valid && c8 != pv;
+                const unsigned long long rsm = __ballot(rs);
+                const uint32_t id = s_map[c8];
+                unsigned long long peers = __ballot(valid);
+#pragma unroll
+                for (int bit = 0; bit < 6; bit++) {
+                    const unsigned long long m = __ballot((id >> bit) & 1u);
+                    peers &= ((id >> bit) & 1u) ? m : ~m;
+                }
+                if (valid && (peers >> lane) == 1ull) {           // the last of its symbol in this window
+                    s_lp[c][id] = p;
+                    s_lr[c][id] = runs + (uint32_t)__popcll(rsm & ((2ull << lane) - 1ull)) - 1u;
+                }
+                runs += (uint32_t)__popcll(rsm);
+                carry = (uint32_t)__shfl((int)c8, 63);
+                rcx_wave_sync();
             }
-            if (valid && (peers >> lane) == 1ull) {               // the last of its symbol in this window
-                s_lp[c][id] = p;
-                s_lr[c][id] = runs + (uint32_t)__popcll(rsm & ((2ull << lane) - 1ull)) - 1u;
-            }
-            runs += (uint32_t)__popcll(rsm);
-            carry = (uint32_t)__shfl((int)c8, 63);
-            rcx_wave_sync();
         }
         if (lane == 0) s_rs[c] = runs;
     }
@@ -548,7 +557,7 @@ __global__ __launch_bounds__(256) void k_dcx_prep(rcx_kargs a)
         {   // list order: the later the last occurrence, the nearer the front
             uint32_t rank = 0;
             for (int d = 0; d < 64; d++) rank += (uint32_t)__shfl((int)cur_last1, d) > cur_last1 ? 1u : 0u;
-            slot[DCX_O_RANK + DCX_RK(lane, c)] = cur_last1 ? (uint8_t)rank : (uint8_t)0xff;
+            slot[DCX_O_RANK + DCX_RK(lane, c)] = cur_last1 ? (uint8_t)(0x80u | rank) : (uint8_t)0xff;      // (bit 7 is always set: see k_dcx_main)
         }
         if (lane == 0) o_rc[c] = basec - 1u;                      // the run position cs - 1 lies in (-1 in front of the block)
         const uint32_t lp = s_lp[c][lane];
@@ -594,31 +603,43 @@ __global__ __launch_bounds__(64) void k_dcx_main(rcx_kargs a)
                 else for (uint32_t t = 0; p + t < n; t++) q[t >> 2] |= (uint32_t)in[p + t] << (8u * (t & 3u));
             }
         }
+        // the sixteen symbols first (sixteen independent table reads), then a step per byte.  A step is straight-line code -- a lane that
+        // stays in its run reads and rewrites its own entries unchanged -- so that its LDS reads (the symbol's entry, its place, the
+        // places of all symbols) are ONE round trip: with branches around them they were four, and a step took ~1500 cycles
+        uint32_t ids[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (uint32_t t = 0; t < 16; t++) ids[t >> 2] |= (uint32_t)s_map[(q[t >> 2] >> (8u * (t & 3u))) & 0xffu] << (8u * (t & 3u));
 #pragma unroll
         for (uint32_t t = 0; t < 16; t++) {
             const uint32_t i = cs + t0 + t;
             const bool act = mine && i < ce;
             const uint32_t c8 = (q[t >> 2] >> (8u * (t & 3u))) & 0xffu;
-            const uint32_t id = s_map[c8];
+            const uint32_t id = (ids[t >> 2] >> (8u * (t & 3u))) & 0xffu;
             const bool sw = act && id != front;                   // a run ends at i - 1, the run of `id` starts at i
             if (!__ballot(sw)) continue;
-            if (sw && front != 0xffu) { s_last[DCX_AT(front, lane)] = i; s_lrun[DCX_AT(front, lane)] = rc; }      // (position i - 1, + 1)
-            uint32_t base1 = 0, lr = 0, r = 0;
-            if (sw) {
-                base1 = s_last[DCX_AT(id, lane)]; lr = s_lrun[DCX_AT(id, lane)]; rc++;
-                r = base1 ? (uint32_t)rankb[DCX_RK(id, lane)] : 64u;           // its place in the list (mtf.rs:63-79); a new symbol pushes the whole list (dc.rs:123-124)
-            }
-            // move to front without a list: every symbol in front of `id` moves one place down -- sixteen places per 16-byte access, four
-            // per instruction (a place is < 64 or 0xff: (x | 0x80) - r keeps its top bit exactly where x >= r, and no byte borrows)
-            const uint32_t rr = r * 0x01010101u;                  // (r = 0 for a lane that stays in its run: nothing moves)
-            for (uint32_t g = 0; g < quads; g++) {
-                rcx_u32x4 v = *(const rcx_u32x4*)&s_rank[(g * DCX_CHUNKS + lane) * 4u];
+            const uint32_t ide = sw ? id : 0u, fre = (sw && front != 0xffu) ? front : ide;
+            // (the open run's entry is closed below; `id` is another symbol, so its entry can be read first)
+            const uint32_t base1r = s_last[DCX_AT(ide, lane)], lrr = s_lrun[DCX_AT(ide, lane)], rb = rankb[DCX_RK(ide, lane)];
+            rcx_u32x4 v[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) v[k] += (~((v[k] | 0x80808080u) - rr) >> 7) & 0x01010101u;
-                *(rcx_u32x4*)&s_rank[(g * DCX_CHUNKS + lane) * 4u] = v;
+            for (int g = 0; g < 4; g++) v[g] = ((uint32_t)g < quads) ? *(const rcx_u32x4*)&s_rank[((uint32_t)g * DCX_CHUNKS + lane) * 4u] : rcx_u32x4{0, 0, 0, 0};
+            const uint32_t base1 = sw ? base1r : 0u, lr = lrr;
+            const uint32_t r = !sw ? 0u : (base1 ? (rb & 0x7fu) : 64u);     // its place in the list (mtf.rs:63-79); a new symbol pushes the whole list (dc.rs:123-124)
+            // move to front without a list: every symbol in front of `id` moves one place down -- sixteen places per 16-byte access, four
+            // per instruction (a byte is 0x80 | place, place < 64, or 0xff: x - r keeps its top bit exactly where place >= r, and no byte borrows)
+            const uint32_t rr = r * 0x01010101u;                  // (r = 0 for a lane that stays in its run: nothing moves)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                if ((uint32_t)g < quads) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[g][k] += (~(v[g][k] - rr) >> 7) & 0x01010101u;
+                    *(rcx_u32x4*)&s_rank[((uint32_t)g * DCX_CHUNKS + lane) * 4u] = v[g];
+                }
             }
             if (sw) {
-                rankb[DCX_RK(id, lane)] = 0;
+                rankb[DCX_RK(id, lane)] = 0x80;
+                if (front != 0xffu) { s_last[DCX_AT(fre, lane)] = i; s_lrun[DCX_AT(fre, lane)] = rc; }     // the open run ends at i - 1 (+ 1)
+                rc++;
                 front = id;
                 if (base1) words[256u + lr] = i - (base1 - 1u) - r - 1u;       // dc.rs:134, stored where EncodeIterator will yield it
                 else words[c8] = i;                                           // first occurrence: init[], dc.rs:126
@@ -633,7 +654,7 @@ __global__ __launch_bounds__(64) void k_dcx_main(rcx_kargs a)
     if (lane == lc && front != 0xffu) { s_last[DCX_AT(front, lane)] = n; s_lrun[DCX_AT(front, lane)] = rc; }
     rcx_wave_sync();
     {
-        const uint32_t my1 = s_last[DCX_AT(lane, lc)], mylr = s_lrun[DCX_AT(lane, lc)], rank = rankb[DCX_RK(lane, lc)];
+        const uint32_t my1 = s_last[DCX_AT(lane, lc)], mylr = s_lrun[DCX_AT(lane, lc)], rank = rankb[DCX_RK(lane, lc)] & 0x7fu;
         if (lane < alpha && my1) words[256u + mylr] = n - (my1 - 1u) - rank - 1u;
     }
     if (lane == 0) { a.status[b] = RCX_OK; a.out_len[b] = 4ull * (256ull + rcl + 1u); if (a.in_used) a.in_used[b] = n; }
