@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void k_dcx_prep(rcx_kargs a)
     const uint32_t nchunks = (n + ch - 1u) / ch;
     for (uint32_t c = w; c < nchunks; c += 4) {
         const uint32_t cs = c * ch, ce = cs + ch < n ? cs + ch : n;
-        s_lp[c][lane] = DCX_NONE; s_lr[c][lane] = 0;
+        s_lp[c][lane] = 0; s_lr[c][lane] = 0;                    // (position + 1 and run + 1 of the symbol's last occurrence in the chunk; 0: none)
         rcx_wave_sync();
         uint32_t runs = 0;
         uint32_t carry = cs ? in[cs - 1] : 0x100u;               // the byte in front of the window
@@ -526,15 +526,12 @@ __global__ __launch_bounds__(256) void k_dcx_prep(rcx_kargs a)
                 const bool rs = valid && c8 != pv;
                 const unsigned long long rsm = __ballot(rs);
                 const uint32_t id = s_map[c8];
-                unsigned long long peers = __ballot(valid);
-#pragma unroll
-                for (int bit = 0; bit < 6; bit++) {
-                    const unsigned long long m = __ballot((id >> bit) & 1u);
-                    peers &= ((id >> bit) & 1u) ? m : ~m;
-                }
-                if (valid && (peers >> lane) == 1ull) {           // the last of its symbol in this window
-                    s_lp[c][id] = p;
-                    s_lr[c][id] = runs + (uint32_t)__popcll(rsm & ((2ull << lane) - 1ull)) - 1u;
+                // a symbol's last occurrence in the chunk ends a run: the lanes in front of a run start (and the chunk's last byte) raise the
+                // symbol's entry -- positions and run numbers only grow, so two LDS max operations replace a match-any ranking of the window
+                const unsigned long long endm = (rsm >> 1) | (1ull << 63);          // lane l ends a run if lane l + 1 starts one (lane 63: decided by the next window; it may raise early, harmlessly)
+                if (valid && (((endm >> lane) & 1ull) || p + 1u == ce)) {
+                    atomicMax(&s_lp[c][id], p + 1u);
+                    atomicMax(&s_lr[c][id], runs + (uint32_t)__popcll(rsm & ((2ull << lane) - 1ull)));    // (run number + 1: the run the chunk begins in is 0)
                 }
                 runs += (uint32_t)__popcll(rsm);
                 carry = (uint32_t)__shfl((int)c8, 63);
@@ -560,8 +557,8 @@ __global__ __launch_bounds__(256) void k_dcx_prep(rcx_kargs a)
             slot[DCX_O_RANK + DCX_RK(lane, c)] = cur_last1 ? (uint8_t)(0x80u | rank) : (uint8_t)0xff;      // (bit 7 is always set: see k_dcx_main)
         }
         if (lane == 0) o_rc[c] = basec - 1u;                      // the run position cs - 1 lies in (-1 in front of the block)
-        const uint32_t lp = s_lp[c][lane];
-        if (lp != DCX_NONE) { cur_last1 = lp + 1u; cur_lr = basec + s_lr[c][lane]; }
+        const uint32_t lp1 = s_lp[c][lane];
+        if (lp1) { cur_last1 = lp1; cur_lr = basec + s_lr[c][lane] - 1u; }
         basec += s_rs[c];
     }
     for (int k = 0; k < 4; k++) slot[DCX_O_MAP + lane + 64 * k] = s_map[lane + 64 * k];
