@@ -5,6 +5,7 @@ import of anything under oracle/.
 """
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RCX_AB=1 loads the A/B build (csrc/librcx_ab.so, -DRCX_AB_VARIANTS: earlier kernel generations, profiling
@@ -61,6 +62,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("rust_compress_amd: %s is missing -- build it with `python __graft_entry__.py build` "
                                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        # PyTorch-ROCm ships its own libamdhip64 and this package hands torch's device pointers and streams to librcx.so: both must
+        # live on ONE HIP runtime, which they do when torch is in the process first (the loader then resolves librcx.so's dependency
+        # to the copy already mapped).  Loaded the other way round, rcx_ctx_create found "no HIP device" on a box with one.
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         L.rcx_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.rcx_ctx_destroy.argtypes = [C.c_void_p]
