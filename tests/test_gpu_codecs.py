@@ -170,6 +170,7 @@ def test_dc_encode_lane_per_chunk(ctx, oracle):
     raws += [b"a" * 10000, b"ab" * 5000, bytes(rng.integers(0, 64, 8192, dtype=np.uint8)), bytes(rng.integers(0, 64, 8193, dtype=np.uint8)),
              bytes(rng.integers(0, 3, 12345, dtype=np.uint8)) + bytes(range(3, 64))]
     raws += [bytes(rng.integers(0, 65, 9000, dtype=np.uint8)), synth.gen("rand", 10000, 5).tobytes(), synth.gen("text", 5000, 6).tobytes(), b""]
+    raws += [synth.gen("text", 4189000, 8).tobytes(), synth.gen("runs", 4200000, 9).tobytes()]        # chunks of 64 K positions
     want = [oracle.dc_encode(r).tobytes() for r in raws]
     for variant in (0, 1):
         ctx.set_variant(N.DC_ENCODE, variant)
