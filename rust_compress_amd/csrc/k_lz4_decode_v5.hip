@@ -181,7 +181,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
             }
         } else if (lit16) { g0 = *(const rcx_u32x4_u*)(in + src); if (L > 16) g1 = *(const rcx_u32x4_u*)(in + src + 16); }
         rcx_u32x4 f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0}, f2 = {0, 0, 0, 0}, f3 = {0, 0, 0, 0};
-        const bool far16 = isfar && (uint64_t)slo + (uint32_t)B::MCAP <= (uint64_t)cap;
+        const bool far16 = isfar && M <= (uint32_t)B::MCAP && (uint64_t)slo + (uint32_t)B::MCAP <= (uint64_t)cap;      // (k_lz4_decode_v8 batches runs of up to 255 bytes: if one is ever outside the window, byte loads)
         const bool farb = isfar && !far16;
         if (far16) {
             f0 = *(const rcx_u32x4_u*)(out + slo);

@@ -298,7 +298,10 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
         V8P_T0();
         fields(tp, on, L, M, off, src, perr);
         V8P_ADD(3);
-        const unsigned long long stop = __ballot(on && (perr != 0 || L > (uint32_t)B::LCAP || M > (uint32_t)B::MCAP));
+        // (a long match with a short period -- a run -- stays in the batch: its lane fills it 16 bytes a round from inside the window, where
+        // a stop per run cut a batch of G-runs to ~14 sequences: 7 % of its runs are longer than 64 bytes)
+        const bool longrun = M > (uint32_t)B::MCAP && M <= 255u && off != 0u && off < 16u;
+        const unsigned long long stop = __ballot(on && (perr != 0 || L > (uint32_t)B::LCAP || (M > (uint32_t)B::MCAP && !longrun)));
         int nt = (int)m, why = B::GO, gerr = 0;                          // nt: tokens that become entries
         uint32_t gL = 0, gM = 0, goff = 0, gsrc = 0;
         int g = -1;
