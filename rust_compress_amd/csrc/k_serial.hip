@@ -658,7 +658,7 @@ __global__ __launch_bounds__(64) void k_dcx_main(rcx_kargs a)
 }
 
 // dc.rs:199-229 driven as decode_simple :236-252; returns the status
-template <class LT>
+template <bool CTX, class LT>
 __device__ __forceinline__ int dc_decode_steps(LT& L, SeqWin<uint32_t>& wwin, uint32_t& i, uint32_t n, uint32_t A, uint32_t& di, uint32_t nwords, uint8_t* out, unsigned lane,
                                                uint32_t* ctxo = nullptr, uint8_t* ranks = nullptr)
 {
@@ -666,9 +666,16 @@ __device__ __forceinline__ int dc_decode_steps(LT& L, SeqWin<uint32_t>& wwin, ui
         const uint32_t sym = L.sym_at(0);
         const uint32_t stop = L.val_at(1);
         if (stop > n) return RCX_E_MALFORMED;                  // output[i] index panic
-        for (uint32_t t = i + lane; t < stop; t += 64) out[t] = (uint8_t)sym;
+        {   // the run: one predicated store (runs are ~5 bytes); a loop only where it is longer than the wave
+            const uint32_t t0 = i + lane;
+            if (t0 < stop) out[t0] = (uint8_t)sym;
+            if (stop > i + 64u) {                                // (uniform)
+#pragma unroll 1
+                for (uint32_t t = t0 + 64u; t < stop; t += 64) out[t] = (uint8_t)sym;
+            }
+        }
         if (stop > i) i = stop;
-        if (ctxo && lane == 0) {                               // Context::new(sym, ranks[sym], n + 1 - i), :208: what the distance callback is handed
+        if (CTX && lane == 0) {                                // Context::new(sym, ranks[sym], n + 1 - i), :208: what the distance callback is handed
             ctxo[2 * (di - 256u)] = sym | ((uint32_t)ranks[sym] << 8);
             ctxo[2 * (di - 256u) + 1] = n + 1u - i;
         }
@@ -680,7 +687,7 @@ __device__ __forceinline__ int dc_decode_steps(LT& L, SeqWin<uint32_t>& wwin, ui
         const uint32_t future = (uint32_t)future64;
         const uint32_t rank = L.first_fit(future, A);          // :214-218
         L.back_v(rank, sym, future + rank - 1);                // lst[0..rank-2] = lst[1..rank-1]; lst[rank-1] = sym, :225-227
-        if (ctxo && lane == 0) ranks[sym] = (uint8_t)(rank - 1u);                  // :228
+        if (CTX && lane == 0) ranks[sym] = (uint8_t)(rank - 1u);                   // :228
     }
     return RCX_OK;
 }
@@ -730,7 +737,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_decode(rcx_kargs a, int withc
         uint32_t cnt = 0;
         bool absent_bad = false;                               // :230 for the symbols the loop never touches
         for (int k = 0; k < 4; k++) cnt += (next[lane + 64 * k] < n) ? 1u : 0u;
-        A = rcx_wave_sum(cnt);
+        A = RCX_UNI(rcx_wave_sum(cnt));                       // (uniform, and SAID so: `i = n` below depends on it, and a loop counter the compiler takes
+                                                               // for divergent turned the whole decode loop into exec-masked code with its counters in VGPRs)
         for (int k = 0; k < 4; k++) { const uint32_t x = next[lane + 64 * k]; absent_bad = absent_bad || (x >= n && x >= n + A); }
         rcx_wave_sync();
         if (A <= 1) {                                          // :180-187 redundant alphabet: no distance is read
@@ -743,12 +751,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_dc_decode(rcx_kargs a, int withc
         auto check = [&](uint32_t, uint32_t, uint32_t x) { bad = bad || x < n || x >= n + A; };           // :230 assert, listed symbols
         if (A <= 64) {                                         // one entry per lane (v = the symbol's next occurrence)
             DcRegs1 L; L.lane = lane; L.sy = lst[lane]; L.v = lane < A ? next[lst[lane]] : 0xffffffffu;
-            st = dc_decode_steps(L, wwin, i, n, A, di, nwords, out, lane, ctxo, ranks);
+            st = withctx ? dc_decode_steps<true>(L, wwin, i, n, A, di, nwords, out, lane, ctxo, ranks) : dc_decode_steps<false>(L, wwin, i, n, A, di, nwords, out, lane);
             L.each(A, check);
         } else {
             DcRegs4 L; L.lane = lane; L.w = *(const uint32_t*)(lst + 4 * lane);
             for (int k = 0; k < 4; k++) L.v[k] = (4u * lane + (uint32_t)k < A) ? next[lst[4 * lane + k]] : 0xffffffffu;
-            st = dc_decode_steps(L, wwin, i, n, A, di, nwords, out, lane, ctxo, ranks);
+            st = withctx ? dc_decode_steps<true>(L, wwin, i, n, A, di, nwords, out, lane, ctxo, ranks) : dc_decode_steps<false>(L, wwin, i, n, A, di, nwords, out, lane);
             L.each(A, check);
         }
         if (!st && A > 1 && __ballot(bad)) st = RCX_E_MALFORMED;
