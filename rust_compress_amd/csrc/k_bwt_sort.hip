@@ -436,15 +436,37 @@ struct BwsLocal {
 
     __device__ __forceinline__ void sync() const { if (NW == 1) rcx_wave_sync(); else __syncthreads(); }
 
-    __device__ void run(const BwsState& s, const BwsSeg sg, uint32_t top_shift)
+    // The NEXT group's keys and suffixes are requested while this one is sorted, and before this one's results are stored: on gfx9 a
+    // wait for a load also sits out every OLDER store (one counter), so a group that loaded its input after the previous group's
+    // scattered stores waited for those to drain at its first barrier.
+    K pk[MAXSTEP]; uint32_t pv[MAXSTEP]; uint32_t pfirst;
+    __device__ __forceinline__ void prefetch(const BwsState& s, const BwsSeg sg)
     {
-        const uint32_t len = sg.len, T = 64u * NW;
-        const uint32_t shift = sg.info & 0xffu;                              // bits [0, shift + 8) of the key are still unsorted
+        const uint32_t T = 64u * NW;
         const int src = (int)((sg.info >> 8) & 1u);
         const K* ks = bws_keys<K>(s, src) + sg.start;
         const uint32_t* ss = bws_sa(s, src) + sg.start;
-        const bool whole = (ss[0] & BWS_RV) != 0;                            // a group an earlier round's sort made (not a bin of this round's radix levels)
-        for (uint32_t i = t; i < len; i += T) { key[i] = ks[i]; val[i] = ss[i] & BWS_IDX; pa[i] = (uint16_t)i; }
+#pragma unroll
+        for (uint32_t k = 0; k < MAXSTEP; k++) {
+            const uint32_t i = t + k * T;
+            pk[k] = 0; pv[k] = 0;
+            if (i < sg.len) { pk[k] = ks[i]; pv[k] = ss[i]; }
+        }
+        pfirst = ss[0];
+    }
+
+    // sorts the group whose input prefetch() has requested; `more`: `nx` is the group after it
+    __device__ void run(const BwsState& s, const BwsSeg sg, uint32_t top_shift, bool more, const BwsSeg nx)
+    {
+        const uint32_t len = sg.len, T = 64u * NW;
+        const uint32_t shift = sg.info & 0xffu;                              // bits [0, shift + 8) of the key are still unsorted
+        const bool whole = (pfirst & BWS_RV) != 0;                           // a group an earlier round's sort made (not a bin of this round's radix levels)
+#pragma unroll
+        for (uint32_t k = 0; k < MAXSTEP; k++) {
+            const uint32_t i = t + k * T;
+            if (i < len) { key[i] = pk[k]; val[i] = pv[k] & BWS_IDX; pa[i] = (uint16_t)i; }
+        }
+        if (more) prefetch(s, nx);
         const uint32_t cs = (((len + NW - 1u) / NW) + 63u) & ~63u;           // a wave's contiguous share
         const uint32_t w0 = w * cs, w1 = (w0 + cs < len) ? w0 + cs : len;
         sync();
@@ -587,7 +609,20 @@ __global__ __launch_bounds__(256, BWS_LW_OCC) void k_bws_local_wave(BwsState s, 
     L.key = s_key + BWS_LWAVE * wave; L.val = s_val + BWS_LWAVE * wave; L.pa = s_pa + BWS_LWAVE * wave; L.pb = s_pb + BWS_LWAVE * wave;
     L.hist = s_hist[wave]; L.bits = s_hist[wave] + 128; L.misc = nullptr;
     L.t = lane; L.w = 0; L.lane = lane;
-    for (uint32_t e = blockIdx.x * 4u + wave; e < nseg; e += gridDim.x * 4u) L.run(s, s.local[e], top_shift);
+    {
+        uint32_t e = blockIdx.x * 4u + wave;
+        const uint32_t step = gridDim.x * 4u;
+        BwsSeg sg{0, 0, 0}, nx{0, 0, 0};
+        if (e < nseg) { sg = s.local[e]; L.prefetch(s, sg); }
+        if (e + step < nseg) nx = s.local[e + step];
+        while (e < nseg) {
+            const bool more = e + step < nseg;
+            BwsSeg nx2{0, 0, 0};                                 // (a descriptor is read two groups ahead: used one group ahead, it would be waited for behind this group's stores)
+            if (e + 2u * step < nseg) nx2 = s.local[e + 2u * step];
+            L.run(s, sg, top_shift, more, nx);
+            sg = nx; nx = nx2; e += step;
+        }
+    }
     Q.flush(s);
 }
 template <class K>
@@ -604,7 +639,19 @@ __global__ __launch_bounds__(256) void k_bws_local_wg(BwsState s, uint32_t top_s
     BwsLocal<K, 4> L; L.Q = &Q;
     L.key = s_key; L.val = s_val; L.pa = s_pa; L.pb = s_pb; L.hist = &s_hist[0][0]; L.bits = &s_hist[0][0] + 128; L.misc = s_misc;
     L.t = threadIdx.x; L.w = threadIdx.x >> 6; L.lane = threadIdx.x & 63u;
-    for (uint32_t e = blockIdx.x; e < nsegw; e += gridDim.x) L.run(s, s.localw[e], top_shift);
+    {
+        uint32_t e = blockIdx.x;
+        BwsSeg sg{0, 0, 0}, nx{0, 0, 0};
+        if (e < nsegw) { sg = s.localw[e]; L.prefetch(s, sg); }
+        if (e + gridDim.x < nsegw) nx = s.localw[e + gridDim.x];
+        while (e < nsegw) {
+            const bool more = e + gridDim.x < nsegw;
+            BwsSeg nx2{0, 0, 0};
+            if (e + 2u * gridDim.x < nsegw) nx2 = s.localw[e + 2u * gridDim.x];
+            L.run(s, sg, top_shift, more, nx);
+            sg = nx; nx = nx2; e += gridDim.x;
+        }
+    }
     Q.flush(s);
 }
 
