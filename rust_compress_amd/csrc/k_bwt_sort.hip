@@ -711,16 +711,18 @@ __device__ __forceinline__ void bws_dense_window(const BwsState& s, uint32_t j0,
         // small groups only (the usual case after the first rounds): a rank sort, 2-3 ds_bpermute per member of the largest group
         const uint32_t klo = (uint32_t)key, khi = sizeof(K) == 8 ? (uint32_t)((uint64_t)key >> 32) : 0u;
         uint32_t less = 0, lt = 0, eq = 0;
+        // (no branch in the body -- a lane outside its group adds zeros -- and four steps per trip: their ds_bpermute round trips overlap;
+        // one step per trip waited ~120 cycles for each)
+#pragma unroll 4
         for (uint32_t t = 0; t < maxlen; t++) {
             const uint32_t srcl = gs + t;
             const int pa = (int)((srcl & 63u) << 2);
             const uint32_t ol = (uint32_t)__builtin_amdgcn_ds_bpermute(pa, (int)klo);
             const uint32_t oh = sizeof(K) == 8 ? (uint32_t)__builtin_amdgcn_ds_bpermute(pa, (int)khi) : 0u;
-            if (mine && srcl < ge) {
-                const bool l = oh < khi || (oh == khi && ol < klo), e = oh == khi && ol == klo;
-                lt += l ? 1u : 0u; eq += e ? 1u : 0u;
-                less += (l || (e && srcl < lane)) ? 1u : 0u;       // equal keys keep the order they stand in (one ds_bpermute less per step)
-            }
+            const bool on = mine && srcl < ge;
+            const bool l = on && (oh < khi || (oh == khi && ol < klo)), e = on && oh == khi && ol == klo;
+            lt += l ? 1u : 0u; eq += e ? 1u : 0u;
+            less += (l || (e && srcl < lane)) ? 1u : 0u;           // equal keys keep the order they stand in (one ds_bpermute less per step)
         }
         if (mine) {
             const bool single = eq == 1u;
@@ -760,10 +762,11 @@ __global__ __launch_bounds__(256) void k_bws_dense(BwsState s, uint32_t off)
     // workgroups resident on it at any time sit in two or three blocks and their scattered rank[] stores (one per suffix moved,
     // anywhere in the block's 1 MiB) meet in that L2 instead of leaving it as partial lines.  (gridDim.x is a multiple of 8.)
     const uint32_t vwg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const uint32_t w0 = (vwg * 4u + (threadIdx.x >> 6)) * BWS_DW;                      // first window (in the grid's own numbering)
-    if ((uint64_t)w0 * 64u >= (uint64_t)s.n + 64u) return;
+    const uint32_t w0 = (vwg * 4u + RCX_UNI(threadIdx.x >> 6)) * BWS_DW;               // first window (in the grid's own numbering); uniform, and said so:
+    if ((uint64_t)w0 * 64u >= (uint64_t)s.n + 64u) return;                           // the window loop below is scalar code then
     uint8_t* act = s.act[s.rs * 2u + (off ? 1u : 0u)];
-    const unsigned long long f = *(const unsigned long long*)(act + w0);
+    const unsigned long long fv = *(const unsigned long long*)(act + w0);
+    const unsigned long long f = (unsigned long long)RCX_UNI((uint32_t)fv) | ((unsigned long long)RCX_UNI((uint32_t)(fv >> 32)) << 32);
     if (!f) return;
     for (uint32_t k = 0; k < BWS_DW; k++) {
         if (!((f >> (8u * k)) & 0xffu)) continue;

@@ -46,14 +46,18 @@ __device__ __forceinline__ uint32_t rcx_wave_incl_scan(uint32_t v)
     v += RCX_DPP0(v, 0x143, 0xc);      // row_bcast:31 into rows 2 and 3
     return v;
 }
+// wave64 maximum, uniform (an SGPR): the same six DPP steps as the scan and one v_readlane -- the butterfly over ds_bpermute it replaces
+// was six dependent LDS-crossbar round trips (~700 cycles on the critical path of every k_bws_dense window)
 __device__ __forceinline__ uint32_t rcx_wave_max(uint32_t v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        uint32_t t = __shfl_xor(v, d);
-        v = t > v ? t : v;
-    }
-    return v;
+    uint32_t t;
+    t = RCX_DPP0(v, 0x111, 0xf); v = t > v ? t : v;
+    t = RCX_DPP0(v, 0x112, 0xf); v = t > v ? t : v;
+    t = RCX_DPP0(v, 0x114, 0xf); v = t > v ? t : v;
+    t = RCX_DPP0(v, 0x118, 0xf); v = t > v ? t : v;
+    t = RCX_DPP0(v, 0x142, 0xa); v = t > v ? t : v;
+    t = RCX_DPP0(v, 0x143, 0xc); v = t > v ? t : v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ uint32_t rcx_wave_sum(uint32_t v)
 {
