@@ -110,7 +110,7 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
     __shared__ uint16_t s_perm[BWS_FT];
     __shared__ uint8_t s_dig[BWS_FT];
     __shared__ uint32_t s_one;
-    const uint32_t b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x, wave = RCX_UNI(tid >> 6), lane = tid & 63u;      // (the wave's number is uniform: said so, what is computed from it stays on the scalar unit)
     const uint32_t n = (uint32_t)a.in_len[b];
     if (n == 0) return;
     const uint8_t* T = a.in_base + a.in_off[b];

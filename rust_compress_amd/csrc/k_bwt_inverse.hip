@@ -436,7 +436,7 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwti_table(rcx_kargs a, uint32
     const uint32_t slot = blockIdx.x;
     const uint32_t b = block0 + slot;
     if (b >= a.nblocks) return;
-    const unsigned tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    const unsigned tid = threadIdx.x, w = RCX_UNI(tid >> 6), lane = tid & 63u;
     const uint8_t* L = a.in_base + a.in_off[b];
     const uint32_t n = (uint32_t)a.in_len[b];
     const uint32_t origin = a.aux ? a.aux[b] : 0u;

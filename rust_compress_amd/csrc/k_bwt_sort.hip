@@ -298,7 +298,7 @@ __global__ __launch_bounds__(512) void k_bws_partition(BwsState s, int level, ui
     BwsSeg* lnext = s.large[(level + 1) & 1];
     uint32_t* clnext = &s.cnt[(level + 1) & 1];
     const uint32_t nseg = s.cnt[level & 1];
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t tid = threadIdx.x, wave = RCX_UNI(tid >> 6), lane = tid & 63u;
     {
         for (uint32_t e = blockIdx.x; e < nseg; e += gridDim.x) {
             const BwsSeg sg = list[e];

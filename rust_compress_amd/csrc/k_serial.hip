@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void k_dcx_prep(rcx_kargs a)
     __shared__ uint32_t s_alpha;
     const uint32_t b = blockIdx.x;
     if (b >= a.nblocks) return;
-    const unsigned tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    const unsigned tid = threadIdx.x, w = RCX_UNI(tid >> 6), lane = tid & 63u;
     const uint8_t* in = a.in_base + a.in_off[b];
     const uint32_t n = (uint32_t)a.in_len[b];
     uint32_t* words = (uint32_t*)(a.out_base + a.out_off[b]);
