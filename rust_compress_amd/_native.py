@@ -65,7 +65,8 @@ def lib():
         # PyTorch-ROCm ships its own libamdhip64 and this package hands torch's device pointers and streams to librcx.so: both must
         # live on ONE HIP runtime, which they do when torch is in the process first (the loader then resolves librcx.so's dependency
         # to the copy already mapped).  Loaded the other way round, rcx_ctx_create found "no HIP device" on a box with one.
-        if "torch" not in sys.modules:
+        # RCX_NO_TORCH_PRELOAD=1 skips this for pure-ctypes users who never hand over torch pointers (no multi-second import).
+        if "torch" not in sys.modules and not os.environ.get("RCX_NO_TORCH_PRELOAD"):
             try:
                 import torch  # noqa: F401
             except ImportError:

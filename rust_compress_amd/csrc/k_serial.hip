@@ -675,7 +675,9 @@ __device__ __forceinline__ int dc_decode_steps(LT& L, SeqWin<uint32_t>& wwin, ui
             }
         }
         if (stop > i) i = stop;
-        if (CTX && lane == 0) {                                // Context::new(sym, ranks[sym], n + 1 - i), :208: what the distance callback is handed
+        if (CTX && lane == 0 && di < nwords) {                 // Context::new(sym, ranks[sym], n + 1 - i), :208: what the distance callback is handed
+            // (di == nwords: the callback finds no distance and the step ends in RCX_E_EOF below -- slot (nwords - 256) lies past
+            //  the coff + 8 * (nwords - 256) bytes the caller provides)
             ctxo[2 * (di - 256u)] = sym | ((uint32_t)ranks[sym] << 8);
             ctxo[2 * (di - 256u) + 1] = n + 1u - i;
         }

@@ -138,7 +138,7 @@ extern "C" uint64_t rcx_scratch_bytes(int codec, uint32_t nblocks, uint64_t max_
     switch (codec) {
     case RCX_LZ4_ENCODE: return rcx_tu_lz4_encode_scratch(nblocks);
     case RCX_BWT_FORWARD: return rcx_tu_bwt_forward_scratch(nblocks, max_block);
-    case RCX_DC_ENCODE: return rcx_tu_dc_encode_scratch(nblocks);       // (optional: without it the wave-per-block kernel encodes every block)
+    case RCX_DC_ENCODE: return rcx_tu_dc_encode_scratch(nblocks, max_block);   // (optional: without it the wave-per-block kernel encodes every block; 0 when no block is long enough for the chunk path)
     case RCX_BWT_INVERSE: case RCX_BWT_INVERSE_MINIMAL: return rcx_tu_bwt_inverse_scratch(nblocks, max_block);
     case RCX_INFLATE: case RCX_ZLIB_DECODE: return rcx_tu_inflate_scratch(nblocks);
     case RCX_GZIP_DECODE: return rcx_tu_gzip_scratch(nblocks) + rcx_tu_inflate_scratch(nblocks) + 512;   // + the carve's alignment slack
@@ -147,7 +147,8 @@ extern "C" uint64_t rcx_scratch_bytes(int codec, uint32_t nblocks, uint64_t max_
 }
 
 // ---- kernel dispatch (the kernels and their launch code live in the tu_*.hip translation units) ------------------
-static int launch_codec(rcx_ctx* c, int codec, rcx_kargs& k)
+// param_over >= 0 replaces the context's codec parameter for this one launch (the *_ctx_batch entry points' `withctx`)
+static int launch_codec(rcx_ctx* c, int codec, rcx_kargs& k, int param_over = -1)
 {
     hipStream_t s = c->stream;
     const uint32_t n = k.nblocks;
@@ -210,7 +211,7 @@ static int launch_codec(rcx_ctx* c, int codec, rcx_kargs& k)
     case RCX_MTF_ENCODE: case RCX_MTF_DECODE: case RCX_DC_ENCODE: case RCX_DC_DECODE:
     case RCX_ARI_PROXY_ENCODE: case RCX_ARI_PROXY_DECODE:
     case RCX_ARI_BYTE_ENCODE: case RCX_ARI_BYTE_DECODE: case RCX_RLE_ENCODE: case RCX_RLE_DECODE:
-        rcx_tu_serial(s, codec, k, v, c->param[codec]);
+        rcx_tu_serial(s, codec, k, v, param_over >= 0 ? (uint32_t)param_over : c->param[codec]);
         break;
     default:
         c->err = "unknown codec";
@@ -237,7 +238,7 @@ extern "C" int rcx_launch_dev(rcx_ctx* c, int codec, const rcx_dev_batch* b, voi
 // Descriptor block layout in HBM (all 8-byte aligned):
 //   in_off[n] in_len[n] out_off[n] out_cap[n] n_out[n] | out_len[n] in_used[n] | status[n] aux[n]
 static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* aux_in, uint32_t* aux_out,
-                     const uint64_t* n_out, bool needs_out)
+                     const uint64_t* n_out, bool needs_out, int param_over = -1)
 {
     if (!c) return RCX_RC_BAD_ARG;
     if (!b || (b->nblocks && (!b->in_off || !b->in_len || !b->status))) { c->err = "null descriptor array"; return RCX_RC_BAD_ARG; }
@@ -302,10 +303,18 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
     k.out_len = d64 + 5 * N; k.in_used = d64 + 6 * N;
     k.status = (int32_t*)(d64 + 7 * N); k.aux = (uint32_t*)(k.status + N);
     k.nblocks = n;
-    const uint64_t sb = rcx_scratch_bytes(codec, n, max_block);
-    HIPCHK(c, c->d_scratch.reserve(sb + 64));
-    k.scratch = c->d_scratch.p; k.scratch_bytes = c->d_scratch.cap;
-    int rc = launch_codec(c, codec, k);
+    uint64_t sb = rcx_scratch_bytes(codec, n, max_block);
+    if (codec == RCX_DC_ENCODE && param_over > 0) sb = 0;          // withctx: the wave-per-block kernel encodes, no chunk states
+    if (codec == RCX_DC_ENCODE && sb && c->d_scratch.reserve(sb + 64) != hipSuccess) {
+        // the chunk states are optional (37 KiB a block): a batch too large for them falls back to the wave-per-block kernel
+        (void)hipGetLastError();
+        k.scratch = nullptr; k.scratch_bytes = 0;
+    } else {
+        HIPCHK(c, c->d_scratch.reserve(sb + 64));
+        k.scratch = c->d_scratch.p; k.scratch_bytes = c->d_scratch.cap;
+        if (codec == RCX_DC_ENCODE && !sb) { k.scratch = nullptr; k.scratch_bytes = 0; }
+    }
+    int rc = launch_codec(c, codec, k, param_over);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(h64 + 5 * N, d64 + 5 * N, 2 * N * 8 + 2 * N * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
@@ -344,18 +353,12 @@ extern "C" int rcx_dc_decode_batch(rcx_ctx* c, const rcx_batch* b, const uint64_
 extern "C" int rcx_dc_encode_ctx_batch(rcx_ctx* c, const rcx_batch* b)
 {
     if (!c) return RCX_RC_BAD_ARG;
-    c->param[RCX_DC_ENCODE] = 1;
-    const int rc = run_batch(c, RCX_DC_ENCODE, b, nullptr, nullptr, nullptr, true);
-    c->param[RCX_DC_ENCODE] = 0;
-    return rc;
+    return run_batch(c, RCX_DC_ENCODE, b, nullptr, nullptr, nullptr, true, 1);
 }
 extern "C" int rcx_dc_decode_ctx_batch(rcx_ctx* c, const rcx_batch* b, const uint64_t* n_out)
 {
     if (!c) return RCX_RC_BAD_ARG;
-    c->param[RCX_DC_DECODE] = 1;
-    const int rc = run_batch(c, RCX_DC_DECODE, b, nullptr, nullptr, n_out, true);
-    c->param[RCX_DC_DECODE] = 0;
-    return rc;
+    return run_batch(c, RCX_DC_DECODE, b, nullptr, nullptr, n_out, true, 1);
 }
 extern "C" int rcx_ari_byte_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_ARI_BYTE_ENCODE, b, nullptr, nullptr, nullptr, true); }
 extern "C" int rcx_ari_byte_decode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_ARI_BYTE_DECODE, b, nullptr, nullptr, nullptr, true); }

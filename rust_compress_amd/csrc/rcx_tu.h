@@ -26,4 +26,4 @@ uint64_t rcx_tu_bwt_forward_scratch(uint32_t nblocks, uint64_t max_block);
 uint64_t rcx_tu_bwt_inverse_scratch(uint32_t nblocks, uint64_t max_block);
 // tu_serial.hip
 void rcx_tu_serial(hipStream_t s, int codec, rcx_kargs& k, int variant, uint32_t param);
-uint64_t rcx_tu_dc_encode_scratch(uint32_t nblocks);
+uint64_t rcx_tu_dc_encode_scratch(uint32_t nblocks, uint64_t max_block);

@@ -78,6 +78,18 @@ def test_mtf_rle_ari_dc(oracle):
         assert y[:n] == r and len(y) == co + 8 * len(oracle.dc_decode(np.frombuffer(e, dtype="<u4"), n, with_ctx=True)[2])
         gotd = np.frombuffer(y[co:], dtype="<u4").reshape(-1, 2)
         assert [(int(a) & 255, (int(a) >> 8) & 255, int(b_)) for a, b_ in gotd] == oracle.dc_decode(np.frombuffer(e, dtype="<u4"), n, with_ctx=True)[2]
+    # distance streams cut short, with contexts: the step that finds no distance ends in EOF and must not write its Context past
+    # the slot (capacity exactly what rcx.h asks for: coff + 8 * (nwords - 256)); simrun's guard checks every byte outside the slots
+    cut, cn = [], []
+    for r, e in zip(raws, enc):
+        k = len(e) // 4 - 256
+        for drop in (1, 2, k // 2, k):
+            if 0 < drop <= k:
+                cut.append(e[: len(e) - 4 * drop]); cn.append(len(r))
+    caps = [((n + 7) & ~7) + 8 * (len(e) // 4 - 256) for n, e in zip(cn, cut)]
+    _, _, _, st, _ = simrun.run(N.DC_DECODE, 1, cut, caps, n_out=np.array(cn, dtype=np.uint64))
+    want = [_oracle_status(oracle.dc_decode, np.frombuffer(e, dtype="<u4"), n) for e, n in zip(cut, cn)]
+    assert list(st) == want and any(want)
 
 
 def test_dc_encode_lane_per_chunk(oracle):
