@@ -153,6 +153,15 @@ int rcx_gzip_decode_batch(rcx_ctx*, const rcx_batch*, uint32_t* flags);
 /* reference: src/bwt/mod.rs:136-219 compute_suffixes + TransformIterator.
  * out block i receives L (n bytes); origin[i] = get_origin(). */
 int rcx_bwt_forward_batch(rcx_ctx*, const rcx_batch*, uint32_t* origin);
+/* reference: src/bwt/mod.rs:136-166 compute_suffixes (pub): the sorted suffix array itself.  out block i receives n
+ * little-endian u32 suffix indices (out_cap >= 4n, the slot 4-byte aligned; out_len = 4n); origin[i] (may be NULL) =
+ * the position of suffix 0, what TransformIterator::get_origin reports for the same array. */
+int rcx_bwt_suffixes_batch(rcx_ctx*, const rcx_batch*, uint32_t* origin);
+/* reference: src/bwt/mod.rs:223-239 compute_inversion_table (pub): in block i = L (n bytes), origin[i]; out block i receives
+ * the n little-endian u32 table entries (out_cap >= 4n, 4-byte aligned; out_len = 4n): table[place(L[origin])] = 0, then
+ * table[place(L[j])] = j + 1 for every other j in order.  status: origin >= n is RCX_E_MALFORMED (the index panic of :230,
+ * also for an empty block). */
+int rcx_bwt_inversion_table_batch(rcx_ctx*, const rcx_batch*, const uint32_t* origin);
 /* reference: src/bwt/mod.rs:223-294 compute_inversion_table + InverseIterator */
 int rcx_bwt_inverse_batch(rcx_ctx*, const rcx_batch*, const uint32_t* origin);
 /* reference: src/bwt/mod.rs:298-315 decode_minimal, what bwt::Decoder runs with extra_mem = false (:397-399): n steps of
@@ -238,7 +247,8 @@ enum rcx_codec {
     RCX_DC_ENCODE, RCX_DC_DECODE, RCX_ARI_BYTE_ENCODE, RCX_ARI_BYTE_DECODE,
     RCX_RLE_ENCODE, RCX_RLE_DECODE, RCX_CRC32, RCX_GZIP_DECODE,
     RCX_ARI_BINARY_ENCODE, RCX_ARI_BINARY_DECODE, RCX_ARI_PROXY_ENCODE, RCX_ARI_PROXY_DECODE,
-    RCX_ARI_APM_ENCODE, RCX_ARI_APM_DECODE, RCX_BWT_INVERSE_MINIMAL, RCX_CODEC_COUNT
+    RCX_ARI_APM_ENCODE, RCX_ARI_APM_DECODE, RCX_BWT_INVERSE_MINIMAL,
+    RCX_BWT_SUFFIXES, RCX_BWT_INVERSION_TABLE, RCX_CODEC_COUNT
 };
 /* scratch bytes (HBM) the codec needs for nblocks blocks of <= max_block bytes.  Required for LZ4 encode, BWT and gzip
  * decode; for RCX_INFLATE / RCX_ZLIB_DECODE it is what the default (wave-per-stream) decoder needs -- without it

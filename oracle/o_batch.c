@@ -36,6 +36,16 @@ static void run_one(job_t* j, uint32_t i)
         st = o_bwt_encode(in, n, out, &origin); olen = n;
         if (j->aux) j->aux[i] = origin;
         break; }
+    case RCX_BWT_SUFFIXES: {
+        if (cap < 4 * n) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
+        st = o_bwt_compute_suffixes(in, n, (uint32_t*)out); olen = 4 * n;
+        if (j->aux) { j->aux[i] = 0; for (size_t q = 0; q < n; q++) if (((uint32_t*)out)[q] == 0) j->aux[i] = (uint32_t)q; }
+        break; }
+    case RCX_BWT_INVERSION_TABLE: {
+        const uint32_t origin = j->aux ? j->aux[i] : 0;
+        if (origin >= n) { st = RCX_E_MALFORMED; break; }
+        if (cap < 4 * n) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
+        st = o_bwt_inversion_table(in, n, origin, (uint32_t*)out); olen = st ? 0 : 4 * n; break; }
     case RCX_BWT_INVERSE:
         if (cap < n) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
         if (n == 0) { olen = 0; break; }

@@ -22,6 +22,28 @@ pub fn decode_simple(input: &[u8], origin: usize) -> Vec<u8> {
     r.out[0].clone()
 }
 
+/// bwt/mod.rs:136-166: the sorted suffix array of `input` into `suf_array` (one kernel call; the reference's generic `SUF`
+/// is any integer type a suffix index fits: `usize`, `u32`, ... through `TryFrom<u32>`).  Panics, as the reference does, when
+/// `suf_array` is shorter than the input (:146) or an index does not fit `SUF` (`NumCast::from(i).unwrap()`).
+pub fn compute_suffixes<SUF: TryFrom<u32>>(input: &[u8], suf_array: &mut [SUF]) {
+    assert!(suf_array.len() >= input.len());
+    let r = run_batch(&[input], &[4 * input.len() as u64], |c, b, o| unsafe { rcx_bwt_suffixes_batch(c, b, o) }).check().unwrap();
+    for (dst, w) in suf_array.iter_mut().zip(r.out[0].chunks_exact(4)) {
+        *dst = SUF::try_from(le32(w)).ok().unwrap();
+    }
+}
+
+/// bwt/mod.rs:223-239: the inversion jump table of the transformed block `input` with `origin` into `table`.
+pub fn compute_inversion_table<SUF: TryFrom<u32>>(input: &[u8], origin: usize, table: &mut [SUF]) {
+    assert_eq!(input.len(), table.len()); // :224
+    assert!(origin < input.len()); // input[origin], :230
+    let og = [origin as u32];
+    let r = run_batch(&[input], &[4 * input.len() as u64], |c, b, _| unsafe { rcx_bwt_inversion_table_batch(c, b, og.as_ptr()) }).check().unwrap();
+    for (dst, w) in table.iter_mut().zip(r.out[0].chunks_exact(4)) {
+        *dst = SUF::try_from(le32(w)).ok().unwrap();
+    }
+}
+
 /// bwt/mod.rs:136-210 in batch-backed form: `encode(input, suf)` returns an iterator over the transformed bytes with the
 /// origin behind it; here the block is transformed by ONE kernel call and the iterator serves the result (there is no suffix
 /// array on the host to hand in: the device sorts in its own scratch).

@@ -103,7 +103,9 @@ pub const RCX_ARI_PROXY_DECODE: c_int = 20;
 pub const RCX_ARI_APM_ENCODE: c_int = 21;
 pub const RCX_ARI_APM_DECODE: c_int = 22;
 pub const RCX_BWT_INVERSE_MINIMAL: c_int = 23;
-pub const RCX_CODEC_COUNT: c_int = 24;
+pub const RCX_BWT_SUFFIXES: c_int = 24;
+pub const RCX_BWT_INVERSION_TABLE: c_int = 25;
+pub const RCX_CODEC_COUNT: c_int = 26;
 
 #[link(name = "rcx")]
 extern "C" {
@@ -126,6 +128,8 @@ extern "C" {
     pub fn rcx_gzip_decode_batch(ctx: *mut rcx_ctx, b: *const rcx_batch, flags: *mut u32) -> c_int;
     // ---- BWT / MTF / DC (src/bwt/mod.rs, mtf.rs, dc.rs)
     pub fn rcx_bwt_forward_batch(ctx: *mut rcx_ctx, b: *const rcx_batch, origin: *mut u32) -> c_int;
+    pub fn rcx_bwt_suffixes_batch(ctx: *mut rcx_ctx, b: *const rcx_batch, origin: *mut u32) -> c_int;
+    pub fn rcx_bwt_inversion_table_batch(ctx: *mut rcx_ctx, b: *const rcx_batch, origin: *const u32) -> c_int;
     pub fn rcx_bwt_inverse_batch(ctx: *mut rcx_ctx, b: *const rcx_batch, origin: *const u32) -> c_int;
     pub fn rcx_bwt_inverse_minimal_batch(ctx: *mut rcx_ctx, b: *const rcx_batch, origin: *const u32) -> c_int;
     pub fn rcx_mtf_encode_batch(ctx: *mut rcx_ctx, b: *const rcx_batch) -> c_int;

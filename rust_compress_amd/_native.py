@@ -20,7 +20,7 @@ INFLATE_VARIANTS = (0, 9, 10, 11, 1) if AB else (0, 9, 10, 11)
 (LZ4_DECODE, LZ4_ENCODE, INFLATE, ZLIB_DECODE, ADLER32, BWT_FORWARD, BWT_INVERSE, MTF_ENCODE, MTF_DECODE,
  DC_ENCODE, DC_DECODE, ARI_BYTE_ENCODE, ARI_BYTE_DECODE, RLE_ENCODE, RLE_DECODE, CRC32, GZIP_DECODE,
  ARI_BINARY_ENCODE, ARI_BINARY_DECODE, ARI_PROXY_ENCODE, ARI_PROXY_DECODE, ARI_APM_ENCODE, ARI_APM_DECODE,
- BWT_INVERSE_MINIMAL, CODEC_COUNT) = range(25)
+ BWT_INVERSE_MINIMAL, BWT_SUFFIXES, BWT_INVERSION_TABLE, CODEC_COUNT) = range(27)
 MEM_HOST, MEM_DEVICE = 0, 1
 # enum rcx_status (the ones Python code names; include/rcx.h has them all)
 E_EOF, E_OUTPUT_TOO_SMALL, E_MALFORMED = 1, 2, 3
@@ -36,6 +36,7 @@ EXPORTS = [
     "rcx_rle_encode_batch", "rcx_rle_decode_batch", "rcx_rle_encode_bound", "rcx_scratch_bytes", "rcx_launch_dev",
     "rcx_ari_binary_encode_batch", "rcx_ari_binary_decode_batch", "rcx_ari_proxy_encode_batch", "rcx_ari_proxy_decode_batch",
     "rcx_ctx_set_param", "rcx_ari_apm_encode_batch", "rcx_ari_apm_decode_batch", "rcx_bwt_inverse_minimal_batch",
+    "rcx_bwt_suffixes_batch", "rcx_bwt_inversion_table_batch",
 ]
 
 
@@ -98,7 +99,8 @@ def lib():
         L.rcx_ctx_set_param.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
         for name in ("rcx_inflate_batch", "rcx_zlib_decode_batch", "rcx_adler32_batch", "rcx_crc32_batch",
                      "rcx_gzip_decode_batch", "rcx_bwt_forward_batch",
-                     "rcx_bwt_inverse_batch", "rcx_bwt_inverse_minimal_batch", "rcx_dc_decode_batch", "rcx_dc_decode_ctx_batch"):
+                     "rcx_bwt_inverse_batch", "rcx_bwt_inverse_minimal_batch", "rcx_dc_decode_batch", "rcx_dc_decode_ctx_batch",
+                     "rcx_bwt_suffixes_batch", "rcx_bwt_inversion_table_batch"):
             getattr(L, name).argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p]
         _lib = L
     return _lib

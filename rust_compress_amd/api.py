@@ -122,6 +122,14 @@ class Context:
     def bwt_forward(self, blobs):
         return self._run_host("rcx_bwt_forward_batch", blobs, [len(b) for b in blobs], extra_out=True)
 
+    def bwt_suffixes(self, blobs):
+        """compute_suffixes (src/bwt/mod.rs:136-166): outputs[i] = the block's suffix array, n little-endian u32; extra[i] = origin."""
+        return self._run_host("rcx_bwt_suffixes_batch", blobs, [4 * len(b) for b in blobs], extra_out=True)
+
+    def bwt_inversion_table(self, blobs, origins):
+        """compute_inversion_table (src/bwt/mod.rs:223-239) of L = blobs[i] with origins[i]: n little-endian u32 entries."""
+        return self._run_host("rcx_bwt_inversion_table_batch", blobs, [4 * len(b) for b in blobs], extra_in=origins)
+
     def bwt_inverse(self, blobs, origins):
         return self._run_host("rcx_bwt_inverse_batch", blobs, [len(b) for b in blobs], extra_in=origins)
 

@@ -435,6 +435,34 @@ class bwt:
         return res.outputs[0], int(res.aux[0])
 
     @staticmethod
+    def compute_suffixes(input, suf_array=None):       # bwt/mod.rs:136-166
+        """The sorted suffix array of `input`.  The reference fills a caller-provided slice (`suf_array: &mut [SUF]`): pass a
+        mutable sequence of len(input) to have it filled in place; the list of indices is returned either way."""
+        input = bytes(input)
+        if suf_array is not None and len(suf_array) < len(input):
+            raise IndexError("suf_array is shorter than the input")          # suf_array[p] index panic, :146
+        out = _check(context().bwt_suffixes([input])).outputs[0]
+        sa = list(struct.unpack("<%dI" % len(input), out))
+        if suf_array is not None:
+            suf_array[:len(sa)] = sa
+        return sa
+
+    @staticmethod
+    def compute_inversion_table(input, origin, table=None):   # bwt/mod.rs:223-239
+        """The inversion jump table of the transformed block `input` with `origin`; fills `table` (len(input) entries, the
+        reference asserts the lengths are equal, :224) when one is given and returns the list."""
+        input = bytes(input)
+        if table is not None and len(table) != len(input):
+            raise AssertionError("input.len() != table.len()")               # assert_eq!, :224
+        if origin >= len(input):
+            raise IndexError("origin out of range")                          # input[origin], :230
+        out = _check(context().bwt_inversion_table([input], [origin])).outputs[0]
+        t = list(struct.unpack("<%dI" % len(input), out))
+        if table is not None:
+            table[:] = t
+        return t
+
+    @staticmethod
     def decode_simple(input, origin):                  # bwt/mod.rs:291-294
         if len(input) == 0:
             return b""

@@ -284,11 +284,35 @@ __global__ void k_bwtf_emit(BwtfArgs a, const uint32_t* sa, uint8_t* out_base, c
         }
     }
 }
-__global__ void k_bwtf_finish(rcx_kargs a)
+// compute_suffixes itself, mod.rs:136-166: the sorted suffix array of the block, a little-endian u32 per suffix (4n bytes, the
+// slot 4-byte aligned); origin (the j with SA[j] == 0) rides in aux as for the transform.  The sorter's SA words index the pass's
+// concatenated text and carry flags: what leaves is the index inside the block.
+__global__ void k_bwtf_emit_sa(BwtfArgs a, const uint32_t* sa, uint8_t* out_base, const uint64_t* out_off, const uint64_t* out_cap, uint32_t* origin)
+{
+    const uint32_t b = blockIdx.y;
+    const uint32_t n = (uint32_t)a.in_len[b];
+    if (out_cap[b] < 4ull * n || ((uintptr_t)(out_base + out_off[b]) & 3u)) return;
+    const uint32_t g0 = a.bstart[b];
+    uint32_t* out = (uint32_t*)(out_base + out_off[b]);
+    for (uint32_t jl = blockIdx.x * blockDim.x + threadIdx.x; jl < n; jl += gridDim.x * blockDim.x) {
+        const uint32_t i = (sa[g0 + jl] & BWS_IDX) - g0;
+        out[jl] = i;
+        if (i == 0 && origin) origin[b] = jl;
+    }
+}
+__global__ void k_bwtf_finish(rcx_kargs a, uint32_t sa_words)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.nblocks) return;
     const uint64_t n = a.in_len[b];
+    if (sa_words) {
+        const bool ok = a.out_cap[b] >= 4 * n && (((uintptr_t)(a.out_base + a.out_off[b]) & 3u) == 0 || n == 0);
+        a.status[b] = ok ? RCX_OK : RCX_E_OUTPUT_TOO_SMALL;
+        a.out_len[b] = ok ? 4 * n : 0;
+        if (a.in_used) a.in_used[b] = n;
+        if (n == 0 && a.aux) a.aux[b] = 0;
+        return;
+    }
     const bool ok = a.out_cap[b] >= n;
     a.status[b] = ok ? RCX_OK : RCX_E_OUTPUT_TOO_SMALL;
     a.out_len[b] = ok ? n : 0;
@@ -316,7 +340,7 @@ static uint64_t bwt_forward_scratch_bytes(uint32_t nblocks, uint64_t max_block)
     return 28 * N + 5 * (N / BWS_WAVE + nblocks + 1024) * sizeof(BwsSeg) + 2 * (N / 16 + 4096) * sizeof(BwsSeg) + 2 * (N / BWS_LWAVE + nblocks + 1024) * sizeof(BwsSeg) + (uint64_t)(nblocks + 2) * 4 + 4 * (N / 64 + 512) + (N / 256 + nblocks + 1024) + (1ull << 20);
 }
 
-static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::string& err)
+static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::string& err, bool sa_words = false)
 {
     const uint32_t pass_blocks = variant > 0 ? (uint32_t)variant : 0xffffffffu;      // A/B knob: at most `variant` blocks per sorting pass
     const uint32_t nb_all = k.nblocks;
@@ -428,9 +452,10 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                 h = round == 0 ? nsym : 2 * h;
             }
             if (!converged) { err = "bwt forward: did not converge"; return RCX_RC_HIP_ERROR; }
-            hipLaunchKernelGGL(k_bwtf_emit, dim3(gxg, nb), dim3(256), 0, s, fa, st.saA, kk.out_base, kk.out_off, kk.out_cap, kk.aux);
+            if (sa_words) hipLaunchKernelGGL(k_bwtf_emit_sa, dim3(gx ? gx : 1, nb), dim3(256), 0, s, fa, st.saA, kk.out_base, kk.out_off, kk.out_cap, kk.aux);
+            else hipLaunchKernelGGL(k_bwtf_emit, dim3(gxg, nb), dim3(256), 0, s, fa, st.saA, kk.out_base, kk.out_off, kk.out_cap, kk.aux);
         }
-        hipLaunchKernelGGL(k_bwtf_finish, dim3((nb + 255) / 256), dim3(256), 0, s, kk);
+        hipLaunchKernelGGL(k_bwtf_finish, dim3((nb + 255) / 256), dim3(256), 0, s, kk, sa_words ? 1u : 0u);
         lo += nb;
     }
     return RCX_RC_OK;

@@ -831,6 +831,79 @@ __global__ __launch_bounds__(256) void k_bwti3_long(rcx_kargs a, uint32_t block0
     }
 }
 
+// compute_inversion_table itself, mod.rs:223-239: table[place(L[origin])] = 0, then table[place(L[i])] = i + 1 for the other i in
+// order -- place() hands out a symbol's slots first come, first served, so origin takes the first slot of its symbol.  One
+// workgroup per block, a wave per slice of L: count per (wave, symbol), prefix over (symbol major, wave minor), stable scatter
+// with the rank among equal bytes of a step from ballots.  Output: a little-endian u32 per entry (4n bytes, slot 4-byte aligned).
+__global__ __launch_bounds__(BWTI_THREADS) void k_bwt_inversion_table(rcx_kargs a)
+{
+    __shared__ uint32_t s_cnt[BWTI_WAVES][256];
+    __shared__ uint32_t s_tot[256];
+    const uint32_t b = blockIdx.x;
+    if (b >= a.nblocks) return;
+    const unsigned tid = threadIdx.x, w = RCX_UNI(tid >> 6), lane = tid & 63u;
+    const uint8_t* L = a.in_base + a.in_off[b];
+    const uint32_t n = (uint32_t)a.in_len[b];
+    const uint32_t origin = a.aux ? a.aux[b] : 0u;
+    uint32_t* table = (uint32_t*)(a.out_base + a.out_off[b]);
+    if (origin >= n || a.out_cap[b] < 4ull * n || ((uintptr_t)table & 3u)) {
+        if (tid == 0) {          // input[origin] is an index panic (:230), also for the empty block
+            a.status[b] = origin >= n ? RCX_E_MALFORMED : RCX_E_OUTPUT_TOO_SMALL;
+            a.out_len[b] = 0; if (a.in_used) a.in_used[b] = n;
+        }
+        return;
+    }
+    for (unsigned i = tid; i < BWTI_WAVES * 256; i += BWTI_THREADS) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t per = ((n + BWTI_WAVES - 1) / BWTI_WAVES + 63u) & ~63u;
+    const uint32_t w0 = w * per < n ? w * per : n, w1 = w0 + per < n ? w0 + per : n;
+    for (uint32_t i0 = w0; i0 < w1; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const bool valid = i < w1 && i != origin;
+        const uint32_t c = i < w1 ? L[i] : 0u;
+        const unsigned long long peers = BWS_PEERS(valid, c);
+        if (valid && (peers & ((1ull << lane) - 1ull)) == 0) s_cnt[w][c] += (uint32_t)__popcll(peers);
+        rcx_wave_sync();
+    }
+    __syncthreads();
+    const uint32_t osym = L[origin];
+    if (tid < 256) {
+        uint32_t tot = tid == osym ? 1u : 0u;
+        for (int ww = 0; ww < BWTI_WAVES; ww++) tot += s_cnt[ww][tid];
+        s_tot[tid] = tot;
+    }
+    __syncthreads();
+    if (tid == 0) { uint32_t acc = 0; for (int c = 0; c < 256; c++) { const uint32_t t = s_tot[c]; s_tot[c] = acc; acc += t; } }
+    __syncthreads();
+    if (tid < 256) {
+        uint32_t acc = s_tot[tid] + (tid == osym ? 1u : 0u);             // slot 0 of origin's symbol is origin's
+        for (int ww = 0; ww < BWTI_WAVES; ww++) { const uint32_t t = s_cnt[ww][tid]; s_cnt[ww][tid] = acc; acc += t; }
+    }
+    __syncthreads();
+    if (tid == 0) table[s_tot[osym]] = 0u;
+    for (uint32_t i0 = w0; i0 < w1; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const bool valid = i < w1 && i != origin;
+        const uint32_t c = i < w1 ? L[i] : 0u;
+        const unsigned long long peers = BWS_PEERS(valid, c);
+        const uint32_t before = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        uint32_t basec = 0;
+        if (valid) basec = s_cnt[w][c];
+        rcx_wave_sync();
+        if (valid) {
+            table[basec + before] = i + 1u;
+            if (before == 0) s_cnt[w][c] = basec + (uint32_t)__popcll(peers);
+        }
+        rcx_wave_sync();
+    }
+    if (tid == 0) { a.status[b] = RCX_OK; a.out_len[b] = 4ull * n; if (a.in_used) a.in_used[b] = n; }
+}
+static int launch_bwt_inversion_table(hipStream_t s, rcx_kargs& k)
+{
+    if (k.nblocks) hipLaunchKernelGGL(k_bwt_inversion_table, dim3(k.nblocks), dim3(BWTI_THREADS), 0, s, k);
+    return RCX_RC_OK;
+}
+
 static int launch_bwt_inverse(hipStream_t s, rcx_kargs& k, int variant, std::string& err, bool minimal = false)
 {
     const uint32_t capx = (variant & 1) ? 1u : BWTI_CAPX;        // variant bit 0: park 16 bytes per walker at most (tests: second chases)

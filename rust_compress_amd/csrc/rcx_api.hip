@@ -138,6 +138,7 @@ extern "C" uint64_t rcx_scratch_bytes(int codec, uint32_t nblocks, uint64_t max_
     switch (codec) {
     case RCX_LZ4_ENCODE: return rcx_tu_lz4_encode_scratch(nblocks);
     case RCX_BWT_FORWARD: return rcx_tu_bwt_forward_scratch(nblocks, max_block);
+    case RCX_BWT_SUFFIXES: return rcx_tu_bwt_forward_scratch(nblocks, max_block);          // max_block: the longest INPUT block (the slot is 4n)
     case RCX_DC_ENCODE: return rcx_tu_dc_encode_scratch(nblocks, max_block);   // (optional: without it the wave-per-block kernel encodes every block; 0 when no block is long enough for the chunk path)
     case RCX_BWT_INVERSE: case RCX_BWT_INVERSE_MINIMAL: return rcx_tu_bwt_inverse_scratch(nblocks, max_block);
     case RCX_INFLATE: case RCX_ZLIB_DECODE: return rcx_tu_inflate_scratch(nblocks);
@@ -177,8 +178,12 @@ static int launch_codec(rcx_ctx* c, int codec, rcx_kargs& k, int param_over = -1
         if (k.scratch_bytes < rcx_tu_gzip_scratch(n)) { c->err = "gzip decode: scratch too small"; return RCX_RC_BAD_ARG; }
         rcx_tu_gzip_decode(s, k, v);
         break;
-    case RCX_BWT_FORWARD: {
-        int rc = rcx_tu_bwt_forward(s, k, v, c->err);
+    case RCX_BWT_FORWARD: case RCX_BWT_SUFFIXES: {
+        int rc = rcx_tu_bwt_forward(s, k, v, c->err, codec == RCX_BWT_SUFFIXES);
+        if (rc) return rc;
+        break; }
+    case RCX_BWT_INVERSION_TABLE: {
+        int rc = rcx_tu_bwt_inversion_table(s, k);
         if (rc) return rc;
         break; }
     case RCX_BWT_INVERSE: case RCX_BWT_INVERSE_MINIMAL: {
@@ -247,7 +252,7 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
     if (n == 0) return RCX_RC_OK;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    uint64_t in_span = 0, out_span = 0, max_block = 0;
+    uint64_t in_span = 0, out_span = 0, max_block = 0, max_in = 0;
     for (uint32_t i = 0; i < n; i++) {
         // the kernels index a block with 32-bit offsets: a block of 4 GiB or more (or a range that wraps) is a caller error,
         // not something to decode a prefix of
@@ -259,6 +264,7 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
         const uint64_t e = b->in_off[i] + b->in_len[i];
         if (e > in_span) in_span = e;
         if (b->in_len[i] > max_block) max_block = b->in_len[i];
+        if (b->in_len[i] > max_in) max_in = b->in_len[i];
         if (needs_out) {
             const uint64_t o = b->out_off[i] + b->out_cap[i];
             if (o > out_span) out_span = o;
@@ -303,7 +309,7 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
     k.out_len = d64 + 5 * N; k.in_used = d64 + 6 * N;
     k.status = (int32_t*)(d64 + 7 * N); k.aux = (uint32_t*)(k.status + N);
     k.nblocks = n;
-    uint64_t sb = rcx_scratch_bytes(codec, n, max_block);
+    uint64_t sb = rcx_scratch_bytes(codec, n, codec == RCX_BWT_SUFFIXES ? max_in : max_block);
     if (codec == RCX_DC_ENCODE && param_over > 0) sb = 0;          // withctx: the wave-per-block kernel encodes, no chunk states
     if (codec == RCX_DC_ENCODE && sb && c->d_scratch.reserve(sb + 64) != hipSuccess) {
         // the chunk states are optional (37 KiB a block): a batch too large for them falls back to the wave-per-block kernel
@@ -343,6 +349,8 @@ extern "C" int rcx_adler32_batch(rcx_ctx* c, const rcx_batch* b, uint32_t* adler
 extern "C" int rcx_crc32_batch(rcx_ctx* c, const rcx_batch* b, uint32_t* crc) { return run_batch(c, RCX_CRC32, b, nullptr, crc, nullptr, false); }
 extern "C" int rcx_gzip_decode_batch(rcx_ctx* c, const rcx_batch* b, uint32_t* flags) { return run_batch(c, RCX_GZIP_DECODE, b, nullptr, flags, nullptr, true); }
 extern "C" int rcx_bwt_forward_batch(rcx_ctx* c, const rcx_batch* b, uint32_t* origin) { return run_batch(c, RCX_BWT_FORWARD, b, nullptr, origin, nullptr, true); }
+extern "C" int rcx_bwt_suffixes_batch(rcx_ctx* c, const rcx_batch* b, uint32_t* origin) { return run_batch(c, RCX_BWT_SUFFIXES, b, nullptr, origin, nullptr, true); }
+extern "C" int rcx_bwt_inversion_table_batch(rcx_ctx* c, const rcx_batch* b, const uint32_t* origin) { return run_batch(c, RCX_BWT_INVERSION_TABLE, b, origin, nullptr, nullptr, true); }
 extern "C" int rcx_bwt_inverse_batch(rcx_ctx* c, const rcx_batch* b, const uint32_t* origin) { return run_batch(c, RCX_BWT_INVERSE, b, origin, nullptr, nullptr, true); }
 extern "C" int rcx_bwt_inverse_minimal_batch(rcx_ctx* c, const rcx_batch* b, const uint32_t* origin) { return run_batch(c, RCX_BWT_INVERSE_MINIMAL, b, origin, nullptr, nullptr, true); }
 extern "C" int rcx_mtf_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_MTF_ENCODE, b, nullptr, nullptr, nullptr, true); }

@@ -20,7 +20,8 @@ void rcx_tu_gzip_decode(hipStream_t s, rcx_kargs& k, int variant);
 uint64_t rcx_tu_inflate_scratch(uint32_t nblocks);
 uint64_t rcx_tu_gzip_scratch(uint32_t nblocks);
 // tu_bwt.hip
-int rcx_tu_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::string& err);
+int rcx_tu_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::string& err, bool sa_words);
+int rcx_tu_bwt_inversion_table(hipStream_t s, rcx_kargs& k);
 int rcx_tu_bwt_inverse(hipStream_t s, rcx_kargs& k, int variant, std::string& err, bool minimal);
 uint64_t rcx_tu_bwt_forward_scratch(uint32_t nblocks, uint64_t max_block);
 uint64_t rcx_tu_bwt_inverse_scratch(uint32_t nblocks, uint64_t max_block);

@@ -389,6 +389,24 @@ inline std::pair<std::vector<uint8_t>, size_t> encode_simple(const std::vector<u
     check(r);
     return {r.out[0], r.aux[0]};
 }
+// bwt/mod.rs:136-166: fills suf_array (at least input.size() entries, as the reference indexes it) with the sorted suffixes
+inline void compute_suffixes(const std::vector<uint8_t>& input, std::vector<uint32_t>& suf_array)
+{
+    if (suf_array.size() < input.size()) throw io_error(ErrorKind::Panic, RCX_E_OUTPUT_TOO_SMALL, "compute_suffixes: suf_array is shorter than the input");
+    auto r = run_batch({input}, {4 * (uint64_t)input.size()}, [](rcx_ctx* c, rcx_batch* b, uint32_t* o) { return rcx_bwt_suffixes_batch(c, b, o); });
+    check(r);
+    if (!input.empty()) memcpy(suf_array.data(), r.out[0].data(), 4 * input.size());
+}
+// bwt/mod.rs:223-239: fills table (exactly input.size() entries: assert_eq!, :224) with the inversion jump table
+inline void compute_inversion_table(const std::vector<uint8_t>& input, size_t origin, std::vector<uint32_t>& table)
+{
+    if (table.size() != input.size()) throw io_error(ErrorKind::Panic, RCX_E_MALFORMED, "compute_inversion_table: input.len() != table.len()");
+    if (origin >= input.size()) throw io_error(ErrorKind::Panic, RCX_E_MALFORMED, "compute_inversion_table: origin out of range");
+    uint32_t og = (uint32_t)origin;
+    auto r = run_batch({input}, {4 * (uint64_t)input.size()}, [&](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_bwt_inversion_table_batch(c, b, &og); });
+    check(r);
+    memcpy(table.data(), r.out[0].data(), 4 * input.size());
+}
 inline std::vector<uint8_t> decode_simple(const std::vector<uint8_t>& input, size_t origin)       // bwt/mod.rs:291-294
 {
     if (input.empty()) return {};

@@ -99,6 +99,20 @@ int main(int argc, char** argv)
         CHECK(bwt::mtf::decode(bwt::mtf::encode(data)) == data);
     }
     { auto e = bwt::encode_simple(B("abracadabra")); CHECK(e.first == B("rdarcaaaabb") && e.second == 2); }
+    {   // compute_suffixes / compute_inversion_table, bwt/mod.rs:136-166, 223-239: "abracadabra" by hand
+        std::vector<uint32_t> sa(11), tab(11);
+        bwt::compute_suffixes(B("abracadabra"), sa);
+        CHECK((sa == std::vector<uint32_t>{10, 7, 0, 3, 5, 8, 1, 4, 6, 9, 2}));
+        bwt::compute_inversion_table(B("rdarcaaaabb"), 2, tab);        // place(): a -> 0.., b -> 5.., c -> 7, d -> 8, r -> 9..; origin (an 'a') first
+        CHECK((tab == std::vector<uint32_t>{0, 6, 7, 8, 9, 10, 11, 5, 2, 1, 4}));
+        // the table drives InverseIterator::next (:266-281)
+        std::vector<uint8_t> back; size_t cur = 2; const auto L = B("rdarcaaaabb");
+        for (int k = 0; k < 11; k++) { cur = (size_t)tab[cur] - 1; const size_t p = cur != (size_t)-1 ? cur : 2; back.push_back(L[p]); if (cur == (size_t)-1) break; }
+        CHECK(back == B("abracadabra"));
+        bool threw = false;
+        try { std::vector<uint32_t> shortt(10); bwt::compute_inversion_table(B("rdarcaaaabb"), 2, shortt); } catch (const io_error&) { threw = true; }
+        CHECK(threw);
+    }
     for (const char* s : {"abracadabra", "banana", "test"}) {                         // extra_mem = false: decode_minimal, bwt/mod.rs:298-315, 549-551
         bwt::Encoder<VecWriter> e(VecWriter(), 64);
         e.write((const uint8_t*)s, strlen(s));

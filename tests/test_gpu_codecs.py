@@ -58,6 +58,43 @@ def test_adler32(ctx, oracle):
     assert list(res.aux) == [oracle.adler32(r) for r in raws] == [zlib.adler32(r) for r in raws]
 
 
+def test_bwt_suffixes_and_inversion_table(ctx, oracle):
+    """compute_suffixes / compute_inversion_table (bwt/mod.rs:136-166, 223-239, both `pub`) as exports of their own: the suffix
+    array and the jump table word for word the oracle's -- the small corpus and one 256 KiB block each of text / dna4 / runs."""
+    from rust_compress_amd import synth, compress
+    raws = corpus.small_corpus(sizes=(17, 1000, 20000))
+    raws += [synth.gen(k, 262144, 40 + i).tobytes() for i, k in enumerate(("text", "dna4", "runs"))]
+    res = ctx.bwt_suffixes(raws).check()
+    assert list(res.out_len) == [4 * len(r) for r in raws]
+    Ls, orgs = [], []
+    for r, sa, og in zip(raws, res.outputs, res.aux):
+        assert np.array_equal(np.frombuffer(sa, dtype="<u4"), oracle.bwt_suffixes(r)), len(r)
+        eL, eo = oracle.bwt_encode(r)
+        assert not r or int(og) == eo
+        if r:
+            Ls.append(eL); orgs.append(eo)
+    tb = ctx.bwt_inversion_table(Ls, orgs).check()
+    for L, og, t in zip(Ls, orgs, tb.outputs):
+        assert np.array_equal(np.frombuffer(t, dtype="<u4"), oracle.bwt_inversion_table(L, og)), len(L)
+    # arbitrary (L, origin), the index panic, a short slot; the table drives the reference's InverseIterator (:266-281)
+    rng = np.random.default_rng(8)
+    arb = [bytes(rng.integers(0, 7, n, dtype=np.uint8)) for n in (1, 2, 64, 65, 4097, 70001)]
+    ao = [int(rng.integers(0, len(a))) for a in arb]
+    tb = ctx.bwt_inversion_table(arb + [b"abc", b""], ao + [3, 0])
+    assert list(tb.status) == [0] * len(arb) + [3, 3]
+    for L, og, t in zip(arb, ao, tb.outputs):
+        assert np.array_equal(np.frombuffer(t, dtype="<u4"), oracle.bwt_inversion_table(L, og))
+    # the mirrors (compress.py): a caller-provided array is filled in place
+    sa = [0] * 11
+    assert compress.bwt.compute_suffixes(b"abracadabra", sa) == sa == list(oracle.bwt_suffixes(b"abracadabra"))
+    L, og = oracle.bwt_encode(b"abracadabra")
+    tab = [0] * 11
+    compress.bwt.compute_inversion_table(L, og, tab)
+    assert tab == list(oracle.bwt_inversion_table(L, og))
+    with pytest.raises(AssertionError):
+        compress.bwt.compute_inversion_table(L, og, [0] * 10)
+
+
 def test_bwt_forward_and_inverse(ctx, oracle):
     from rust_compress_amd import synth
     raws = corpus.small_corpus(sizes=(17, 1000, 20000, 262144))

@@ -265,6 +265,41 @@ def test_bwt_forward(oracle):
     check([synth.gen("text", 30000, 2).tobytes(), synth.gen("words", 5000, 3).tobytes(), b"", b"x"])   # ~6 bits per symbol, groups of every size class
 
 
+def test_bwt_suffixes_and_inversion_table(oracle):
+    """The reference's two public helpers as exports of their own (mod.rs:136-166, 223-239): the suffix array the sorter holds
+    and the scattered jump table, word for word the oracle's."""
+    import simrun
+    from rust_compress_amd import synth
+    raws = corpus.small_corpus(sizes=(17, 1000)) + [synth.gen("text", 9000, 2).tobytes(), synth.gen("dna4", 3000, 1).tobytes(),
+                                                   b"abracadabra" * 50, bytes(700), b"x", b""]
+    total = sum(len(r) for r in raws)
+    outs, olen, _, st, aux = simrun.run(N.BWT_SUFFIXES, 0, raws, [4 * len(r) for r in raws], scratch_bytes=64 * total + (8 << 20))
+    assert not st.any() and list(olen) == [4 * len(r) for r in raws]
+    Ls, orgs = [], []
+    for r, sa, og in zip(raws, outs, aux):
+        want = oracle.bwt_suffixes(r)
+        assert np.array_equal(np.frombuffer(sa, dtype="<u4"), want), len(r)
+        eL, eo = oracle.bwt_encode(r)
+        assert not r or int(og) == eo
+        Ls.append(eL); orgs.append(eo)
+    outs, olen, _, st, _ = simrun.run(N.BWT_INVERSION_TABLE, 0, Ls, [4 * len(r) for r in Ls], aux=np.array(orgs, dtype=np.uint32))
+    for L, og, t, s_ in zip(Ls, orgs, outs, st):
+        if not L:
+            assert s_ == 3                                        # input[origin] panics on the empty block (:230)
+            continue
+        assert s_ == 0 and np.array_equal(np.frombuffer(t, dtype="<u4"), oracle.bwt_inversion_table(L, og))
+    # arbitrary (L, origin) pairs, origin out of range, short slots
+    rng = np.random.default_rng(5)
+    arb = [bytes(rng.integers(0, 5, n, dtype=np.uint8)) for n in (1, 2, 63, 64, 65, 1500, 5000)]
+    ao = [int(rng.integers(0, len(a))) for a in arb]
+    arb += [b"abc", b"abcd"]; ao += [3, 1]
+    caps = [4 * len(a) for a in arb]; caps[-1] = 15
+    outs, _, _, st, _ = simrun.run(N.BWT_INVERSION_TABLE, 0, arb, caps, aux=np.array(ao, dtype=np.uint32))
+    assert list(st[-2:]) == [3, 2]
+    for L, og, t in list(zip(arb, ao, outs))[:-2]:
+        assert np.array_equal(np.frombuffer(t, dtype="<u4"), oracle.bwt_inversion_table(L, og))
+
+
 def _gzip_members(raws):
     """gzip members with every optional header field (RFC 1952), made with Python's gzip/zlib (the checker here:
     the reference crate has no gzip code, see include/rcx.h)."""

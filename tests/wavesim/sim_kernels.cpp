@@ -67,7 +67,8 @@ extern "C" int sim_launch(int codec, int variant, const rcx_kargs* a)
     case RCX_CRC32: launch_crc32(0, k); return 0;
     case RCX_GZIP_DECODE: launch_gzip_decode(0, k, variant); return 0;
     case RCX_BWT_INVERSE: case RCX_BWT_INVERSE_MINIMAL: { std::string err; int st = 0; return launch_bwt_inverse(st, k, variant, err, codec == RCX_BWT_INVERSE_MINIMAL); }
-    case RCX_BWT_FORWARD: { std::string err; int st = 0; const int rc = launch_bwt_forward(st, k, variant, err); if (rc) fprintf(stderr, "wavesim: %s\n", err.c_str()); return rc; }
+    case RCX_BWT_FORWARD: case RCX_BWT_SUFFIXES: { std::string err; int st = 0; const int rc = launch_bwt_forward(st, k, variant, err, codec == RCX_BWT_SUFFIXES); if (rc) fprintf(stderr, "wavesim: %s\n", err.c_str()); return rc; }
+    case RCX_BWT_INVERSION_TABLE: { int st = 0; return launch_bwt_inversion_table(st, k); }
     default:
         return -1;
     }
