@@ -7,6 +7,7 @@ like the reference's own tests:
     compress::bwt::{Encoder, Decoder, encode_simple, decode_simple}                   src/bwt/mod.rs
     compress::bwt::mtf::{Encoder, Decoder}, compress::bwt::dc::{encode_simple, decode_simple}
     compress::entropy::ari::{ByteEncoder, ByteDecoder}                                src/entropy/ari/table.rs
+    compress::entropy::ari::{RangeEncoder, Model, Encoder, Decoder, table, bin, apm}  src/entropy/ari/*.rs (per symbol: host code, ari_symbol.py)
     compress::rle::{Encoder, Decoder}                                                 src/rle.rs
     compress::Adler32                                                                 src/checksum/adler.rs
 
@@ -551,6 +552,13 @@ class _ari:
             res = _check(_grow_caps(lambda cap: context().ari_byte_decode([data], [cap]), max(1 << 12, 4 * len(data))))
             self.consumed = int(res.in_used[0])        # mod.rs:289-292: the reader ends exactly after this stream
             return res.outputs[0]
+
+
+# the per-symbol surface (RangeEncoder, the Model trait, the generic Encoder / Decoder, table / bin / apm models): host
+# integer code, ari_symbol.py -- one decision per call against a caller-owned model has no batch to give the device
+from . import ari_symbol as _sym   # noqa: E402
+for _n in ("RangeEncoder", "Model", "Encoder", "Decoder", "table", "bin", "apm", "RANGE_DEFAULT_THRESHOLD", "PanicError"):
+    setattr(_ari, _n, getattr(_sym, _n))
 
 
 class entropy:

@@ -12,6 +12,7 @@
 //   compress::flate::Decoder, compress::zlib::Decoder, compress::Adler32           src/flate.rs, zlib.rs, adler.rs
 //   compress::bwt::{Encoder,Decoder,encode_simple,decode_simple}, bwt::mtf, bwt::dc src/bwt/*.rs
 //   compress::entropy::ari::{ByteEncoder,ByteDecoder}                              src/entropy/ari/table.rs
+//   compress::entropy::ari::{RangeEncoder,Model,Encoder,Decoder,table,bin,apm}     src/entropy/ari/*.rs (ari_symbol.hpp)
 //   compress::rle::{Encoder,Decoder}                                               src/rle.rs
 #pragma once
 #include <cstdint>
@@ -25,6 +26,7 @@
 #include <vector>
 
 #include "../../include/rcx.h"
+#include "ari_symbol.hpp"     // entropy::ari::{RangeEncoder, Model, Encoder, Decoder, table, bin, apm}: the per-symbol surface, host code
 
 namespace compress {
 namespace detail { constexpr uint64_t MAX_BLOCK = 0xFFFFFFFFull; }    // the kernels index a block with 32 bits (run_batch rejects a larger slot)
