@@ -37,6 +37,81 @@
 #endif
 #include <type_traits>
 
+// The copy rounds of emit5 as ISA (gfx950): every round, the lanes whose producers are done (no pending lane among `dep`) and
+// whose match does not overlap itself copy up to 16 bytes -- five aligned dword reads + v_alignbyte, the exec-narrowing byte
+// stores of rcx_lds_store16 -- and the loop ends when no such lane is left (all done, or only self-overlapping matches: emit5's
+// portable loop takes those).  hipcc's loop for the same source carries the lane sets as booleans through v_cndmask / v_cmp_ne
+// pairs and re-derives exec at every `if`: ~35 vector + ~25 scalar instructions a round around the stores; this is 17 + 9.
+// The pending set is ONE compiler-allocated SGPR pair (its halves are read through vcc): a first version named six SGPRs of its
+// own (s84..s89), which raised the kernel's SGPR count from 78 to 96, cost the eighth wave per SIMD, and ran 0.89 instead of
+// 0.63 ms.  The wave runs with all lanes on (exec is restored to -1).
+//   src_a / dst_a: LDS byte addresses of the lane's source and destination; mc: bytes to copy; prog: bytes done (in / out)
+// Returns the lanes still pending.
+#ifndef RCX_NO_ROUNDS_ASM
+__device__ __forceinline__ uint64_t rcx_lz4_rounds(uint32_t src_a, uint32_t dst_a, uint32_t mc, uint32_t dep_lo, uint32_t dep_hi, uint64_t pend, uint64_t ovl, uint32_t& prog)
+{
+    uint32_t t0, t1, a, a4, nv, da, d0, d1, d2, d3, d4;
+#define RCX_RB4(V, O0, O1, O2, O3)                                         \
+        "v_cmpx_lt_u32_e32 vcc, " #O0 ", %[nv]\n\t"                        \
+        "s_cbranch_execz L_sdone_%=\n\t"                                   \
+        "ds_write_b8 %[da], %[" V "] offset:" #O0 "\n\t"                    \
+        "v_cmpx_lt_u32_e32 vcc, " #O1 ", %[nv]\n\t"                        \
+        "v_lshrrev_b32_e32 %[t0], 8, %[" V "]\n\t"                          \
+        "ds_write_b8 %[da], %[t0] offset:" #O1 "\n\t"                       \
+        "v_cmpx_lt_u32_e32 vcc, " #O2 ", %[nv]\n\t"                        \
+        "ds_write_b8_d16_hi %[da], %[" V "] offset:" #O2 "\n\t"             \
+        "v_cmpx_lt_u32_e32 vcc, " #O3 ", %[nv]\n\t"                        \
+        "ds_write_b8_d16_hi %[da], %[t0] offset:" #O3 "\n\t"
+    asm volatile(
+        "L_top_%=:\n\t"
+        "s_mov_b64 vcc, %[pend]\n\t"
+        "v_and_b32_e32 %[t0], vcc_lo, %[dlo]\n\t"
+        "v_and_b32_e32 %[t1], vcc_hi, %[dhi]\n\t"
+        "v_or_b32_e32 %[t0], %[t0], %[t1]\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"
+        "s_and_b64 vcc, vcc, %[pend]\n\t"
+        "s_andn2_b64 vcc, vcc, %[ovl]\n\t"
+        "s_cbranch_vccz L_out_%=\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "v_add_u32_e32 %[a], %[srca], %[prog]\n\t"
+        "v_sub_u32_e32 %[nv], %[mc], %[prog]\n\t"
+        "v_and_b32_e32 %[a4], -4, %[a]\n\t"
+        "ds_read_b32 %[d0], %[a4]\n\t"
+        "ds_read_b32 %[d1], %[a4] offset:4\n\t"
+        "ds_read_b32 %[d2], %[a4] offset:8\n\t"
+        "ds_read_b32 %[d3], %[a4] offset:12\n\t"
+        "ds_read_b32 %[d4], %[a4] offset:16\n\t"
+        "v_and_b32_e32 %[a], 3, %[a]\n\t"
+        "v_min_u32_e32 %[nv], 16, %[nv]\n\t"
+        "v_add_u32_e32 %[da], %[dsta], %[prog]\n\t"
+        "v_add_u32_e32 %[prog], %[prog], %[nv]\n\t"
+        "v_cmp_lt_u32_e32 vcc, %[prog], %[mc]\n\t"             // of this round's lanes, those with bytes left
+        "s_andn2_b64 %[pend], %[pend], exec\n\t"
+        "s_or_b64 %[pend], %[pend], vcc\n\t"
+        "s_waitcnt lgkmcnt(3)\n\t"
+        "v_alignbyte_b32 %[d0], %[d1], %[d0], %[a]\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        "v_alignbyte_b32 %[d1], %[d2], %[d1], %[a]\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t"
+        "v_alignbyte_b32 %[d2], %[d3], %[d2], %[a]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_alignbyte_b32 %[d3], %[d4], %[d3], %[a]\n\t"
+        RCX_RB4("d0", 0, 1, 2, 3) RCX_RB4("d1", 4, 5, 6, 7) RCX_RB4("d2", 8, 9, 10, 11) RCX_RB4("d3", 12, 13, 14, 15)
+        "L_sdone_%=:\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_cmp_lg_u64 %[pend], 0\n\t"
+        "s_cbranch_scc1 L_top_%=\n\t"
+        "L_out_%=:\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        : [pend] "+s"(pend), [prog] "+v"(prog), [t0] "=&v"(t0), [t1] "=&v"(t1), [a] "=&v"(a), [a4] "=&v"(a4), [nv] "=&v"(nv), [da] "=&v"(da),
+          [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4)
+        : [ovl] "s"(ovl), [srca] "v"(src_a), [dsta] "v"(dst_a), [mc] "v"(mc), [dlo] "v"(dep_lo), [dhi] "v"(dep_hi)
+        : "vcc", "scc", "memory");
+#undef RCX_RB4
+    return pend;
+}
+#endif
+
 // SB: bytes of a gathered (old) match that are staged per lane and ride the copy rounds; the rest is stored straight to its place
 template <int CB, int TC = 2560, int HH = 2048, bool PROF5 = false, int SB = 32>
 struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
@@ -119,7 +194,9 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
     // LITLDS: the literal bytes sit in an LDS buffer (`litbuf`, with 32 bytes of slack) instead of the input in HBM --
     // that is how the inflate front end (k_inflate3.hip) feeds this executor.
     // NORED: the parser has already shortened the chains (k_lz4_decode_v8.hip: the offsets ARE the shifts).
-    template <bool LITLDS = false, bool NORED = false>
+    // CUT (A/B builds, results wrong on purpose): phases left out so that instruction counters can be attributed -- 1: copy
+    // rounds, 2: chain analysis, 4: literal / gather stores, 16: window drain
+    template <bool LITLDS = false, bool NORED = false, int CUT = 0>
     __device__ int emit5(int ns, int& lo, uint32_t w0, uint32_t w1, const uint8_t* litbuf = nullptr)
     {
         const unsigned lane = this->lane;
@@ -195,7 +272,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
         unsigned long long dep = 0;
         bool inb = M && !isfar && shi > oend0;
         uint32_t S = off;
-        if (__ballot(inb)) {
+        if (!(CUT & 2) && __ballot(inb)) {
             uint32_t ka, kb;
             if (LMOK && lmap != nullptr && !__ballot(act && len == 0u)) {       // (an empty entry shares its first byte with the next one: the search handles that)
                 uint8_t* const lcnt = (uint8_t*)(lmap + LMW);
@@ -245,13 +322,13 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
 
         V5P_ADD(5);
         // ---- literals, then gathered matches: registers -> their place in the window
-        if (__ballot(L != 0)) {
+        if (!(CUT & 4) && __ballot(L != 0)) {
             RCX_LDS_STORE16(wb_ + li_o, g0[0], g0[1], g0[2], g0[3], lit16 ? (L < 16u ? L : 16u) : 0u);
             if (__ballot(lit16 && L > 16)) RCX_LDS_STORE16(wb_ + li_o + 16, g1[0], g1[1], g1[2], g1[3], (lit16 && L > 16u) ? L - 16u : 0u);
             for (uint32_t i = 0; __ballot(litb && i < L); i++)
                 if (litb && i < L) wb_[li_o + (int32_t)i] = in[src + i];
         }
-        if (__ballot(isfar)) {
+        if (!(CUT & 4) && __ballot(isfar)) {
             uint8_t* d = wb_ + li_m;
             const uint32_t mf = far16 ? M : 0u;
             if (SB != 0 && far16) { uint8_t* sl = wb_ + STAGE5 + SB * (int32_t)lane; *(rcx_u32x4*)sl = f0; if (SB == 32) *(rcx_u32x4*)(sl + 16) = f1; }
@@ -273,12 +350,23 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
             const int32_t sbase0 = far16 ? STAGE5 + SB * (int32_t)lane : (int32_t)(mdst - S) - lbase;
             const bool ovl0 = M && !isfar && off < 16u && off < M;
             const uint32_t Mc = far16 ? (M < (uint32_t)SB ? M : (uint32_t)SB) : M;     // staged gathers ride the rounds for their first SB bytes
+            bool pending0 = M != 0 && !farb && !(SB == 0 && far16);
+            uint32_t prog0 = 0;
+#ifndef RCX_NO_ROUNDS_ASM
+            if (!PROF5 && !(CUT & 1) && !(CUT & 64)) {    // the hand-written loop takes every round the plain (non-overlapping) lanes can make
+                if (CUT & 128) __builtin_amdgcn_s_setprio(1);
+                const uint32_t wa = (uint32_t)(uintptr_t)wb_;      // (low half of a generic LDS pointer = the LDS byte address)
+                const uint64_t left = rcx_lz4_rounds(wa + (uint32_t)sbase0, wa + (uint32_t)li_m, Mc, (uint32_t)dep, (uint32_t)(dep >> 32),
+                                                     __ballot(pending0), __ballot(ovl0), prog0);
+                pending0 = RCX_INV_BALLOT(left);
+            }
+#endif
             auto rounds = [&](auto conv) __attribute__((always_inline)) {
                 constexpr bool CONV = decltype(conv)::value;
                 int32_t sbase = sbase0;
                 bool ovl = ovl0;
-                bool pending = M != 0 && !farb && !(SB == 0 && far16);
-                uint32_t prog = 0, r = 0;
+                bool pending = pending0;
+                uint32_t prog = prog0, r = 0;
                 for (;;) {
                     const unsigned long long pm = __ballot(pending);
                     if (!pm) break;
@@ -312,12 +400,12 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
                     }
                 }
             };
-            if (__ballot(ovl0 && M > 16u)) rounds(std::true_type{}); else rounds(std::false_type{});
+            if (CUT & 1) {} else if (__ballot(ovl0 && M > 16u)) rounds(std::true_type{}); else rounds(std::false_type{});
             if (!LITLDS) __builtin_amdgcn_s_setprio(RCX_FLUSH_PRIO); else if (RCX_INF_ROUNDS_PRIO) __builtin_amdgcn_s_setprio(0);
         }
         V5P_ADD(7);
         this->oend = RCX_U(oend0 + T);
-        this->flush(this->oend, false);
+        if (!(CUT & 16)) this->flush(this->oend, false); else this->gflush = this->oend & ~15u;
         if (!LITLDS && RCX_FLUSH_PRIO != RCX_EXEC_PRIO) __builtin_amdgcn_s_setprio(RCX_EXEC_PRIO);
         V5P_ADD(8);
         if (PROF5) pw[10] += 1;

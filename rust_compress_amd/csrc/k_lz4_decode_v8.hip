@@ -27,7 +27,7 @@
 #define V8P_T0() uint64_t t0_ = PROF8 ? (uint64_t)__builtin_readcyclecounter() : 0
 #define V8P_ADD(slot) do { if (PROF8) { const uint64_t t1_ = (uint64_t)__builtin_readcyclecounter(); pp[slot] += t1_ - t0_; t0_ = t1_; } } while (0)
 
-template <int TC = 1024, int HH = 1024, int SB = 16, bool PROF8 = false, int PRE_ = 128, int SPLIT_ = 32, bool PRED = false, int PRR = 2>
+template <int TC = 1024, int HH = 1024, int SB = 16, bool PROF8 = false, int PRE_ = 128, int SPLIT_ = 32, bool PRED = false, int PRR = 2, int CUT = 0>
 struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
     // A match longer than SPLIT bytes is handed over as TWO entries -- (L, SPLIT, offset) and (0, M - SPLIT, offset): the same
     // bytes -- so that the executor's copy rounds, 16 bytes a lane and round, are paced by SPLIT and not by the 64-byte cap
@@ -367,7 +367,9 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
             const uint32_t hop = ((int)lane < bt.ns && !cont) ? 3u + L + (L >= 15u ? 1u : 0u) + (M >= 19u ? 1u : 0u) : 0u;
             const uint32_t w0 = p0 + rcx_wave_incl_scan(hop) - hop + 1u + (L >= 15u ? 1u : 0u);
             int lo = 0, e = 0;
-            while (lo < bt.ns && !e) e = this->template emit5<false, PRED>(bt.ns, lo, w0, w1);
+            // CUT 8 (A/B): the executor only drains the ring -- what is left is the parser wave's instructions; 32: nor its own scan
+            if (CUT & 8) { if (!(CUT & 32)) this->oend += RCX_U(__builtin_amdgcn_readlane(w0, 63)) & 1u; lo = bt.ns; }
+            while (lo < bt.ns && !e) e = this->template emit5<false, PRED, CUT>(bt.ns, lo, w0, w1);
             if (e) { st = e; break; }
             if (this->after_batch(bt, st)) break;
         }
@@ -520,10 +522,10 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
     }
 };
 
-template <int TC = 1024, int HH = 768, bool PROF8 = false, int PRE_ = 128, int SPLIT_ = 32, bool PRED = false, int PRR = 2>
+template <int TC = 1024, int HH = 768, bool PROF8 = false, int PRE_ = 128, int SPLIT_ = 32, bool PRED = false, int PRR = 2, int CUT = 0>
 __global__ __launch_bounds__(128, 8) void k_lz4_decode_v8(rcx_kargs a, int only_status = 0)
 {
-    typedef Lz4V8<TC, HH, 16, PROF8, PRE_, SPLIT_, PRED, PRR> S;
+    typedef Lz4V8<TC, HH, 16, PROF8, PRE_, SPLIT_, PRED, PRR, CUT> S;
     const uint64_t tk0 = PROF8 ? (uint64_t)__builtin_readcyclecounter() : 0;
     __shared__ __align__(16) uint8_t s_wbuf[S::WBUF5 + 16];
     __shared__ __align__(16) typename S::Ring8 s_ring;

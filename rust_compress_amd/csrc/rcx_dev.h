@@ -35,17 +35,34 @@ __device__ __forceinline__ unsigned rcx_lane() { return threadIdx.x & 63u; }
 // row_bcast:15 = 0x142, row_bcast:31 = 0x143 (gfx9 encodings).
 #define RCX_DPP0(v, ctrl, row_mask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (row_mask), 0xf, false))
 
-// wave64 inclusive prefix sum on the VALU (6 DPP adds, no LDS crossbar round trips)
+// wave64 inclusive prefix sum on the VALU: six DPP adds, no LDS crossbar round trips.  Written as ISA: from the builtin form
+// (v += update_dpp(0, v, ...)) hipcc makes v_mov 0 + v_mov_dpp + v_add per step, 18 VALU a scan -- three scans a batch were
+// 5 % of the LZ4 decoder's vector instructions.  `v_add_u32_dpp v, v, v`: a lane whose DPP source is outside its row (or whose
+// row is masked off) is disabled and keeps v, which is what a scan wants; gfx9 needs two wait states between a VALU write of a
+// VGPR and a DPP read of it, and nothing inserts them inside an asm block.  The wave simulator keeps the builtin form
+// (RCX_WAVE_INCL_SCAN hook).
+#ifndef RCX_WAVE_INCL_SCAN
 __device__ __forceinline__ uint32_t rcx_wave_incl_scan(uint32_t v)
 {
-    v += RCX_DPP0(v, 0x111, 0xf);      // row_shr:1
-    v += RCX_DPP0(v, 0x112, 0xf);      // row_shr:2
-    v += RCX_DPP0(v, 0x114, 0xf);      // row_shr:4
-    v += RCX_DPP0(v, 0x118, 0xf);      // row_shr:8   -> inclusive scan inside each row of 16
-    v += RCX_DPP0(v, 0x142, 0xa);      // row_bcast:15 into rows 1 and 3
-    v += RCX_DPP0(v, 0x143, 0xc);      // row_bcast:31 into rows 2 and 3
+    asm("s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        : "+v"(v));
     return v;
 }
+#define RCX_WAVE_INCL_SCAN rcx_wave_incl_scan
+#else
+__device__ __forceinline__ uint32_t rcx_wave_incl_scan(uint32_t v) { return RCX_WAVE_INCL_SCAN(v); }
+#endif
 // wave64 maximum, uniform (an SGPR): the same six DPP steps as the scan and one v_readlane -- the butterfly over ds_bpermute it replaces
 // was six dependent LDS-crossbar round trips (~700 cycles on the critical path of every k_bws_dense window)
 __device__ __forceinline__ uint32_t rcx_wave_max(uint32_t v)

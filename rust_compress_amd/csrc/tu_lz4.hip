@@ -60,6 +60,14 @@ int rcx_tu_lz4_decode(hipStream_t s, rcx_kargs& k, int v, std::string& err)
     else if (v == 26) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1024, 1024, false, 16>), dim3(n), dim3(128), 0, s, k, 0);
     else if (v == 27) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1280, 1024, false, 0>), dim3(n), dim3(128), 0, s, k, 0);
     else if (v == 28) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1536, 2048, false, 16>), dim3(n), dim3(128), 0, s, k, 0);
+    // instruction attribution (results wrong on purpose; bench.py --variant 4x with RCX_BENCH_EXPERIMENT_NOCHECK=1): phases cut out
+    else if (v == 41) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 1>), dim3(n), dim3(128), 0, s, k, 0);     // no copy rounds
+    else if (v == 42) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 3>), dim3(n), dim3(128), 0, s, k, 0);     // nor chain analysis
+    else if (v == 43) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 7>), dim3(n), dim3(128), 0, s, k, 0);     // nor literal / gather stores
+    else if (v == 44) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 23>), dim3(n), dim3(128), 0, s, k, 0);    // nor the drain
+    else if (v == 45) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 8>), dim3(n), dim3(128), 0, s, k, 0);     // executor only empties the ring: the parser wave's share
+    else if (v == 46) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 64>), dim3(n), dim3(128), 0, s, k, 0);    // the compiled copy-round loop only (exact)
+    else if (v == 47) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 128>), dim3(n), dim3(128), 0, s, k, 0);   // hand-written rounds at priority 1 (exact)
     else if (v == 19) hipLaunchKernelGGL((k_lz4_decode_v6<8, true>), dim3(n), dim3(512), 0, s, k);      // phase timers -> scratch, no second pass
 #endif
     else { err = "lz4 decode: unknown kernel variant (A/B variants need a -DRCX_AB_VARIANTS build)"; return RCX_RC_BAD_ARG; }

@@ -46,10 +46,13 @@ def _group(ops):
             r.wait()
 
 
-def scatter_blocks(base, off, lens, bounds, root=0, device=None):
+def scatter_blocks(base, off, lens, bounds, root=0, device=None, with_desc=False):
     """Root holds (base uint8 tensor, off, lens numpy, bounds); every rank returns
-    (local_base tensor, local_off uint64, local_len uint64, bounds).
-    Two grouped exchanges: the descriptors (a fixed-size header broadcast, then one int64 tensor per peer), the payload bytes."""
+    (local_base tensor, local_off uint64, local_len uint64, bounds) -- and, with_desc, the int64 tensor [offsets | lengths] as it
+    arrived on `device`, so that a device consumer need not upload the descriptors again.
+    Two grouped exchanges: the descriptors (a fixed-size header broadcast, then one int64 tensor per peer), the payload bytes.
+    The root's own share is a VIEW of `base` (nothing is copied for the rank that already holds the bytes); a peer's buffer
+    has 64 bytes of slack behind it (16-byte loads of the last block)."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -67,7 +70,7 @@ def scatter_blocks(base, off, lens, bounds, root=0, device=None):
     a, b = int(bounds[rank]), int(bounds[rank + 1])
     lo, hi = int(spans[rank][0]), int(spans[rank][1])
     desc = torch.empty(2 * (b - a), dtype=torch.int64, device=dev)           # local offsets | lengths of my blocks
-    local = torch.empty(hi - lo, dtype=torch.uint8, device=dev)
+    local = torch.empty(hi - lo + 64, dtype=torch.uint8, device=dev)[: hi - lo] if rank != root else None
     ops = []
     if rank == root:
         keep = []                                                            # tensors a pending isend reads
@@ -78,7 +81,7 @@ def scatter_blocks(base, off, lens, bounds, root=0, device=None):
             d = torch.from_numpy(np.concatenate([off[ga:gb] - int(spans[g][0]), lens[ga:gb]])).to(dev)
             if g == root:
                 desc = d
-                local = base[lo:hi].clone()
+                local = base[lo:hi]
                 continue
             keep.append(d)
             if gb > ga:
@@ -92,7 +95,8 @@ def scatter_blocks(base, off, lens, bounds, root=0, device=None):
             ops.append(dist.P2POp(dist.irecv, local, root))
     _group(ops)
     d = desc.cpu().numpy()
-    return local, d[: b - a].astype(np.uint64), d[b - a:].astype(np.uint64), bounds
+    res = (local, d[: b - a].astype(np.uint64), d[b - a:].astype(np.uint64), bounds)
+    return res + (desc,) if with_desc else res
 
 
 def gather_blocks(local_out, local_off, local_len, bounds, root=0):
@@ -124,6 +128,8 @@ def gather_blocks(local_out, local_off, local_len, bounds, root=0):
             ops.append(dist.P2POp(dist.isend, packed.contiguous(), root))
         _group(ops)
         return None, None
+    if world == 1:                                                           # nobody to receive from: the packed bytes ARE the result
+        return packed, local_len.copy()
     counts = np.diff(bounds)
     lens_all = torch.empty(int(bounds[-1]), dtype=torch.int64, device=dev)
     lens_all[int(bounds[root]): int(bounds[root + 1])] = mylens

@@ -295,6 +295,19 @@ static inline uint32_t ws_inf_walk(uint32_t pk1, uint32_t pk2, uint32_t& pos, ui
         }
     }
 }
+// the kernels' scan is an asm block of v_add_u32_dpp; here the same six steps through the simulator's update_dpp
+static inline uint32_t ws_wave_incl_scan(uint32_t v)
+{
+    v += (uint32_t)ws::update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)ws::update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)ws::update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)ws::update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)ws::update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)ws::update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+#define RCX_WAVE_INCL_SCAN ws_wave_incl_scan
+#define RCX_NO_ROUNDS_ASM 1            // emit5's hand-written copy-round loop: the simulator runs the portable loop alone
 #define RCX_LDS_STORE16 ws_lds_store16
 #define RCX_INF_WALK ws_inf_walk
 #define BWS_PEERS ws_bws_peers
