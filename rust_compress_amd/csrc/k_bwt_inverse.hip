@@ -521,7 +521,7 @@ __device__ __forceinline__ bool bwti3_map(uint32_t nslots, uint32_t SL, uint32_t
 
 // OCC bytes of LDS nobody uses: they bound the workgroups resident on a CU, and with them the blocks whose tables an XCD chases at once
 template <int THREADS, int SLOTS, int OCC>
-__global__ __launch_bounds__(THREADS) void k_bwti3_chase(rcx_kargs a, uint32_t block0, uint32_t nslots, bwti3_layout lay, uint32_t shortpark, uint32_t SL)
+__global__ __launch_bounds__(THREADS) RCX_SGPR_CAP void k_bwti3_chase(rcx_kargs a, uint32_t block0, uint32_t nslots, bwti3_layout lay, uint32_t shortpark, uint32_t SL)
 {
     __shared__ uint8_t s_occ[OCC];
     uint32_t slot, slice;

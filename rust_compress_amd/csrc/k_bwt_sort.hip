@@ -289,7 +289,7 @@ __device__ __forceinline__ unsigned long long bws_peers(bool ok, uint32_t d)
 #endif
 
 template <class K>
-__global__ __launch_bounds__(512) void k_bws_partition(BwsState s, int level, uint32_t top_shift)
+__global__ __launch_bounds__(512) RCX_SGPR_CAP void k_bws_partition(BwsState s, int level, uint32_t top_shift)
 {
     __shared__ uint32_t s_hist[8][256];           // per wave; after the scan: the wave's next free place in each bin
     __shared__ uint32_t s_tot[256], s_beg[256];
@@ -595,7 +595,7 @@ struct BwsLocal {
 #define BWS_LW_OCC 6
 #endif
 template <class K>
-__global__ __launch_bounds__(256, BWS_LW_OCC) void k_bws_local_wave(BwsState s, uint32_t top_shift)
+__global__ __launch_bounds__(256, BWS_LW_OCC) RCX_SGPR_CAP void k_bws_local_wave(BwsState s, uint32_t top_shift)
 {
     __shared__ __align__(16) K s_key[4 * BWS_LWAVE];
     __shared__ uint32_t s_val[4 * BWS_LWAVE];
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256) void k_bws_local_wg(BwsState s, uint32_t top_s
 
 // ---- the few groups of <= 64 the dense passes cannot take (33..64 suffixes across both window grids): one wave per group ----
 template <class K>
-__global__ __launch_bounds__(256) void k_bws_small(BwsState s, uint32_t top_shift)
+__global__ __launch_bounds__(256) RCX_SGPR_CAP void k_bws_small(BwsState s, uint32_t top_shift)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nseg = s.cnt[2];
@@ -755,7 +755,7 @@ __device__ __forceinline__ void bws_dense_window(const BwsState& s, uint32_t j0,
 #define BWS_DW 8u
 #endif
 template <class K>
-__global__ __launch_bounds__(256) void k_bws_dense(BwsState s, uint32_t off)
+__global__ __launch_bounds__(256) RCX_SGPR_CAP void k_bws_dense(BwsState s, uint32_t off)
 {
     const uint32_t lane = threadIdx.x & 63u;
     // Workgroups go round-robin to the 8 XCDs, each with its own 4 MiB L2: XCD x takes the x-th EIGHTH of the windows, so that the

@@ -196,7 +196,9 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
     // NORED: the parser has already shortened the chains (k_lz4_decode_v8.hip: the offsets ARE the shifts).
     // CUT (A/B builds, results wrong on purpose): phases left out so that instruction counters can be attributed -- 1: copy
     // rounds, 2: chain analysis, 4: literal / gather stores, 16: window drain
-    template <bool LITLDS = false, bool NORED = false, int CUT = 0>
+    // FARCAP: the longest match that is gathered with 16-byte loads when its source has left the window (a longer one takes the
+    // byte path): k_lz4_decode_v8 hands over matches of at most 32 bytes, so two of the four gathers and their stores are not compiled
+    template <bool LITLDS = false, bool NORED = false, int CUT = 0, int FARCAP = 64>
     __device__ int emit5(int ns, int& lo, uint32_t w0, uint32_t w1, const uint8_t* litbuf = nullptr)
     {
         const unsigned lane = this->lane;
@@ -224,7 +226,9 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
         const uint32_t ostart = oend0 + incl - len;
         const uint32_t mdst = ostart + L;
         int err = 0;
-        if (act) {
+        if ((uint64_t)oend0 + T <= (uint64_t)cap) {                   // (uniform) the whole batch fits: only the offsets can be wrong
+            if (act && M && (off == 0 || off > mdst)) err = RCX_E_MALFORMED;
+        } else if (act) {
             if (L > cap - ostart || ostart > cap) err = RCX_E_OUTPUT_TOO_SMALL;
             else if (M && (off == 0 || off > mdst)) err = RCX_E_MALFORMED;
             else if (M && M > cap - mdst) err = RCX_E_OUTPUT_TOO_SMALL;
@@ -256,15 +260,23 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
                     g1 = rcx_u32x4{x0, x1, x2, x3};
                 }
             }
-        } else if (lit16) { g0 = *(const rcx_u32x4_u*)(in + src); if (L > 16) g1 = *(const rcx_u32x4_u*)(in + src + 16); }
+        } else if (__ballot(lit16)) {
+            // EVERY lane loads (a lane without such literals reads the block's first bytes -- there are >= 32 of them when any lane
+            // has lit16 -- and its store below has length 0): no exec juggling, no zeroed registers for the lanes left out
+            const uint32_t q = lit16 ? src : 0u;
+            g0 = *(const rcx_u32x4_u*)(in + q);
+            if (__ballot(lit16 && L > 16)) g1 = *(const rcx_u32x4_u*)(in + q + 16);
+        }
         rcx_u32x4 f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0}, f2 = {0, 0, 0, 0}, f3 = {0, 0, 0, 0};
-        const bool far16 = isfar && M <= (uint32_t)B::MCAP && (uint64_t)slo + (uint32_t)B::MCAP <= (uint64_t)cap;      // (k_lz4_decode_v8 batches runs of up to 255 bytes: if one is ever outside the window, byte loads)
+        constexpr uint32_t FC = FARCAP < B::MCAP ? (uint32_t)FARCAP : (uint32_t)B::MCAP;
+        const bool far16 = isfar && M <= FC && (uint64_t)slo + (uint32_t)B::MCAP <= (uint64_t)cap;      // (k_lz4_decode_v8 batches runs of up to 255 bytes: if one is ever outside the window, byte loads)
         const bool farb = isfar && !far16;
-        if (far16) {
-            f0 = *(const rcx_u32x4_u*)(out + slo);
-            if (M > 16) f1 = *(const rcx_u32x4_u*)(out + slo + 16);
-            if (M > 32) f2 = *(const rcx_u32x4_u*)(out + slo + 32);
-            if (M > 48) f3 = *(const rcx_u32x4_u*)(out + slo + 48);
+        if (__ballot(far16)) {                                       // the same: all lanes load, from the output's first 64 bytes where there is no far match
+            const uint32_t q = far16 ? slo : 0u;
+            f0 = *(const rcx_u32x4_u*)(out + q);
+            if (FC > 16 && __ballot(far16 && M > 16)) f1 = *(const rcx_u32x4_u*)(out + q + 16);
+            if (FC > 32 && __ballot(far16 && M > 32)) f2 = *(const rcx_u32x4_u*)(out + q + 32);
+            if (FC > 48 && __ballot(far16 && M > 48)) f3 = *(const rcx_u32x4_u*)(out + q + 48);
         }
 
         if (RCX_INF_ROUNDS_PRIO || !LITLDS) __builtin_amdgcn_s_setprio(RCX_ROUND_PRIO);
@@ -334,8 +346,8 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
             if (SB != 0 && far16) { uint8_t* sl = wb_ + STAGE5 + SB * (int32_t)lane; *(rcx_u32x4*)sl = f0; if (SB == 32) *(rcx_u32x4*)(sl + 16) = f1; }
             if (SB == 0) RCX_LDS_STORE16(d, f0[0], f0[1], f0[2], f0[3], mf < 16u ? mf : 16u);     // no staging: every gathered byte goes straight to its place
             if (SB <= 16 && __ballot(mf > 16)) RCX_LDS_STORE16(d + 16, f1[0], f1[1], f1[2], f1[3], mf > 16u ? (mf < 32u ? mf - 16u : 16u) : 0u);
-            if (__ballot(mf > 32)) RCX_LDS_STORE16(d + 32, f2[0], f2[1], f2[2], f2[3], mf > 32u ? (mf < 48u ? mf - 32u : 16u) : 0u);
-            if (__ballot(mf > 48)) RCX_LDS_STORE16(d + 48, f3[0], f3[1], f3[2], f3[3], mf > 48u ? mf - 48u : 0u);
+            if (FC > 32 && __ballot(mf > 32)) RCX_LDS_STORE16(d + 32, f2[0], f2[1], f2[2], f2[3], mf > 32u ? (mf < 48u ? mf - 32u : 16u) : 0u);
+            if (FC > 48 && __ballot(mf > 48)) RCX_LDS_STORE16(d + 48, f3[0], f3[1], f3[2], f3[3], mf > 48u ? mf - 48u : 0u);
             for (uint32_t i = 0; __ballot(farb && i < M); i++)
                 if (farb && i < M) d[i] = out[slo + i];
         }

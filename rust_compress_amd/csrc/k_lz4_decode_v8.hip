@@ -369,7 +369,7 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
             int lo = 0, e = 0;
             // CUT 8 (A/B): the executor only drains the ring -- what is left is the parser wave's instructions; 32: nor its own scan
             if (CUT & 8) { if (!(CUT & 32)) this->oend += RCX_U(__builtin_amdgcn_readlane(w0, 63)) & 1u; lo = bt.ns; }
-            while (lo < bt.ns && !e) e = this->template emit5<false, PRED, CUT>(bt.ns, lo, w0, w1);
+            while (lo < bt.ns && !e) e = this->template emit5<false, PRED, CUT, (SPLIT ? SPLIT : 64)>(bt.ns, lo, w0, w1);
             if (e) { st = e; break; }
             if (this->after_batch(bt, st)) break;
         }

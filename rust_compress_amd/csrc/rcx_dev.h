@@ -23,6 +23,15 @@ struct rcx_kargs {
 
 #define RCX_WAVE 64
 
+// A wave's SGPRs come out of 800 per SIMD in granules of 16, and the trap handler takes 16 more per wave: eight waves per SIMD
+// need <= 80.  hipcc counts without the trap handler's share and reports "Occupancy: 8" up to 96 -- a kernel with 81..96 SGPRs
+// runs seven waves per SIMD (found the hard way: six SGPRs named in an asm block took k_lz4_decode_v8 from 78 to 96 and from
+// 0.63 to 0.89 ms, the sixteenth workgroup of a CU waiting for a second residency round).  Kernels whose registers would allow
+// eight waves carry this cap; what does not fit is spilled to VGPR lanes, of which those kernels have plenty.
+#ifndef RCX_SGPR_CAP
+#define RCX_SGPR_CAP __attribute__((amdgpu_num_sgpr(80)))
+#endif
+
 // 16-byte vector; the _u flavour may sit at any byte address (global memory only: unaligned DS is slow)
 typedef unsigned int rcx_u32x4 __attribute__((vector_size(16)));
 typedef rcx_u32x4 __attribute__((aligned(1))) rcx_u32x4_u;
