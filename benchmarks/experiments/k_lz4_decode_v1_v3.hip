@@ -1,4 +1,4 @@
-// k_lz4_decode.hip -- batched LZ4 block decode for gfx950 (wave64), one wave per LZ4 block.
+// k_lz4_decode_v1_v3.hip (round 1: k_lz4_decode.hip) -- batched LZ4 block decode for gfx950 (wave64), one wave per LZ4 block.
 //
 // Replaces the reference's BlockDecoder::decode (src/lz4.rs:67-110: token -> length() :112-122 ->
 // literal memcpy :78-82 -> u16 LE offset :91 -> cp() byte loop :131-140) for a whole batch of
@@ -13,7 +13,7 @@
 //       lane-per-sequence into an LDS output ring (wave prefix-sum for the output positions, multi-round
 //       resolution for matches that read this batch's own output) and the ring is drained to HBM with
 //       coalesced 16-byte stores.  Compressed bytes are staged through LDS in 2 KiB pieces.
-#include "rcx_dev.h"
+#include "../../rust_compress_amd/csrc/rcx_dev.h"   // (experiment: lives outside the product tree, built only into librcx_ab.so)
 
 // ------------------------------------------------------------------------------------------------
 // v1: sequence-serial, wave-cooperative copies in global memory

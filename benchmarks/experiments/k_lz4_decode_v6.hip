@@ -22,7 +22,7 @@
 // Exactness by fallback: this kernel only has to be right on blocks it accepts.  Anything unusual -- malformed input,
 // a short output slot, more than 64 KiB of output, long extension chains (incompressible or run-only data) -- ends the
 // block with the internal status RCX_ST_BAIL6 and the exact kernel (k_lz4_decode_v5) re-runs those blocks.
-#include "rcx_dev.h"
+#include "../../rust_compress_amd/csrc/rcx_dev.h"   // (experiment: lives outside the product tree, built only into librcx_ab.so)
 
 #define RCX_ST_BAIL6 0x7ff00002           /* internal, never leaves the library */
 #ifdef RCX_SIM_TRACE

@@ -22,7 +22,7 @@
 // a match lying wholly inside one earlier match of the batch is re-pointed at that match's own source (pointer doubling).
 // Simulated on G-text (64 chunks of 16 bytes): 16 rounds per KiB without redirection, 7.8 with four levels cut.
 // A self-overlapping match with a period below 16 builds its chunk from the period's bytes (byte gathers: the run-heavy path).
-#include "rcx_dev.h"
+#include "../../rust_compress_amd/csrc/rcx_dev.h"   // (experiment: lives outside the product tree, built only into librcx_ab.so)
 #ifndef RCX_V7_STAT
 #define RCX_V7_STAT(slot, v) ((void)0)                       // the wave simulator counts rounds / pieces here
 #endif

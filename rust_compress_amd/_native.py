@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 AB = bool(os.environ.get("RCX_AB"))
 LIB_PATH = os.path.join(_HERE, "csrc", os.environ.get("RCX_LIB_FILE") or ("librcx_ab.so" if AB else "librcx.so"))    # RCX_LIB_FILE: a build made with RCX_EXTRA_FLAGS (experiments)
 # kernel variants each build accepts (rcx_ctx_set_variant): default + one fallback per codec in the shipped library
-LZ4_DECODE_VARIANTS = (0, 15, 11, 20, 1, 2, 3, 4, 5, 6, 7, 8, 10, 17) if AB else (0, 15, 11, 20)
+LZ4_DECODE_VARIANTS = (0, 15, 11, 20, 1, 2, 3, 4, 5, 6, 7, 8, 10, 17) if AB else (0, 15)
 INFLATE_VARIANTS = (0, 9, 10, 11, 1) if AB else (0, 9, 10, 11)
 
 # enum rcx_codec

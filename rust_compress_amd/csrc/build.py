@@ -25,6 +25,9 @@ def build(force=False, verbose=False, ab=None):
     out = _out(ab)
     deps = [os.path.join(HERE, f) for f in sorted(os.listdir(HERE)) if f.endswith((".hip", ".h"))]
     deps.append(os.path.join(HERE, "..", "..", "include", "rcx.h"))
+    if ab:                                        # the experiment kernels live outside the product tree
+        exp = os.path.join(HERE, "..", "..", "benchmarks", "experiments")
+        deps += [os.path.join(exp, f) for f in sorted(os.listdir(exp)) if f.endswith(".hip")]
     newest = max(os.path.getmtime(d) for d in deps)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
     if ab:

@@ -260,7 +260,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
                     g1 = rcx_u32x4{x0, x1, x2, x3};
                 }
             }
-        } else if (__ballot(lit16)) {
+        } else if (!(CUT & 0x400) && __ballot(lit16)) {
             // EVERY lane loads (a lane without such literals reads the block's first bytes -- there are >= 32 of them when any lane
             // has lit16 -- and its store below has length 0): no exec juggling, no zeroed registers for the lanes left out
             const uint32_t q = lit16 ? src : 0u;
@@ -271,7 +271,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
         constexpr uint32_t FC = FARCAP < B::MCAP ? (uint32_t)FARCAP : (uint32_t)B::MCAP;
         const bool far16 = isfar && M <= FC && (uint64_t)slo + (uint32_t)B::MCAP <= (uint64_t)cap;      // (k_lz4_decode_v8 batches runs of up to 255 bytes: if one is ever outside the window, byte loads)
         const bool farb = isfar && !far16;
-        if (__ballot(far16)) {                                       // the same: all lanes load, from the output's first 64 bytes where there is no far match
+        if (!(CUT & 0x200) && __ballot(far16)) {                     // the same: all lanes load, from the output's first 64 bytes where there is no far match
             const uint32_t q = far16 ? slo : 0u;
             f0 = *(const rcx_u32x4_u*)(out + q);
             if (FC > 16 && __ballot(far16 && M > 16)) f1 = *(const rcx_u32x4_u*)(out + q + 16);

@@ -1,17 +1,19 @@
 // tu_lz4.hip -- LZ4 block decode / encode kernels + their launch code (one translation unit).
-// Shipped variants of the decoder: 0 = two waves per block with the segment-parallel parser (k_lz4_decode_v8), 15 = with the
-// serial-walk parser (k_lz4_decode_v5), 11 = one wave per block (k_lz4_decode_v4), 20 = the chunk-centric executor experiment (v7).  Everything else -- the earlier kernel generations, profiling instantiations and the
-// workgroup-per-block experiment (k_lz4_decode_v6) -- is compiled only with -DRCX_AB_VARIANTS (benchmarks/, A/B history).
+// The shipped library holds the default decoder and one exact fallback: 0 = two waves per block with the segment-parallel parser
+// (k_lz4_decode_v8), 15 = with the serial-walk parser (k_lz4_decode_v5; k_lz4_decode_v4 is the base class both build on).
+// Everything else -- the one-wave kernel as a variant of its own (11), the earlier generations (v1-v3), the workgroup-per-block
+// and chunk-centric experiments (v6, v7; benchmarks/experiments/), profiling and attribution instantiations -- is compiled only
+// with -DRCX_AB_VARIANTS into librcx_ab.so, for benchmarks/ and the A/B history in DESIGN.md.
 #include "rcx_tu.h"
 #ifdef RCX_AB_VARIANTS
-#include "k_lz4_decode.hip"
+#include "../../benchmarks/experiments/k_lz4_decode_v1_v3.hip"
 #endif
 #include "k_lz4_decode_v4.hip"
 #include "k_lz4_decode_v5.hip"
-#include "k_lz4_decode_v7.hip"
 #include "k_lz4_decode_v8.hip"
 #ifdef RCX_AB_VARIANTS
-#include "k_lz4_decode_v6.hip"
+#include "../../benchmarks/experiments/k_lz4_decode_v7.hip"
+#include "../../benchmarks/experiments/k_lz4_decode_v6.hip"
 #endif
 #include "k_lz4_encode.hip"
 
@@ -21,15 +23,15 @@ uint64_t rcx_tu_lz4_encode_scratch(uint32_t nblocks) { return (uint64_t)(nblocks
 
 // Default (0): two waves per block with the SEGMENT-PARALLEL parser wave (k_lz4_decode_v8: the token walk no longer owns the
 // CU's scalar port; 4096 x 64 KiB: text 0.636 against 0.662 ms, words 0.80 / 0.84, rand 0.151 / 0.155, runs 1.19 / 1.17).
-// 15: the serial-walk parser wave (k_lz4_decode_v5, the default of rounds 1-2).  11: one wave per block (k_lz4_decode_v4).
+// 15: the serial-walk parser wave (k_lz4_decode_v5, the default of rounds 1-2).  A/B library: 11 = one wave per block (k_lz4_decode_v4), 20 = v7.
 int rcx_tu_lz4_decode(hipStream_t s, rcx_kargs& k, int v, std::string& err)
 {
     const uint32_t n = k.nblocks;
     if (v == 0 || v == 23) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768>), dim3(n), dim3(128), 0, s, k, 0);
     else if (v == 15) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1536, 2048>), dim3(n), dim3(128), 0, s, k, 0);
+#ifdef RCX_AB_VARIANTS
     else if (v == 11) hipLaunchKernelGGL((k_lz4_decode_v4<1024, 1>), dim3(n), dim3(64), 0, s, k);
     else if (v == 20) hipLaunchKernelGGL((k_lz4_decode_v7<1024, 1008, 2048, 2048>), dim3(n), dim3(128), 0, s, k, 0);
-#ifdef RCX_AB_VARIANTS
     else if (v == 1) hipLaunchKernelGGL(k_lz4_decode_v1, dim3(n), dim3(64), 0, s, k);
     else if (v == 2) hipLaunchKernelGGL((k_lz4_decode_v3<2048, 2048, 64, 64, 4>), dim3((n + 3) / 4), dim3(256), 0, s, k);
     else if (v == 3) hipLaunchKernelGGL((k_lz4_decode_v3<4096, 2048, 64, 64, 1>), dim3(n), dim3(64), 0, s, k);
@@ -68,6 +70,8 @@ int rcx_tu_lz4_decode(hipStream_t s, rcx_kargs& k, int v, std::string& err)
     else if (v == 45) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 8>), dim3(n), dim3(128), 0, s, k, 0);     // executor only empties the ring: the parser wave's share
     else if (v == 46) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 64>), dim3(n), dim3(128), 0, s, k, 0);    // the compiled copy-round loop only (exact)
     else if (v == 47) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 128>), dim3(n), dim3(128), 0, s, k, 0);   // hand-written rounds at priority 1 (exact)
+    else if (v == 48) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 0x200>), dim3(n), dim3(128), 0, s, k, 0);   // no gathers of old matches (their latency)
+    else if (v == 49) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 0x600>), dim3(n), dim3(128), 0, s, k, 0);   // nor literal loads
     else if (v == 19) hipLaunchKernelGGL((k_lz4_decode_v6<8, true>), dim3(n), dim3(512), 0, s, k);      // phase timers -> scratch, no second pass
 #endif
     else { err = "lz4 decode: unknown kernel variant (A/B variants need a -DRCX_AB_VARIANTS build)"; return RCX_RC_BAD_ARG; }

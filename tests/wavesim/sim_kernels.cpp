@@ -1,12 +1,12 @@
 // sim_kernels.cpp -- runs the UNMODIFIED .hip kernel sources on the wave64 simulator (TEST INFRASTRUCTURE).
 // Built by tests/wavesim/build.py with:  g++ -include wavesim.h sim_kernels.cpp wavesim.cpp
 #define RCX_AB_VARIANTS 1              /* the simulator runs every kernel generation */
-#include "../../rust_compress_amd/csrc/k_lz4_decode.hip"
+#include "../../benchmarks/experiments/k_lz4_decode_v1_v3.hip"
 #include "../../rust_compress_amd/csrc/k_lz4_decode_v4.hip"
 #include "../../rust_compress_amd/csrc/k_lz4_decode_v5.hip"
-#include "../../rust_compress_amd/csrc/k_lz4_decode_v7.hip"
+#include "../../benchmarks/experiments/k_lz4_decode_v7.hip"
 #include "../../rust_compress_amd/csrc/k_lz4_decode_v8.hip"
-#include "../../rust_compress_amd/csrc/k_lz4_decode_v6.hip"
+#include "../../benchmarks/experiments/k_lz4_decode_v6.hip"
 #include "../../rust_compress_amd/csrc/k_lz4_encode.hip"
 #define hipStream_t int
 #define hipLaunchKernelGGL(kern, grid, block, shm, stream, ...) ws::launch(grid, block, [&] { kern(__VA_ARGS__); })
