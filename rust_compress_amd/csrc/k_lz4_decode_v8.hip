@@ -24,6 +24,14 @@
 // batch -- and linking by "is the entry byte marked" without the head start: 68 of 94 segments needed the hand walk.)
 #include "rcx_dev.h"
 
+// how long the waves sleep between looks at the ring (x 64 cycles): the parser waits for one of eight slots that free up
+// every ~14 K cycles, the executor for a batch it needs at once
+#ifndef RCX_V8_PSLEEP
+#define RCX_V8_PSLEEP 16
+#endif
+#ifndef RCX_V8_ESLEEP
+#define RCX_V8_ESLEEP 4
+#endif
 #define V8P_T0() uint64_t t0_ = PROF8 ? (uint64_t)__builtin_readcyclecounter() : 0
 #define V8P_ADD(slot) do { if (PROF8) { const uint64_t t1_ = (uint64_t)__builtin_readcyclecounter(); pp[slot] += t1_ - t0_; t0_ = t1_; } } while (0)
 
@@ -225,7 +233,7 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
             if (RCX_U(ring->abort_)) return false;
             if (head - t < (uint32_t)NSLOT8) break;
             __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_s_sleep(16);
+            __builtin_amdgcn_s_sleep(RCX_V8_PSLEEP);
         }
         __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO);
         rcx_wave_sync();
@@ -346,7 +354,7 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
         auto ring = this->ring8;
         for (;;) {
             uint64_t te0 = PROF8 ? (uint64_t)__builtin_readcyclecounter() : 0;
-            while (RCX_U(ring->head) == tail) __builtin_amdgcn_s_sleep(4);
+            while (RCX_U(ring->head) == tail) __builtin_amdgcn_s_sleep(RCX_V8_ESLEEP);
             if (PROF8) { this->pw[0] += (uint64_t)__builtin_readcyclecounter() - te0; this->pw[2] += 1; }
             rcx_wave_sync();
             const RCX_LDS_AS Slot8* sl = &ring->slot[tail % NSLOT8];

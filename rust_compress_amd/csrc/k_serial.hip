@@ -1462,6 +1462,215 @@ __global__ __launch_bounds__(64 * WAVES) void k_ari_byte_wave(rcx_kargs a)
 }
 
 // -------------------------------------------------------------------------------------------------
+// The same coder, a QUAD of lanes per stream (k_ari_byte_quad): 16 streams a wave.
+// Why: one lane per stream is the cheapest form in instructions (64 streams per wave instruction) but a symbol is a chain of
+// ~300 dependent instructions for its lane -- sixteen block sums and sixteen entries read, multiplied, compared and selected one
+// after the other -- and BASELINE config 5 has 15 260 streams: 239 waves on 1024 SIMDs, each alone on its SIMD and bound by that
+// chain (18 ms, the largest kernel of the pipeline's decode).  Four lanes share a stream here: each reads FOUR sums / entries with
+// one 8-byte LDS load, the quad's prefix and the position of the hit come from quad-permute DPP moves (VALU, no LDS round trip),
+// the scalar state (low, hai, code, total) is kept identically in all four lanes, and the one division of a symbol is a
+// reciprocal + two corrections (exact for the divisors a table total can take, 257..8191: the compiler's 32-bit division is two
+// v_mul_hi and ~30 instructions).  A symbol is ~150 instructions; 15 260 streams are 954 waves, one per SIMD.
+// Table in LDS, stream-major: 272 u16 entries (257 + zero padding: a padded entry never wins a search and stays zero when the
+// table is halved), then 20 u16 block sums (17 + padding): 584 bytes a stream, every quad load 8-byte aligned.
+// -------------------------------------------------------------------------------------------------
+#define ARIQ_TAB 272
+#define ARIQ_BS 20
+#define RCX_QPERM(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+template <int CTRL> __device__ __forceinline__ uint32_t rcx_qp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t rcx_quad_sum(uint32_t v) { v += rcx_qp<RCX_QPERM(1, 0, 3, 2)>(v); v += rcx_qp<RCX_QPERM(2, 3, 0, 1)>(v); return v; }
+__device__ __forceinline__ uint32_t rcx_quad_max(uint32_t v)
+{
+    uint32_t t = rcx_qp<RCX_QPERM(1, 0, 3, 2)>(v); v = t > v ? t : v;
+    t = rcx_qp<RCX_QPERM(2, 3, 0, 1)>(v); return t > v ? t : v;
+}
+__device__ __forceinline__ uint32_t rcx_quad_min(uint32_t v)
+{
+    uint32_t t = rcx_qp<RCX_QPERM(1, 0, 3, 2)>(v); v = t < v ? t : v;
+    t = rcx_qp<RCX_QPERM(2, 3, 0, 1)>(v); return t < v ? t : v;
+}
+// the sum of v over the quad's lanes below q
+__device__ __forceinline__ uint32_t rcx_quad_excl(uint32_t v, unsigned q)
+{
+    const uint32_t a = rcx_qp<RCX_QPERM(0, 0, 0, 0)>(v), b = rcx_qp<RCX_QPERM(1, 1, 1, 1)>(v), c = rcx_qp<RCX_QPERM(2, 2, 2, 2)>(v);
+    return (q > 0 ? a : 0u) + (q > 1 ? b : 0u) + (q > 2 ? c : 0u);
+}
+#ifndef RCX_RCPF
+#define RCX_RCPF(x) __builtin_amdgcn_rcpf(x)
+#endif
+// n / d for 257 <= d < 8192, exact whatever the last bits of the reciprocal are (checked over 10^9 (n, d) with the reciprocal
+// off by up to two ulps either way): the first estimate is within 5 of the quotient, the remainder then fits a float exactly.
+__device__ __forceinline__ uint32_t rcx_div_u13(uint32_t n, uint32_t d)
+{
+    const float r = RCX_RCPF((float)d);
+    uint32_t q = (uint32_t)((float)n * r);
+    int32_t rem = (int32_t)(n - __umul24(q, d));               // q <= (2^32 - 1) / 257 < 2^24
+    const int32_t q2 = (int32_t)__builtin_floorf((float)rem * r);
+    q += (uint32_t)q2; rem -= q2 * (int32_t)d;
+    if (rem < 0) q--; else if (rem >= (int32_t)d) q++;
+    return q;
+}
+struct AriQuad {
+    uint16_t* tab; uint16_t* bs; unsigned q; uint32_t total;
+    __device__ void init()
+    {
+        for (uint32_t e = q; e < ARIQ_TAB; e += 4) tab[e] = e < ARI_N ? 1 : 0;
+        for (uint32_t k = q; k < ARIQ_BS; k += 4) bs[k] = k < 16 ? 16 : (k == 16 ? 1 : 0);
+        total = ARI_N;
+        rcx_wave_sync();
+    }
+    struct Hit { uint32_t cnt, lo, hi; };
+    // four consecutive cumulative ends past c0 per lane (w4: their four u16 steps): how many ends e of the quad's sixteen have
+    // e * range <= x (cnt), the largest such end or c0 (lo), the smallest end beyond (hi).  The ends only grow, so the flags are
+    // ones then zeros.
+    __device__ __forceinline__ Hit find4(uint64_t w4, uint32_t c0, uint32_t range, uint32_t x) const
+    {
+        const uint32_t lo32 = (uint32_t)w4, hi32 = (uint32_t)(w4 >> 32);
+        const uint32_t l1 = lo32 & 0xffffu, l2 = l1 + (lo32 >> 16), l3 = l2 + (hi32 & 0xffffu), l4 = l3 + (hi32 >> 16);
+        const uint32_t base = c0 + rcx_quad_excl(l4, q);
+        const uint32_t e0 = base + l1, e1 = base + l2, e2 = base + l3, e3 = base + l4;
+        const bool b0 = __umul24(e0, range) <= x, b1 = __umul24(e1, range) <= x, b2 = __umul24(e2, range) <= x, b3 = __umul24(e3, range) <= x;
+        const uint32_t mylo = b3 ? e3 : b2 ? e2 : b1 ? e1 : b0 ? e0 : 0u;
+        const uint32_t myhi = !b0 ? e0 : !b1 ? e1 : !b2 ? e2 : !b3 ? e3 : 0xffffffffu;
+        Hit h;
+        h.cnt = rcx_quad_sum((uint32_t)b0 + (uint32_t)b1 + (uint32_t)b2 + (uint32_t)b3);
+        const uint32_t m = rcx_quad_max(mylo);
+        h.lo = m > c0 ? m : c0;
+        h.hi = rcx_quad_min(myhi);
+        return h;
+    }
+    // find_value for offset = x / range without forming it (AriTab::find_x): -> the value, [lo, hi)
+    __device__ __forceinline__ uint32_t find_x(uint32_t x, uint32_t range, uint32_t& lo, uint32_t& hi) const
+    {
+        const Hit hb = find4(*(const uint64_t*)(bs + 4 * q), 0u, range, x);          // sixteen block sums (the 17th block is what is left)
+        const Hit he = find4(*(const uint64_t*)(tab + 16 * hb.cnt + 4 * q), hb.lo, range, x);
+        lo = he.lo; hi = he.hi;
+        return 16u * hb.cnt + he.cnt;
+    }
+    // get_range, table.rs:100-103
+    __device__ __forceinline__ void range_of(uint32_t v, uint32_t& lo, uint32_t& hi) const
+    {
+        const uint32_t kb = v >> 4, jb = v & 15u;
+        const uint64_t sw = *(const uint64_t*)(bs + 4 * q), ew = *(const uint64_t*)(tab + (v & ~15u) + 4 * q);
+        auto part = [&](uint64_t w4, uint32_t upto, uint32_t& at) -> uint32_t {       // the lane's entries with index < upto, and the one at upto
+            const uint32_t f0 = (uint32_t)w4 & 0xffffu, f1 = (uint32_t)w4 >> 16, f2 = (uint32_t)(w4 >> 32) & 0xffffu, f3 = (uint32_t)(w4 >> 48);
+            const uint32_t i0 = 4 * q;
+            at = i0 == upto ? f0 : i0 + 1 == upto ? f1 : i0 + 2 == upto ? f2 : i0 + 3 == upto ? f3 : 0u;
+            return (i0 < upto ? f0 : 0u) + (i0 + 1 < upto ? f1 : 0u) + (i0 + 2 < upto ? f2 : 0u) + (i0 + 3 < upto ? f3 : 0u);
+        };
+        uint32_t dummy, fv;
+        const uint32_t sb = part(sw, kb, dummy);
+        const uint32_t se = part(ew, jb, fv);
+        lo = rcx_quad_sum(sb + se);
+        hi = lo + rcx_quad_max(fv);
+    }
+    // update(value, 10, 1), table.rs:69-91.  Frequencies stay below 2^13, so a 32-bit add on the dword that holds the u16 is exact.
+    __device__ __forceinline__ void update(uint32_t v)
+    {
+        const uint32_t add = (total >> 10) + 1;
+        if (q == 0) {
+            atomicAdd((uint32_t*)tab + (v >> 1), add << (16u * (v & 1u)));
+            atomicAdd((uint32_t*)bs + (v >> 5), add << (16u * ((v >> 4) & 1u)));
+        }
+        total += add;
+        rcx_wave_sync();
+        if (total >= 4096) {                                  // downscale (cut_shift = 1): four entries a lane and step, halved in place
+            total = 0;
+            for (uint32_t k = 0; k < 17; k++) {
+                uint64_t* pw = (uint64_t*)(tab + 16 * k + 4 * q);
+                uint64_t w = *pw;
+                w = ((w + 0x0001000100010001ull) >> 1) & 0x7fff7fff7fff7fffull;
+                *pw = w;
+                const uint32_t a = (uint32_t)w, b = (uint32_t)(w >> 32);
+                const uint32_t bsum = rcx_quad_sum((a & 0xffffu) + (a >> 16) + (b & 0xffffu) + (b >> 16));
+                if (q == 0) bs[k] = (uint16_t)bsum;
+                total += bsum;
+            }
+            rcx_wave_sync();
+        }
+    }
+};
+
+template <bool DEC>
+__global__ __launch_bounds__(256) void k_ari_byte_quad(rcx_kargs a)
+{
+    __shared__ __align__(16) uint16_t s_q[64 * (ARIQ_TAB + ARIQ_BS)];
+    const unsigned tid = threadIdx.x, q = tid & 3u, sl = tid >> 2;
+    const uint32_t b = blockIdx.x * 64 + sl;
+    if (b >= a.nblocks) return;                                // (whole quads leave)
+    AriQuad T; T.tab = s_q + sl * (ARIQ_TAB + ARIQ_BS); T.bs = T.tab + ARIQ_TAB; T.q = q; T.init();
+    uint32_t low = 0, hai = 0xffffffffu;
+    const uint8_t* in = a.in_base + a.in_off[b];
+    const uint64_t n = a.in_len[b];
+    uint8_t* out = a.out_base + a.out_off[b];
+    const uint64_t cap = a.out_cap[b];
+    uint64_t o = 0, used = 0;
+    int st = RCX_OK;
+    AriBytes src; src.start(in, n);
+    // RangeEncoder::process, mod.rs:117-150, with the symbol's range already divided: the bytes that leave, most significant
+    // first in the low bytes of `ob`; returns their number
+    auto process = [&](uint32_t range, uint32_t from, uint32_t to, uint32_t& ob) -> unsigned {
+        uint32_t lo_ = low + __umul24(range, from), hi_ = low + __umul24(range, to);
+        unsigned k = 0;
+        ob = 0;
+        for (;;) {
+            if (((lo_ ^ hi_) & 0xff000000u) != 0) {
+                if (hi_ - lo_ > (1u << 14)) break;
+                const uint32_t lim = hi_ & 0xff000000u;
+                if (hi_ - lim >= lim - lo_) lo_ = lim; else hi_ = lim - 1;
+            }
+            ob = (ob << 8) | (lo_ >> 24);
+            k++;
+            lo_ <<= 8; hi_ <<= 8;
+        }
+        low = lo_; hai = hi_;
+        return k;
+    };
+    if (!DEC) {                                                // ByteEncoder::write + finish, table.rs:203-219
+        for (uint64_t i = 0; i <= n; i++) {
+            const uint32_t v = i < n ? src.next() : 256u;
+            uint32_t lo, hi, ob;
+            T.range_of(v, lo, hi);
+            const unsigned k = process(rcx_div_u13(hai - low, T.total), lo, hi, ob);
+            if (o + k > cap) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
+            if (q == 0) for (unsigned j = 0; j < k; j++) out[o + j] = (uint8_t)(ob >> (8 * (k - 1 - j)));
+            o += k;
+            if (i < n) T.update(v);
+        }
+        if (!st) {                                             // Encoder::finish: 4-byte BE tail of `low`, mod.rs:230-237
+            if (o + 4 > cap) st = RCX_E_OUTPUT_TOO_SMALL;
+            else { if (q == 0) { out[o] = (uint8_t)(low >> 24); out[o + 1] = (uint8_t)(low >> 16); out[o + 2] = (uint8_t)(low >> 8); out[o + 3] = (uint8_t)low; } o += 4; }
+        }
+        used = n;
+    } else {                                                   // ByteDecoder::read to EOF + finish, table.rs:256-272
+        uint32_t code = 0; unsigned pending = 4;
+        for (;;) {
+            while (pending) {                                  // feed(), mod.rs:271-278
+                if (src.p >= n) { st = RCX_E_MALFORMED; break; }
+                code = (code << 8) + src.next(); pending--;
+            }
+            if (st) break;
+            const uint32_t total = T.total;
+            const uint32_t range = rcx_div_u13(hai - low, total);  // query(), mod.rs:153-159
+            const uint32_t x = code - low;
+            if (x >= __umul24(total, range)) { st = RCX_E_MALFORMED; break; }   // offset >= total: table.rs:106 assert
+            uint32_t lo, hi, ob;
+            const uint32_t v = T.find_x(x, range, lo, hi);
+            pending = process(range, lo, hi, ob);
+            if (v == 256) break;
+            if (o >= cap) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
+            T.update(v);
+            if (q == 0) out[o] = (uint8_t)v;
+            o++;
+        }
+        uint64_t p = src.p;
+        if (!st) { while (pending) { if (p >= n) { st = RCX_E_EOF; break; } p++; pending--; } }   // finish(), mod.rs:289-292
+        used = p;
+    }
+    if (q == 0) { a.status[b] = st; a.out_len[b] = o; if (a.in_used) a.in_used[b] = used; }
+}
+
+// -------------------------------------------------------------------------------------------------
 static void launch_serial(hipStream_t s, int codec, rcx_kargs& k, int v, uint32_t param)
 {
     const uint32_t n = k.nblocks;
@@ -1480,14 +1689,17 @@ static void launch_serial(hipStream_t s, int codec, rcx_kargs& k, int v, uint32_
     case RCX_RLE_ENCODE: hipLaunchKernelGGL((k_rle_encode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k); break;
     case RCX_RLE_DECODE: hipLaunchKernelGGL((k_rle_decode<4>), dim3((n + 3) / 4), dim3(256), 0, s, k); break;
     case RCX_ARI_BYTE_ENCODE: case RCX_ARI_BYTE_DECODE: {
-        // one wave per stream while the waves fit one residency round, one LANE per stream beyond (variant 1 / 2 pin it)
+        // Three kernels (benchmarks/ari_variant_sweep.py, 16 K symbols a stream, encode / decode ms): a WAVE per stream has the
+        // shortest chain per symbol (7.8 / 9.0 up to 1024 streams) but holds a wave slot per stream (4096 streams: 10.7 / 15.7,
+        // 16 384: 30 / 49); a QUAD of lanes per stream (16 streams a wave) takes 12.2 / 15.0 up to 16 K streams and stays ahead of
+        // a LANE per stream (17.7 / 24.4) at every size measured (262 144 streams: 69 / 105 against 74 / 127).  So: waves below
+        // 4096 streams, quads from there on; the lane-per-stream kernel is variant 1 (2 / 3 pin the other two).
         const int dec = codec == RCX_ARI_BYTE_DECODE ? 1 : 0;
-        // measured (config 5): a wave-per-stream step is ~0.9 us at 15 waves per CU, a lane-per-stream step ~1.7 us but for 64
-        // streams at once and nearly independent of the stream count: once the waves no longer fit one residency round
-        // (8192), lanes win (15 260 streams of 49 K symbols: 82 against 127 ms)
-        const bool per_wave = v == 2 ? true : v == 1 ? false : n < 12288u;
-        if (per_wave && dec) hipLaunchKernelGGL((k_ari_byte_wave<4, true>), dim3((n + 3) / 4), dim3(256), 0, s, k);
-        else if (per_wave) hipLaunchKernelGGL((k_ari_byte_wave<4, false>), dim3((n + 3) / 4), dim3(256), 0, s, k);
+        const int kind = v == 1 ? 1 : v == 2 ? 2 : v == 3 ? 3 : (n < 4096u ? 2 : 3);
+        if (kind == 3 && dec) hipLaunchKernelGGL((k_ari_byte_quad<true>), dim3((n + 63) / 64), dim3(256), 0, s, k);
+        else if (kind == 3) hipLaunchKernelGGL((k_ari_byte_quad<false>), dim3((n + 63) / 64), dim3(256), 0, s, k);
+        else if (kind == 2 && dec) hipLaunchKernelGGL((k_ari_byte_wave<4, true>), dim3((n + 3) / 4), dim3(256), 0, s, k);
+        else if (kind == 2) hipLaunchKernelGGL((k_ari_byte_wave<4, false>), dim3((n + 3) / 4), dim3(256), 0, s, k);
         else hipLaunchKernelGGL(k_ari_byte, dim3((n + 63) / 64), dim3(64), 0, s, k, dec);
         break;
     }

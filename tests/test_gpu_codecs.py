@@ -173,10 +173,22 @@ def test_mtf_dc_ari_rle(ctx, oracle):
     e = ctx.rle_encode(raws).check()
     assert e.outputs == [oracle.rle_encode(r) for r in raws]
     assert ctx.rle_decode(e.outputs, lens).check().outputs == raws
-    e = ctx.ari_byte_encode(raws).check()
-    assert e.outputs == [oracle.ari_byte_encode(r) for r in raws]
-    d = ctx.ari_byte_decode([x + b"tail" for x in e.outputs], lens).check()
-    assert d.outputs == raws and list(d.in_used) == [len(x) for x in e.outputs]
+    want = [oracle.ari_byte_encode(r) for r in raws]
+    for variant in (0, 1, 2, 3):                       # auto, a lane / a wave / a quad of lanes per stream
+        ctx.set_variant(N.ARI_BYTE_ENCODE, variant); ctx.set_variant(N.ARI_BYTE_DECODE, variant)
+        e = ctx.ari_byte_encode(raws).check()
+        assert e.outputs == want, variant
+        d = ctx.ari_byte_decode([x + b"tail" for x in e.outputs], lens).check()
+        assert d.outputs == raws and list(d.in_used) == [len(x) for x in e.outputs], variant
+        # mutated streams and short slots: status, bytes and consumed count as the oracle's
+        blobs, caps = corpus.mutate(want[:12], 300, 5 + variant, [10, 300, 30000])
+        res = ctx.ari_byte_decode(blobs, caps)
+        for i, (b_, c_) in enumerate(zip(blobs, caps)):
+            eo = oracle.ari_byte_decode(b_, cap=c_, raise_on_error=False)
+            assert eo[-1] == res.status[i], (variant, i, eo[-1], res.status[i])
+            if eo[-1] == 0:
+                assert eo[0] == res.outputs[i]
+    ctx.set_variant(N.ARI_BYTE_ENCODE, 0); ctx.set_variant(N.ARI_BYTE_DECODE, 0)
     e = ctx.dc_encode(raws).check()
     assert e.outputs == [oracle.dc_encode(r).tobytes() for r in raws]
     assert ctx.dc_decode(e.outputs, lens).check().outputs == raws

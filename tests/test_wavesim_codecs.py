@@ -46,7 +46,7 @@ def test_mtf_rle_ari_dc(oracle):
     for (eo, es), s, o_ in zip(exp, st, outs):
         assert es == s and (s != 0 or eo == o_)
 
-    for variant in (1, 2):                         # one lane per stream, one wave per stream
+    for variant in (1, 2, 3):                      # one lane per stream, one wave per stream, a quad of lanes per stream
         enc, _, _, st, _ = simrun.run(N.ARI_BYTE_ENCODE, variant, raws, [2 * n + 16 for n in lens])
         assert not st.any() and enc == [oracle.ari_byte_encode(r) for r in raws], variant
         dec, _, used, st, _ = simrun.run(N.ARI_BYTE_DECODE, variant, [e + b"xyz" for e in enc], lens)
