@@ -57,15 +57,17 @@ def scatter_blocks(base, off, lens, bounds, root=0, device=None, with_desc=False
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = torch.device(device) if device is not None else (base.device if base is not None else torch.device("cpu"))
-    hdr = torch.zeros(3 * world + 1, dtype=torch.int64, device=dev)          # bounds[world+1] | span lo, hi per rank
+    hdr = None
     if rank == root:
         bounds = np.asarray(bounds, dtype=np.int64)
         off = np.asarray(off, dtype=np.int64)
         lens = np.asarray(lens, dtype=np.int64)
         spans = _spans(bounds, off, lens)
-        hdr = torch.from_numpy(np.concatenate([bounds, spans.reshape(-1)])).to(dev)
-    dist.broadcast(hdr, src=root)
-    h = hdr.cpu().numpy()
+        h = np.concatenate([bounds, spans.reshape(-1)])                      # bounds[world+1] | span lo, hi per rank
+    if world > 1:                                                            # (one rank: the root already has everything, on the host)
+        hdr = torch.from_numpy(h).to(dev) if rank == root else torch.zeros(3 * world + 1, dtype=torch.int64, device=dev)
+        dist.broadcast(hdr, src=root)
+        h = hdr.cpu().numpy()
     bounds, spans = h[: world + 1], h[world + 1:].reshape(world, 2)
     a, b = int(bounds[rank]), int(bounds[rank + 1])
     lo, hi = int(spans[rank][0]), int(spans[rank][1])
@@ -76,11 +78,13 @@ def scatter_blocks(base, off, lens, bounds, root=0, device=None, with_desc=False
         keep = []                                                            # tensors a pending isend reads
         if base.device != dev:                                               # (a host-resident stream on a device backend: the sends
             base = base.to(dev)                                              # and the root's own share live where the peers receive)
+        mine = None
         for g in range(world):
             ga, gb = int(bounds[g]), int(bounds[g + 1])
-            d = torch.from_numpy(np.concatenate([off[ga:gb] - int(spans[g][0]), lens[ga:gb]])).to(dev)
+            dh = np.concatenate([off[ga:gb] - int(spans[g][0]), lens[ga:gb]])
+            d = torch.from_numpy(dh).to(dev, non_blocking=True)
             if g == root:
-                desc = d
+                desc, mine = d, dh
                 local = base[lo:hi]
                 continue
             keep.append(d)
@@ -94,7 +98,7 @@ def scatter_blocks(base, off, lens, bounds, root=0, device=None, with_desc=False
         if hi > lo:
             ops.append(dist.P2POp(dist.irecv, local, root))
     _group(ops)
-    d = desc.cpu().numpy()
+    d = mine if rank == root else desc.cpu().numpy()                          # (the root built its descriptors on the host: no read-back)
     res = (local, d[: b - a].astype(np.uint64), d[b - a:].astype(np.uint64), bounds)
     return res + (desc,) if with_desc else res
 
