@@ -22,6 +22,7 @@ and the block codec taken from the module named by RCX_BENCH_DRY_CODEC (the test
 imports the oracle outside cpu_baseline).
 """
 import argparse
+import ctypes as C
 import hashlib
 import importlib
 import json
@@ -95,36 +96,33 @@ class GpuEngine:
 
     def decode_packed(self, local, loff, llen, nblk, desc=None):
         """decode blocks that arrived packed (end-to-end leg) -> (out tensor, offsets, lengths as numpy).  `desc`: the
-        descriptors as they arrived on the device ([offsets | lengths], int64): the batch's descriptor arrays are persistent
-        device tensors, so a call is one small device copy, the launch, and ONE read-back (worst status + the lengths)."""
-        torch, R = self.torch, self.R
+        descriptors as they arrived on the device ([offsets | lengths], int64) -- the kernel reads them where they are; the
+        result arrays are persistent, so a call is the launch, two small read-backs (statuses, lengths) and one sync."""
+        torch, N = self.torch, self.N
         ar = np.arange(nblk, dtype=np.int64)
         if nblk == 0:
             return torch.zeros(64, dtype=torch.uint8, device=self.dev), ar, np.zeros(0, np.int64)
         st = getattr(self, "_e2e", None)
         if st is None or st["n"] != nblk:
             i64 = lambda a: torch.tensor(np.asarray(a, dtype=np.int64), dtype=torch.int64, device=self.dev)
-            st = {"n": nblk, "out": torch.zeros(nblk * BLOCK + 64, dtype=torch.uint8, device=self.dev), "desc": torch.zeros(2 * nblk, dtype=torch.int64, device=self.dev),
-                  "ooff": i64(ar * BLOCK), "ocap": i64(np.full(nblk, BLOCK)), "res": torch.zeros(nblk + 1, dtype=torch.int64, device=self.dev),
-                  "host": torch.zeros(nblk + 1, dtype=torch.int64).pin_memory(), "db": None, "in_ptr": None}
+            st = {"n": nblk, "out": torch.zeros(nblk * BLOCK + 64, dtype=torch.uint8, device=self.dev),
+                  "ooff": i64(ar * BLOCK), "ocap": i64(np.full(nblk, BLOCK)),
+                  "olen": torch.zeros(nblk, dtype=torch.int64, device=self.dev), "used": torch.zeros(nblk, dtype=torch.int64, device=self.dev),
+                  "stat": torch.full((nblk,), -1, dtype=torch.int32, device=self.dev), "aux": torch.zeros(nblk, dtype=torch.int32, device=self.dev),
+                  "h_olen": torch.zeros(nblk, dtype=torch.int64).pin_memory(), "h_stat": torch.zeros(nblk, dtype=torch.int32).pin_memory()}
             self._e2e = st
-        if desc is not None:
-            st["desc"].copy_(desc)
-        else:
-            st["desc"].copy_(torch.from_numpy(np.concatenate([np.asarray(loff, dtype=np.int64), np.asarray(llen, dtype=np.int64)])))
+        if desc is None:
+            desc = torch.from_numpy(np.concatenate([np.asarray(loff, dtype=np.int64), np.asarray(llen, dtype=np.int64)])).to(self.dev)
+        st["desc"] = desc                                       # (kept alive while the kernel reads it)
         # (the kernels read a block's last bytes with 16-byte loads only inside the block: no padding of the packed bytes)
-        if st["db"] is None or st["in_ptr"] != local.data_ptr():
-            st["db"] = R.DeviceBatch(local, st["desc"][:nblk], st["desc"][nblk:], st["out"], st["ooff"], st["ocap"])
-            st["in_ptr"] = local.data_ptr()
-        db = st["db"]
-        self.ctx.launch_dev(self.N.LZ4_DECODE, db)
-        st["res"][0] = db.status[:nblk].abs().max()
-        st["res"][1:] = db.out_len[:nblk]
-        st["host"].copy_(st["res"], non_blocking=True)
+        db = N.DevBatch(local.data_ptr(), desc.data_ptr(), desc.data_ptr() + 8 * nblk, st["out"].data_ptr(), st["ooff"].data_ptr(), st["ocap"].data_ptr(),
+                        st["olen"].data_ptr(), st["used"].data_ptr(), st["stat"].data_ptr(), st["aux"].data_ptr(), nblk)
+        self.ctx._chk(N.lib().rcx_launch_dev(self.ctx._h, N.LZ4_DECODE, C.byref(db), C.c_void_p(None), 0))
+        st["h_stat"].copy_(st["stat"], non_blocking=True)
+        st["h_olen"].copy_(st["olen"], non_blocking=True)
         torch.cuda.current_stream().synchronize()
-        h = st["host"].numpy()
-        assert int(h[0]) == 0
-        return st["out"], ar * BLOCK, h[1:].copy()
+        assert not st["h_stat"].numpy().any()
+        return st["out"], ar * BLOCK, st["h_olen"].numpy().copy()
 
     def block_crcs(self, base, offs, lens):
         """CRC-32 of every block (the product's k_crc32): what the end-to-end leg compares, block by block"""

@@ -20,6 +20,21 @@ def _zmember(args):
     return zlib.compress(data, (1, 6, 9, 0)[i % 4] if i % 64 else 0)
 
 
+def test_config1_one_mebibyte_deflate_stream(ctx, oracle):
+    """BASELINE configs[0] names the reference's own CPU case, one 1 MiB RFC-1951 stream (tests/test_oracle_golden.py decodes it
+    with the oracle); the same bytes through rcx_inflate_batch, every kernel variant: output, consumed count and flags == the oracle's."""
+    d = synth.gen("text", 1 << 20, 42).tobytes()
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    z = c.compress(d) + c.flush()
+    want, used, flags = oracle.inflate(z, cap=len(d))
+    assert want == d
+    for variant in N.INFLATE_VARIANTS:
+        ctx.set_variant(N.INFLATE, variant)
+        res = ctx.inflate([z], [len(d)]).check()
+        assert res.outputs[0] == d and int(res.in_used[0]) == used == len(z) and int(res.aux[0]) == flags, variant
+    ctx.set_variant(N.INFLATE, 0)
+
+
 def test_config3_zlib_65536_members(ctx, oracle):
     """65536 independent zlib members of 16 KiB (levels 0/1/6/9 + Z_FIXED), Adler-32 verified on the GPU."""
     import torch
