@@ -1,0 +1,7 @@
+#!/bin/bash
+# phase cycle totals of k_inflate3 on config 3 (-DINF3_PROF build): where a member's time goes
+RCX_EXTRA_FLAGS="-DINF3_PROF=1" python -c "
+import sys; sys.path.insert(0, '.')
+from rust_compress_amd.csrc import build
+build.build()" > /dev/null 2>&1
+RCX_EXTRA_FLAGS="-DINF3_PROF=1" RCX_INF3_PROF=1 RCX_CFG_NOCHECK=1 RCX_INFLATE_VARIANT=12 timeout 300 python benchmarks/bench_configs.py --configs 3 2>&1 | grep "per member\|\"ms\"" | cut -c1-400

@@ -174,6 +174,29 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
     // scratch memory (first version: 947 scratch instructions, 4x slower than k_inflate2).
     enum { P_BLOCK = 0, P_STORED, P_DYNHDR, P_BUILD, P_CLENS, P_SYMBOLS, P_DONE };
 
+    // The canonical limits and bases of the codes LONGER than the lookup tables (lit/len 10..15 bits, distance 9..15), packed
+    // `limit | base << 16` (a limit is <= 2^15, a base lies in (-2^15, 288]) and kept in registers -- they are wave-uniform, i.e.
+    // SGPRs.  The segment pass decodes 64 candidate symbols at once, and among 64 there is nearly always one with a long code:
+    // the search over LDS-resident limits (two dependent LDS reads per code length, thirteen lengths) ran on every step of every
+    // walk and was most of a tile's cost (phase timers, -DINF3_PROF: tile builds 862 K of a member's 1.66 M cycles).
+    uint32_t lcL[6] = {0, 0, 0, 0, 0, 0}, lcD[7] = {0, 0, 0, 0, 0, 0, 0};
+    // the length of the code `rev` (its 15 bits, left-justified) starts with, K0 <= length < K0 + N, and its place in the symbol
+    // table; 0: none (flate.rs:129-146, the lengths beyond the lookup table)
+    template <int N, int K0>
+    static __device__ __forceinline__ uint32_t long_code(const uint32_t (&lc)[N], uint32_t rev, uint32_t& idx)
+    {
+        uint32_t l = 0;
+        idx = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const uint32_t lim = lc[i] & 0xffffu, base = (uint32_t)((int32_t)lc[i] >> 16);
+            const bool hit = l == 0 && rev < lim;
+            l = hit ? (uint32_t)(K0 + i) : l;
+            idx = hit ? (rev >> (15 - (K0 + i))) + base : idx;
+        }
+        return l;
+    }
+
     // ---- bits ---------------------------------------------------------------------------------------------------
     __device__ __forceinline__ bool staged(uint32_t bytes) const { return (int32_t)p - this->cbase + (int32_t)bytes <= CB; }
     __device__ __forceinline__ void refill()                         // the caller made sure the dword at p is staged
@@ -223,6 +246,8 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
             over = over || left < 0;
             run[l] = o;
             if (lane == 0) { lim[l] = (code + c) << (15 - l); base[l] = o - code; }
+            if (fused && l > LUTBITS) lcL[l - LUTBITS - 1] = ((code + c) << (15 - l)) | ((o - code) << 16);
+            if (nodist30 && l > DBITS) lcD[l - DBITS - 1] = ((code + c) << (15 - l)) | ((o - code) << 16);
             code = (code + c) << 1; o += c;
         }
         rcx_wave_sync();
@@ -419,6 +444,12 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
         else m.lo &= ~((1ull << r) - 1ull);
     }
     Map tmap = {0, 0};
+#ifdef INF3_PROF
+    uint64_t pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // cycles: [0] emit [1] wide copies [2] staging [3] block headers + tables [4] symbol passes in all [5] of them tile builds [6] chunks consumed [7] symbols booked
+#define INF3_T(slot, code) do { const uint64_t t0__ = __builtin_readcyclecounter(); code; pf[slot] += __builtin_readcyclecounter() - t0__; } while (0)
+#else
+#define INF3_T(slot, code) do { code; } while (0)
+#endif
     uint32_t tb_ = 0, tns_ = 0; int32_t tcb_ = 0;    // tile: first bit (relative to cbuf[0]), segments (0: none), the staging it was built on
     static constexpr uint32_t SEGB4 = 128, PRE4 = 256, XEOB = 0xfffffffeu, XGEN = 0xffffffffu;
 
@@ -448,11 +479,9 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
             if (sp == 0u) { kind = 0; val = (eL >> 4) & 0xffu; nb = eL & 15u; }
             else if (sp == 1u) { kind = 1; nb = eL & 15u; }
             else if (sp == 2u) {
-                const uint32_t rev = __brev(w32) >> 17;
-                uint32_t sym = 0x7fffu, l = 0;
-#pragma unroll 1
-                for (uint32_t k = LUTBITS + 1; k <= 15; k++)
-                    if (l == 0 && rev < tab[k]) { l = k; sym = symL[(rev >> (15u - k)) + tab[16 + k]]; }
+                uint32_t ix;
+                const uint32_t l = long_code<6, LUTBITS + 1>(lcL, __brev(w32) >> 17, ix);
+                const uint32_t sym = l ? symL[ix] : 0x7fffu;
                 if (l) {
                     if (sym < 256u) { kind = 0; val = sym; nb = l; }
                     else if (sym == 256u) { kind = 1; nb = l; }
@@ -473,10 +502,9 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
             const uint32_t eD = lutD[wd & (uint32_t)(DLUTN - 1)];
             uint32_t nbD = eD & 15u, dsy = (eD >> 4) & 31u;
             if (nbD == 0u) {
-                const uint32_t rev = __brev(wd) >> 17;
-#pragma unroll 1
-                for (uint32_t k = DBITS + 1; k <= 15; k++)
-                    if (nbD == 0u && rev < tab[32 + k]) { nbD = k; dsy = symD[(rev >> (15u - k)) + tab[48 + k]]; }
+                uint32_t ix;
+                nbD = long_code<7, DBITS + 1>(lcD, __brev(wd) >> 17, ix);
+                if (nbD) dsy = symD[ix];
             }
             if (nbD != 0u && dsy < 30u) {
                 const uint32_t xbD = dsy < 4u ? 0u : (dsy - 2u) >> 1;                        // EXTRADIST / EXTRADBITS (flate.rs:275-284)
@@ -498,11 +526,9 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
             const uint32_t sp = eL >> 12;
             kind = sp == 1u ? 1u : 4u;
             if (sp == 2u) {                                          // a code longer than the table
-                const uint32_t rev = __brev(w32) >> 17;
-                uint32_t sym = 0x7fffu, l = 0;
-#pragma unroll 1
-                for (uint32_t k = LUTBITS + 1; k <= 15; k++)
-                    if (l == 0 && rev < tab[k]) { l = k; sym = symL[(rev >> (15u - k)) + tab[16 + k]]; }
+                uint32_t ix;
+                const uint32_t l = long_code<6, LUTBITS + 1>(lcL, __brev(w32) >> 17, ix);
+                const uint32_t sym = l ? symL[ix] : 0x7fffu;
                 if (l && sym <= 256u) { kind = sym == 256u ? 1u : 0u; nb = l; }
                 else if (l && sym - 257u < 29u) {
                     const uint32_t nn = sym - 257u;
@@ -516,10 +542,9 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
             const uint32_t eD = lutD[wd & (uint32_t)(DLUTN - 1)];
             uint32_t nbD = eD & 15u, dsy = (eD >> 4) & 31u;
             if (nbD == 0u) {
-                const uint32_t rev = __brev(wd) >> 17;
-#pragma unroll 1
-                for (uint32_t k = DBITS + 1; k <= 15; k++)
-                    if (nbD == 0u && rev < tab[32 + k]) { nbD = k; dsy = symD[(rev >> (15u - k)) + tab[48 + k]]; }
+                uint32_t ix;
+                nbD = long_code<7, DBITS + 1>(lcD, __brev(wd) >> 17, ix);
+                if (nbD) dsy = symD[ix];
             }
             if (nbD != 0u && dsy < 30u) nb += nbD + (dsy < 4u ? 0u : (dsy - 2u) >> 1);
             else kind = 4;
@@ -621,7 +646,7 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
                 tns_ = 0;
                 if (bp + 2u * SEGB4 > LIMB) return pass(flen, fdist);               // too few staged bits for a tile: the window pass (it knows when to restage)
                 const uint32_t nseg = (LIMB - bp) / SEGB4 < 64u ? (LIMB - bp) / SEGB4 : 64u;
-                tile4(bp, nseg);
+                INF3_T(5, tile4(bp, nseg));
             }
             {                                                        // marks below the stream's position are history
                 const int32_t rel = (int32_t)bp - (int32_t)(tb_ + SEGB4 * lane);
@@ -633,6 +658,9 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
             const uint32_t total = RCX_U(__builtin_amdgcn_readlane(incl, 63));
             if (total == 0u) { tns_ = 0; continue; }                // (cannot happen right after a build: bp itself is marked)
             const uint32_t nv = total < 64u ? total : 64u;
+#ifdef INF3_PROF
+            pf[6] += 1;
+#endif
             uint32_t j = 0;                                          // the lane whose map holds symbol `lane`: the number of lanes with incl <= lane
 #pragma unroll
             for (int step = 32; step >= 1; step >>= 1) {
@@ -683,6 +711,9 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
                 desc[2 * eidx] = closes ? litn0 + lbefore + 1u - 32u : litn0 + lbefore - (R & 31u);
                 desc[2 * eidx + 1] = closes ? 32u : ((R & 31u) | (val << 8) | (dist << 16));
             }
+#ifdef INF3_PROF
+            pf[7] += c;
+#endif
             // the state behind symbol c - 1
             if (c) {
                 const int cl = (int)c - 1;
@@ -740,12 +771,21 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
         while (!st && (phase != P_DONE || want_flush || pend_why)) {
             // ---- 1. emit the open batch (the one emit5 site)
             if (want_flush) {
+#ifdef INF3_PROF
+                const uint64_t tfl0 = __builtin_readcyclecounter();
+#endif
                 want_flush = false;
                 if (runL) post(runL, 0, 0);
                 if (ns) {
                     rcx_wave_sync();
                     const uint32_t w0 = (int)lane < ns ? desc[2 * lane] : 0u, w1 = (int)lane < ns ? desc[2 * lane + 1] : 0u;
                     int lo = 0, e = 0;
+#ifdef INF3_CUT_EMIT                                       /* attribution build (wrong output on purpose): the front end alone */
+                    lo = ns;
+                    this->oend = RCX_U(otot - (pend_why ? pend_L + pend_M : 0u));
+                    this->gflush = this->oend & ~15u;
+                    this->lbase = (int32_t)RCX_U(this->lbase_for(this->oend));
+#endif
                     while (lo < ns && !e) e = this->template emit5<true>(ns, lo, w0, w1, litbuf);
 #ifdef RCX_SIM_TRACE
                     if (e && this->lane == 0) { fprintf(stderr, "SPEC%d emit5 -> %d ns %d litn %u otot %u oend %u\n", (int)SPEC, e, ns, litn, otot, this->oend);
@@ -754,12 +794,16 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
                     if (e) { st = RCX_ST_FALLBACK; break; }
                 }
                 ns = 0; litn = 0; runL = 0; runsrc = 0;
+#ifdef INF3_PROF
+                pf[0] += __builtin_readcyclecounter() - tfl0;
+#endif
             }
             // ---- 2. a long match or a stored block: the wave-wide paths of the LZ4 decoder (the one after_batch site)
             if (pend_why) {
                 typename B::Batch bt; bt.ns = 0; bt.why = (int)pend_why; bt.perr = 0; bt.gL = pend_L; bt.gM = pend_M; bt.goff = pend_off; bt.gsrc = pend_src; bt.gnext = 0;
                 int e = 0;
-                if (this->after_batch(bt, e)) { st = RCX_ST_FALLBACK; break; }
+                bool ab_; INF3_T(1, ab_ = this->after_batch(bt, e));
+                if (ab_) { st = RCX_ST_FALLBACK; break; }
                 if (pend_why == (uint32_t)B::WIDE_) { want_stage = true; realign = true; stage_at = after_pos; }   // stored block: bits resume behind it
                 pend_why = 0;
             }
@@ -769,6 +813,9 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
             }
             // ---- 3. (re)stage compressed bytes (the one stage site); realign: the next bit is bit 0 of byte stage_at
             if (want_stage) {
+#ifdef INF3_PROF
+                const uint64_t tst0 = __builtin_readcyclecounter();
+#endif
                 want_stage = false;
                 if (realign) {
                     this->stage(stage_at);
@@ -778,9 +825,16 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
                     bb >>= 8 * mis; bc -= 8 * mis;
                     realign = false;
                 } else this->stage(p - ((bc + 7u) >> 3));              // from the byte of the next unread bit: pass() reads the bits from the buffer
+#ifdef INF3_PROF
+                pf[2] += __builtin_readcyclecounter() - tst0;
+#endif
             }
             if (!staged(16)) { want_stage = true; continue; }          // every step below reads at most 12 bytes
             refill();
+#ifdef INF3_PROF
+            const uint64_t tph0 = __builtin_readcyclecounter();
+            const int ph0 = phase;
+#endif
 
             if (phase == P_BLOCK) {
                 if (ns || litn || runL) { want_flush = true; continue; }   // `lens` lives in the literal buffer: no open batch across a header
@@ -931,6 +985,9 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
                     }
                 }
             }
+#ifdef INF3_PROF
+            pf[ph0 == P_SYMBOLS ? 4 : 3] += __builtin_readcyclecounter() - tph0;
+#endif
         }
         if (!st) {                                                     // the tail of the last batch
             if (runL) post(runL, 0, 0);
@@ -980,6 +1037,12 @@ __global__ __launch_bounds__(64, INF3_OCC) void k_inflate3(rcx_kargs a, int zlib
     s.lmap = s_desc;                                             // (the descriptors are in registers while emit5 runs: its scratch)
     int32_t st; uint32_t olen, used, flags;
     s.run(zlib, &st, &olen, &used, &flags);
+#ifdef INF3_PROF
+    if ((threadIdx.x & 63u) == 0 && a.scratch && a.scratch_bytes >= 128) {       // phase totals -> the last 128 bytes of the scratch
+        unsigned long long* q = (unsigned long long*)((uint8_t*)a.scratch + ((a.scratch_bytes - 128) & ~7ull));
+        for (int i = 0; i < 8; i++) atomicAdd(&q[i], (unsigned long long)s.pf[i]);
+    }
+#endif
     if ((threadIdx.x & 63u) == 0) {
         a.status[b] = st;
         a.out_len[b] = olen;
