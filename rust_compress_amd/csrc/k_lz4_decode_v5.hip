@@ -110,6 +110,87 @@ __device__ __forceinline__ uint64_t rcx_lz4_rounds(uint32_t src_a, uint32_t dst_
 #undef RCX_RB4
     return pend;
 }
+
+// The same loop for batches that hold SELF-OVERLAPPING matches (offset < 16 and < length: runs).  Such a lane copies by period
+// doubling: its source stays at match - offset while `offset + done` bytes of the pattern stand -- round k may copy that many,
+// a whole number of periods, without reading a byte it has yet to write -- and once 16 bytes could be copied at a time the lane
+// switches to a source D = offset * ceil(16 / offset) bytes back (same phase, no overlap) and is an ordinary lane from then on.
+// Per lane: `sa` the source address, `pm` the mask on `done` in the source offset (0 while doubling, -1 after), `cb` the cap base
+// (bytes of a round <= done + cb: the offset while doubling, 16 after); `sconv` = sa after the switch (an ordinary lane's own
+// sa: the switch is idempotent for it, so no lane mask is needed).  Eight more vector instructions a round than the loop above,
+// which batches without such matches keep.  The portable loop of emit5 reads such a source byte by byte, eight bytes a pass
+// (~100 instructions), twice, before its lanes go on as ordinary ones.
+// Every pending lane is eligible here, and the lowest pending lane never waits: the loop ends with nothing pending.
+__device__ __forceinline__ uint64_t rcx_lz4_rounds_ovl(uint32_t sa, uint32_t sconv, uint32_t pm, uint32_t cb, uint32_t dst_a, uint32_t mc,
+                                                       uint32_t dep_lo, uint32_t dep_hi, uint64_t pend, uint32_t& prog)
+{
+    uint32_t t0, t1, a, a4, nv, da, d0, d1, d2, d3, d4;
+#define RCX_RB4(V, O0, O1, O2, O3)                                         \
+        "v_cmpx_lt_u32_e32 vcc, " #O0 ", %[nv]\n\t"                        \
+        "s_cbranch_execz L_sdone_%=\n\t"                                   \
+        "ds_write_b8 %[da], %[" V "] offset:" #O0 "\n\t"                    \
+        "v_cmpx_lt_u32_e32 vcc, " #O1 ", %[nv]\n\t"                        \
+        "v_lshrrev_b32_e32 %[t0], 8, %[" V "]\n\t"                          \
+        "ds_write_b8 %[da], %[t0] offset:" #O1 "\n\t"                       \
+        "v_cmpx_lt_u32_e32 vcc, " #O2 ", %[nv]\n\t"                        \
+        "ds_write_b8_d16_hi %[da], %[" V "] offset:" #O2 "\n\t"             \
+        "v_cmpx_lt_u32_e32 vcc, " #O3 ", %[nv]\n\t"                        \
+        "ds_write_b8_d16_hi %[da], %[t0] offset:" #O3 "\n\t"
+    asm volatile(
+        "L_top_%=:\n\t"
+        "s_mov_b64 vcc, %[pend]\n\t"
+        "v_and_b32_e32 %[t0], vcc_lo, %[dlo]\n\t"
+        "v_and_b32_e32 %[t1], vcc_hi, %[dhi]\n\t"
+        "v_or_b32_e32 %[t0], %[t0], %[t1]\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"
+        "s_and_b64 vcc, vcc, %[pend]\n\t"
+        "s_cbranch_vccz L_out_%=\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "v_and_b32_e32 %[a], %[prog], %[pm]\n\t"
+        "v_add_u32_e32 %[a], %[sa], %[a]\n\t"
+        "v_sub_u32_e32 %[nv], %[mc], %[prog]\n\t"
+        "v_and_b32_e32 %[a4], -4, %[a]\n\t"
+        "ds_read_b32 %[d0], %[a4]\n\t"
+        "ds_read_b32 %[d1], %[a4] offset:4\n\t"
+        "ds_read_b32 %[d2], %[a4] offset:8\n\t"
+        "ds_read_b32 %[d3], %[a4] offset:12\n\t"
+        "ds_read_b32 %[d4], %[a4] offset:16\n\t"
+        "v_and_b32_e32 %[a], 3, %[a]\n\t"
+        "v_add_u32_e32 %[t1], %[prog], %[cb]\n\t"              // what stands of the pattern (an ordinary lane: >= 16)
+        "v_min_u32_e32 %[nv], 16, %[nv]\n\t"
+        "v_min_u32_e32 %[nv], %[nv], %[t1]\n\t"
+        "v_add_u32_e32 %[da], %[dsta], %[prog]\n\t"
+        "v_add_u32_e32 %[prog], %[prog], %[nv]\n\t"
+        "v_cmp_lt_u32_e32 vcc, %[prog], %[mc]\n\t"
+        "s_andn2_b64 %[pend], %[pend], exec\n\t"
+        "s_or_b64 %[pend], %[pend], vcc\n\t"
+        "v_add_u32_e32 %[t1], %[prog], %[cb]\n\t"              // 16 bytes a round possible from now on: the lane turns ordinary
+        "v_cmp_le_u32_e32 vcc, 16, %[t1]\n\t"
+        "v_cndmask_b32_e32 %[sa], %[sa], %[sconv], vcc\n\t"
+        "v_cndmask_b32_e64 %[pm], %[pm], -1, vcc\n\t"
+        "v_cndmask_b32_e64 %[cb], %[cb], 16, vcc\n\t"
+        "s_waitcnt lgkmcnt(3)\n\t"
+        "v_alignbyte_b32 %[d0], %[d1], %[d0], %[a]\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        "v_alignbyte_b32 %[d1], %[d2], %[d1], %[a]\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t"
+        "v_alignbyte_b32 %[d2], %[d3], %[d2], %[a]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_alignbyte_b32 %[d3], %[d4], %[d3], %[a]\n\t"
+        RCX_RB4("d0", 0, 1, 2, 3) RCX_RB4("d1", 4, 5, 6, 7) RCX_RB4("d2", 8, 9, 10, 11) RCX_RB4("d3", 12, 13, 14, 15)
+        "L_sdone_%=:\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_cmp_lg_u64 %[pend], 0\n\t"
+        "s_cbranch_scc1 L_top_%=\n\t"
+        "L_out_%=:\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        : [pend] "+s"(pend), [prog] "+v"(prog), [sa] "+v"(sa), [pm] "+v"(pm), [cb] "+v"(cb), [t0] "=&v"(t0), [t1] "=&v"(t1), [a] "=&v"(a), [a4] "=&v"(a4),
+          [nv] "=&v"(nv), [da] "=&v"(da), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4)
+        : [sconv] "v"(sconv), [dsta] "v"(dst_a), [mc] "v"(mc), [dlo] "v"(dep_lo), [dhi] "v"(dep_hi)
+        : "vcc", "scc", "memory");
+#undef RCX_RB4
+    return pend;
+}
 #endif
 
 // SB: bytes of a gathered (old) match that are staged per lane and ride the copy rounds; the rest is stored straight to its place
@@ -368,8 +449,15 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
             if (!PROF5 && !(CUT & 1) && !(CUT & 64)) {    // the hand-written loop takes every round the plain (non-overlapping) lanes can make
                 if (CUT & 128) __builtin_amdgcn_s_setprio(1);
                 const uint32_t wa = (uint32_t)(uintptr_t)wb_;      // (low half of a generic LDS pointer = the LDS byte address)
-                const uint64_t left = rcx_lz4_rounds(wa + (uint32_t)sbase0, wa + (uint32_t)li_m, Mc, (uint32_t)dep, (uint32_t)(dep >> 32),
-                                                     __ballot(pending0), __ballot(ovl0), prog0);
+                uint64_t left;
+                if (!(CUT & 0x800) && __ballot(ovl0)) {            // runs in the batch: the loop that also copies them, by period doubling
+                    const uint32_t D = off * ((((uint32_t)(0x11111111223357F0ull >> (4u * (off & 15u)))) & 15u) + 1u);   // off * ceil(16 / off)
+                    const uint32_t sa = wa + (uint32_t)sbase0;
+                    left = rcx_lz4_rounds_ovl(sa, ovl0 ? wa + (uint32_t)li_m - D : sa, ovl0 ? 0u : 0xffffffffu, ovl0 ? off : 16u, wa + (uint32_t)li_m, Mc,
+                                              (uint32_t)dep, (uint32_t)(dep >> 32), __ballot(pending0), prog0);
+                } else
+                    left = rcx_lz4_rounds(wa + (uint32_t)sbase0, wa + (uint32_t)li_m, Mc, (uint32_t)dep, (uint32_t)(dep >> 32),
+                                          __ballot(pending0), __ballot(ovl0), prog0);
                 pending0 = RCX_INV_BALLOT(left);
             }
 #endif

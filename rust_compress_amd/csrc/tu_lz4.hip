@@ -72,6 +72,7 @@ int rcx_tu_lz4_decode(hipStream_t s, rcx_kargs& k, int v, std::string& err)
     else if (v == 47) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 128>), dim3(n), dim3(128), 0, s, k, 0);   // hand-written rounds at priority 1 (exact)
     else if (v == 48) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 0x200>), dim3(n), dim3(128), 0, s, k, 0);   // no gathers of old matches (their latency)
     else if (v == 49) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 0x600>), dim3(n), dim3(128), 0, s, k, 0);   // nor literal loads
+    else if (v == 50) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 0x800>), dim3(n), dim3(128), 0, s, k, 0);   // runs copied by the portable loop (exact): what period doubling in the hand-written loop buys
     else if (v == 19) hipLaunchKernelGGL((k_lz4_decode_v6<8, true>), dim3(n), dim3(512), 0, s, k);      // phase timers -> scratch, no second pass
 #endif
     else { err = "lz4 decode: unknown kernel variant (A/B variants need a -DRCX_AB_VARIANTS build)"; return RCX_RC_BAD_ARG; }
