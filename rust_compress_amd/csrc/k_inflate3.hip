@@ -133,6 +133,100 @@ __device__ __forceinline__ uint32_t rcx_inf_walk(uint32_t pk1, uint32_t pk2, uin
 #define RCX_INF_WALK rcx_inf_walk
 #endif
 
+// The segment walks of the speculative pass (Inf3::tile4) as ISA.  A step of a walk -- "how many bits does the symbol at bit q take"
+// -- is, for a literal or a length whose codes are in the lookup tables, three aligned dword reads + two v_alignbit (the bits),
+// one table read (lit/len: the entry's low four bits are the code's length, a length entry's its code + extra bits), for a length
+// a second one at the bits behind it (distance code + its extra bits), a mark in the lane's 128-bit map when q lies inside its own
+// segment, and an add.  hipcc compiles Inf3::hop4 and the loop around it into ~100 vector + ~40 scalar instructions a step: three
+// nested divergent branches (end of block / long code / length), each with its exec bookkeeping, and the search for codes longer
+// than the tables executed on nearly every step because one lane in 64 needs it.  Here every lane computes both the literal's and
+// the length's answer and selects (45 vector + 12 scalar instructions a step); a lane that meets anything else -- end of block, a
+// code longer than the tables, symbols 286 / 287 / 30 / 31 -- STALLS with q on that symbol, and the caller takes that one step
+// with the portable code (which knows all the cases) before it calls again.  Phase timers had the tile builds at half of a
+// member's time (-DINF3_PROF: 801 K of 1.6 M cycles).
+//   q, e, s: the lane's position, the end of its walk, the start of its own segment (bits, relative to the staged bytes)
+//   m0..m3: its map; act: the lanes still walking; cb / ll / ld: LDS byte addresses of the staged bytes and the two tables
+// Returns the lanes that stalled.  The wave runs with all lanes on.
+#ifndef RCX_NO_INF_WALK_ASM
+__device__ __forceinline__ uint64_t rcx_inf_hops(uint32_t& q, uint32_t e, uint32_t s, uint32_t& m0, uint32_t& m1, uint32_t& m2, uint32_t& m3,
+                                                 uint64_t act, uint32_t cb, uint32_t ll, uint32_t ld)
+{
+    uint32_t a, w0, w1, w2, lo, hi, eL, nb, eD, t, u, bit;
+    uint64_t stall, tmp;
+    asm volatile(
+        "s_mov_b64 %[stall], 0\n\t"
+        "L_top_%=:\n\t"
+        "v_cmp_lt_u32_e32 vcc, %[q], %[e]\n\t"
+        "s_and_b64 vcc, vcc, %[act]\n\t"
+        "s_cbranch_vccz L_out_%=\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "v_lshrrev_b32_e32 %[a], 5, %[q]\n\t"
+        "v_lshl_add_u32 %[a], %[a], 2, %[cb]\n\t"                 // the dword that holds bit q
+        "ds_read_b32 %[w0], %[a]\n\t"
+        "ds_read_b32 %[w1], %[a] offset:4\n\t"
+        "ds_read_b32 %[w2], %[a] offset:8\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t"
+        "v_alignbit_b32 %[lo], %[w1], %[w0], %[q]\n\t"            // 32 bits from bit q (the shift is q's low five bits)
+        "v_and_b32_e32 %[t], 0x1ff, %[lo]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 1, %[ll]\n\t"
+        "ds_read_u16 %[eL], %[t]\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t"
+        "v_alignbit_b32 %[hi], %[w2], %[w1], %[q]\n\t"            // and the 32 behind them
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_and_b32_e32 %[nb], 15, %[eL]\n\t"                      // a literal's code bits / a length's code + extra bits
+        "v_alignbit_b32 %[t], %[hi], %[lo], %[nb]\n\t"            // the bits behind a length: its distance code
+        "v_and_b32_e32 %[t], 0xff, %[t]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 1, %[ld]\n\t"
+        "ds_read_u16 %[eD], %[t]\n\t"
+        "v_sub_u32_e32 %[bit], %[q], %[s]\n\t"                    // (the mark, while the table read is under way)
+        "v_lshrrev_b32_e32 %[a], 5, %[bit]\n\t"                   // map word 0..3, or beyond when q is in front of the lane's segment
+        "v_lshlrev_b32_e64 %[bit], %[bit], 1\n\t"
+        "v_cmp_gt_u32_e32 vcc, 0x1000, %[eL]\n\t"                 // a literal
+        "v_cndmask_b32_e64 %[u], -1, 0, vcc\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_and_b32_e32 %[t], 15, %[eD]\n\t"                       // distance code bits (0: not in the table)
+        "v_bfe_u32 %[eD], %[eD], 4, 5\n\t"                        // distance symbol
+        "v_add_u32_e32 %[w0], -1, %[t]\n\t"
+        "v_sub_u32_e32 %[w1], 29, %[eD]\n\t"
+        "v_or_b32_e32 %[w0], %[w0], %[w1]\n\t"                    // negative: no code, or symbol 30 / 31
+        "v_add_u32_e32 %[eD], -2, %[eD]\n\t"
+        "v_ashrrev_i32_e32 %[eD], 1, %[eD]\n\t"
+        "v_max_i32_e32 %[eD], 0, %[eD]\n\t"                       // its extra bits
+        "v_add3_u32 %[t], %[nb], %[t], %[eD]\n\t"
+        "v_cmp_lt_u32_e32 vcc, 0x7fff, %[eL]\n\t"                 // a length
+        "v_cndmask_b32_e32 %[u], %[u], %[w0], vcc\n\t"
+        "v_cndmask_b32_e32 %[nb], %[nb], %[t], vcc\n\t"
+        "v_cmp_le_i32_e32 vcc, 0, %[u]\n\t"                       // the lanes this path takes
+        "s_andn2_b64 %[tmp], exec, vcc\n\t"
+        "s_or_b64 %[stall], %[stall], %[tmp]\n\t"
+        "s_andn2_b64 %[act], %[act], %[tmp]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, %[a]\n\t"
+        "v_cndmask_b32_e32 %[t], 0, %[bit], vcc\n\t"
+        "v_or_b32_e32 %[m0], %[m0], %[t]\n\t"
+        "v_cmp_eq_u32_e32 vcc, 1, %[a]\n\t"
+        "v_cndmask_b32_e32 %[t], 0, %[bit], vcc\n\t"
+        "v_or_b32_e32 %[m1], %[m1], %[t]\n\t"
+        "v_cmp_eq_u32_e32 vcc, 2, %[a]\n\t"
+        "v_cndmask_b32_e32 %[t], 0, %[bit], vcc\n\t"
+        "v_or_b32_e32 %[m2], %[m2], %[t]\n\t"
+        "v_cmp_eq_u32_e32 vcc, 3, %[a]\n\t"
+        "v_cndmask_b32_e32 %[t], 0, %[bit], vcc\n\t"
+        "v_or_b32_e32 %[m3], %[m3], %[t]\n\t"
+        "v_add_u32_e32 %[q], %[q], %[nb]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch L_top_%=\n\t"
+        "L_out_%=:\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        : [q] "+v"(q), [m0] "+v"(m0), [m1] "+v"(m1), [m2] "+v"(m2), [m3] "+v"(m3), [act] "+s"(act), [stall] "=&s"(stall), [tmp] "=&s"(tmp),
+          [a] "=&v"(a), [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [lo] "=&v"(lo), [hi] "=&v"(hi), [eL] "=&v"(eL), [nb] "=&v"(nb),
+          [eD] "=&v"(eD), [t] "=&v"(t), [u] "=&v"(u), [bit] "=&v"(bit)
+        : [e] "v"(e), [s] "v"(s), [cb] "s"(cb), [ll] "s"(ll), [ld] "s"(ld)
+        : "vcc", "scc", "memory");
+    return stall;
+}
+#endif
+
 #ifndef INF3_TCAP
 #define INF3_TCAP 1024
 #endif
@@ -569,6 +663,14 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
         uint32_t ex = 0;
         bool live = mine;
         for (;;) {
+#ifndef RCX_NO_INF_WALK_ASM
+            {   // the hand-written loop walks until every lane is through or has stalled on a symbol it leaves to hop4 below
+                uint32_t m0 = (uint32_t)map.lo, m1 = (uint32_t)(map.lo >> 32), m2 = (uint32_t)map.hi, m3 = (uint32_t)(map.hi >> 32);
+                (void)rcx_inf_hops(q, e, s, m0, m1, m2, m3, __ballot(live), RCX_U((uint32_t)(uintptr_t)this->cbuf), RCX_U((uint32_t)(uintptr_t)lutL),
+                                   RCX_U((uint32_t)(uintptr_t)lutD));
+                map.lo = (uint64_t)m0 | ((uint64_t)m1 << 32); map.hi = (uint64_t)m2 | ((uint64_t)m3 << 32);
+            }
+#endif
             const bool go = live && q < e;
             if (!__ballot(go)) break;
             if (go) {

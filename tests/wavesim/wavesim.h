@@ -308,6 +308,7 @@ static inline uint32_t ws_wave_incl_scan(uint32_t v)
 }
 #define RCX_WAVE_INCL_SCAN ws_wave_incl_scan
 #define RCX_RCPF(x) (1.0f / (x))       // v_rcp_f32: rcx_div_u13 is exact whatever the reciprocal's last bits are
+#define RCX_NO_INF_WALK_ASM 1          // Inf3::tile4's hand-written hop loop: the simulator walks with the portable hop4 alone
 #define RCX_NO_ROUNDS_ASM 1            // emit5's hand-written copy-round loop: the simulator runs the portable loop alone
 #define RCX_LDS_STORE16 ws_lds_store16
 #define RCX_INF_WALK ws_inf_walk
