@@ -545,7 +545,10 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
 #define INF3_T(slot, code) do { code; } while (0)
 #endif
     uint32_t tb_ = 0, tns_ = 0; int32_t tcb_ = 0;    // tile: first bit (relative to cbuf[0]), segments (0: none), the staging it was built on
-    static constexpr uint32_t SEGB4 = 128, PRE4 = 256, XEOB = 0xfffffffeu, XGEN = 0xffffffffu;
+#ifndef INF3_PRE4
+#define INF3_PRE4 448
+#endif
+    static constexpr uint32_t SEGB4 = 128, PRE4 = INF3_PRE4, XEOB = 0xfffffffeu, XGEN = 0xffffffffu;
 
     __device__ __forceinline__ uint64_t bits64(uint32_t b) const                 // 64 bits from bit b of the staged bytes
     {
