@@ -379,7 +379,7 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
             const size_t nact = ((size_t)N / 64 + 64 + 7) & ~(size_t)7;
             const size_t ndone = (size_t)N / 256 + nb + 64;                    // k_bws_gather's chunk flags (blockDim 256), cleared with act[]
             uint8_t* act0 = (uint8_t*)carve(4 * nact + ndone);
-            for (int q = 0; q < 4; q++) st.act[q] = act0 + q * nact;
+            st.act0 = act0; st.nact = (uint32_t)nact;
             st.gdone = act0 + 4 * nact;
             st.n = N; st.par = 0; st.rs = 0;
             if ((uint64_t)(p - (uint8_t*)k.scratch) > k.scratch_bytes) { err = "bwt forward: scratch too small"; return RCX_RC_BAD_ARG; }
@@ -443,6 +443,12 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                 hc[5] = 0;
                 for (uint32_t f = 0; f < BWS_NFLAG; f++) hc[5] |= hc[64 + f];
                 if (getenv("RCX_BWT_TRACE")) fprintf(stderr, "bwt forward round %d: h=%u unresolved %u (listed: %u large, %u + %u local, %u small)\n", round, h, hc[5], hc[3], hc[7], hc[10], hc[4]);
+#ifdef BWS_PROF
+                if (getenv("RCX_BWT_TRACE")) {
+                    fprintf(stderr, "  k_bws_local_wg phases (ticks >> 8, all waves, cumulative): fill %u count %u scan %u scatter %u runs+store %u; passes x waves %u skipped %u groups x waves %u suffixes x waves %u\n",
+                            hc[32], hc[33], hc[34], hc[35], hc[36], hc[40], hc[41], hc[42], hc[43]);
+                }
+#endif
                 if (hc[5] == 0) { converged = true; break; }
                 if (hc[3] > nlarge || hc[7] > nlarge || hc[6] > nlarge || hc[4] > nmid || hc[9] > nlw || hc[10] > nlw) { err = "bwt forward: group list overflow"; return RCX_RC_HIP_ERROR; }
                 std::swap(st.large[0], st.nlarge); std::swap(st.small, st.nsmall); std::swap(st.local, st.nlocal); std::swap(st.localw, st.nlocalw);

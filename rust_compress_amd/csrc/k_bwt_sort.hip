@@ -42,8 +42,8 @@ struct BwsState {
     uint32_t* cnt;
     uint32_t n;                               // suffixes in this pass
     uint32_t par;                             // parity bit groups made in THIS round carry (BWS_PAR or 0)
-    uint8_t* act[4];                          // "a group for the dense passes lies in this window": [round parity * 2 + grid], one byte
-    uint32_t rs;                              // per 64-suffix window (grid 0: aligned, grid 1: shifted by 32); rs = round & 1
+    uint8_t* act0; uint32_t nact;             // "a group for the dense passes lies in this window": four arrays of nact bytes, [round parity * 2
+    uint32_t rs;                              // + grid], one byte per 64-suffix window (grid 0: aligned, grid 1: shifted by 32); rs = round & 1
     uint8_t* gdone;                           // k_bws_gather: "every suffix of this workgroup's chunk is FINAL" (it stays so)
 };
 
@@ -60,8 +60,12 @@ __device__ __forceinline__ bool bws_dense_ok(uint32_t a, uint32_t len)
 // inside one (the aligned pass runs first and takes it), else the shifted one.
 __device__ __forceinline__ void bws_flag_dense(const BwsState& s, uint32_t set, uint32_t a, uint32_t len)
 {
+    // (the four arrays are one allocation and the address is COMPUTED: four pointers indexed by a lane's value are a vector load from
+    // the kernel arguments, and the wait for it -- vmcnt(0), one counter for loads and stores on gfx9 -- sat out every scattered
+    // saA / rank store the wave had just issued)
     const uint32_t z = a + len - 1u;
-    if ((a >> 6) == (z >> 6)) s.act[set * 2u][a >> 6] = 1; else s.act[set * 2u + 1u][(a + 32u) >> 6] = 1;
+    const bool aligned = (a >> 6) == (z >> 6);
+    s.act0[(size_t)(set * 2u + (aligned ? 0u : 1u)) * s.nact + (aligned ? (a >> 6) : ((a + 32u) >> 6))] = 1;
 }
 // Append `seg` to a list for the lanes with `want`: ONE atomic per wave (a single word takes ~88 atomics per microsecond on
 // this chip: one atomic per group made the first version's passes take 40 ms whatever else they did).  Wave-uniform call.
@@ -424,8 +428,25 @@ struct BwsQueue {
     }
 };
 
+// -DBWS_PROF: where a team's time goes (s_memtime ticks per phase, summed over the waves into cnt[32 ..]; RCX_BWT_TRACE prints them)
+#ifdef BWS_PROF
+#define BWS_LAP0() do { tl = __builtin_readcyclecounter(); } while (0)
+#define BWS_LAP(slot) do { const uint64_t n__ = __builtin_readcyclecounter(); pf[slot] += n__ - tl; tl = n__; } while (0)
+#define BWS_CNT(slot, v) do { pf[slot] += (v); } while (0)
+#else
+#define BWS_LAP0() do { } while (0)
+#define BWS_LAP(slot) do { } while (0)
+#define BWS_CNT(slot, v) do { } while (0)
+#endif
 template <class K, int NW>
 struct BwsLocal {
+#ifdef BWS_PROF
+    uint64_t pf[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tl = 0;
+    __device__ void report(const BwsState& s, uint32_t base) const
+    {
+        if (lane == 0) for (int q = 0; q < 12; q++) atomicAdd(&s.cnt[base + q], (uint32_t)(pf[q] >> (q < 8 ? 8 : 0)));
+    }
+#endif
     static constexpr uint32_t CAP = NW == 1 ? BWS_LWAVE : BWS_LMAX;
     static constexpr uint32_t MAXSTEP = CAP / (64u * NW);
     K* key; uint32_t* val; uint16_t* pa; uint16_t* pb; uint32_t* hist;      // hist: [NW][256]
@@ -439,7 +460,30 @@ struct BwsLocal {
     // The NEXT group's keys and suffixes are requested while this one is sorted, and before this one's results are stored: on gfx9 a
     // wait for a load also sits out every OLDER store (one counter), so a group that loaded its input after the previous group's
     // scattered stores waited for those to drain at its first barrier.
+    // A wave-uniform load (a group's descriptor, its first SA word) is a vector load all the same, and the compiler moves its result
+    // to scalar registers AT ONCE -- behind an s_waitcnt vmcnt(0) that sits out everything in flight, the prefetch itself and the
+    // previous group's scattered stores.  Such values are loaded through a lane's index (RCX_VGPR) and stay in vector registers
+    // until the next fill has waited for the prefetch anyway: pfirst, and the descriptor of the group after the next (pend()).
     K pk[MAXSTEP]; uint32_t pv[MAXSTEP]; uint32_t pfirst;
+    uint32_t qs, ql, qi;
+    __device__ __forceinline__ void pend(const BwsSeg* list, uint32_t idx, bool have)
+    {
+        qs = 0; ql = 0; qi = 0;
+        if (have) { const uint32_t* p = (const uint32_t*)(list + idx) + RCX_VGPR(0u); qs = p[0]; ql = p[1]; qi = p[2]; }
+    }
+    // What prefetch() and pend() requested has arrived (it was requested a whole sort ago): said HERE, before this group's stores go
+    // out, because the compiler cannot count the stores of a loop and would wait for vmcnt(0) -- the loads and every store after
+    // them -- where the next group first touches these registers.
+    __device__ __forceinline__ void settle()
+    {
+#pragma unroll
+        for (uint32_t k = 0; k < MAXSTEP; k++) {
+            if (sizeof(K) == 8) pk[k] = (K)((uint64_t)RCX_VGPR((uint32_t)pk[k]) | ((uint64_t)RCX_VGPR((uint32_t)((uint64_t)pk[k] >> 32)) << 32));
+            else pk[k] = (K)RCX_VGPR((uint32_t)pk[k]);
+            pv[k] = RCX_VGPR(pv[k]);
+        }
+        pfirst = RCX_VGPR(pfirst); qs = RCX_VGPR(qs); ql = RCX_VGPR(ql); qi = RCX_VGPR(qi);
+    }
     __device__ __forceinline__ void prefetch(const BwsState& s, const BwsSeg sg)
     {
         const uint32_t T = 64u * NW;
@@ -452,24 +496,29 @@ struct BwsLocal {
             pk[k] = 0; pv[k] = 0;
             if (i < sg.len) { pk[k] = ks[i]; pv[k] = ss[i]; }
         }
-        pfirst = ss[0];
+        pfirst = ss[RCX_VGPR(0u)];
     }
 
-    // sorts the group whose input prefetch() has requested; `more`: `nx` is the group after it
-    __device__ void run(const BwsState& s, const BwsSeg sg, uint32_t top_shift, bool more, const BwsSeg nx)
+    // sorts the group whose input prefetch() has requested and returns the group after it (len 0: none), whose input it requests;
+    // list[idx2] (if `have2`) is the group after that one
+    __device__ BwsSeg run(const BwsState& s, const BwsSeg sg, uint32_t top_shift, const BwsSeg* list, uint32_t idx2, bool have2)
     {
         const uint32_t len = sg.len, T = 64u * NW;
         const uint32_t shift = sg.info & 0xffu;                              // bits [0, shift + 8) of the key are still unsorted
         const bool whole = (pfirst & BWS_RV) != 0;                           // a group an earlier round's sort made (not a bin of this round's radix levels)
+        BWS_LAP0(); BWS_CNT(10, 1); BWS_CNT(11, len);
 #pragma unroll
         for (uint32_t k = 0; k < MAXSTEP; k++) {
             const uint32_t i = t + k * T;
             if (i < len) { key[i] = pk[k]; val[i] = pv[k] & BWS_IDX; pa[i] = (uint16_t)i; }
         }
-        if (more) prefetch(s, nx);
+        const BwsSeg nx{RCX_UNI(qs), RCX_UNI(ql), RCX_UNI(qi)};              // (it came with this group's input)
+        if (nx.len) prefetch(s, nx);
+        pend(list, idx2, have2);
         const uint32_t cs = (((len + NW - 1u) / NW) + 63u) & ~63u;           // a wave's contiguous share
         const uint32_t w0 = w * cs, w1 = (w0 + cs < len) ? w0 + cs : len;
         sync();
+        BWS_LAP(0);
         for (uint32_t sh = 0; sh < shift + 8u; sh += 8) {
             uint32_t* myh = hist + 256u * w;
 #pragma unroll
@@ -496,6 +545,7 @@ struct BwsLocal {
                 }
             }
             sync();
+            BWS_LAP(1);
             // ---- totals, "one digit only", exclusive scan, per-wave cursors
             bool one;
             if (NW == 1) {
@@ -523,7 +573,9 @@ struct BwsLocal {
                 }
                 __syncthreads();
             }
-            if (one) continue;                                               // the whole group shares this digit: nothing moves
+            BWS_LAP(2);
+            if (one) { BWS_CNT(9, 1); continue; }                            // the whole group shares this digit: nothing moves
+            BWS_CNT(8, 1);
             // ---- scatter (stable): the wave's cursor of the digit + rank among the peers
 #pragma unroll
             for (uint32_t st = 0; st < MAXSTEP; st++) {
@@ -539,8 +591,10 @@ struct BwsLocal {
                 }
             }
             sync();
+            BWS_LAP(3);
             { uint16_t* x = pa; pa = pb; pb = x; }
         }
+        settle();
         // ---- runs of equal keys: a bitmap of run heads, then every position looks up its run
         const uint32_t nwords = (len + 31u) >> 5;
         for (uint32_t c0 = 64u * w; c0 < len; c0 += T) {
@@ -580,11 +634,19 @@ struct BwsLocal {
                 g = val[pa[p]];
                 const bool single = re - rs == 1u;
                 s.saA[sg.start + p] = g | (rs == p ? (BWS_HEAD | BWS_RV | s.par) : 0u) | (single ? BWS_FINAL : 0u);
+#if defined(BWS_CUT_RANK) && BWS_CUT_RANK == 2
+                s.rank[sg.start + p] = sg.start + rs;
+#elif defined(BWS_CUT_RANK) && BWS_CUT_RANK == 3
+                s.rank[(sg.start & ~0x3ffffu) + ((g * 2654435761u) & 0x3ffffu)] = sg.start + rs;
+#elif !defined(BWS_CUT_RANK)
                 if (!(whole && rs == 0u)) s.rank[g] = sg.start + rs;             // the run at the start of a group whose ranks stand keeps its rank
+#endif
             }
             Q->push(s, in && rs == p && re - rs >= 2u, sg.start + rs, re - rs, top_shift);
         }
         sync();
+        BWS_LAP(4);
+        return nx;
     }
 };
 
@@ -612,15 +674,11 @@ __global__ __launch_bounds__(256, BWS_LW_OCC) RCX_SGPR_CAP void k_bws_local_wave
     {
         uint32_t e = blockIdx.x * 4u + wave;
         const uint32_t step = gridDim.x * 4u;
-        BwsSeg sg{0, 0, 0}, nx{0, 0, 0};
-        if (e < nseg) { sg = s.local[e]; L.prefetch(s, sg); }
-        if (e + step < nseg) nx = s.local[e + step];
+        BwsSeg sg{0, 0, 0};
+        if (e < nseg) { sg = s.local[e]; L.prefetch(s, sg); L.pend(s.local, e + step, e + step < nseg); L.settle(); }      // (settled here too: the loop below then never waits where a group starts)
         while (e < nseg) {
-            const bool more = e + step < nseg;
-            BwsSeg nx2{0, 0, 0};                                 // (a descriptor is read two groups ahead: used one group ahead, it would be waited for behind this group's stores)
-            if (e + 2u * step < nseg) nx2 = s.local[e + 2u * step];
-            L.run(s, sg, top_shift, more, nx);
-            sg = nx; nx = nx2; e += step;
+            sg = L.run(s, sg, top_shift, s.local, e + 2u * step, e + 2u * step < nseg);
+            e += step;
         }
     }
     Q.flush(s);
@@ -641,18 +699,17 @@ __global__ __launch_bounds__(256) void k_bws_local_wg(BwsState s, uint32_t top_s
     L.t = threadIdx.x; L.w = threadIdx.x >> 6; L.lane = threadIdx.x & 63u;
     {
         uint32_t e = blockIdx.x;
-        BwsSeg sg{0, 0, 0}, nx{0, 0, 0};
-        if (e < nsegw) { sg = s.localw[e]; L.prefetch(s, sg); }
-        if (e + gridDim.x < nsegw) nx = s.localw[e + gridDim.x];
+        BwsSeg sg{0, 0, 0};
+        if (e < nsegw) { sg = s.localw[e]; L.prefetch(s, sg); L.pend(s.localw, e + gridDim.x, e + gridDim.x < nsegw); L.settle(); }
         while (e < nsegw) {
-            const bool more = e + gridDim.x < nsegw;
-            BwsSeg nx2{0, 0, 0};
-            if (e + 2u * gridDim.x < nsegw) nx2 = s.localw[e + 2u * gridDim.x];
-            L.run(s, sg, top_shift, more, nx);
-            sg = nx; nx = nx2; e += gridDim.x;
+            sg = L.run(s, sg, top_shift, s.localw, e + 2u * gridDim.x, e + 2u * gridDim.x < nsegw);
+            e += gridDim.x;
         }
     }
     Q.flush(s);
+#ifdef BWS_PROF
+    L.report(s, 32u);
+#endif
 }
 
 // ---- the few groups of <= 64 the dense passes cannot take (33..64 suffixes across both window grids): one wave per group ----
@@ -686,13 +743,32 @@ __global__ __launch_bounds__(256) RCX_SGPR_CAP void k_bws_small(BwsState s, uint
 // Windows of 64 suffixes starting at `off` (0 or 32: a group of <= 32 suffixes that straddles an aligned window lies inside a
 // shifted one).  The lanes of a window sort by (start of my group, key, lane): that orders every group the window contains
 // and moves nothing else -- a wave-wide bitonic sort over ds_bpermute (21 compare-exchange steps whatever the group sizes).
+// A window's input: its SA words, the word after it (is the next window's first suffix a head?) and its keys.  Requested one window
+// ahead -- BEFORE the window in hand stores its results -- and waited for (settle) before those stores go out too: loads and stores
+// share one counter, and a wait for loads requested after a window's scattered rank[] stores sat those out, window after window.
+template <class K> struct BwsWin {
+    uint32_t v, nv; K key;
+    __device__ __forceinline__ void load(const BwsState& s, uint32_t j0, uint32_t lane)
+    {
+        const uint32_t j = j0 + lane;
+        v = j < s.n ? s.saA[j] : (BWS_HEAD | BWS_FINAL);
+        nv = (j0 + 64u >= s.n) ? BWS_HEAD : s.saA[j0 + 64u + RCX_VGPR(0u)];      // (through a lane's index: a uniform load is waited for at once)
+        key = j < s.n ? bws_keys<K>(s, 0)[j] : (K)0;
+    }
+    __device__ __forceinline__ void settle()
+    {
+        v = RCX_VGPR(v); nv = RCX_VGPR(nv);
+        if (sizeof(K) == 8) key = (K)((uint64_t)RCX_VGPR((uint32_t)key) | ((uint64_t)RCX_VGPR((uint32_t)((uint64_t)key >> 32)) << 32));
+        else key = (K)RCX_VGPR((uint32_t)key);
+    }
+};
 template <class K>
-__device__ __forceinline__ void bws_dense_window(const BwsState& s, uint32_t j0, uint32_t lane)
+__device__ __forceinline__ void bws_dense_window(const BwsState& s, uint32_t j0, uint32_t lane, const BwsWin<K>& W, BwsWin<K>& next)
 {
     const uint32_t j = j0 + lane;
     const bool in = j < s.n;
-    const uint32_t v = in ? s.saA[j] : (BWS_HEAD | BWS_FINAL);
-    const bool nexthead = (j0 + 64u >= s.n) || (s.saA[j0 + 64u] & BWS_HEAD);
+    const uint32_t v = W.v;
+    const bool nexthead = (W.nv & BWS_HEAD) != 0;
     const unsigned long long heads = __ballot((v & BWS_HEAD) != 0);
     const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
     const unsigned long long hb = heads & le, ha = heads & ~le;
@@ -702,50 +778,52 @@ __device__ __forceinline__ void bws_dense_window(const BwsState& s, uint32_t j0,
     // my group lies inside this window, is not final, and was made BEFORE this round (this round's groups are sorted already)
     const uint32_t hv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(gs << 2), (int)v);
     const bool mine = in && has_head && (ha != 0 || nexthead) && ge - gs >= 2u && (hv & BWS_PAR) != s.par && !(hv & BWS_FINAL);
-    if (!__ballot(mine)) return;
-    const K key = in ? bws_keys<K>(s, 0)[j] : (K)0;
-    const uint32_t maxlen = rcx_wave_max(mine ? ge - gs : 0u);
+    // (one way through, whatever the window holds: sort, settle the next window's input, store)
+    const bool any = __ballot(mine) != 0;
+    const K key = W.key;
     uint32_t val = v & BWS_IDX, was = mine ? 1u : 0u;
-    bool rhead; uint32_t rs, re, gpos;
-    if (maxlen <= 12u) {
-        // small groups only (the usual case after the first rounds): a rank sort, 2-3 ds_bpermute per member of the largest group
-        const uint32_t klo = (uint32_t)key, khi = sizeof(K) == 8 ? (uint32_t)((uint64_t)key >> 32) : 0u;
-        uint32_t less = 0, lt = 0, eq = 0;
-        // (no branch in the body -- a lane outside its group adds zeros -- and four steps per trip: their ds_bpermute round trips overlap;
-        // one step per trip waited ~120 cycles for each)
+    uint32_t sp = 0, sw = 0, rv = 0, gpos = 0, glen = 0;         // saA[sp] = sw (st), rank[val] = rv (rk); a new group [gpos, gpos + glen) (newg)
+    bool st = false, rk = false, newg = false;
+    if (any) {
+        const uint32_t maxlen = rcx_wave_max(mine ? ge - gs : 0u);
+        if (maxlen <= 12u) {
+            // small groups only (the usual case after the first rounds): a rank sort, 2-3 ds_bpermute per member of the largest group
+            const uint32_t klo = (uint32_t)key, khi = sizeof(K) == 8 ? (uint32_t)((uint64_t)key >> 32) : 0u;
+            uint32_t less = 0, lt = 0, eq = 0;
+            // (no branch in the body -- a lane outside its group adds zeros -- and four steps per trip: their ds_bpermute round trips overlap;
+            // one step per trip waited ~120 cycles for each)
 #pragma unroll 4
-        for (uint32_t t = 0; t < maxlen; t++) {
-            const uint32_t srcl = gs + t;
-            const int pa = (int)((srcl & 63u) << 2);
-            const uint32_t ol = (uint32_t)__builtin_amdgcn_ds_bpermute(pa, (int)klo);
-            const uint32_t oh = sizeof(K) == 8 ? (uint32_t)__builtin_amdgcn_ds_bpermute(pa, (int)khi) : 0u;
-            const bool on = mine && srcl < ge;
-            const bool l = on && (oh < khi || (oh == khi && ol < klo)), e = on && oh == khi && ol == klo;
-            lt += l ? 1u : 0u; eq += e ? 1u : 0u;
-            less += (l || (e && srcl < lane)) ? 1u : 0u;           // equal keys keep the order they stand in (one ds_bpermute less per step)
+            for (uint32_t t = 0; t < maxlen; t++) {
+                const uint32_t srcl = gs + t;
+                const int pa = (int)((srcl & 63u) << 2);
+                const uint32_t ol = (uint32_t)__builtin_amdgcn_ds_bpermute(pa, (int)klo);
+                const uint32_t oh = sizeof(K) == 8 ? (uint32_t)__builtin_amdgcn_ds_bpermute(pa, (int)khi) : 0u;
+                const bool on = mine && srcl < ge;
+                const bool l = on && (oh < khi || (oh == khi && ol < klo)), e = on && oh == khi && ol == klo;
+                lt += l ? 1u : 0u; eq += e ? 1u : 0u;
+                less += (l || (e && srcl < lane)) ? 1u : 0u;           // equal keys keep the order they stand in (one ds_bpermute less per step)
+            }
+            st = mine; sp = j0 + gs + less;
+            sw = val | (less == lt ? (BWS_HEAD | BWS_RV | s.par) : 0u) | (eq == 1u ? BWS_FINAL : 0u);
+            rk = mine && !((hv & BWS_RV) && lt == 0u); rv = j0 + gs + lt;       // the run at the start of a group whose ranks stand keeps its rank
+            newg = mine && less == lt && eq >= 2u; gpos = j0 + gs + lt; glen = eq;
+        } else {
+            uint32_t c0 = mine ? gs : lane;                          // composite sort key: (group start or my own lane, key)
+            uint32_t klo = (uint32_t)key, khi = sizeof(K) == 8 ? (uint32_t)((uint64_t)key >> 32) : 0u;
+            if (sizeof(K) == 4) { klo = (mine ? klo : 0u) | (c0 << 24); c0 = 0; }   // 32-bit keys are local ranks (< 2^24): the group rides in the key's top bits (a bystander's stale key must not)
+            bool rhead; uint32_t rs, re;
+            bws_wave_sort<K>(lane, c0, klo, khi, val, was);
+            bws_wave_runs<K>(lane, c0, klo, khi, rhead, rs, re);
+            st = was != 0; sp = j;
+            sw = val | (rhead ? (BWS_HEAD | BWS_RV | s.par) : 0u) | (re - rs == 1u ? BWS_FINAL : 0u);
+            rk = was && !((hv & BWS_RV) && rs == gs); rv = j0 + rs;
+            newg = was && rhead && re - rs >= 2u; gpos = j0 + rs; glen = re - rs;
         }
-        if (mine) {
-            const bool single = eq == 1u;
-            s.saA[j0 + gs + less] = val | (less == lt ? (BWS_HEAD | BWS_RV | s.par) : 0u) | (single ? BWS_FINAL : 0u);
-            if (!((hv & BWS_RV) && lt == 0u)) s.rank[val] = j0 + gs + lt;       // the run at the start of a group whose ranks stand keeps its rank:
-                                                                                  // these scattered 4-byte stores are what the dense passes wait for
-        }
-        rhead = less == lt; rs = 0; re = eq; gpos = j0 + gs + lt;
-    } else {
-        uint32_t c0 = mine ? gs : lane;                          // composite sort key: (group start or my own lane, key)
-        uint32_t klo = (uint32_t)key, khi = sizeof(K) == 8 ? (uint32_t)((uint64_t)key >> 32) : 0u;
-        if (sizeof(K) == 4) { klo = (mine ? klo : 0u) | (c0 << 24); c0 = 0; }   // 32-bit keys are local ranks (< 2^24): the group rides in the key's top bits (a bystander's stale key must not)
-        bws_wave_sort<K>(lane, c0, klo, khi, val, was);
-        bws_wave_runs<K>(lane, c0, klo, khi, rhead, rs, re);
-        if (was) {
-            const bool single = re - rs == 1u;
-            s.saA[j] = val | (rhead ? (BWS_HEAD | BWS_RV | s.par) : 0u) | (single ? BWS_FINAL : 0u);
-            if (!((hv & BWS_RV) && rs == gs)) s.rank[val] = j0 + rs;
-        }
-        gpos = j0 + rs;
     }
-    const bool newg = was && rhead && re - rs >= 2u;                                    // (rank-sort path: rs = 0, re = run length)
-    if (newg) bws_flag_dense(s, s.rs ^ 1u, gpos, re - rs);                              // next round's dense passes
+    next.settle();
+    if (st) s.saA[sp] = sw;
+    if (rk) s.rank[val] = rv;
+    if (newg) bws_flag_dense(s, s.rs ^ 1u, gpos, glen);                                 // next round's dense passes
     const unsigned long long newgroups = __ballot(newg);
     if (lane == 0 && newgroups) bws_flag_unresolved(s);
 }
@@ -764,16 +842,30 @@ __global__ __launch_bounds__(256) RCX_SGPR_CAP void k_bws_dense(BwsState s, uint
     const uint32_t vwg = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const uint32_t w0 = (vwg * 4u + RCX_UNI(threadIdx.x >> 6)) * BWS_DW;               // first window (in the grid's own numbering); uniform, and said so:
     if ((uint64_t)w0 * 64u >= (uint64_t)s.n + 64u) return;                           // the window loop below is scalar code then
-    uint8_t* act = s.act[s.rs * 2u + (off ? 1u : 0u)];
+    uint8_t* act = s.act0 + (size_t)(s.rs * 2u + (off ? 1u : 0u)) * s.nact;
     const unsigned long long fv = *(const unsigned long long*)(act + w0);
     const unsigned long long f = (unsigned long long)RCX_UNI((uint32_t)fv) | ((unsigned long long)RCX_UNI((uint32_t)(fv >> 32)) << 32);
     if (!f) return;
-    for (uint32_t k = 0; k < BWS_DW; k++) {
-        if (!((f >> (8u * k)) & 0xffu)) continue;
-        const uint32_t win = w0 + k;
-        if (off && win == 0) continue;                           // the shifted window [-32, 32) holds nothing the aligned pass cannot take
-        const uint32_t j0 = off ? win * 64u - 32u : win * 64u;
-        if (j0 < s.n) bws_dense_window<K>(s, j0, lane);
+    // the flagged windows, each one's input requested while the one before it is sorted
+    auto start_of = [&](uint32_t k) { const uint32_t win = w0 + k; return off ? win * 64u - 32u : win * 64u; };
+    auto next_flagged = [&](uint32_t k) {
+        for (; k < BWS_DW; k++) {
+            if (!((f >> (8u * k)) & 0xffu)) continue;
+            if (off && w0 + k == 0) continue;                    // the shifted window [-32, 32) holds nothing the aligned pass cannot take
+            if (start_of(k) < s.n) break;
+        }
+        return k;
+    };
+    uint32_t k = next_flagged(0);
+    BwsWin<K> W, Wn;
+    W.v = 0; W.nv = 0; W.key = 0;
+    if (k < BWS_DW) { W.load(s, start_of(k), lane); W.settle(); }
+    while (k < BWS_DW) {
+        const uint32_t k2 = next_flagged(k + 1u);
+        Wn.v = 0; Wn.nv = 0; Wn.key = 0;
+        if (k2 < BWS_DW) Wn.load(s, start_of(k2), lane);
+        bws_dense_window<K>(s, start_of(k), lane, W, Wn);
+        W = Wn; k = k2;
     }
     if (lane == 0) *(unsigned long long*)(act + w0) = 0ull;
 }
