@@ -445,8 +445,8 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                 if (getenv("RCX_BWT_TRACE")) fprintf(stderr, "bwt forward round %d: h=%u unresolved %u (listed: %u large, %u + %u local, %u small)\n", round, h, hc[5], hc[3], hc[7], hc[10], hc[4]);
 #ifdef BWS_PROF
                 if (getenv("RCX_BWT_TRACE")) {
-                    fprintf(stderr, "  k_bws_local_wg phases (ticks >> 8, all waves, cumulative): fill %u count %u scan %u scatter %u runs+store %u; passes x waves %u skipped %u groups x waves %u suffixes x waves %u\n",
-                            hc[32], hc[33], hc[34], hc[35], hc[36], hc[40], hc[41], hc[42], hc[43]);
+                    fprintf(stderr, "  k_bws_local_wg phases (ticks >> 8, all waves, cumulative): fill %u count %u scan %u scatter %u heads %u wordscan %u store %u last-barrier %u; passes x waves %u skipped %u groups x waves %u suffixes x waves %u\n",
+                            hc[32], hc[33], hc[34], hc[35], hc[36], hc[37], hc[38], hc[39], hc[40], hc[41], hc[42], hc[43]);
                 }
 #endif
                 if (hc[5] == 0) { converged = true; break; }

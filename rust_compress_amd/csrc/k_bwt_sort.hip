@@ -525,23 +525,40 @@ struct BwsLocal {
             for (int q = 0; q < 4; q++) myh[lane + 64 * q] = 0;
             if (NW > 1 && t == 0) misc[0] = 0;
             rcx_wave_sync();
-            // ---- count: digit, peers, rank among the peers; the wave's histogram
-            uint32_t inf[MAXSTEP], el[MAXSTEP];
+            // ---- count: digit, peers, rank among the peers; the wave's histogram.  A step's LDS round trips (permutation entry -> that
+            // key's digit byte -> the histogram) are not waited for one by one: the entries of all steps are read, then the digits, and
+            // the histogram takes each step's count with a returning add -- what comes back is the number of this wave's EARLIER elements
+            // with the digit, so that the scatter below is one independent read per element (cursors advanced step by step were
+            // MAXSTEP dependent round trips more).
+            uint32_t inf[MAXSTEP];                                           // digit [0, 8) | ok << 8 | place among the wave's elements with the digit << 9 (12 bits) | entry << 21
+            {
+                uint32_t ev[MAXSTEP], dv[MAXSTEP], bf[MAXSTEP];
+                const uint8_t* kb = (const uint8_t*)key + (sh >> 3);         // (sh is a multiple of 8: the digit is a byte of the little-endian key)
 #pragma unroll
-            for (uint32_t st = 0; st < MAXSTEP; st++) {
-                inf[st] = 0; el[st] = 0;
-                const uint32_t i = w0 + 64u * st + lane;
-                if (w0 + 64u * st < w1) {                                    // wave-uniform
-                    const bool ok = i < w1;
-                    const uint32_t e = ok ? pa[i] : 0u;
-                    const uint32_t d = ok ? (uint32_t)(key[e] >> sh) & 0xffu : 0x100u;
-                    const unsigned long long peers = BWS_PEERS(ok, d);
-                    const uint32_t leader = (uint32_t)__ffsll(peers) - 1u, cnt = (uint32_t)__popcll(peers);
-                    const uint32_t rk = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
-                    if (ok && leader == lane) myh[d] += cnt;
-                    inf[st] = (d & 0xffu) | (rk << 8) | ((leader & 63u) << 14) | (cnt << 20) | ((uint32_t)ok << 28);
-                    el[st] = e;
-                    rcx_wave_sync();
+                for (uint32_t st = 0; st < MAXSTEP; st++) { const uint32_t i = w0 + 64u * st + lane; ev[st] = pa[i]; ev[st] = i < w1 ? ev[st] : 0u; }   // (i < CAP whatever the step)
+#pragma unroll
+                for (uint32_t st = 0; st < MAXSTEP; st++) dv[st] = kb[ev[st] * (uint32_t)sizeof(K)];
+#pragma unroll
+                for (uint32_t st = 0; st < MAXSTEP; st++) {
+                    inf[st] = 0; bf[st] = 0;
+                    if (w0 + 64u * st < w1) {                                // wave-uniform
+                        const bool ok = w0 + 64u * st + lane < w1;
+                        const uint32_t d = ok ? dv[st] : 0x100u;
+                        const unsigned long long peers = BWS_PEERS(ok, d);
+                        const uint32_t leader = (uint32_t)__ffsll(peers) - 1u, cnt = (uint32_t)__popcll(peers);
+                        const uint32_t rk = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+                        if (ok && leader == lane) bf[st] = atomicAdd(&myh[d], cnt);
+                        inf[st] = (d & 0xffu) | ((uint32_t)ok << 8) | (rk << 9) | ((leader & 63u) << 15) | (ev[st] << 21);
+                        rcx_wave_sync();
+                    }
+                }
+#pragma unroll
+                for (uint32_t st = 0; st < MAXSTEP; st++) {
+                    if (w0 + 64u * st < w1) {
+                        const uint32_t f = inf[st];
+                        const uint32_t before = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((f >> 15) & 63u) << 2), (int)bf[st]);
+                        inf[st] = (f & 0xffe001ffu) | ((before + ((f >> 9) & 63u)) << 9);
+                    }
                 }
             }
             sync();
@@ -576,18 +593,12 @@ struct BwsLocal {
             BWS_LAP(2);
             if (one) { BWS_CNT(9, 1); continue; }                            // the whole group shares this digit: nothing moves
             BWS_CNT(8, 1);
-            // ---- scatter (stable): the wave's cursor of the digit + rank among the peers
+            // ---- scatter (stable): where the wave's elements with the digit start + the element's place among them
 #pragma unroll
             for (uint32_t st = 0; st < MAXSTEP; st++) {
                 if (w0 + 64u * st < w1) {
                     const uint32_t f = inf[st];
-                    const bool ok = (f >> 28) & 1u;
-                    const uint32_t d = f & 0xffu, rk = (f >> 8) & 63u, leader = (f >> 14) & 63u, cnt = (f >> 20) & 0x7fu;
-                    uint32_t bse = 0;
-                    if (ok && leader == lane) { bse = myh[d]; myh[d] = bse + cnt; }
-                    bse = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(leader << 2), (int)bse);
-                    if (ok) pb[bse + rk] = (uint16_t)el[st];
-                    rcx_wave_sync();
+                    if ((f >> 8) & 1u) pb[myh[f & 0xffu] + ((f >> 9) & 0xfffu)] = (uint16_t)(f >> 21);
                 }
             }
             sync();
@@ -605,6 +616,7 @@ struct BwsLocal {
             if (lane == 0) { bits[c0 >> 5] = (uint32_t)hm; bits[(c0 >> 5) + 1] = (uint32_t)(hm >> 32); }
         }
         sync();
+        BWS_LAP(4);
         // per bitmap word: the last head at or before its end and the first head at or after its start (a wave scan over the <= 64
         // words; a position that walked the bitmap to its run's ends took ~100 K cycles in a group of 2048 equal keys)
         if (w == 0) {
@@ -620,6 +632,7 @@ struct BwsLocal {
             hist[lane] = lastp; hist[64u + lane] = firstp;
         }
         sync();
+        BWS_LAP(5);
         for (uint32_t c0 = 64u * w; c0 < len; c0 += T) {
             const uint32_t p = c0 + lane;
             const bool in = p < len;
@@ -644,8 +657,9 @@ struct BwsLocal {
             }
             Q->push(s, in && rs == p && re - rs >= 2u, sg.start + rs, re - rs, top_shift);
         }
+        BWS_LAP(6);
         sync();
-        BWS_LAP(4);
+        BWS_LAP(7);
         return nx;
     }
 };
