@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_bwtf_init(BwtfArgs a, uint64_t* keys, u
 // written to saA / keyA marked for the dense passes, a larger bin goes to the other buffer and on the list its size asks for.
 #define BWS_FTHREADS 1024u      /* threads of k_bws_first: one workgroup per block, so its waves are all the latency hiding a CU gets */
 #define BWS_FT 8192u            /* suffixes per LDS tile of k_bws_first */
-__global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs a, const uint8_t* map, uint32_t nsym, uint32_t bits, uint32_t plus1,
+__global__ __launch_bounds__(BWS_FTHREADS, 8) RCX_SGPR_CAP void k_bws_first(BwsState s, BwtfArgs a, const uint8_t* map, uint32_t nsym, uint32_t bits, uint32_t plus1,
                                                    uint32_t top_shift, uint32_t topn)
 {
     __shared__ uint32_t s_map[256];
@@ -120,9 +120,41 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
     if (tid < 256) { s_tot[tid] = 0; s_vlo[tid] = 0xffffffffu; s_vhi[tid] = 0; }
     if (tid == 0) s_one = 0;
     __syncthreads();
-    auto tile = [&](uint32_t i0) {                             // symbols of suffixes i0 .. i0+BWS_FT-1 and the 16 that follow (0 = past the end)
+    // A tile: the symbols of suffixes i0 .. i0+BWS_FT-1 and the 16 that follow (0 = past the end).  Its text is REQUESTED (fetch) as
+    // one aligned 8-byte word per thread (+ three threads' second word) while the tile before it is worked on, and turned into symbols
+    // (tile) when that one is done: read a byte per thread and trip, a tile was nine dependent round trips to memory with every wave
+    // of the block waiting at the barrier behind them -- most of this kernel's time.  (An aligned word that holds one byte of the
+    // text lies in the text's pages: the bytes of it before or behind the text are read and not used.)
+    static_assert(BWS_FT == 8u * BWS_FTHREADS, "a word per thread and tile");
+    const uint32_t mis = (uint32_t)((uintptr_t)T & 7u);
+    const uint64_t* Tw = (const uint64_t*)(T - mis);
+    uint64_t tw0 = 0, tw1 = 0;
+    auto fetch = [&](uint32_t i0) {
+        tw0 = 0; tw1 = 0;
+        if (i0 < n) {
+            const uint64_t* q = Tw + (i0 >> 3);
+            if (i0 + 8u * tid < n + mis) tw0 = q[tid];
+            if (tid < 3u && i0 + BWS_FT + 8u * tid < n + mis) tw1 = q[BWS_FTHREADS + tid];
+        }
+    };
+    auto settle = [&]() {                                      // (before a tile's stores go out: see BwsLocal::settle)
+        tw0 = (uint64_t)RCX_VGPR((uint32_t)tw0) | ((uint64_t)RCX_VGPR((uint32_t)(tw0 >> 32)) << 32);
+        tw1 = (uint64_t)RCX_VGPR((uint32_t)tw1) | ((uint64_t)RCX_VGPR((uint32_t)(tw1 >> 32)) << 32);
+    };
+    auto tile = [&](uint32_t i0) {                             // from what fetch(i0) requested
         __syncthreads();
-        for (uint32_t t = tid; t < BWS_FT + 16u; t += BWS_FTHREADS) s_sym[t] = (i0 + t < n) ? (uint16_t)s_map[T[i0 + t]] : (uint16_t)0;
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) {
+            const uint32_t t = 8u * tid + j - mis;                                              // (wraps below 0: not a tile position)
+            if (t < BWS_FT + 16u) s_sym[t] = (i0 + t < n) ? (uint16_t)s_map[(uint32_t)(tw0 >> (8u * j)) & 0xffu] : (uint16_t)0;
+        }
+        if (tid < 3u) {
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; j++) {
+                const uint32_t t = BWS_FT + 8u * tid + j - mis;
+                if (t < BWS_FT + 16u) s_sym[t] = (i0 + t < n) ? (uint16_t)s_map[(uint32_t)(tw1 >> (8u * j)) & 0xffu] : (uint16_t)0;
+            }
+        }
         __syncthreads();
     };
     auto key_at = [&](uint32_t t) {
@@ -139,7 +171,7 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
     const uint32_t kbits = top_shift + 8u, b12 = kbits < 12u ? kbits : 12u, sh12 = kbits - b12, m12 = (1u << b12) - 1u;
     if (n <= BWS_LMAX) {                                       // a small block: keys and identity order, listed as one group (what k_bws_seed did)
         for (uint32_t i0 = 0; i0 < n; i0 += BWS_FT) {
-            tile(i0);
+            fetch(i0); tile(i0);
             for (uint32_t t = tid; t < BWS_FT; t += BWS_FTHREADS) {
                 const uint32_t i = i0 + t;
                 if (i < n) { s.keyA[g0 + i] = key_at(t); s.saA[g0 + i] = (g0 + i) | (i == 0 ? (BWS_HEAD | (s.par ^ BWS_PAR)) : 0u); }
@@ -155,11 +187,14 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
         return;
     }
     // ---- count
+    fetch(0);
     for (uint32_t i0 = 0; i0 < n; i0 += BWS_FT) {
         tile(i0);
+        fetch(i0 + BWS_FT);
         for (uint32_t t = tid; t < BWS_FT; t += BWS_FTHREADS)
             if (i0 + t < n) atomicAdd(&s_h12[(uint32_t)(key_at(t) >> sh12) & m12], 1u);
     }
+    fetch(0);                                                  // (the placing pass's first tile, or the one-digit pass's: requested across the scan)
     __syncthreads();
     static_assert(BWS_FTHREADS * 4u == 4096u, "four top-12 values per thread");
     {   // exclusive scan of the 4096 counts (4 per thread, wave scans, the waves' totals), then the bin of every top-12 value
@@ -181,6 +216,7 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
     if (s_one) {                                               // every suffix starts with the same digit: the generic levels go on from the next one
         for (uint32_t i0 = 0; i0 < n; i0 += BWS_FT) {
             tile(i0);
+            fetch(i0 + BWS_FT); settle();
             for (uint32_t t = tid; t < BWS_FT; t += BWS_FTHREADS) {
                 const uint32_t i = i0 + t;
                 if (i < n) { s.keyA[g0 + i] = key_at(t); s.saA[g0 + i] = (g0 + i) | (i == 0 ? (BWS_HEAD | (s.par ^ BWS_PAR)) : 0u); }
@@ -203,6 +239,7 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
     if (tid < 256) { s_gcur[tid] = s_beg[tid]; s_th[tid] = 0; }
     for (uint32_t i0 = 0; i0 < n; i0 += BWS_FT) {
         tile(i0);
+        fetch(i0 + BWS_FT);
         const uint32_t tn = n - i0 < BWS_FT ? n - i0 : BWS_FT;
         for (uint32_t t = tid; t < BWS_FT; t += BWS_FTHREADS) {         // digits of the tile + their counts
             const bool ok = t < tn;
@@ -230,6 +267,7 @@ __global__ __launch_bounds__(BWS_FTHREADS) void k_bws_first(BwsState s, BwtfArgs
             if (ok) s_perm[bse + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull))] = (uint16_t)t;
         }
         __syncthreads();
+        settle();
         for (uint32_t q = tid; q < tn; q += BWS_FTHREADS) {
             const uint32_t t = s_perm[q], d = s_dig[t];
             const uint64_t k = key_at(t);
