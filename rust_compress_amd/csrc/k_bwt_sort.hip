@@ -292,6 +292,9 @@ __device__ __forceinline__ unsigned long long bws_peers(bool ok, uint32_t d)
 #define BWS_PEERS bws_peers
 #endif
 
+#ifndef BWS_PU
+#define BWS_PU 4u                       /* chunks of 512 suffixes a partition step has in flight */
+#endif
 template <class K>
 __global__ __launch_bounds__(512) RCX_SGPR_CAP void k_bws_partition(BwsState s, int level, uint32_t top_shift)
 {
@@ -314,11 +317,20 @@ __global__ __launch_bounds__(512) RCX_SGPR_CAP void k_bws_partition(BwsState s, 
                 for (uint32_t i = tid; i < 8 * 256; i += 512) ((uint32_t*)s_hist)[i] = 0;
                 if (tid == 0) s_one = 0;
                 __syncthreads();
-                for (uint32_t i0 = 0; i0 < sg.len; i0 += 512) {            // text digits are skewed: lanes with the same digit count once
-                    const uint32_t i = i0 + tid; const bool ok = i < sg.len;
-                    const uint32_t d = ok ? (uint32_t)(ks[i] >> shift) & 0xffu : 0x100u;
-                    const unsigned long long peers = BWS_PEERS(ok, d);
-                    if (ok && (uint32_t)__ffsll(peers) - 1u == lane) atomicAdd(&s_hist[wave][d], (uint32_t)__popcll(peers));
+                // (BWS_PU chunks of 512 keys requested together: a chunk per trip was one round trip to memory per 512 suffixes, with
+                // eight waves a workgroup and few workgroups -- these groups are the large ones -- to hide it)
+                for (uint32_t i0 = 0; i0 < sg.len; i0 += 512u * BWS_PU) {
+                    K kk[BWS_PU];
+#pragma unroll
+                    for (uint32_t u = 0; u < BWS_PU; u++) { const uint32_t i = i0 + 512u * u + tid; kk[u] = i < sg.len ? ks[i] : (K)0; }
+#pragma unroll
+                    for (uint32_t u = 0; u < BWS_PU; u++) {
+                        if (i0 + 512u * u >= sg.len) break;                // (uniform)
+                        const bool ok = i0 + 512u * u + tid < sg.len;
+                        const uint32_t d = ok ? (uint32_t)(kk[u] >> shift) & 0xffu : 0x100u;      // text digits are skewed: lanes with the same digit count once
+                        const unsigned long long peers = BWS_PEERS(ok, d);
+                        if (ok && (uint32_t)__ffsll(peers) - 1u == lane) atomicAdd(&s_hist[wave][d], (uint32_t)__popcll(peers));
+                    }
                 }
                 __syncthreads();
                 if (tid < 256) {
@@ -346,29 +358,69 @@ __global__ __launch_bounds__(512) RCX_SGPR_CAP void k_bws_partition(BwsState s, 
                 for (int w = 0; w < 8; w++) { const uint32_t c = s_hist[w][tid]; s_hist[w][tid] = o; o += c; }
             }
             __syncthreads();
-            for (uint32_t i0 = 0; i0 < sg.len; i0 += 512) {
-                const uint32_t i = i0 + tid; const bool ok = i < sg.len;
-                const K k = ok ? ks[i] : (K)0;
-                const uint32_t d = ok ? (uint32_t)(k >> shift) & 0xffu : 0x100u;
-                const unsigned long long peers = BWS_PEERS(ok, d);
-                const uint32_t leader = (uint32_t)__ffsll(peers) - 1u;
-                uint32_t bse = 0;
-                if (ok && leader == lane) bse = atomicAdd(&s_hist[wave][d], (uint32_t)__popcll(peers));
-                bse = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((leader & 63u) << 2), (int)bse);
-                if (ok) {
-                    const uint32_t p = bse + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull)), g = ss[i] & BWS_IDX;
-                    // the group lies in buffer B: a bin that is finished or goes to the dense passes is written to saA / keyA at once
-                    // (from buffer A that would overwrite suffixes other threads have yet to read: the pass below does it then)
-                    if (src == 1 && (s_tot[d] <= BWS_WAVE || done)) bws_mark<K>(s, sg, p, k, g, s_tot[d], s_beg[d], done, dst);
-                    else { kd[p] = k; sd[p] = g; }
+            // the scatter: BWS_PU chunks at a time, the next batch's keys and suffixes requested before this batch's stores go out and
+            // waited for (settle) before them too
+            K ka[BWS_PU], kb[BWS_PU]; uint32_t ga[BWS_PU], gb[BWS_PU];
+            auto request = [&](uint32_t i0, K* kk, uint32_t* gg) {
+#pragma unroll
+                for (uint32_t u = 0; u < BWS_PU; u++) {
+                    const uint32_t i = i0 + 512u * u + tid;
+                    kk[u] = 0; gg[u] = 0;
+                    if (i < sg.len) { kk[u] = ks[i]; gg[u] = ss[i]; }
                 }
+            };
+            auto settle = [&](K* kk, uint32_t* gg) {
+#pragma unroll
+                for (uint32_t u = 0; u < BWS_PU; u++) {
+                    if (sizeof(K) == 8) kk[u] = (K)((uint64_t)RCX_VGPR((uint32_t)kk[u]) | ((uint64_t)RCX_VGPR((uint32_t)((uint64_t)kk[u] >> 32)) << 32));
+                    else kk[u] = (K)RCX_VGPR((uint32_t)kk[u]);
+                    gg[u] = RCX_VGPR(gg[u]);
+                }
+            };
+            request(0, ka, ga);
+            for (uint32_t i0 = 0; i0 < sg.len; i0 += 512u * BWS_PU) {
+                request(i0 + 512u * BWS_PU, kb, gb);
+                uint32_t pp[BWS_PU];
+#pragma unroll
+                for (uint32_t u = 0; u < BWS_PU; u++) {
+                    pp[u] = 0;
+                    if (i0 + 512u * u >= sg.len) break;                    // (uniform)
+                    const bool ok = i0 + 512u * u + tid < sg.len;
+                    const uint32_t d = ok ? (uint32_t)(ka[u] >> shift) & 0xffu : 0x100u;
+                    const unsigned long long peers = BWS_PEERS(ok, d);
+                    const uint32_t leader = (uint32_t)__ffsll(peers) - 1u;
+                    uint32_t bse = 0;
+                    if (ok && leader == lane) bse = atomicAdd(&s_hist[wave][d], (uint32_t)__popcll(peers));
+                    bse = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((leader & 63u) << 2), (int)bse);
+                    pp[u] = bse + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+                }
+                settle(kb, gb);
+#pragma unroll
+                for (uint32_t u = 0; u < BWS_PU; u++) {
+                    if (i0 + 512u * u + tid < sg.len) {
+                        const K k = ka[u];
+                        const uint32_t d = (uint32_t)(k >> shift) & 0xffu, g = ga[u] & BWS_IDX, p = pp[u];
+                        // the group lies in buffer B: a bin that is finished or goes to the dense passes is written to saA / keyA at once
+                        // (from buffer A that would overwrite suffixes other threads have yet to read: the pass below does it then)
+                        if (src == 1 && (s_tot[d] <= BWS_WAVE || done)) bws_mark<K>(s, sg, p, k, g, s_tot[d], s_beg[d], done, dst);
+                        else { kd[p] = k; sd[p] = g; }
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < BWS_PU; u++) { ka[u] = kb[u]; ga[u] = gb[u]; }
             }
             __syncthreads();
             if (src == 0) {
-                for (uint32_t p = tid; p < sg.len; p += 512) {
-                    const K k = kd[p];
-                    const uint32_t d = (uint32_t)(k >> shift) & 0xffu;
-                    bws_mark<K>(s, sg, p, k, sd[p], s_tot[d], s_beg[d], done, dst);
+                for (uint32_t p0 = 0; p0 < sg.len; p0 += 512u * BWS_PU) {
+                    K kk[BWS_PU]; uint32_t gg[BWS_PU];
+#pragma unroll
+                    for (uint32_t u = 0; u < BWS_PU; u++) { const uint32_t p = p0 + 512u * u + tid; kk[u] = 0; gg[u] = 0; if (p < sg.len) { kk[u] = kd[p]; gg[u] = sd[p]; } }
+                    settle(kk, gg);                                            // (one wait for the batch, before the first chunk's stores)
+#pragma unroll
+                    for (uint32_t u = 0; u < BWS_PU; u++) {
+                        const uint32_t p = p0 + 512u * u + tid;
+                        if (p < sg.len) { const uint32_t d = (uint32_t)(kk[u] >> shift) & 0xffu; bws_mark<K>(s, sg, p, kk[u], gg[u], s_tot[d], s_beg[d], done, dst); }
+                    }
                 }
             }
             if (tid < 256) bws_route_bin(s, lnext, clnext, done, s_tot[tid], sg.start + s_beg[tid], shift, dst, top_shift);
