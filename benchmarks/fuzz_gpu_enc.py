@@ -59,7 +59,7 @@ for v in (0, 1, 2):
     res = ctx.lz4_encode_blocks(raws)
     cmp("lz4 encode", v, res.outputs, exp, not res.status.any())
 ctx.set_variant(N.LZ4_ENCODE, 0)
-for v in (0, 11):
+for v in (0, 15):
     ctx.set_variant(N.LZ4_DECODE, v)
     cmp("lz4 roundtrip", v, ctx.lz4_decode_blocks(exp, lens).outputs, raws)
 ctx.set_variant(N.LZ4_DECODE, 0)
@@ -77,7 +77,7 @@ cmp("dc roundtrip", 0, ctx.dc_decode(exp, lens).outputs, raws)
 small = [r[:20000] for r in raws]
 slens = [len(r) for r in small]
 exp, _, _ = oracle_batch(N.ARI_BYTE_ENCODE, small, [2 * n + 16 for n in slens])
-for v in (1, 2):
+for v in (1, 2, 3):
     ctx.set_variant(N.ARI_BYTE_ENCODE, v); ctx.set_variant(N.ARI_BYTE_DECODE, v)
     res = ctx.ari_byte_encode(small); cmp("ari encode", v, res.outputs, exp, not res.status.any())
     cmp("ari roundtrip", v, ctx.ari_byte_decode(exp, slens).outputs, small)

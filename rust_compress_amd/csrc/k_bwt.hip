@@ -169,6 +169,14 @@ __global__ __launch_bounds__(BWS_FTHREADS, 8) RCX_SGPR_CAP void k_bws_first(BwsS
     // of a key prefix keeps the bins in key order; what changes is that the levels below may take no key bit for sorted (the bins
     // are listed with the first level's own shift), and that nearly every bin of a text goes straight to the LDS sorts.
     const uint32_t kbits = top_shift + 8u, b12 = kbits < 12u ? kbits : 12u, sh12 = kbits - b12, m12 = (1u << b12) - 1u;
+    // (the key's top b12 bits lie in its first n12 symbols -- two of a text's ten, four of DNA's sixteen: the two passes that only bin
+    // a suffix read those, not the whole key)
+    const uint32_t n12 = (b12 + bits - 1u) / bits, drop12 = n12 * bits - b12;
+    auto top12_at = [&](uint32_t t) {
+        uint32_t v = 0;
+        for (uint32_t c = 0; c < n12; c++) v = (v << bits) | (uint32_t)s_sym[t + c];
+        return (v >> drop12) & m12;
+    };
     if (n <= BWS_LMAX) {                                       // a small block: keys and identity order, listed as one group (what k_bws_seed did)
         for (uint32_t i0 = 0; i0 < n; i0 += BWS_FT) {
             fetch(i0); tile(i0);
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(BWS_FTHREADS, 8) RCX_SGPR_CAP void k_bws_first(BwsS
         tile(i0);
         fetch(i0 + BWS_FT);
         for (uint32_t t = tid; t < BWS_FT; t += BWS_FTHREADS)
-            if (i0 + t < n) atomicAdd(&s_h12[(uint32_t)(key_at(t) >> sh12) & m12], 1u);
+            if (i0 + t < n) atomicAdd(&s_h12[top12_at(t)], 1u);
     }
     fetch(0);                                                  // (the placing pass's first tile, or the one-digit pass's: requested across the scan)
     __syncthreads();
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(BWS_FTHREADS, 8) RCX_SGPR_CAP void k_bws_first(BwsS
         const uint32_t tn = n - i0 < BWS_FT ? n - i0 : BWS_FT;
         for (uint32_t t = tid; t < BWS_FT; t += BWS_FTHREADS) {         // digits of the tile + their counts
             const bool ok = t < tn;
-            const uint32_t d = ok ? (uint32_t)s_lut[(uint32_t)(key_at(t) >> sh12) & m12] : 0x100u;
+            const uint32_t d = ok ? (uint32_t)s_lut[top12_at(t)] : 0x100u;
             if (ok) s_dig[t] = (uint8_t)d;
             const unsigned long long peers = BWS_PEERS(ok, d);
             if (ok && (uint32_t)__ffsll(peers) - 1u == lane) atomicAdd(&s_th[d], (uint32_t)__popcll(peers));
