@@ -157,10 +157,18 @@ __global__ __launch_bounds__(BWS_FTHREADS, 8) RCX_SGPR_CAP void k_bws_first(BwsS
         }
         __syncthreads();
     };
+    // (the key is put together from 32-bit pieces of as many symbols as fit one, a shift-and-or per symbol: built in 64 bits symbol by
+    // symbol it was three to four times the vector instructions, and this kernel builds 2^27 of them a pass)
+    const uint32_t nper = 32u / bits;
+    const uint64_t kblock = nsym * bits < 64u ? (uint64_t)b << (nsym * bits) : 0ull;
     auto key_at = [&](uint32_t t) {
-        uint64_t k = b;
-        for (uint32_t c = 0; c < nsym; c++) k = (k << bits) | (uint64_t)s_sym[t + c];
-        return k;
+        uint64_t k = 0; uint32_t acc = 0, m = 0;
+        for (uint32_t c = 0; c < nsym; c++) {
+            acc = (acc << bits) | (uint32_t)s_sym[t + c];
+            if (++m == nper) { k = (k << (nper * bits)) | acc; acc = 0; m = 0; }      // (uniform)
+        }
+        if (m) k = (k << (m * bits)) | acc;
+        return k | kblock;
     };
     const uint32_t nshift = top_shift > 8u ? top_shift - 8u : 0u;
     // The first level does not split by the key's top 8 bits (a text's first symbol and a quarter: ~160 bins of very unequal size, most
@@ -449,6 +457,21 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                 for (int v = 0; v < 256; v++) h_map[v] = present(v) ? (uint8_t)(++sigma > 255 ? 255 : sigma) : 0;
                 if (sigma < 256) { sbits = bits_for(sigma); nsym = 64 / sbits; if (nsym > 16) nsym = 16; plain_bytes = false; }
                 else for (int v = 0; v < 256; v++) h_map[v] = (uint8_t)v;                  // codes 1..256 do not fit a byte: symbol = byte + 1 (9 bits)
+                // Not every symbol that fits is worth a place in the first key: behind the first level's 12 bits the key is sorted in
+                // 8-bit LSD passes over ALL suffixes, and symbols that fill only part of a last digit cost a whole pass -- the first
+                // doubling round sorts them for the suffixes still tied then, which is cheaper (DNA: 12 symbols = 12 + 24 bits, three
+                // passes, 8.9 ms; 16 symbols = 12 + 36, five passes, 9.7 ms.  Text's 10 x 6 = 12 + 48 bits fill six digits exactly).
+                // Among the top quarter of the symbol counts that fit: a smaller count where its bits fill their digits 5 % better.
+                if (nsym * sbits > 20) {
+                    uint32_t best = nsym; double beff = 0;
+                    for (uint32_t c = nsym; c >= nsym - nsym / 4 && c * sbits > 20; c--) {
+                        const uint32_t r = c * sbits - 12, passes = (r + 7) / 8;
+                        const double eff = (double)r / (8.0 * passes);
+                        if (c == nsym || eff > beff * 1.05) { beff = eff; best = c; }
+                    }
+                    nsym = best;
+                }
+                if (const char* e = getenv("RCX_BWT_NSYM")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 2 && v <= nsym) nsym = v; }   // (experiments)
                 if (hipMemcpyAsync(symmap, h_map, 256, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
                     err = "bwt forward: symbol map"; return RCX_RC_HIP_ERROR; }
             }
