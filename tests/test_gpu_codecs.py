@@ -157,6 +157,12 @@ def test_bwt_forward_key_layouts(ctx, oracle):
     check([skew + bytes(range(256))])                                                                     # all 256 bytes occur, low entropy: plain bytes
     check([bytes(rng.integers(0, 255, 40000, dtype=np.uint8))])                                           # 255 symbols, high entropy: plain bytes
     check([bytes(rng.choice(200, 30000, p=np.r_[[0.5], np.full(199, 0.5 / 199)]).astype(np.uint8))])      # 200 symbols, 8-bit codes
+    # the symbol count of the first key follows the alphabet (k_bwt.hip: the count whose bits fill the LSD passes): 2-3 symbols -> 14 per
+    # key, 4-7 -> 12, 8-15 -> 15, 16-31 -> 12, 32-63 -> 10, 64-127 -> 9; each with long repeats (ties carried into the doubling rounds)
+    for alpha in (2, 3, 5, 11, 20, 50, 100):
+        body = rng.integers(0, alpha, 30000, dtype=np.uint8)
+        rep = np.concatenate([body[:9000], body[2000:9000], body[:9000]])                                  # LCPs of thousands
+        check([bytes(body + 7), bytes(rep + 1)])
     small = [synth.gen(("text", "runs", "dna4", "rand")[i % 4], int(rng.integers(1, 400)), 100 + i).tobytes() for i in range(2500)]
     ctx.set_variant(N.BWT_FORWARD, 700)                                                                   # at most 700 blocks per sorting pass: four passes
     check(small)

@@ -263,6 +263,10 @@ def test_bwt_forward(oracle):
     check(corpus.small_corpus(sizes=(17, 1000, 9000)))                                   # text, runs, rand, dna: 9-bit plain-byte keys (all 256 bytes occur)
     check([synth.gen("dna4", 6000, 1).tobytes(), b"ab" * 2500, bytes(3000), b"abracadabra" * 300])     # 1-4 symbols: 16+ per key, long shared prefixes
     check([synth.gen("text", 30000, 2).tobytes(), synth.gen("words", 5000, 3).tobytes(), b"", b"x"])   # ~6 bits per symbol, groups of every size class
+    rng = np.random.default_rng(12)
+    for alpha in (2, 5, 11, 20, 100):                                                    # 14 / 12 / 15 / 12 / 9 symbols per key (the count follows the alphabet)
+        body = rng.integers(0, alpha, 5000, dtype=np.uint8)
+        check([bytes(np.concatenate([body[:1500], body[300:1500], body]) + 3)])
 
 
 def test_bwt_suffixes_and_inversion_table(oracle):

@@ -227,8 +227,8 @@ static inline unsigned __byte_perm_(unsigned a, unsigned b, unsigned s) { (void)
 #define RCX_LDS_AS
 #define RCX_GLOBAL_AS
 #define __builtin_amdgcn_sched_barrier(n) ((void)0)
-#define __builtin_amdgcn_mbcnt_lo(m, b) ((int)(ws::cur->tid & 63) < 32 ? (int)(ws::cur->tid & 63) + (b) : 32 + (b))
-#define __builtin_amdgcn_mbcnt_hi(m, b) ((int)(ws::cur->tid & 63) < 32 ? (b) : (int)(ws::cur->tid & 63) - 32 + (b))
+#define __builtin_amdgcn_mbcnt_lo(m, b) (__builtin_popcount((uint32_t)(m) & ((ws::cur->tid & 63) < 32 ? (1u << (ws::cur->tid & 31)) - 1u : 0xffffffffu)) + (b))
+#define __builtin_amdgcn_mbcnt_hi(m, b) (__builtin_popcount((uint32_t)(m) & ((ws::cur->tid & 63) < 32 ? 0u : (1u << (ws::cur->tid & 31)) - 1u)) + (b))
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 namespace ws { extern unsigned long long g_stat[16]; }
