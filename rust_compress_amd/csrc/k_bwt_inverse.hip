@@ -737,6 +737,8 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwti3_emit(rcx_kargs a, uint32
     bwti_node rn[U];                                                    // the NEXT step's records: in flight while this step's chains are stored
 #pragma unroll
     for (int u = 0; u < U; u++) { const uint32_t m = tid + (uint32_t)u * BWTI_THREADS; rn[u].a = 0; rn[u].b = 0; if (m < g.M) rn[u] = nodes[m]; }
+#pragma unroll
+    for (int u = 0; u < U; u++) { rn[u].a = RCX_VGPR(rn[u].a); rn[u].b = RCX_VGPR(rn[u].b); }       // (settled here and at the end of every step: see there)
     for (uint32_t mb = 0; mb < g.M; mb += BWTI_THREADS * U) {          // (every thread makes every step: the stores below are wave-wide)
         const uint32_t m0 = mb + tid;
         bwti_node r[U];
@@ -763,7 +765,13 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwti3_emit(rcx_kargs a, uint32
             }
             pv[u] = rcx_u32x4{0, 0, 0, 0};
             if (in[u]) pv[u] = *(const rcx_u32x4*)(park + (size_t)m * 16u);
-            if (shortpark && in[u]) pv[u] = bwti_shr128(pv[u], (c < 16u ? c : 16u) - len[u]);     // (cap = 1: the chain's first byte is the group's last)
+        }
+        if (shortpark) {                                         // (a loop of its own: used where it is loaded, each slot was waited for before the next was requested)
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t c = r[u].b >> 15;
+                if (in[u]) pv[u] = bwti_shr128(pv[u], (c < 16u ? c : 16u) - len[u]);             // (cap = 1: the chain's first byte is the group's last)
+            }
         }
         // group k of a chain (its bytes 16k .. 16k + e - 1, parked in output order) is out[hi - 16k - e + 1 ..]: one unaligned store of
         // e <= 16 bytes into the tile (RCX_LDS_STORE16: byte stores under a narrowing EXEC)
@@ -792,6 +800,10 @@ __global__ __launch_bounds__(BWTI_THREADS) void k_bwti3_emit(rcx_kargs a, uint32
                 }
             }
         }
+        // the next step's records have arrived by now, and the compiler is told so HERE: left to itself it waits for them at the top
+        // of the next step with vmcnt(0), right behind the request for the step after -- which is then never in flight during a step
+#pragma unroll
+        for (int u = 0; u < U; u++) { rn[u].a = RCX_VGPR(rn[u].a); rn[u].b = RCX_VGPR(rn[u].b); }
     }
     __syncthreads();
     const uint32_t tn = thi - tlo;
