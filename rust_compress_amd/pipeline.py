@@ -69,8 +69,8 @@ class BwtDcAri:
         self.ctx.launch_dev(N.BWT_FORWARD, bw, sc)
         # 2. DC into the record slot, 12 bytes in (n, origin, k go in front)
         slot = (4 * (HDR_WORDS + 256 + maxn) + 63) // 64 * 64
-        rec = torch.zeros(nb * slot + 64, dtype=torch.uint8, device=self.dev)
-        roff = np.arange(nb, dtype=np.int64) * slot
+        rec = torch.empty(nb * slot + 64, dtype=torch.uint8, device=self.dev)       # (every byte the range coder reads is written below: the slots are
+        roff = np.arange(nb, dtype=np.int64) * slot                                  # worst-case sized, 4 GB for 10^9 bytes, and zeroing them was 1 ms)
         dc = DeviceBatch(bw.out_base, bw.out_off, bw.out_len, rec, self._i64(roff + 4 * HDR_WORDS),
                          self._i64(np.full(nb, slot - 4 * HDR_WORDS)))
         self.ctx.launch_dev(N.DC_ENCODE, dc, self._scratch(N.DC_ENCODE, nb, maxn))       # (37 KiB a block: the lane-per-chunk encoder's chunk states)
@@ -111,7 +111,7 @@ class BwtDcAri:
         _need(nb == 0 or ((praw >= 0).all() and (praw.sum(axis=1) <= slot).all()), "container piece lengths exceed the block record")
         pstart = np.concatenate([np.zeros((nb, 1), np.int64), np.cumsum(praw, axis=1)[:, :-1]], axis=1)
         ar = DeviceBatch(comp, self._i64(np.asarray(comp_off).reshape(-1)), self._i64(np.asarray(comp_len).reshape(-1)),
-                         torch.zeros(nb * slot + 64, dtype=torch.uint8, device=self.dev),
+                         torch.empty(nb * slot + 64, dtype=torch.uint8, device=self.dev),          # (what is read of a record is what its pieces decode to)
                          self._i64((roff[:, None] + pstart).reshape(-1)), self._i64(praw.reshape(-1)))
         self.ctx.launch_dev(N.ARI_BYTE_DECODE, ar)
         torch.cuda.synchronize()
