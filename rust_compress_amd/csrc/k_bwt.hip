@@ -238,7 +238,7 @@ __global__ __launch_bounds__(BWS_FTHREADS, 8) RCX_SGPR_CAP void k_bws_first(BwsS
                 if (i < n) { s.keyA[g0 + i] = key_at(t); s.saA[g0 + i] = (g0 + i) | (i == 0 ? (BWS_HEAD | (s.par ^ BWS_PAR)) : 0u); }
             }
         }
-        if (tid == 0) { const uint32_t q = atomicAdd(&s.cnt[1], 1u); s.large[1][q] = BwsSeg{g0, n, nshift}; }
+        if (tid == 0) { const uint32_t q = atomicAdd(&s.cnt[BWS_CLEVEL + 1u], 1u); s.large[1][q] = BwsSeg{g0, n, nshift}; }
         return;
     }
     if (tid < 64) {
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(BWS_FTHREADS, 8) RCX_SGPR_CAP void k_bws_first(BwsS
         const uint32_t unsorted = sh12 + (dv ? 32u - (uint32_t)__clz((int)dv) : 0u);      // bits [0, unsorted) may differ inside the bin
         const uint32_t shift = unsorted > 8u ? unsorted - 8u : 0u;                        // the first digit: the eight highest bits that may differ
         const BwsSeg nx{at, c, shift | (1u << 8)};
-        bws_append(s.large[1], &s.cnt[1], c > BWS_LMAX, nx);
+        bws_append(s.large[1], &s.cnt[BWS_CLEVEL + 1u], c > BWS_LMAX, nx);
         bws_append(s.local, &s.cnt[6], c > BWS_WAVE && c <= BWS_LWAVE, nx);
         bws_append(s.localw, &s.cnt[9], c > BWS_LWAVE && c <= BWS_LMAX, nx);
         bws_append(s.small, &s.cnt[2], c >= 2u && c <= BWS_WAVE && !bws_dense_ok(at, c), BwsSeg{at, c, 0u});
@@ -444,6 +444,7 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
             // Alphabet compaction: the bytes that occur get dense, order-preserving codes, so that more symbols fit the first
             // key when the alphabet is small and skewed (text: 10 symbols of 6 bits instead of 7 of 9; DNA: 16).
             uint32_t nsym = 7, sbits = 9; bool plain_bytes = true;
+            uint8_t h_map[256];                                   // (lives as long as the pass: its upload is not waited for on its own)
             {
                 uint32_t h_hist[264];
                 if (hipMemsetAsync(hist, 0, 1056, s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
@@ -452,7 +453,7 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                 hipLaunchKernelGGL(k_bwtf_hist, dim3(gxh ? gxh : 1, nb), dim3(256), 0, s, fa, hist);
                 if (hipMemcpyAsync(h_hist, hist, 1056, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
                     err = "bwt forward: histogram"; return RCX_RC_HIP_ERROR; }
-                uint8_t h_map[256]; uint32_t sigma = 0;
+                uint32_t sigma = 0;
                 auto present = [&](int v) { return (h_hist[256 + (v >> 5)] >> (v & 31)) & 1u; };
                 for (int v = 0; v < 256; v++) h_map[v] = present(v) ? (uint8_t)(++sigma > 255 ? 255 : sigma) : 0;
                 if (sigma < 256) { sbits = bits_for(sigma); nsym = 64 / sbits; if (nsym > 16) nsym = 16; plain_bytes = false; }
@@ -472,8 +473,7 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                     nsym = best;
                 }
                 if (const char* e = getenv("RCX_BWT_NSYM")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 2 && v <= nsym) nsym = v; }   // (experiments)
-                if (hipMemcpyAsync(symmap, h_map, 256, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-                    err = "bwt forward: symbol map"; return RCX_RC_HIP_ERROR; }
+                if (hipMemcpyAsync(symmap, h_map, 256, hipMemcpyHostToDevice, s) != hipSuccess) { err = "bwt forward: symbol map"; return RCX_RC_HIP_ERROR; }
             }
             if (hipMemsetAsync(st.cnt, 0, 4 * (64 + BWS_NFLAG), s) != hipSuccess || hipMemsetAsync(act0, 0, 4 * nact + ndone, s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
             const uint32_t kbits0 = nsym * sbits, top0 = kbits0 > 8 ? kbits0 - 8 : 0;
@@ -498,7 +498,6 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                 if (round) { if (wide) hipLaunchKernelGGL(k_bws_gather<uint64_t>, dim3(gxg, nb), dim3(256), 0, s, st, bstart, nb, h); else hipLaunchKernelGGL(k_bws_gather<uint32_t>, dim3(gxg, nb), dim3(256), 0, s, st, bstart, nb, h); }
                 const int levels = (int)((top + 7) / 8) + 1 + ((round == 0 && fused_first) ? 1 : 0);   // (k_bws_first's bins start from the top digit again)
                 for (int lv = (round == 0 && fused_first) ? 1 : 0; lv < levels; lv++) {
-                    if (hipMemsetAsync(&st.cnt[(lv + 1) & 1], 0, 4, s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
                     if (wide) hipLaunchKernelGGL(k_bws_partition<uint64_t>, dim3(gpart), dim3(512), 0, s, st, lv, topn);
                     else hipLaunchKernelGGL(k_bws_partition<uint32_t>, dim3(gpart), dim3(512), 0, s, st, lv, topn);
                 }
@@ -508,7 +507,10 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                 else { hipLaunchKernelGGL(k_bws_small<uint32_t>, dim3(gsm), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_dense<uint32_t>, dim3(gdense), dim3(256), 0, s, st, 0u); hipLaunchKernelGGL(k_bws_dense<uint32_t>, dim3(gdense), dim3(256), 0, s, st, 32u); }
                 std::vector<uint32_t> hcv(64 + BWS_NFLAG);
                 uint32_t* hc = hcv.data();
-                if (hipMemcpyAsync(hc, st.cnt, 4 * (64 + BWS_NFLAG), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { err = "bwt forward: sync failed"; return RCX_RC_HIP_ERROR; }
+                // (one synchronisation a round: the counters are copied out, THEN k_bws_round_end turns them into the next round's)
+                if (hipMemcpyAsync(hc, st.cnt, 4 * (64 + BWS_NFLAG), hipMemcpyDeviceToHost, s) != hipSuccess) { err = "bwt forward: sync failed"; return RCX_RC_HIP_ERROR; }
+                hipLaunchKernelGGL(k_bws_round_end, dim3(1), dim3(256), 0, s, st);
+                if (hipStreamSynchronize(s) != hipSuccess) { err = "bwt forward: sync failed"; return RCX_RC_HIP_ERROR; }
                 hc[5] = 0;
                 for (uint32_t f = 0; f < BWS_NFLAG; f++) hc[5] |= hc[64 + f];
                 if (getenv("RCX_BWT_TRACE")) fprintf(stderr, "bwt forward round %d: h=%u unresolved %u (listed: %u large, %u + %u local, %u small)\n", round, h, hc[5], hc[3], hc[7], hc[10], hc[4]);
@@ -521,9 +523,6 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                 if (hc[5] == 0) { converged = true; break; }
                 if (hc[3] > nlarge || hc[7] > nlarge || hc[6] > nlarge || hc[4] > nmid || hc[9] > nlw || hc[10] > nlw) { err = "bwt forward: group list overflow"; return RCX_RC_HIP_ERROR; }
                 std::swap(st.large[0], st.nlarge); std::swap(st.small, st.nsmall); std::swap(st.local, st.nlocal); std::swap(st.localw, st.nlocalw);
-                const uint32_t nc[12] = {hc[3], 0, hc[4], 0, 0, 0, hc[7], 0, 0, hc[10], 0, 0};
-                if (hipMemsetAsync(st.cnt + 64, 0, 4 * BWS_NFLAG, s) != hipSuccess ||
-                    hipMemcpyAsync(st.cnt, nc, 48, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { err = "bwt forward: H2D"; return RCX_RC_HIP_ERROR; }
                 h = round == 0 ? nsym : 2 * h;
             }
             if (!converged) { err = "bwt forward: did not converge"; return RCX_RC_HIP_ERROR; }

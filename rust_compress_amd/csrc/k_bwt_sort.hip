@@ -31,7 +31,7 @@
 #endif
 
 struct BwsSeg { uint32_t start, len, info; };                 // info: key shift of the next radix step | buffer << 8
-// counters: [0] large list A, [1] large list B, [2] small list, [3] next round's large list, [4] next round's small list,
+// counters: [16 + l] the large list of radix level l (large[l & 1]), [2] small list, [3] next round's large list, [4] next round's small list,
 // [6] local list (groups of BWS_WAVE+1 .. BWS_LWAVE: sorted in LDS by one wave), [7] next round's; [9] / [10] the same for the
 // groups of BWS_LWAVE+1 .. BWS_LMAX (a workgroup each)
 struct BwsState {
@@ -56,6 +56,7 @@ __device__ __forceinline__ bool bws_dense_ok(uint32_t a, uint32_t len)
     return len <= BWS_WAVE && ((a >> 6) == (z >> 6) || ((a + 32u) >> 6) == ((z + 32u) >> 6));
 }
 
+#define BWS_CLEVEL 16u                   /* cnt[16 + l]: groups on the list of radix level l (large[l & 1]) */
 // Tell the dense passes of round parity `set` about the group [a, a + len) (which bws_dense_ok): the aligned window if it lies
 // inside one (the aligned pass runs first and takes it), else the shifted one.
 __device__ __forceinline__ void bws_flag_dense(const BwsState& s, uint32_t set, uint32_t a, uint32_t len)
@@ -224,7 +225,7 @@ __global__ void k_bws_seed(BwsState s, const uint32_t* bstart, uint32_t nblocks,
     if (len == 1) { s.saA[a] = a | BWS_HEAD | BWS_FINAL; s.rank[a] = a; return; }
     // the seed groups carry the parity of "the round before round 0" so that the dense passes take the small ones
     s.saA[a] |= BWS_HEAD | (s.par ^ BWS_PAR);
-    if (len > BWS_LMAX) { const uint32_t i = atomicAdd(&s.cnt[0], 1u); s.large[0][i] = BwsSeg{a, len, top_shift}; }
+    if (len > BWS_LMAX) { const uint32_t i = atomicAdd(&s.cnt[BWS_CLEVEL], 1u); s.large[0][i] = BwsSeg{a, len, top_shift}; }
     else if (len > BWS_LWAVE) { const uint32_t i = atomicAdd(&s.cnt[9], 1u); s.localw[i] = BwsSeg{a, len, top_shift}; }
     else if (len > BWS_WAVE) { const uint32_t i = atomicAdd(&s.cnt[6], 1u); s.local[i] = BwsSeg{a, len, top_shift}; }
     else if (!bws_dense_ok(a, len)) { const uint32_t i = atomicAdd(&s.cnt[2], 1u); s.small[i] = BwsSeg{a, len, 0u}; }
@@ -303,8 +304,8 @@ __global__ __launch_bounds__(512) RCX_SGPR_CAP void k_bws_partition(BwsState s, 
     __shared__ uint32_t s_one;
     const BwsSeg* list = s.large[level & 1];
     BwsSeg* lnext = s.large[(level + 1) & 1];
-    uint32_t* clnext = &s.cnt[(level + 1) & 1];
-    const uint32_t nseg = s.cnt[level & 1];
+    uint32_t* clnext = &s.cnt[BWS_CLEVEL + level + 1];      // (a counter per level: two that alternate wanted a memset between the launches)
+    const uint32_t nseg = s.cnt[BWS_CLEVEL + level];
     const uint32_t tid = threadIdx.x, wave = RCX_UNI(tid >> 6), lane = tid & 63u;
     {
         for (uint32_t e = blockIdx.x; e < nseg; e += gridDim.x) {
@@ -776,6 +777,19 @@ __global__ __launch_bounds__(256) void k_bws_local_wg(BwsState s, uint32_t top_s
 #ifdef BWS_PROF
     L.report(s, 32u);
 #endif
+}
+
+// ---- between two rounds: the lists the round filled for the next one become its own (the host swaps the pointers), the flag words and
+// the level counters are cleared.  On the device, behind the host's copy of the counters in stream order: done from the host (a
+// memset, an upload of the counts, a second synchronisation a round) the GPU stood idle ~40 us more per round.
+__global__ void k_bws_round_end(BwsState s)
+{
+    const uint32_t t = threadIdx.x;
+    __shared__ uint32_t s_n[4];
+    if (t == 0) { s_n[0] = s.cnt[3]; s_n[1] = s.cnt[4]; s_n[2] = s.cnt[7]; s_n[3] = s.cnt[10]; }
+    __syncthreads();
+    if (t < 32u) s.cnt[t] = t == BWS_CLEVEL ? s_n[0] : t == 2u ? s_n[1] : t == 6u ? s_n[2] : t == 9u ? s_n[3] : 0u;
+    for (uint32_t f = t; f < BWS_NFLAG; f += blockDim.x) s.cnt[64u + f] = 0u;
 }
 
 // ---- the few groups of <= 64 the dense passes cannot take (33..64 suffixes across both window grids): one wave per group ----
