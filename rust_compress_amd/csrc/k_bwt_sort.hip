@@ -583,9 +583,9 @@ struct BwsLocal {
             // the histogram takes each step's count with a returning add -- what comes back is the number of this wave's EARLIER elements
             // with the digit, so that the scatter below is one independent read per element (cursors advanced step by step were
             // MAXSTEP dependent round trips more).
-            uint32_t inf[MAXSTEP];                                           // digit [0, 8) | ok << 8 | place among the wave's elements with the digit << 9 (12 bits) | entry << 21
+            uint32_t inf[MAXSTEP];                                           // digit (0x100: not an element) | place among the wave's elements with the digit << 9 (12 bits) | entry << 21
             {
-                uint32_t ev[MAXSTEP], dv[MAXSTEP], bf[MAXSTEP];
+                uint32_t ev[MAXSTEP], dv[MAXSTEP], bf[MAXSTEP], ld[MAXSTEP];
                 const uint8_t* kb = (const uint8_t*)key + (sh >> 3);         // (sh is a multiple of 8: the digit is a byte of the little-endian key)
 #pragma unroll
                 for (uint32_t st = 0; st < MAXSTEP; st++) { const uint32_t i = w0 + 64u * st + lane; ev[st] = pa[i]; ev[st] = i < w1 ? ev[st] : 0u; }   // (i < CAP whatever the step)
@@ -593,25 +593,24 @@ struct BwsLocal {
                 for (uint32_t st = 0; st < MAXSTEP; st++) dv[st] = kb[ev[st] * (uint32_t)sizeof(K)];
 #pragma unroll
                 for (uint32_t st = 0; st < MAXSTEP; st++) {
-                    inf[st] = 0; bf[st] = 0;
+                    inf[st] = 0x100u; bf[st] = 0; ld[st] = 0;
                     if (w0 + 64u * st < w1) {                                // wave-uniform
                         const bool ok = w0 + 64u * st + lane < w1;
                         const uint32_t d = ok ? dv[st] : 0x100u;
                         const unsigned long long peers = BWS_PEERS(ok, d);
-                        const uint32_t leader = (uint32_t)__ffsll(peers) - 1u, cnt = (uint32_t)__popcll(peers);
-                        const uint32_t rk = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
-                        if (ok && leader == lane) bf[st] = atomicAdd(&myh[d], cnt);
-                        inf[st] = (d & 0xffu) | ((uint32_t)ok << 8) | (rk << 9) | ((leader & 63u) << 15) | (ev[st] << 21);
+                        const uint32_t plo = (uint32_t)peers, phi = (uint32_t)(peers >> 32);
+                        // (the first peer: v_ffbl gives -1 for 0, so the smaller of the two halves' answers; my place among them: v_mbcnt)
+                        const uint32_t lo1 = (uint32_t)__ffs((int)plo) - 1u, hi1 = (uint32_t)__ffs((int)phi) - 1u + 32u;
+                        ld[st] = (lo1 < hi1 ? lo1 : hi1) << 2;
+                        const uint32_t rk = (uint32_t)__builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+                        if (ok && rk == 0u) bf[st] = atomicAdd(&myh[d], (uint32_t)__popc(plo) + (uint32_t)__popc(phi));
+                        inf[st] = (ev[st] << 21) | (rk << 9) | d;
                         rcx_wave_sync();
                     }
                 }
 #pragma unroll
                 for (uint32_t st = 0; st < MAXSTEP; st++) {
-                    if (w0 + 64u * st < w1) {
-                        const uint32_t f = inf[st];
-                        const uint32_t before = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((f >> 15) & 63u) << 2), (int)bf[st]);
-                        inf[st] = (f & 0xffe001ffu) | ((before + ((f >> 9) & 63u)) << 9);
-                    }
+                    if (w0 + 64u * st < w1) inf[st] += (uint32_t)__builtin_amdgcn_ds_bpermute((int)ld[st], (int)bf[st]) << 9;
                 }
             }
             sync();
@@ -651,7 +650,7 @@ struct BwsLocal {
             for (uint32_t st = 0; st < MAXSTEP; st++) {
                 if (w0 + 64u * st < w1) {
                     const uint32_t f = inf[st];
-                    if ((f >> 8) & 1u) pb[myh[f & 0xffu] + ((f >> 9) & 0xfffu)] = (uint16_t)(f >> 21);
+                    if (!(f & 0x100u)) pb[myh[f & 0xffu] + ((f >> 9) & 0xfffu)] = (uint16_t)(f >> 21);
                 }
             }
             sync();
