@@ -42,6 +42,10 @@ class BwtDcAri:
         self.ctx, self.dev, self.torch, self.S = ctx, device, torch, int(parts)
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
+    def _sync(self):
+        """Wait for this pipeline's stream only: several pipelines may run side by side on streams of their own (PipelineLanes)."""
+        self.torch.cuda.current_stream().synchronize()
+
     def _i64(self, a):
         return self.torch.as_tensor(np.asarray(a, dtype=np.int64), device=self.dev)
 
@@ -54,13 +58,15 @@ class BwtDcAri:
             self._sc = self.torch.empty(need, dtype=self.torch.uint8, device=self.dev)
         return self._sc
 
-    def encode(self, raw, lens, keep_stages=False):
+    def encode(self, raw, lens, keep_stages=False, maxn=None, comp=None):
         """raw: uint8 tensor holding the blocks back to back; lens: block lengths (numpy).
-        -> (comp tensor, comp_off[nb, S], comp_len[nb, S], raw_part_len[nb, S] numpy, stages dict)"""
+        -> (comp tensor, comp_off[nb, S], comp_len[nb, S], raw_part_len[nb, S] numpy, stages dict)
+        maxn / comp: the slot geometry's block length and the buffer the coded pieces go to, when this call is one lane's
+        share of a larger stream (PipelineLanes); default: this call's own."""
         torch = self.torch
         lens = np.asarray(lens, dtype=np.int64)
         nb = len(lens)
-        maxn = int(lens.max()) if nb else 0
+        maxn = int(maxn) if maxn is not None else (int(lens.max()) if nb else 0)
         off = np.concatenate([[0], np.cumsum(lens)[:-1]]) if nb else np.zeros(0, np.int64)
         # 1. BWT
         bw = DeviceBatch(raw, self._i64(off), self._i64(lens), torch.empty(int(lens.sum()) + 64, dtype=torch.uint8, device=self.dev),
@@ -87,19 +93,21 @@ class BwtDcAri:
         pin = (self._i64(roff)[:, None] + cuts[:, :S]).contiguous()
         cslot = (2 * (slot // S + 8) + 16 + 63) // 64 * 64
         coff = np.arange(nb * S, dtype=np.int64) * cslot
-        ar = DeviceBatch(rec, pin.view(-1), plen.view(-1).clone(), torch.empty(nb * S * cslot + 64, dtype=torch.uint8, device=self.dev),
-                         self._i64(coff), self._i64(np.full(nb * S, cslot)))
+        if comp is None:
+            comp = torch.empty(nb * S * cslot + 64, dtype=torch.uint8, device=self.dev)
+        ar = DeviceBatch(rec, pin.view(-1), plen.view(-1).clone(), comp, self._i64(coff), self._i64(np.full(nb * S, cslot)))
         self.ctx.launch_dev(N.ARI_BYTE_ENCODE, ar)
-        torch.cuda.synchronize()
+        self._sync()
         assert int(bw.status[:nb].abs().max()) == 0 and int(dc.status[:nb].abs().max()) == 0 and int(ar.status[: nb * S].abs().max()) == 0, \
             "pipeline stage failed"
-        stages = {"bwt": bw, "dc": dc, "rec": rec, "rec_off": roff, "rec_len": rec_len, "ari": ar, "cuts": cuts} if keep_stages else None
+        stages = {"bwt": bw, "dc": dc, "rec": rec, "rec_off": roff, "rec_len": rec_len, "ari": ar, "cuts": cuts, "nblocks": nb} if keep_stages else None
         return (ar.out_base, coff.reshape(nb, S), ar.out_len[: nb * S].cpu().numpy().astype(np.int64).reshape(nb, S),
                 plen.cpu().numpy().astype(np.int64), stages)
 
-    def decode(self, comp, comp_off, comp_len, praw, lens):
+    def decode(self, comp, comp_off, comp_len, praw, lens, out=None):
         """comp_off / comp_len / praw: [nb, S] (offset and length of every coded piece, its decoded length)
-        -> uint8 tensor with the blocks back to back"""
+        -> uint8 tensor with the blocks back to back (written to `out` when given: >= sum(lens) + 64 bytes, or exactly the
+        blocks' bytes when more blocks follow in the same buffer)"""
         torch = self.torch
         lens = np.asarray(lens, dtype=np.int64)
         nb = len(lens)
@@ -114,7 +122,7 @@ class BwtDcAri:
                          torch.empty(nb * slot + 64, dtype=torch.uint8, device=self.dev),          # (what is read of a record is what its pieces decode to)
                          self._i64((roff[:, None] + pstart).reshape(-1)), self._i64(praw.reshape(-1)))
         self.ctx.launch_dev(N.ARI_BYTE_DECODE, ar)
-        torch.cuda.synchronize()
+        self._sync()
         _need(nb == 0 or int(ar.status[: nb * S].abs().max()) == 0, "ari decode failed")
         _need(bool((ar.out_len[: nb * S].cpu().numpy().astype(np.int64) == praw.reshape(-1)).all()), "container piece length mismatch")
         rec32 = ar.out_base[: nb * slot].view(torch.int32).view(nb, slot // 4)
@@ -137,13 +145,105 @@ class BwtDcAri:
                     p(status), nb, N.MEM_DEVICE)
         self.ctx._chk(N.lib().rcx_dc_decode_batch(self.ctx._h, C.byref(b), C.c_void_p(p(n_out))))
         _need(not status.any(), "dc decode failed")
-        inv = DeviceBatch(L, self._i64(ooff), self._i64(lens), torch.empty(total + 64, dtype=torch.uint8, device=self.dev),
+        if out is None:
+            out = torch.empty(total + 64, dtype=torch.uint8, device=self.dev)
+        inv = DeviceBatch(L, self._i64(ooff), self._i64(lens), out,
                           self._i64(ooff), self._i64(lens), aux=torch.as_tensor(origin.astype(np.int32), device=self.dev))
         sc = self._scratch(N.BWT_INVERSE, nb, maxn)
         self.ctx.launch_dev(N.BWT_INVERSE, inv, sc)
-        torch.cuda.synchronize()
+        self._sync()
         _need(nb == 0 or int(inv.status[:nb].abs().max()) == 0, "bwt inverse failed")
         return inv.out_base[:total]
+
+
+class PipelineLanes:
+    """The same pipeline with the block range cut into contiguous GROUPS that LANES work through side by side: a lane is a host
+    thread with an rcx_ctx and a HIP stream of its own.  Why: every stage of the decode is one wave per block or per sixteen
+    streams (3.7 waves a SIMD for 10^9 bytes) and bound by its own dependent chain, and the forward transform waits for the
+    host once a round; with two lanes the chains of one stage run under those of another and one lane's round trip hides
+    behind the other's kernels.  Measured, 10^9 bytes of text (benchmarks/r4_pipe_lanes.py): 1 lane 0.1226 s encode /
+    0.0501 s decode, 2 lanes 0.1173 / 0.0443, 3 lanes 0.1186 / 0.0446, 4 lanes 0.137 / 0.082 (the host threads' round trips
+    queue up behind each other).  Same bytes as one lane: blocks are independent in every stage and the slot geometry is the
+    whole stream's."""
+
+    def __init__(self, device, parts=PARTS, lanes=2, groups=None):
+        import torch
+        from concurrent.futures import ThreadPoolExecutor
+        from .api import Context
+        self.torch, self.dev, self.S, self.lanes = torch, device, int(parts), int(lanes)
+        self.groups = int(groups) if groups else self.lanes
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(self.lanes)]
+        self.pipes = []
+        for st in self.streams:
+            with torch.cuda.stream(st):
+                self.pipes.append(BwtDcAri(Context(idx), device, parts))
+        self.pool = ThreadPoolExecutor(self.lanes)
+
+    def _ranges(self, lens):
+        """The groups' block ranges [a, b): contiguous, balanced by bytes, none empty."""
+        from .dist import partition
+        bounds = partition(lens, max(1, min(self.groups, len(lens))))
+        return [(int(a), int(b)) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
+
+    def _run(self, jobs):
+        """jobs[g](pipe) for every group; lane l takes groups l, l + lanes, ... in order, on its own stream."""
+        torch = self.torch
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())                   # what the caller enqueued (the input) is in place first
+        res = [None] * len(jobs)
+
+        def lane(l):
+            torch.cuda.set_device(self.dev)                              # (the current device is a property of the thread)
+            with torch.cuda.stream(self.streams[l]):
+                self.streams[l].wait_event(ready)
+                for g in range(l, len(jobs), self.lanes):
+                    res[g] = jobs[g](self.pipes[l])
+                self.streams[l].synchronize()
+        for f in [self.pool.submit(lane, l) for l in range(self.lanes)]:
+            f.result()
+        return res
+
+    def encode(self, raw, lens, keep_stages=False):
+        """-> what BwtDcAri.encode returns; with keep_stages the stages of the FIRST group (blocks [0, stages["nblocks"]))."""
+        torch = self.torch
+        lens = np.asarray(lens, dtype=np.int64)
+        nb, S = len(lens), self.S
+        if nb == 0:
+            return self.pipes[0].encode(raw, lens, keep_stages)
+        maxn = int(lens.max())
+        slot = (4 * (HDR_WORDS + 256 + maxn) + 63) // 64 * 64
+        cslot = (2 * (slot // S + 8) + 16 + 63) // 64 * 64
+        comp = torch.empty(nb * S * cslot + 64, dtype=torch.uint8, device=self.dev)
+        offs = np.concatenate([[0], np.cumsum(lens)])
+
+        def job(a, b):
+            return lambda pipe: pipe.encode(raw[int(offs[a]):int(offs[b])], lens[a:b], keep_stages and a == 0, maxn=maxn,
+                                            comp=comp[a * S * cslot:])
+        res = self._run([job(a, b) for a, b in self._ranges(lens)])
+        coff = np.arange(nb * S, dtype=np.int64).reshape(nb, S) * cslot
+        return comp, coff, np.concatenate([r[2] for r in res]), np.concatenate([r[3] for r in res]), res[0][4]
+
+    def decode(self, comp, comp_off, comp_len, praw, lens):
+        torch = self.torch
+        lens = np.asarray(lens, dtype=np.int64)
+        nb = len(lens)
+        if nb == 0:
+            return self.pipes[0].decode(comp, comp_off, comp_len, praw, lens)
+        comp_off, comp_len, praw = (np.asarray(x).reshape(nb, -1) for x in (comp_off, comp_len, praw))
+        total = int(lens.sum())
+        out = torch.empty(total + 64, dtype=torch.uint8, device=self.dev)
+        offs = np.concatenate([[0], np.cumsum(lens)])
+
+        def job(a, b):
+            return lambda pipe: pipe.decode(comp, comp_off[a:b], comp_len[a:b], praw[a:b], lens[a:b], out=out[int(offs[a]):])
+        self._run([job(a, b) for a, b in self._ranges(lens)])
+        return out[:total]
+
+    def close(self):
+        self.pool.shutdown()
+        for p in self.pipes:
+            p.ctx.close()
 
 
 # ---------------------------------------------------------------------------------------------- container (host side, no device)

@@ -155,6 +155,34 @@ def test_config5_pipeline_roundtrip_and_stage_parity(ctx, oracle):
     ctx.set_stream(0)
 
 
+def test_config5_pipeline_lanes_same_bytes(ctx, oracle):
+    """pipeline.PipelineLanes (the block range cut into groups that host threads with a context and a stream of their own
+    work through side by side) writes, piece for piece, the bytes the one-lane pipeline writes, and decodes them back; ragged
+    block lengths, more groups than lanes, more lanes than blocks."""
+    import torch
+    from rust_compress_amd import pipeline as P
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    lens = np.concatenate([rng.integers(1, 70000, size=37), [262144, 5, 131072]]).astype(np.int64)
+    data = synth.gen("text", int(lens.sum()), 0x1A9E5)
+    raw = torch.from_numpy(data).to(dev)
+    one = P.BwtDcAri(ctx, dev)
+    comp0, coff0, clen0, praw0, _ = one.encode(raw, lens)
+    pieces0 = [comp0[int(o):int(o) + int(n)].cpu().numpy().tobytes() for o, n in zip(coff0.reshape(-1), clen0.reshape(-1))]
+    for lanes, groups, ll in ((2, 2, lens), (2, 5, lens), (3, 3, lens), (4, 4, lens[:2]), (2, 2, lens[:1])):
+        nb = len(ll)
+        nbytes = int(ll.sum())
+        pipe = P.PipelineLanes(dev, lanes=lanes, groups=groups)
+        comp, coff, clen, praw, _ = pipe.encode(raw[:nbytes], ll)
+        assert np.array_equal(clen, clen0[:nb]) and np.array_equal(praw, praw0[:nb])
+        pieces = [comp[int(o):int(o) + int(n)].cpu().numpy().tobytes() for o, n in zip(coff.reshape(-1), clen.reshape(-1))]
+        assert pieces == pieces0[: nb * praw0.shape[1]]
+        assert torch.equal(pipe.decode(comp, coff, clen, praw, ll), raw[:nbytes])
+        assert torch.equal(pipe.decode(comp0, coff0[:nb], clen0[:nb], praw0[:nb], ll), raw[:nbytes])     # and the one-lane pipeline's buffer
+        pipe.close()
+    ctx.set_stream(0)
+
+
 def test_config5_sharded_container_on_the_device(ctx, oracle):
     """BASELINE config 5's sharding on the GPU: the container the device writes for a stream is, byte for byte, the one the
     oracle's stages write on the CPU; split by block ranges (dist.partition) every shard decodes on its own, the decoded ranges
