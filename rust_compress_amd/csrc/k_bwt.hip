@@ -394,10 +394,22 @@ static uint64_t bwt_forward_scratch_bytes(uint32_t nblocks, uint64_t max_block)
     return 28 * N + 5 * (N / BWS_WAVE + nblocks + 1024) * sizeof(BwsSeg) + 2 * (N / 16 + 4096) * sizeof(BwsSeg) + 2 * (N / BWS_LWAVE + nblocks + 1024) * sizeof(BwsSeg) + (uint64_t)(nblocks + 2) * 4 + 4 * (N / 64 + 512) + (N / 256 + nblocks + 1024) + (1ull << 20);
 }
 
+// Page-locked words for the per-round read-backs (the counters of a round, the histogram): a copy into pageable memory goes
+// through the runtime's staging buffer and costs the host tens of microseconds more per round, with the GPU idle behind it.
+// One small allocation per host thread, kept for the life of the process (a context may be driven from any thread).
+static uint32_t* bwtf_pinned_words()
+{
+    static thread_local uint32_t* p = nullptr;
+    if (!p) { void* q = nullptr; if (hipHostMalloc(&q, 4 * (64 + BWS_NFLAG) + 4 * 264, hipHostMallocDefault) == hipSuccess) p = (uint32_t*)q; }
+    return p;
+}
+
 static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::string& err, bool sa_words = false)
 {
     const uint32_t pass_blocks = variant > 0 ? (uint32_t)variant : 0xffffffffu;      // A/B knob: at most `variant` blocks per sorting pass
     const uint32_t nb_all = k.nblocks;
+    uint32_t* const pinned = bwtf_pinned_words();
+    if (!pinned) { err = "bwt forward: cannot allocate page-locked memory"; return RCX_RC_NO_MEMORY; }
     std::vector<uint64_t> h_len(nb_all);
     if (nb_all && (hipMemcpyAsync(h_len.data(), k.in_len, nb_all * 8ull, hipMemcpyDeviceToHost, s) != hipSuccess ||
                    hipStreamSynchronize(s) != hipSuccess)) { err = "bwt forward: cannot read in_len"; return RCX_RC_HIP_ERROR; }
@@ -446,7 +458,7 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
             uint32_t nsym = 7, sbits = 9; bool plain_bytes = true;
             uint8_t h_map[256];                                   // (lives as long as the pass: its upload is not waited for on its own)
             {
-                uint32_t h_hist[264];
+                uint32_t* const h_hist = pinned + (64 + BWS_NFLAG);
                 if (hipMemsetAsync(hist, 0, 1056, s) != hipSuccess) { err = "bwt forward: memset"; return RCX_RC_HIP_ERROR; }
                 // (eight 16-byte chunks per thread: a workgroup per 4 KiB ended in 1 M workgroups' worth of atomics on the same 264 words)
                 const uint32_t gxh = (uint32_t)((maxn + 32767) / 32768 < 1024 ? (maxn + 32767) / 32768 : 1024);
@@ -490,6 +502,9 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
             auto grid_for = [&](uint32_t min_group, uint32_t per_wg, uint32_t cap) { const uint32_t g = N / min_group / per_wg + 8u; return g < cap ? g : cap; };
             const uint32_t gpart = grid_for(BWS_LMAX, 1, 2048), glw = grid_for(BWS_WAVE, 4, 8192), glg = grid_for(BWS_LWAVE, 1, 4096), gsm = grid_for(BWS_WAVE, 4, 2048);
             bool converged = false;
+            // what the round before listed for this one (the host has the counts anyway): a kernel whose lists are empty is not
+            // launched -- an empty launch is ~5 us of kernel and ~5 us of dependency gap, nine of them in a late round
+            uint32_t n_large = 1, n_local = 1, n_localw = 1, n_small = 1;
             for (int round = 0; round < 64; round++) {
                 st.par = (round & 1) ? BWS_PAR : 0u; st.rs = (uint32_t)(round & 1);
                 const uint32_t top = round == 0 ? top0 : top1, topn = top1;
@@ -497,16 +512,25 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
                 const bool wide = round == 0 || kbits1 > 24;
                 if (round) { if (wide) hipLaunchKernelGGL(k_bws_gather<uint64_t>, dim3(gxg, nb), dim3(256), 0, s, st, bstart, nb, h); else hipLaunchKernelGGL(k_bws_gather<uint32_t>, dim3(gxg, nb), dim3(256), 0, s, st, bstart, nb, h); }
                 const int levels = (int)((top + 7) / 8) + 1 + ((round == 0 && fused_first) ? 1 : 0);   // (k_bws_first's bins start from the top digit again)
-                for (int lv = (round == 0 && fused_first) ? 1 : 0; lv < levels; lv++) {
+                // (a partition step lists for the next level and for the three local sorts of THIS round; the local sorts and the dense
+                //  passes list for the next round)
+                const bool do_part = round == 0 || n_large, do_lw = do_part || n_local, do_lg = do_part || n_localw, do_sm = do_part || n_small;
+                for (int lv = (round == 0 && fused_first) ? 1 : 0; lv < levels && do_part; lv++) {
                     if (wide) hipLaunchKernelGGL(k_bws_partition<uint64_t>, dim3(gpart), dim3(512), 0, s, st, lv, topn);
                     else hipLaunchKernelGGL(k_bws_partition<uint32_t>, dim3(gpart), dim3(512), 0, s, st, lv, topn);
                 }
-                if (wide) { hipLaunchKernelGGL(k_bws_local_wave<uint64_t>, dim3(glw), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_local_wg<uint64_t>, dim3(glg), dim3(256), 0, s, st, topn); }
-                else { hipLaunchKernelGGL(k_bws_local_wave<uint32_t>, dim3(glw), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_local_wg<uint32_t>, dim3(glg), dim3(256), 0, s, st, topn); }
-                if (wide) { hipLaunchKernelGGL(k_bws_small<uint64_t>, dim3(gsm), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_dense<uint64_t>, dim3(gdense), dim3(256), 0, s, st, 0u); hipLaunchKernelGGL(k_bws_dense<uint64_t>, dim3(gdense), dim3(256), 0, s, st, 32u); }
-                else { hipLaunchKernelGGL(k_bws_small<uint32_t>, dim3(gsm), dim3(256), 0, s, st, topn); hipLaunchKernelGGL(k_bws_dense<uint32_t>, dim3(gdense), dim3(256), 0, s, st, 0u); hipLaunchKernelGGL(k_bws_dense<uint32_t>, dim3(gdense), dim3(256), 0, s, st, 32u); }
-                std::vector<uint32_t> hcv(64 + BWS_NFLAG);
-                uint32_t* hc = hcv.data();
+                if (wide) {
+                    if (do_lw) hipLaunchKernelGGL(k_bws_local_wave<uint64_t>, dim3(glw), dim3(256), 0, s, st, topn);
+                    if (do_lg) hipLaunchKernelGGL(k_bws_local_wg<uint64_t>, dim3(glg), dim3(256), 0, s, st, topn);
+                    if (do_sm) hipLaunchKernelGGL(k_bws_small<uint64_t>, dim3(gsm), dim3(256), 0, s, st, topn);
+                    hipLaunchKernelGGL(k_bws_dense<uint64_t>, dim3(gdense), dim3(256), 0, s, st, 0u); hipLaunchKernelGGL(k_bws_dense<uint64_t>, dim3(gdense), dim3(256), 0, s, st, 32u);
+                } else {
+                    if (do_lw) hipLaunchKernelGGL(k_bws_local_wave<uint32_t>, dim3(glw), dim3(256), 0, s, st, topn);
+                    if (do_lg) hipLaunchKernelGGL(k_bws_local_wg<uint32_t>, dim3(glg), dim3(256), 0, s, st, topn);
+                    if (do_sm) hipLaunchKernelGGL(k_bws_small<uint32_t>, dim3(gsm), dim3(256), 0, s, st, topn);
+                    hipLaunchKernelGGL(k_bws_dense<uint32_t>, dim3(gdense), dim3(256), 0, s, st, 0u); hipLaunchKernelGGL(k_bws_dense<uint32_t>, dim3(gdense), dim3(256), 0, s, st, 32u);
+                }
+                uint32_t* const hc = pinned;
                 // (one synchronisation a round: the counters are copied out, THEN k_bws_round_end turns them into the next round's)
                 if (hipMemcpyAsync(hc, st.cnt, 4 * (64 + BWS_NFLAG), hipMemcpyDeviceToHost, s) != hipSuccess) { err = "bwt forward: sync failed"; return RCX_RC_HIP_ERROR; }
                 hipLaunchKernelGGL(k_bws_round_end, dim3(1), dim3(256), 0, s, st);
@@ -522,6 +546,7 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
 #endif
                 if (hc[5] == 0) { converged = true; break; }
                 if (hc[3] > nlarge || hc[7] > nlarge || hc[6] > nlarge || hc[4] > nmid || hc[9] > nlw || hc[10] > nlw) { err = "bwt forward: group list overflow"; return RCX_RC_HIP_ERROR; }
+                n_large = hc[3]; n_small = hc[4]; n_local = hc[7]; n_localw = hc[10];
                 std::swap(st.large[0], st.nlarge); std::swap(st.small, st.nsmall); std::swap(st.local, st.nlocal); std::swap(st.localw, st.nlocalw);
                 h = round == 0 ? nsym : 2 * h;
             }

@@ -22,6 +22,8 @@ static inline int hipMemcpyAsync(void* d, const void* s, size_t n, int, int) { m
 static inline int hipStreamSynchronize(int) { return 0; }
 #define hipMemcpyHostToDevice 1
 static inline int hipMemsetAsync(void* d, int v, size_t n, int) { memset(d, v, n); return 0; }
+#define hipHostMallocDefault 0
+static inline int hipHostMalloc(void** p, size_t n, int) { *p = malloc(n); return *p ? 0 : 1; }
 #include "../../rust_compress_amd/csrc/k_bwt_inverse.hip"
 #include "../../rust_compress_amd/csrc/k_bwt.hip"
 
