@@ -1591,6 +1591,34 @@ struct AriQuad {
     }
 };
 
+// The decoder's byte source without a loop: `need` <= 4 bytes enter the code word at once.  cw / nw are the 8-byte words at
+// P = p & ~7 and P + 8 (nw requested a word ahead of its use); the four bytes at p are cut out of the pair, reversed and
+// shifted in -- sixteen streams a wave are in sixteen different phases, and with a loop per byte every symbol paid the longest
+// refill of the sixteen (two passes of ~35 instructions on average; this is ~15).
+struct AriWin {
+    const uint8_t* in; uint32_t n, p; uint64_t cw, nw;
+    __device__ __forceinline__ uint64_t load8(uint32_t q) const
+    {
+        if (q + 8u <= n && q + 8u >= q) return *(const rcx_u64_u*)(in + q);
+        uint64_t w = 0;
+        for (uint32_t i = q; i < n; i++) w |= (uint64_t)in[i] << (8u * (i - q));
+        return w;
+    }
+    __device__ __forceinline__ void start(const uint8_t* in_, uint32_t n_) { in = in_; n = n_; p = 0; cw = load8(0); nw = n > 8u ? load8(8) : 0ull; }
+    // (code << 8 * need) + the next `need` bytes, most significant first (feed(), mod.rs:271-278); the caller made sure p + need <= n
+    __device__ __forceinline__ uint32_t take(uint32_t code, uint32_t need)
+    {
+        const uint32_t sh = 8u * (p & 7u);
+        const uint64_t w = (cw >> sh) | ((nw << 1) << (63u - sh));
+        const uint32_t be = __builtin_bswap32((uint32_t)w);
+        code = (uint32_t)(((((uint64_t)code) << 32) | (uint64_t)be) << (8u * need) >> 32);
+        const uint32_t P = p & ~7u;
+        p += need;
+        if ((p & ~7u) != P) { cw = nw; nw = (P + 16u < n && P + 16u >= P) ? load8(P + 16u) : 0ull; }
+        return code;
+    }
+};
+
 template <bool DEC>
 __global__ __launch_bounds__(256) void k_ari_byte_quad(rcx_kargs a)
 {
@@ -1611,8 +1639,14 @@ __global__ __launch_bounds__(256) void k_ari_byte_quad(rcx_kargs a)
     // first in the low bytes of `ob`; returns their number
     auto process = [&](uint32_t range, uint32_t from, uint32_t to, uint32_t& ob) -> unsigned {
         uint32_t lo_ = low + __umul24(range, from), hi_ = low + __umul24(range, to);
-        unsigned k = 0;
-        ob = 0;
+        // The loop below leaves through its `break` only; the bytes on which lo_ and hi_ agree leave first, whatever the range is, so
+        // they are counted with one v_ffbh and shifted out at once (at most three: a fourth, or the underflow case, is the loop's).
+        // Nearly every call ends there -- and a wave's loop ran as long as the longest of its sixteen streams'.
+        const uint32_t x_ = lo_ ^ hi_;
+        unsigned k = x_ ? (unsigned)__builtin_clz(x_) >> 3 : 3u;
+        k = k < 3u ? k : 3u;
+        ob = (uint32_t)(((uint64_t)lo_ << (8u * k)) >> 32);
+        lo_ <<= 8u * k; hi_ <<= 8u * k;
         for (;;) {
             if (((lo_ ^ hi_) & 0xff000000u) != 0) {
                 if (hi_ - lo_ > (1u << 14)) break;
@@ -1644,12 +1678,11 @@ __global__ __launch_bounds__(256) void k_ari_byte_quad(rcx_kargs a)
         used = n;
     } else {                                                   // ByteDecoder::read to EOF + finish, table.rs:256-272
         uint32_t code = 0; unsigned pending = 4;
+        uint64_t acc0 = 0, acc1 = 0;
+        AriWin win; win.start(in, (uint32_t)n);
         for (;;) {
-            while (pending) {                                  // feed(), mod.rs:271-278
-                if (src.p >= n) { st = RCX_E_MALFORMED; break; }
-                code = (code << 8) + src.next(); pending--;
-            }
-            if (st) break;
+            if (pending > win.n - win.p) { win.p = win.n; st = RCX_E_MALFORMED; break; }     // feed(), mod.rs:271-278: the stream ends inside it
+            code = win.take(code, pending);
             const uint32_t total = T.total;
             const uint32_t range = rcx_div_u13(hai - low, total);  // query(), mod.rs:153-159
             const uint32_t x = code - low;
@@ -1660,10 +1693,23 @@ __global__ __launch_bounds__(256) void k_ari_byte_quad(rcx_kargs a)
             if (v == 256) break;
             if (o >= cap) { st = RCX_E_OUTPUT_TOO_SMALL; break; }
             T.update(v);
-            if (q == 0) out[o] = (uint8_t)v;
+            // Sixteen decoded bytes leave with two 8-byte stores (every stream of the wave is at the same o: a symbol a step).  A byte
+            // store per symbol was what the kernel's time consisted of: the next refill of the byte window -- some stream's, nearly
+            // every step -- is a wait for vmcnt(0), and on gfx9 that is a wait for the store of the step before to reach memory.
+            const uint32_t ph = (uint32_t)o & 15u;
+            const uint64_t vb = (uint64_t)v << (8u * (ph & 7u));
+            if (ph & 8u) acc1 |= vb; else acc0 |= vb;
             o++;
+            if (ph == 15u) {
+                if (q == 0) { *(rcx_u64_u*)(out + o - 16) = acc0; *(rcx_u64_u*)(out + o - 8) = acc1; }
+                acc0 = 0; acc1 = 0;
+            }
         }
-        uint64_t p = src.p;
+        if (q == 0) {                                          // the bytes still in the registers (the stream's end, or an error: what was decoded is delivered)
+            const uint32_t rem = (uint32_t)o & 15u;
+            for (uint32_t j = 0; j < rem; j++) out[o - rem + j] = (uint8_t)((j < 8u ? acc0 : acc1) >> (8u * (j & 7u)));
+        }
+        uint64_t p = win.p;
         if (!st) { while (pending) { if (p >= n) { st = RCX_E_EOF; break; } p++; pending--; } }   // finish(), mod.rs:289-292
         used = p;
     }
