@@ -62,12 +62,16 @@ class GpuEngine:
         import rust_compress_amd as R
         from rust_compress_amd import _native as N
         self.torch, self.R, self.N = torch, R, N
-        torch.cuda.set_device(local_rank)
+        # RCX_BENCH_SHARE_GPU=1: the ranks share the GPUs there are (a check of the N-rank path on a one-GPU box; with
+        # RCX_BENCH_BACKEND=gloo, since RCCL refuses two ranks on one device) -- its rates are not a scaling measurement
+        share = bool(os.environ.get("RCX_BENCH_SHARE_GPU"))
+        torch.cuda.set_device(local_rank % torch.cuda.device_count() if share else local_rank)
         self.dev = torch.device("cuda", torch.cuda.current_device())
         self.ctx = R.Context(torch.cuda.current_device())
         self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         self.ctx.set_variant(N.LZ4_DECODE, args.variant)
-        self.backend = "nccl"
+        self.backend = os.environ.get("RCX_BENCH_BACKEND", "nccl")
+        self.shared_gpu = share
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -568,6 +572,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": round(kern_ms, 4),
                          "kernel_ms_median": round(kern_med, 4)},
             "per_distribution": None,
+            **({"shared_gpu_check": "the %d ranks share the box's GPUs over %s (RCX_BENCH_SHARE_GPU): a check of the N-rank path, not a scaling measurement"
+                                    % (world, eng.backend)} if getattr(eng, "shared_gpu", False) else {}),
             "end_to_end": e2e,
         }
         pd = {"G-" + args.kind: {"GiB/s": res["value"], "ms_per_step": res["ms_per_step"], "kernel_ms_avg": round(kern_ms, 4),
