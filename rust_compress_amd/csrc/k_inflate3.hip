@@ -1005,6 +1005,55 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
                 phase = bjob == 0 ? P_CLENS : P_SYMBOLS;
             } else if (phase == P_CLENS) {                             // :421-442
                 const uint32_t ntot = hlit + hdist;
+#ifndef INF3_SERIAL_CLENS
+                // The code-length symbols of a header, a WINDOW of 64 bits at a time: lane l decodes the symbol that would start at bit l of
+                // the window (a code of <= 7 bits and its <= 7 extra bits: one table read), a scalar walk over the lanes' "next" offsets
+                // picks the real ones (~13 of 64), a wave scan gives each its place in `lens`, a repeat (16) takes its value from the last
+                // symbol before it that set one (17 / 18 write zeros, which `lens` already holds).  One symbol at a time this was ~50
+                // instructions a symbol and 7 % of a member's time.  Anything the reference rejects (:428, :439, :442) goes to the exact kernel.
+                while (ci < ntot && !st) {
+                    const uint32_t bp = RCX_U(8u * (uint32_t)((int32_t)p - this->cbase) - bc);   // the next unread bit, relative to cbuf[0]
+                    if (bp + 192u > 8u * (uint32_t)CB) { want_stage = true; break; }            // (lane 63 reads 12 bytes from bit bp + 63 on)
+                    const uint64_t w = bits64(bp + lane);
+                    const uint32_t e = lutD[(uint32_t)w & (uint32_t)(DLUTN - 1)];
+                    const uint32_t cl = e & 15u, sy = (e >> 4) & 0x7ffu;
+                    const uint32_t xb = sy == 16u ? 2u : sy == 17u ? 3u : sy == 18u ? 7u : 0u;
+                    const uint32_t xv = (uint32_t)(w >> cl) & ((1u << xb) - 1u);
+                    const uint32_t nxt = lane + cl + xb;                                        // where the symbol behind this one starts
+                    const uint32_t cnt = sy < 16u ? 1u : sy == 18u ? 11u + xv : 3u + xv;       // entries of `lens` it stands for
+                    const unsigned long long badm = __ballot(cl == 0u || sy > 18u);            // no code starts like this
+                    unsigned long long real = 0;
+                    for (uint32_t q = 0; q < 64u;) {                                           // (wave-uniform)
+                        real |= 1ull << q;
+                        if ((badm >> q) & 1ull) break;
+                        q = RCX_U(__builtin_amdgcn_readlane(nxt, (int)q));
+                    }
+                    const bool isreal = ((real >> lane) & 1ull) != 0;
+                    const uint32_t c = isreal ? cnt : 0u;
+                    const uint32_t incl = rcx_wave_incl_scan(c);
+                    const uint32_t cik = ci + incl - c;                                        // the entries in front of this symbol
+                    const bool act = isreal && cik < ntot;                                     // (the reference's loop ends at ntot)
+                    const unsigned long long actm = __ballot(act);
+                    if ((actm & badm) || __ballot(act && (cik + cnt > ntot || (sy == 16u && cik == 0u)))) { st = RCX_ST_FALLBACK; break; }   // :439, :442 / a repeat past the end, :428
+                    const unsigned long long setm = __ballot(act && sy != 16u) & ((1ull << lane) - 1ull);   // the symbols in front that set the running value
+                    const uint32_t carry = RCX_U(lens[ci ? ci - 1u : 0u]);
+                    const uint32_t sv = (uint32_t)__shfl((int)sy, setm ? 63 - (int)__clzll(setm) : 0);
+                    const uint32_t val = setm ? (sv < 16u ? sv : 0u) : carry;
+                    if (act && sy < 16u) lens[cik] = (uint8_t)sy;
+                    if (act && sy == 16u) {
+#pragma unroll
+                        for (uint32_t j = 0; j < 6u; j++) if (j < cnt) lens[cik + j] = (uint8_t)val;
+                    }
+                    rcx_wave_sync();
+                    const int lastl = 63 - (int)__clzll(actm);                                 // (lane 0 is real and ci < ntot: actm != 0)
+                    ci = RCX_U(ci + (uint32_t)__builtin_amdgcn_readlane(incl, lastl));
+                    const uint32_t nbp = bp + RCX_U(__builtin_amdgcn_readlane(nxt, lastl));
+                    const uint32_t pa = (nbp >> 3) & ~3u, drop = nbp - 8u * pa;                // the bit reader resumes at bit nbp
+                    p = (uint32_t)(this->cbase + (int32_t)pa); bb = 0; bc = 0;
+                    refill();
+                    bb >>= drop; bc -= drop;
+                }
+#else
                 while (ci < ntot && !st) {
                     if (!staged(16)) { want_stage = true; break; }
                     refill();
@@ -1026,6 +1075,7 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
                     else { st = RCX_ST_FALLBACK; break; }              // :439
                     ci = RCX_U(ci);
                 }
+#endif
                 if (!st && !want_stage) {
                     if (ci > ntot) st = RCX_ST_FALLBACK;               // :442
                     rcx_wave_sync();
@@ -1091,7 +1141,11 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
                 }
             }
 #ifdef INF3_PROF
+#ifdef INF3_PROF_CLENS                                         /* (attribution: the code-length decode counted apart, in the wide copies' slot) */
+            pf[ph0 == P_SYMBOLS ? 4 : ph0 == P_CLENS ? 1 : 3] += __builtin_readcyclecounter() - tph0;
+#else
             pf[ph0 == P_SYMBOLS ? 4 : 3] += __builtin_readcyclecounter() - tph0;
+#endif
 #endif
         }
         if (!st) {                                                     // the tail of the last batch
