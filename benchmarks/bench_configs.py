@@ -337,6 +337,8 @@ def config5(ctx, torch, dev, scale=1.0, reps=4, cpu=False, rank=0, world=1, dist
         if sharded:
             dist.barrier()
         t0 = time.perf_counter(); back = pipe.decode(comp, coff, clen, praw, llen); torch.cuda.synchronize(); d_ = time.perf_counter() - t0
+        if os.environ.get("RCX_CFG_VERBOSE"):
+            print("config 5 rep %d: encode %.4f s decode %.4f s" % (rep, e_, d_), file=sys.stderr)
         if rep or n_rep == 1:
             te, td = min(te, e_), min(td, d_)
     csum = int(clen.sum())
@@ -392,6 +394,10 @@ def main():
                 print(json.dumps(r), flush=True)
         elif cfg == "5":
             print(json.dumps(config5(ctx, torch, dev, args.scale, cpu=args.cpu, once=args.once)), flush=True)
+        if os.environ.get("RCX_CFG_KEEP_CACHE") is None:    # as bench.py does between its side configs: the next one starts from an empty allocator cache
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
     ctx.close()
 
 
