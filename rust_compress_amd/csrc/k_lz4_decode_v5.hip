@@ -35,6 +35,24 @@
 #ifndef RCX_ROUND_PRIO
 #define RCX_ROUND_PRIO 3
 #endif
+// RCX_AGE_PRIO: among waves of one priority a SIMD issues the OLDEST first, so of the sixteen blocks of a CU the four dispatched
+// first run 17 % faster than the four dispatched last (1.23 M against 1.46 M timer ticks, in four steps that follow the executor
+// wave's slot on its SIMD: benchmarks/r4_lz4_tail.py) and the launch ends with the last.  An executor knows its age rank among the
+// four of its SIMD from its wave slot (HW_ID: on a GPU that starts the launch empty the slots fill in dispatch order), and the
+// older half gives way where it hurts least.  Measured on the headline, same box, two runs each (benchmarks/r4_lz4_age.sh):
+//   0 (no age term) 0.612-0.617 ms | bit 1, the older half's copy rounds one level down: 0.605-0.612 | bits 1 + 3, its drain too
+//   (10, the default): 0.598-0.605 | bit 0, the younger half's default phase one level up: 0.639-0.642 | bit 4, the younger half's parser one up: 0.625 | bit 5, the older half's default phase one down:
+//   no change | the split after one or three ranks instead of two: 0.602-0.616.
+#ifndef RCX_AGE_PRIO
+#define RCX_AGE_PRIO 10
+#endif
+#ifndef RCX_AGE_SPLIT
+#define RCX_AGE_SPLIT 2                  /* age ranks below this are "old" */
+#endif
+#define RCX_SETPRIO_EXEC(young) do { if ((RCX_AGE_PRIO & 1) && (young)) __builtin_amdgcn_s_setprio(RCX_EXEC_PRIO + 1); else if ((RCX_AGE_PRIO & 32) && !(young)) __builtin_amdgcn_s_setprio(RCX_EXEC_PRIO - 1); else __builtin_amdgcn_s_setprio(RCX_EXEC_PRIO); } while (0)
+#define RCX_SETPRIO_ROUND(young) do { if ((RCX_AGE_PRIO & 2) && !(young)) __builtin_amdgcn_s_setprio(RCX_ROUND_PRIO - 1); else __builtin_amdgcn_s_setprio(RCX_ROUND_PRIO); } while (0)
+// bit 3: the older half drains one level down
+#define RCX_SETPRIO_FLUSH(young) do { if ((RCX_AGE_PRIO & 8) && !(young)) __builtin_amdgcn_s_setprio(RCX_FLUSH_PRIO - 1); else __builtin_amdgcn_s_setprio(RCX_FLUSH_PRIO); } while (0)
 #include <type_traits>
 
 // The copy rounds of emit5 as ISA (gfx950): every round, the lanes whose producers are done (no pending lane among `dep`) and
@@ -280,7 +298,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
     // FARCAP: the longest match that is gathered with 16-byte loads when its source has left the window (a longer one takes the
     // byte path): k_lz4_decode_v8 hands over matches of at most 32 bytes, so two of the four gathers and their stores are not compiled
     template <bool LITLDS = false, bool NORED = false, int CUT = 0, int FARCAP = 64>
-    __device__ int emit5(int ns, int& lo, uint32_t w0, uint32_t w1, const uint8_t* litbuf = nullptr)
+    __device__ int emit5(int ns, int& lo, uint32_t w0, uint32_t w1, const uint8_t* litbuf = nullptr, bool young = true)   // young: RCX_AGE_PRIO (true: the plain levels)
     {
         const unsigned lane = this->lane;
         const uint8_t* in = this->in; uint8_t* out = this->out; uint8_t* wb_ = this->wb_;
@@ -360,7 +378,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
             if (FC > 48 && __ballot(far16 && M > 48)) f3 = *(const rcx_u32x4_u*)(out + q + 48);
         }
 
-        if (RCX_INF_ROUNDS_PRIO || !LITLDS) __builtin_amdgcn_s_setprio(RCX_ROUND_PRIO);
+        if (!LITLDS) RCX_SETPRIO_ROUND(young); else if (RCX_INF_ROUNDS_PRIO) __builtin_amdgcn_s_setprio(RCX_ROUND_PRIO);   // (the inflate executor: the plain level)
         // ---- producer lanes of [slo, shi) inside this batch, chains redirected (see Lz4V4::emit) while the loads fly
         unsigned long long dep = 0;
         bool inb = M && !isfar && shi > oend0;
@@ -501,12 +519,12 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH> {
                 }
             };
             if (CUT & 1) {} else if (__ballot(ovl0 && M > 16u)) rounds(std::true_type{}); else rounds(std::false_type{});
-            if (!LITLDS) __builtin_amdgcn_s_setprio(RCX_FLUSH_PRIO); else if (RCX_INF_ROUNDS_PRIO) __builtin_amdgcn_s_setprio(0);
+            if (!LITLDS) RCX_SETPRIO_FLUSH(young); else if (RCX_INF_ROUNDS_PRIO) __builtin_amdgcn_s_setprio(0);
         }
         V5P_ADD(7);
         this->oend = RCX_U(oend0 + T);
         if (!(CUT & 16)) this->flush(this->oend, false); else this->gflush = this->oend & ~15u;
-        if (!LITLDS && RCX_FLUSH_PRIO != RCX_EXEC_PRIO) __builtin_amdgcn_s_setprio(RCX_EXEC_PRIO);
+        if (!LITLDS && RCX_FLUSH_PRIO != RCX_EXEC_PRIO) RCX_SETPRIO_EXEC(young);
         V5P_ADD(8);
         if (PROF5) pw[10] += 1;
 #undef V5P_ADD

@@ -42,6 +42,7 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
     // (3.8 of its 4.6 rounds per batch of text were the long matches').  0: off.
     static constexpr int SPLIT = SPLIT_;
     static_assert(SPLIT_ == 0 || 2 * SPLIT_ >= 64, "two entries cover the 64-byte cap");
+    bool agey = true;                             // RCX_AGE_PRIO (k_lz4_decode_v5.hip): this wave is in the younger half of its SIMD's (true: the plain levels)
     typedef Lz4V5<1024, TC, HH, PROF8, SB> P5;
     typedef typename P5::B B;
     static constexpr int SEGB = 64, NSEG = 64, CH = SEGB * NSEG;      // a chunk: 64 segments of 64 bytes, a lane each
@@ -235,7 +236,7 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_sleep(RCX_V8_PSLEEP);
         }
-        __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO);
+        if ((RCX_AGE_PRIO & 16) && this->agey) __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO + 1); else __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO);
         rcx_wave_sync();
         RCX_LDS_AS Slot8* sl = &ring->slot[head % NSLOT8];
         if (put) { sl->d[idx] = w1; if (w1b) sl->d[idx + 1] = w1b; }
@@ -377,7 +378,7 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
             int lo = 0, e = 0;
             // CUT 8 (A/B): the executor only drains the ring -- what is left is the parser wave's instructions; 32: nor its own scan
             if (CUT & 8) { if (!(CUT & 32)) this->oend += RCX_U(__builtin_amdgcn_readlane(w0, 63)) & 1u; lo = bt.ns; }
-            while (lo < bt.ns && !e) e = this->template emit5<false, PRED, CUT, (SPLIT ? SPLIT : 64)>(bt.ns, lo, w0, w1);
+            while (lo < bt.ns && !e) e = this->template emit5<false, PRED, CUT, (SPLIT ? SPLIT : 64)>(bt.ns, lo, w0, w1, nullptr, agey);
             if (e) { st = e; break; }
             if (this->after_batch(bt, st)) break;
         }
@@ -399,7 +400,7 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
         uint32_t lcnt = 0;                                           // list entries carried over from the last chunk
         while (c < n) {
             V8P_T0();
-            __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO);             // (the ring drains while a chunk is staged, walked and linked)
+            if ((RCX_AGE_PRIO & 16) && this->agey) __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO + 1); else __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO);   // (the ring drains while a chunk is staged, walked and linked)
             stage8(cs);
             const int nseg = ((int64_t)n - cs >= CH) ? NSEG : (int)(((int64_t)n - cs + SEGB - 1) / SEGB);
             const int k0 = (int)(((int32_t)c - cs) / SEGB);
@@ -560,6 +561,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_decode_v8(rcx_kargs a, int only_
     s.list = s_list;
     s.lmap = s_lmap;
     if (role == 0) {
+        if (RCX_AGE_PRIO & 16) s.agey = (((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) >> 1) & 7u) >= (uint32_t)RCX_AGE_SPLIT;
         s.run_parser8();
         if (PROF8 && a.scratch && (threadIdx.x & 63u) == 0) {          // [0..9] parser phases, [10] parser total
             uint64_t* q = (uint64_t*)a.scratch + (size_t)b * 32;
@@ -569,11 +571,16 @@ __global__ __launch_bounds__(128, 8) void k_lz4_decode_v8(rcx_kargs a, int only_
         return;
     }
     int32_t st; uint32_t olen;
-    __builtin_amdgcn_s_setprio(RCX_EXEC_PRIO);
+    // HW_ID[3:0] = the wave's slot on its SIMD; on a GPU that starts the launch empty the slots fill in dispatch order (a workgroup's
+    // two waves take a pair), so slot >> 1 is the executor's age rank among the four of its SIMD
+    const uint32_t hwid = (PROF8 || RCX_AGE_PRIO) ? (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) : 0u;
+    s.agey = RCX_AGE_PRIO ? ((hwid >> 1) & 7u) >= (uint32_t)RCX_AGE_SPLIT : true;
+    RCX_SETPRIO_EXEC(s.agey);
     s.run_executor8(&st, &olen);
-    if (PROF8 && a.scratch && (threadIdx.x & 63u) == 0) {              // [11] executor total, [16..] executor phases (Lz4V5::pw)
+    if (PROF8 && a.scratch && (threadIdx.x & 63u) == 0) {              // [11] executor total, [12] its wave slot, [16..] executor phases (Lz4V5::pw)
         uint64_t* q = (uint64_t*)a.scratch + (size_t)b * 32;
         q[11] = (uint64_t)__builtin_readcyclecounter() - tk0;
+        q[12] = hwid;
         for (int i = 0; i < 12; i++) q[16 + i] = s.pw[i];
     }
     if ((threadIdx.x & 63u) == 0) {

@@ -224,6 +224,7 @@ static inline unsigned __byte_perm_(unsigned a, unsigned b, unsigned s) { (void)
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) ws::yield_()        // spin-wait loops let the other waves of the block run
 #define __builtin_amdgcn_s_setprio(n) ((void)0)
+#define __builtin_amdgcn_s_getreg(n) (0u)              // (HW_ID: every wave in slot 0 here; only issue priorities depend on it)
 #define RCX_LDS_AS
 #define RCX_GLOBAL_AS
 #define __builtin_amdgcn_sched_barrier(n) ((void)0)
