@@ -1627,6 +1627,24 @@ __global__ __launch_bounds__(256) void k_ari_byte_quad(rcx_kargs a)
     const uint32_t b = blockIdx.x * 64 + sl;
     if (b >= a.nblocks) return;                                // (whole quads leave)
     AriQuad T; T.tab = s_q + sl * (ARIQ_TAB + ARIQ_BS); T.bs = T.tab + ARIQ_TAB; T.q = q; T.init();
+    // The four waves of a SIMD (one of each of a CU's four workgroups) would finish one after the other: among waves of one priority
+    // a SIMD issues the oldest first, the kernel is bound by the vector ALU, and the last wave alone keeps it a quarter busy.  So the
+    // priority order rotates: every RCX_ARI_ROTATE symbols a wave takes the level (its slot + the period's number) mod 4.
+#ifndef RCX_ARI_ROTATE
+#define RCX_ARI_ROTATE 64
+#endif
+    const uint32_t wslot = RCX_ARI_ROTATE ? (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) : 0u;   // HW_ID[3:0]: the wave's slot on its SIMD
+    uint32_t rot = 0;
+    auto rotate = [&]() {
+        if (RCX_ARI_ROTATE && (rot++ & (uint32_t)(RCX_ARI_ROTATE - 1)) == 0u) {
+            switch ((wslot + rot / (uint32_t)(RCX_ARI_ROTATE ? RCX_ARI_ROTATE : 1)) & 3u) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+            }
+        }
+    };
     uint32_t low = 0, hai = 0xffffffffu;
     const uint8_t* in = a.in_base + a.in_off[b];
     const uint64_t n = a.in_len[b];
@@ -1662,6 +1680,7 @@ __global__ __launch_bounds__(256) void k_ari_byte_quad(rcx_kargs a)
     };
     if (!DEC) {                                                // ByteEncoder::write + finish, table.rs:203-219
         for (uint64_t i = 0; i <= n; i++) {
+            rotate();
             const uint32_t v = i < n ? src.next() : 256u;
             uint32_t lo, hi, ob;
             T.range_of(v, lo, hi);
@@ -1681,6 +1700,7 @@ __global__ __launch_bounds__(256) void k_ari_byte_quad(rcx_kargs a)
         uint64_t acc0 = 0, acc1 = 0;
         AriWin win; win.start(in, (uint32_t)n);
         for (;;) {
+            rotate();
             if (pending > win.n - win.p) { win.p = win.n; st = RCX_E_MALFORMED; break; }     // feed(), mod.rs:271-278: the stream ends inside it
             code = win.take(code, pending);
             const uint32_t total = T.total;
