@@ -259,7 +259,7 @@ def cpu_baseline(dec, raw, torch, nblocks, budget_s=10.0):
     out = np.zeros(nblocks * BLOCK + 64, dtype=np.uint8)
     cores = os.cpu_count() or 1
     total_s, reps, nbytes = 0.0, 0, 0
-    while total_s < budget_s and reps < 64:
+    while total_s < budget_s and reps < 2000:                   # ~10 s of CPU work on the workload's own blocks (the contract's bounded sample)
         secs, out_len, _, status = O.batch_run(N.LZ4_DECODE, in_base, in_off, in_len, out, out_off, out_cap, threads=cores)
         assert not status.any()
         total_s += secs
@@ -406,6 +406,111 @@ def dry_sharded_pipeline(eng, dist, rank, world, nblocks=11, block=4096):
             "blocks": int(len(lens)), "block_ranges": np.diff(bounds).tolist(), "container_bytes": len(whole)}
 
 
+# ------------------------------------------------------------------------------------------------ side legs
+class SideLegs:
+    """Everything bench.py measures AFTER the headline (other distributions, end_to_end, configs 3-5, CPU baselines) runs
+    through here, so that none of it can cost the line the driver reads:
+
+    * `run(name, fn)`: every rank catches its own exception; with peers, ONE all_reduce(MAX) of an error flag then decides
+      together whether the leg counts as done.  A leg that failed on any rank is reported as {"error": ...}, and the legs
+      after it that need the process group are skipped (a rank that left a scatter half way has unmatched sends behind it:
+      the group's state is unknown) -- local legs still run.
+    * the process group carries a timeout (RCX_BENCH_PG_TIMEOUT seconds), so a peer that never shows up is an exception on
+      gloo; on RCCL, where a stuck collective is a stuck device, the WATCHDOG thread is what ends it: RCX_BENCH_SIDE_TIMEOUT
+      seconds after the headline it prints the stashed line (rank 0) with the legs finished so far and exits the process.
+    * `finish()`: the one JSON line, printed once (the watchdog and the main thread share a lock)."""
+
+    def __init__(self, eng, dist, rank, world, res):
+        import threading
+        self.eng, self.dist, self.rank, self.world, self.res = eng, dist, rank, world, res
+        self.broken = None            # why the process group is not used any more
+        self.failed = []
+        self.lock = threading.Lock()
+        self.printed = False
+        self.current = None
+
+    def run(self, name, fn, collective=True):
+        multi = self.world > 1 and self.dist is not None
+        if collective and multi and self.broken:
+            return {"error": "skipped: " + self.broken}
+        self.current = name
+        out, err = None, None
+        try:
+            out = fn()
+        except Exception as e:                                  # (KeyboardInterrupt / SystemExit pass)
+            err = "%s: %s" % (type(e).__name__, str(e)[:300])
+        if collective and multi:
+            torch = self.eng.torch
+            try:
+                flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float32, device=self.eng.dev)
+                self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+                if float(flag.item()) > 0 and err is None:
+                    err = "another rank failed in this leg"
+                if float(flag.item()) > 0:
+                    self.broken = "the leg '%s' failed on some rank; the process group is not used after that" % name
+            except Exception as e:
+                self.broken = "process group unusable after the leg '%s' (%s)" % (name, str(e)[:160])
+                err = err or self.broken
+        self.current = None
+        if err is not None:
+            self.failed.append(name)
+            print("bench.py: rank %d: side leg %s failed: %s" % (self.rank, name, err), file=sys.stderr, flush=True)
+            return {"error": err}
+        return out
+
+    def _emit(self, note=None):
+        with self.lock:
+            if self.printed:
+                return
+            self.printed = True
+            if self.res is not None:
+                if self.failed:
+                    self.res["side_legs_failed"] = list(self.failed)
+                if note:
+                    self.res["side_legs_note"] = note
+                print(json.dumps(self.res), flush=True)
+
+    def start_watchdog(self, seconds):
+        import threading
+
+        def fire():
+            self._emit("side legs did not finish within %.0f s (running: %s): the line carries what was finished" % (seconds, self.current))
+            try:
+                sys.stdout.flush(); sys.stderr.flush()
+            finally:
+                os._exit(0 if self.res is not None or self.rank != 0 else 1)
+        self.timer = threading.Timer(seconds, fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def finish(self):
+        # RCCL writes its version banner to stdout through C stdio, which is flushed at exit -- after anything Python prints.
+        # Every rank pushes it out first; rank 0 prints the JSON line after a barrier, as the last line of the job's stdout.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        multi = self.dist is not None
+        if multi and not self.broken:
+            try:
+                self.dist.barrier()
+            except Exception as e:
+                self.broken = "final barrier: %s" % str(e)[:120]
+        self._emit()
+        if getattr(self, "timer", None) is not None:
+            self.timer.cancel()
+        if multi and not self.broken:
+            try:
+                self.dist.barrier()
+                self.dist.destroy_process_group()
+            except Exception:
+                pass
+        elif multi:
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)                                         # (a broken group's destructor may wait for peers that are gone)
+
+
 # ------------------------------------------------------------------------------------------------ launcher
 def self_spawn(args):
     """`python bench.py --gpus N` outside torch.distributed.run: start one rank per GPU and pass their output through."""
@@ -454,10 +559,14 @@ def main():
                 os.environ["MASTER_PORT"] = str(s.getsockname()[1])
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         try:
+            import datetime
+            # a peer that never arrives is an exception after this long, not a hang (SideLegs); RCCL's own watchdog would end the
+            # process at this point, so it lies BEHIND the side legs' watchdog, which prints the line first
+            pg_to = datetime.timedelta(seconds=float(os.environ.get("RCX_BENCH_PG_TIMEOUT", "1500")))
             if eng.backend == "nccl":
-                dist.init_process_group("nccl", device_id=eng.dev)
+                dist.init_process_group("nccl", device_id=eng.dev, timeout=pg_to)
             else:
-                dist.init_process_group("gloo")
+                dist.init_process_group("gloo", timeout=pg_to)
         except Exception as e:
             if world > 1:
                 raise
@@ -480,64 +589,12 @@ def main():
     wall = float(t.item())
     total_out = float(tot[0].item())
 
-    # ---- config 2's other distributions (SURVEY 8d: reported separately), same timing discipline, every rank
-    per_dist = {}
-    if not args.no_dists and not args.dry_gloo:
-        for kind in ("runs", "rand"):
-            w2 = eng.make_workload(kind, args.nblocks, 0x4C5A3401 + 7919 * rank + len(kind))
-            eng.check(w2)
-            wall2, km2, _ = time_steps(eng, w2, max(5, args.steps // 2), 2, dist if world > 1 else None)
-            tt2 = torch.tensor([wall2, float(w2["out_bytes"]), float(w2["comp_bytes"])], dtype=torch.float64, device=eng.dev)
-            if dist is not None:
-                mx = tt2.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-                sm = tt2.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-                wall2, tot_out2 = float(mx[0]), float(sm[1])
-            else:
-                tot_out2 = float(w2["out_bytes"])
-            st2 = max(5, args.steps // 2)
-            alg2 = w2["comp_bytes"] + w2["out_bytes"]
-            per_dist["G-" + kind] = {"GiB/s": round(tot_out2 * st2 / wall2 / 2**30, 2), "ms_per_step": round(wall2 / st2 * 1e3, 4), "kernel_ms_avg": round(km2, 4),
-                                     "lz4_ratio": round(w2["out_bytes"] / w2["comp_bytes"], 3),
-                                     "roofline_frac": round(alg2 / (km2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": alg2}
-            del w2
-            torch.cuda.empty_cache()
-
-    e2e = selfp2p = None
-    if dist is not None and not args.no_e2e:
-        e2e = end_to_end(eng, wl, dist, rank, world)
-        if eng.backend == "nccl":
-            selfp2p = rccl_self_sendrecv(eng, dist, rank)
-
-    cpu_base = None
-    if rank == 0 and world == 1 and not args.no_cpu and not args.dry_gloo:
-        cpu_base = cpu_baseline(wl["dec"], wl["raw"], torch, args.nblocks)
-    # ---- BASELINE configs 3, 4, 5 on the same ranks: 3 and 4 weak (every rank its own members / blocks), 5 ONE stream sharded
-    others = None
-    if not args.no_others:
-        others = []
-        if args.dry_gloo:
-            r5 = dry_sharded_pipeline(eng, dist, rank, world)
-            if r5 is not None:
-                others.append(r5)
-        else:
-            sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
-            import bench_configs as BC
-            del wl
-            torch.cuda.empty_cache()
-            cpu_legs = world == 1 and not args.no_cpu
-            kw = dict(rank=rank, world=world, dist=dist if world > 1 else None)
-            for fn in (lambda: [BC.config3(eng.ctx, torch, eng.dev, args.others_scale, cpu=cpu_legs, **kw)],
-                       lambda: BC.config4(eng.ctx, torch, eng.dev, args.others_scale, cpu=cpu_legs, **kw),
-                       lambda: [BC.config5(eng.ctx, torch, eng.dev, args.others_scale, reps=3, cpu=cpu_legs, **kw)]):
-                try:
-                    others += [r for r in fn() if r is not None]
-                except Exception as e:                          # a failing side config must not lose the headline line
-                    if world > 1:
-                        raise                                   # (but with peers in a collective there is no carrying on)
-                    others.append({"error": "%s: %s" % (type(e).__name__, str(e)[:200])})
-                torch.cuda.empty_cache()
-            wl = None
-
+    # ---- the headline is complete here.  Rank 0 stashes the line now; everything below is a SIDE LEG that runs under
+    # SideLegs.run (every rank catches, one all_reduce(MAX) of an error flag decides together whether the ranks can go on
+    # using the process group) and under a watchdog that prints the stashed line if the legs do not come back in time:
+    # no failure or hang after this point can cost the headline value.
+    comp_total = float(tot[1].item())
+    res = None
     if rank == 0:
         alg_bytes = comp_bytes + out_bytes                     # per launch on this rank
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
@@ -563,7 +620,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic",
+            "data": "synthetic (dry run on CPU: plumbing test, not a measurement)" if args.dry_gloo else "synthetic",
             "config": {"workload": "LZ4 block decode, %d independent 64 KiB blocks per GPU (BASELINE configs[1])" % args.nblocks,
                        "distribution": "G-%s" % args.kind, "lz4_ratio": round(out_bytes / comp_bytes, 3),
                        "kernel_variant": args.variant, "parallelism": "blocks sharded, %d per rank, no collective" % args.nblocks},
@@ -571,58 +628,104 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": round(kern_ms, 4),
                          "kernel_ms_median": round(kern_med, 4)},
-            "per_distribution": None,
+            "per_distribution": {"G-" + args.kind: {"GiB/s": round(total_out * args.steps / wall / 2**30, 3), "ms_per_step": round(wall / args.steps * 1e3, 4),
+                                                    "kernel_ms_avg": round(kern_ms, 4), "lz4_ratio": round(out_bytes / comp_bytes, 3),
+                                                    "roofline_frac": round(achieved / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": alg_bytes}},
             **({"shared_gpu_check": "the %d ranks share the box's GPUs over %s (RCX_BENCH_SHARE_GPU): a check of the N-rank path, not a scaling measurement"
                                     % (world, eng.backend)} if getattr(eng, "shared_gpu", False) else {}),
-            "end_to_end": e2e,
+            "end_to_end": None,
         }
-        pd = {"G-" + args.kind: {"GiB/s": res["value"], "ms_per_step": res["ms_per_step"], "kernel_ms_avg": round(kern_ms, 4),
-                                 "lz4_ratio": round(out_bytes / comp_bytes, 3), "roofline_frac": res["roofline"]["frac"], "algorithmic_bytes_per_launch": alg_bytes}}
-        pd.update(per_dist)
-        res["per_distribution"] = pd
-        if others is not None:
-            res["other_configs"] = others
-        if selfp2p is not None:
-            res["rccl_self_sendrecv"] = selfp2p
+    legs = SideLegs(eng, dist, rank, world, res)
+    legs.start_watchdog(float(os.environ.get("RCX_BENCH_SIDE_TIMEOUT", "900")))
+
+    # ---- config 2's other distributions (SURVEY 8d: reported separately), same timing discipline, every rank
+    def leg_dists():
+        per_dist = {}
+        for kind in ("runs", "rand"):
+            w2 = eng.make_workload(kind, args.nblocks, 0x4C5A3401 + 7919 * rank + len(kind))
+            eng.check(w2)
+            wall2, km2, _ = time_steps(eng, w2, max(5, args.steps // 2), 2, dist if world > 1 else None)
+            tt2 = torch.tensor([wall2, float(w2["out_bytes"]), float(w2["comp_bytes"])], dtype=torch.float64, device=eng.dev)
+            if dist is not None:
+                mx = tt2.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+                sm = tt2.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+                wall2, tot_out2 = float(mx[0]), float(sm[1])
+            else:
+                tot_out2 = float(w2["out_bytes"])
+            st2 = max(5, args.steps // 2)
+            alg2 = w2["comp_bytes"] + w2["out_bytes"]
+            per_dist["G-" + kind] = {"GiB/s": round(tot_out2 * st2 / wall2 / 2**30, 2), "ms_per_step": round(wall2 / st2 * 1e3, 4), "kernel_ms_avg": round(km2, 4),
+                                     "lz4_ratio": round(w2["out_bytes"] / w2["comp_bytes"], 3),
+                                     "roofline_frac": round(alg2 / (km2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": alg2}
+            del w2
+            torch.cuda.empty_cache()
+        return per_dist
+    if not args.no_dists and not args.dry_gloo:
+        pdist = legs.run("per_distribution", leg_dists)
+        if rank == 0:
+            res["per_distribution"].update(pdist if "error" not in pdist else {"others": pdist})
+
+    if dist is not None and not args.no_e2e:
+        e2e = legs.run("end_to_end", lambda: end_to_end(eng, wl, dist, rank, world))
+        if rank == 0:
+            res["end_to_end"] = e2e
+        if eng.backend == "nccl":
+            sp = legs.run("rccl_self_sendrecv", lambda: rccl_self_sendrecv(eng, dist, rank), collective=False)
+            if rank == 0:
+                res["rccl_self_sendrecv"] = sp
+
+    if rank == 0 and world == 1 and not args.no_cpu and not args.dry_gloo:
+        res["cpu_baseline"] = legs.run("cpu_baseline", lambda: cpu_baseline(wl["dec"], wl["raw"], torch, args.nblocks), collective=False)
+    # ---- BASELINE configs 3, 4, 5 on the same ranks: 3 and 4 weak (every rank its own members / blocks), 5 ONE stream sharded
+    if not args.no_others:
+        others = []
         if args.dry_gloo:
-            res["data"] = "synthetic (dry run on CPU: plumbing test, not a measurement)"
-        if cpu_base is not None:
-            res["cpu_baseline"] = cpu_base
+            r5 = legs.run("config5_dry", lambda: dry_sharded_pipeline(eng, dist, rank, world))
+            if r5 is not None:
+                others.append(r5)
+        else:
+            sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
+            import bench_configs as BC
+            del wl
+            torch.cuda.empty_cache()
+            cpu_legs = world == 1 and not args.no_cpu
+            kw = dict(rank=rank, world=world, dist=dist if world > 1 else None)
+            for name, fn in (("config3", lambda: [BC.config3(eng.ctx, torch, eng.dev, args.others_scale, cpu=cpu_legs, **kw)]),
+                             ("config3_gzip", lambda: [BC.config3(eng.ctx, torch, eng.dev, args.others_scale, cpu=cpu_legs, gzip_framing=True, **kw)]),
+                             ("config4", lambda: BC.config4(eng.ctx, torch, eng.dev, args.others_scale, cpu=cpu_legs, **kw)),
+                             ("config5", lambda: [BC.config5(eng.ctx, torch, eng.dev, args.others_scale, reps=3, cpu=cpu_legs, **kw)])):
+                r = legs.run(name, fn)                          # a failing side config must not lose the headline line
+                if isinstance(r, dict):                         # ({"error": ...})
+                    others.append(dict(r, leg=name))
+                elif r:
+                    others += [x for x in r if x is not None]
+                torch.cuda.empty_cache()
+            wl = None
+        if rank == 0:
+            res["other_configs"] = others
+
+    if rank == 0:
         if world == 1 and not args.no_others and not args.dry_gloo:
-            res["hbm_ceiling_measured"] = hbm_ceiling(torch, eng.dev)
+            res["hbm_ceiling_measured"] = legs.run("hbm_ceiling", lambda: hbm_ceiling(torch, eng.dev), collective=False)
         if args.extras and world == 1 and not args.dry_gloo:
-            N = eng.N
-            extras = {}
-            for kind in ("text", "words", "runs", "rand", "mix"):
-                w2 = eng.make_workload(kind, args.nblocks, 0x77 + len(kind))
-                for v in N.LZ4_DECODE_VARIANTS:
-                    eng.ctx.set_variant(N.LZ4_DECODE, v)
-                    eng.decode(w2); eng.sync()
-                    d2 = w2["dec"]
-                    ok = torch.equal(d2.out_base[: args.nblocks * BLOCK], w2["raw"][: args.nblocks * BLOCK]) and int(d2.status.abs().max()) == 0
-                    _, km, _ = time_steps(eng, w2, 5, 1, None)
-                    extras["%s/v%d" % (kind, v)] = {"GiB/s": round(w2["out_bytes"] / (km * 1e-3) / 2**30, 2), "ratio": round(w2["out_bytes"] / w2["comp_bytes"], 2),
-                                                    "hbm_frac": round((w2["comp_bytes"] + w2["out_bytes"]) / (km * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ok": bool(ok)}
-                del w2
-            eng.ctx.set_variant(N.LZ4_DECODE, args.variant)
-            res["extras"] = extras
-        line = json.dumps(res)
-    else:
-        line = None
-    # RCCL writes its version banner to stdout through C stdio, which is flushed at exit -- after anything Python prints.
-    # Every rank pushes it out first; rank 0 prints the JSON line after a barrier, as the last line of the job's stdout.
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
-    if dist is not None:
-        dist.barrier()
-    if line is not None:
-        print(line, flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+            def leg_extras():
+                N = eng.N
+                extras = {}
+                for kind in ("text", "words", "runs", "rand", "mix"):
+                    w2 = eng.make_workload(kind, args.nblocks, 0x77 + len(kind))
+                    for v in N.LZ4_DECODE_VARIANTS:
+                        eng.ctx.set_variant(N.LZ4_DECODE, v)
+                        eng.decode(w2); eng.sync()
+                        d2 = w2["dec"]
+                        ok = torch.equal(d2.out_base[: args.nblocks * BLOCK], w2["raw"][: args.nblocks * BLOCK]) and int(d2.status.abs().max()) == 0
+                        _, km, _ = time_steps(eng, w2, 5, 1, None)
+                        extras["%s/v%d" % (kind, v)] = {"GiB/s": round(w2["out_bytes"] / (km * 1e-3) / 2**30, 2), "ratio": round(w2["out_bytes"] / w2["comp_bytes"], 2),
+                                                        "hbm_frac": round((w2["comp_bytes"] + w2["out_bytes"]) / (km * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ok": bool(ok)}
+                    del w2
+                eng.ctx.set_variant(N.LZ4_DECODE, args.variant)
+                return extras
+            res["extras"] = legs.run("extras", leg_extras, collective=False)
+    legs.finish()
     eng.close()
 
 

@@ -32,7 +32,15 @@ class RangeEncoder:
 
     def process(self, total, frm, to):
         """[frm/total, to/total) of the current interval -> the bytes that leave"""
+        # mod.rs:118-122: the reference's asserts; a zero-width interval would otherwise ship bytes for ever (the reference's
+        # release build dies on output[4]: the slice has BORDER_BYTES = 4 entries)
+        if total == 0:
+            raise PanicError("attempt to divide by zero (RangeEncoder.process: total == 0)")
+        if not (frm < to <= total):
+            raise PanicError("assertion failed: from<to && to<=total")
         width = ((self.hai - self.low) & M32) // total
+        if width == 0:
+            raise PanicError("RangeCoder range is too narrow for the total")
         a, b = (self.low + width * frm) & M32, (self.low + width * to) & M32
         out = bytearray()
         while True:
@@ -44,6 +52,8 @@ class RangeEncoder:
                     a = edge
                 else:
                     b = (edge - 1) & M32
+            if len(out) == 4:
+                raise PanicError("index out of bounds: the len is 4 but the index is 4 (RangeEncoder.process)")
             out.append(a >> 24)
             a, b = (a << 8) & M32, (b << 8) & M32
         self.low, self.hai = a, b

@@ -45,7 +45,12 @@ public:
     // [from/total, to/total) of the current interval; the bytes that leave go to output[0..], their number is returned
     size_t process(Border total, Border from, Border to, Symbol* output)
     {
-        const Border width = (hai_ - low_) / total;              // total == 0 is a division panic in the reference as well
+        // mod.rs:118-122: `from < to && to <= total` and `range > 0` are the reference's asserts; a zero-width interval would
+        // otherwise ship bytes for ever (the reference's release build dies on output[4], the slice has BORDER_BYTES entries)
+        if (total == 0) throw panic_error("attempt to divide by zero (RangeEncoder::process: total == 0)");
+        if (!(from < to && to <= total)) throw panic_error("assertion failed: from<to && to<=total");
+        const Border width = (hai_ - low_) / total;
+        if (width == 0) throw panic_error("RangeCoder range is too narrow for the total");
         Border a = low_ + width * from, b = low_ + width * to;
         size_t shipped = 0;
         for (;;) {
@@ -54,6 +59,7 @@ public:
                 const Border edge = b & TOP_BYTE;
                 if (b - edge >= edge - a) a = edge; else b = edge - 1;
             }
+            if (shipped == BORDER_BYTES) throw panic_error("index out of bounds: the len is 4 but the index is 4 (RangeEncoder::process)");
             output[shipped++] = (Symbol)(a >> 24);
             a <<= 8; b <<= 8;
         }

@@ -109,6 +109,13 @@ int main(int argc, char** argv)
         const ari::Border lo = re.low();
         CHECK(re.get_code_tail() == lo && re.low() == 0 && re.hai() == 0);
     }
+    {   // a zero-width interval panics (the reference: assert / output[4] out of bounds) instead of shipping bytes for ever
+        auto panics = [](auto&& f) { try { f(); } catch (const ari::panic_error&) { return true; } return false; };
+        CHECK(panics([] { ari::Encoder<VecWriter> e{VecWriter()}; e.encode(false, ari::bin::Model::new_custom(0, 1u << 11, 5)); }));
+        CHECK(panics([] { ari::RangeEncoder re(ari::RANGE_DEFAULT_THRESHOLD); uint8_t o[8]; re.process(10, 3, 3, o); }));
+        CHECK(panics([] { ari::RangeEncoder re(ari::RANGE_DEFAULT_THRESHOLD); uint8_t o[8]; re.process(10, 3, 11, o); }));
+        CHECK(panics([] { ari::RangeEncoder re(ari::RANGE_DEFAULT_THRESHOLD); uint8_t o[8]; re.process(0, 0, 0, o); }));
+    }
     printf("ARI_SYMBOL_OK\n");
     return 0;
 }

@@ -169,6 +169,17 @@ def test_python_apm_and_model_panics(oracle):
         A.table.SumProxy(1, m, 1, A.table.Model.new_flat(5, 64), 0)
     with pytest.raises(A.PanicError):
         A.Decoder(io.BytesIO(b"\x01\x02")).decode(m)
+    # a zero-width interval (here: a custom binary model whose P(0) is 0 coding `false`) panics in the reference -- assert in a debug
+    # build, output[4] out of bounds in a release build -- and must not ship bytes for ever here (mod.rs:117-150)
+    with pytest.raises(A.PanicError):
+        A.Encoder(io.BytesIO()).encode(False, A.bin.Model.new_custom(0, 1 << 11, 5))
+    re = A.RangeEncoder(A.RANGE_DEFAULT_THRESHOLD)
+    for bad in ((10, 3, 3), (10, 4, 3), (10, 3, 11), (0, 0, 0)):
+        with pytest.raises(A.PanicError):
+            re.process(*bad)
+    re.low, re.hai = 5, 9                                       # narrower than the total: range == 0
+    with pytest.raises(A.PanicError):
+        re.process(10, 0, 1)
     # table.rs:37-50: new_custom downscales until the sum is below the threshold; update's halving keeps entries positive
     c = A.table.Model.new_custom(4, 16, lambda i: 10)
     assert c.get_frequencies() == [3, 3, 3, 3] and c.get_denominator() == 12

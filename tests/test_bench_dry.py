@@ -32,6 +32,41 @@ def test_bench_gpus_n_spawns_n_ranks(gpus, oracle):
     assert sum(c5["block_ranges"]) == c5["blocks"] == 11 and len(c5["block_ranges"]) == gpus and min(c5["block_ranges"]) >= 1
 
 
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_bench_line_survives_a_rank_failing_inside_the_scatter(gpus, oracle):
+    """A side leg that dies on ONE rank in the middle of a collective exchange (here: rank 1 raises inside the end-to-end leg's
+    scatter, its peers are left waiting) must not cost the headline: rank 0 still prints exactly one line, with the value,
+    and the failed leg reported as {"error": ...}."""
+    env = dict(os.environ, RCX_BENCH_DRY_CODEC="_dry_codec_faulty", RCX_DRY_FAULT_RANK="1", RCX_BENCH_PG_TIMEOUT="6", RCX_BENCH_SIDE_TIMEOUT="120",
+               PYTHONPATH=os.path.join(ROOT, "tests") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--dry-gloo", "--nblocks", "5", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:] + p.stderr[-3000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == gpus and res["value"] > 0 and res["ms_per_step"] > 0 and res["roofline"]["frac"] > 0
+    assert "error" in res["end_to_end"] and "end_to_end" in res["side_legs_failed"]
+    # what came after the failed leg and needs the process group is skipped, not attempted on a group in an unknown state
+    assert all("error" in o for o in res["other_configs"])
+
+
+def test_bench_watchdog_prints_the_line_when_a_leg_hangs(oracle):
+    """The same with the process group's own timeout far away (what RCCL looks like: a stuck collective never raises): the
+    watchdog ends the legs and rank 0's line is still there."""
+    env = dict(os.environ, RCX_BENCH_DRY_CODEC="_dry_codec_faulty", RCX_DRY_FAULT_RANK="1", RCX_BENCH_PG_TIMEOUT="600", RCX_BENCH_SIDE_TIMEOUT="12",
+               PYTHONPATH=os.path.join(ROOT, "tests") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-gloo", "--nblocks", "5", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:] + p.stderr[-3000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["value"] > 0 and "side_legs_note" in res
+
+
 def test_bench_single_rank_dry(oracle):
     env = dict(os.environ, RCX_BENCH_DRY_CODEC="_dry_codec", PYTHONPATH=os.path.join(ROOT, "tests") + os.pathsep + os.environ.get("PYTHONPATH", ""))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
