@@ -112,9 +112,9 @@ def oracle_rate(codec, in_base, in_off, in_len, out_total, out_off, out_cap, byt
             "_out_len": out_len}, out
 
 
-def _libz_rate(members, nbytes, budget_s=6.0):
+def _libz_rate(members, nbytes, budget_s=6.0, wbits=15):
     """'Strong CPU' line for DEFLATE: libz inflate through Python's zlib (releases the GIL) on every host core,
-    and on one thread over a bounded sample."""
+    and on one thread over a bounded sample.  wbits 31: gzip members (header, CRC-32 and ISIZE checked by libz)."""
     from concurrent.futures import ThreadPoolExecutor
     cores = os.cpu_count() or 1
     sample = members[: max(1024, min(len(members), 16384))]
@@ -122,7 +122,7 @@ def _libz_rate(members, nbytes, budget_s=6.0):
     def work(chunk):
         n = 0
         for m in chunk:
-            n += len(zlib.decompress(m))
+            n += len(zlib.decompress(m, wbits))
         return n
     chunks = [sample[i::cores] for i in range(cores)]
     t0 = time.perf_counter(); reps = 0; got = 0
@@ -193,6 +193,11 @@ def config3(ctx, torch, dev, scale=1.0, gzip_framing=False, cpu=True, rank=0, wo
            "roofline": _roof(alg, t, None if gzip_framing else pmc_traffic(3))}
     if cliff is not None:
         res["fallback_cliff"] = cliff
+    if cpu and gzip_framing and rank == 0 and world == 1:
+        # the reference crate has no gzip reader (an extension), so there is no oracle leg for this framing:
+        # the CPU line is libz itself -- inflate + CRC-32 + ISIZE per member, every host core
+        res["cpu_baseline"] = _libz_rate(members, nb * BLOCK, wbits=31)
+        res["cpu_baseline"]["kind"] = "libz gzip members (zlib.decompress(wbits=31), %d threads)" % (os.cpu_count() or 1)
     if cpu and not gzip_framing and rank == 0 and world == 1:
         res["cpu_baseline_libz"] = _libz_rate(members, nb * BLOCK)
         ns = min(nb, 4096)                                  # the oracle walks its Huffman trees bit by bit: a bounded sample

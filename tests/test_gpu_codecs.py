@@ -307,3 +307,31 @@ def test_inflate_large_and_ragged_streams(ctx):
     res9 = ctx.zlib_decode(zs[:12], [max(0, len(e) - 1) for e in exp[:12]])
     ctx.set_variant(N.ZLIB_DECODE, 0)
     assert [int(s) for s in res0.status] == [int(s) for s in res9.status]
+
+
+def test_hip_vs_derived_golden(ctx):
+    """The encoder-side kernels against tests/golden/derived directly -- expected bytes that come from neither the device nor
+    oracle/*.c but from an independent plain-Python restatement of SURVEY Appendix A (tests/gen_derived_golden.py): LZ4 block
+    encode, MTF, dc::encode_simple words + contexts, ByteEncoder, the binary (rate 5) and the SumProxy coders, 36 inputs each."""
+    import derived
+    recs = list(derived.records())
+    raws = [d for _, d in recs]
+    assert len(recs) == 36
+    lz = ctx.lz4_encode_blocks(raws).check()
+    mt = ctx.mtf_encode(raws).check()
+    dw = ctx.dc_encode(raws).check()
+    dx = ctx.dc_encode_ctx(raws).check()
+    ab = ctx.ari_byte_encode(raws).check()
+    bn = ctx.ari_binary_encode(raws, 5).check()
+    px = ctx.ari_proxy_encode(raws).check()
+    for i, (rec, data) in enumerate(recs):
+        derived.check(rec, "lz4_encode", lz.outputs[i])
+        derived.check(rec, "mtf_encode", mt.outputs[i])
+        derived.check(rec, "dc_words", dw.outputs[i])
+        n = len(data)
+        assert dx.outputs[i][: len(dw.outputs[i])] == dw.outputs[i]
+        derived.check(rec, "dc_ctx", dx.outputs[i][4 * (256 + n):])
+        derived.check(rec, "ari_byte", ab.outputs[i])
+        derived.check(rec, "ari_bin5", bn.outputs[i])
+        derived.check(rec, "ari_proxy", px.outputs[i])
+

@@ -62,6 +62,62 @@ def test_config3_zlib_65536_members(ctx, oracle):
     ctx.set_stream(0)
 
 
+def _gzmember(args):
+    import gzip
+    i, data = args
+    if i % 64 == 63:                                                             # a member with FNAME + FEXTRA + FHCRC set (RFC 1952 2.3)
+        import struct
+        body = zlib.compressobj(6, zlib.DEFLATED, -15)
+        raw = body.compress(data) + body.flush()
+        head = b"\x1f\x8b\x08" + bytes([0x02 | 0x04 | 0x08]) + b"\0\0\0\0\0\xff" + struct.pack("<H", 5) + b"extra" + b"name.txt\0"
+        head += struct.pack("<H", zlib.crc32(head) & 0xffff)
+        return head + raw + struct.pack("<II", zlib.crc32(data), len(data) & 0xffffffff)
+    return gzip.compress(data, compresslevel=(1, 6, 9)[i % 3], mtime=0)
+
+
+def test_config3_gzip_65536_members(ctx):
+    """BASELINE configs[2] as it is worded: 65536 independent GZIP members of 16 KiB.  Header parsed, DEFLATE body decoded,
+    CRC-32 and ISIZE verified on the device (status 0 means they matched); bytes == the source; consumed == the member's
+    length; a sample against Python's gzip module (the reference has no gzip code: an independent implementation is the checker);
+    and a member with a flipped payload bit must come back with the CRC status."""
+    import gzip
+    import torch
+    import rust_compress_amd as R
+    nb, BLOCK = 65536, 16384
+    dev = torch.device("cuda", 0)
+    raw_np = np.concatenate([synth.gen_blocks(k, nb // 4, BLOCK, 0x6A11 + j) for j, k in enumerate(("text", "text", "runs", "dna4"))])
+    blocks = [raw_np[i * BLOCK:(i + 1) * BLOCK].tobytes() for i in range(nb)]
+    with Pool(32) as pool:
+        members = pool.map(_gzmember, list(enumerate(blocks)), chunksize=512)
+    bad = 12345                                                                  # one corrupted member among them: flip a bit in the literal-heavy middle
+    mb = bytearray(members[bad]); mb[len(mb) // 2] ^= 0x10; members[bad] = bytes(mb)
+    from rust_compress_amd import batch as B
+    base, off, lens = B.pack(members)
+    ar = np.arange(nb, dtype=np.int64)
+    db = R.DeviceBatch.from_host(base, off, lens, nb * BLOCK, (ar * BLOCK).astype(np.uint64), np.full(nb, BLOCK, dtype=np.uint64), dev)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    sc = torch.empty(ctx.scratch_bytes(N.GZIP_DECODE, nb, BLOCK) + 256, dtype=torch.uint8, device=dev)
+    ctx.launch_dev(N.GZIP_DECODE, db, sc)
+    torch.cuda.synchronize()
+    st = db.status[:nb].cpu().numpy()
+    good = np.ones(nb, dtype=bool); good[bad] = False
+    assert not st[good].any()
+    assert int(st[bad]) != 0                                                      # (whatever the flipped bit turned into: never status 0 with wrong bytes)
+    try:
+        py = gzip.decompress(members[bad])
+    except Exception:
+        py = None
+    assert py is None or py != blocks[bad]
+    assert bool((db.out_len[:nb].cpu().numpy()[good] == BLOCK).all())
+    assert bool((db.in_used[:nb].cpu().numpy()[good] == lens.astype(np.int64)[good]).all())
+    out = db.out_base[: nb * BLOCK].cpu().numpy().reshape(nb, BLOCK)
+    assert np.array_equal(out[good], raw_np.reshape(nb, BLOCK)[good])
+    for i in list(range(0, nb, 4099)) + [63, 127]:
+        if i != bad:
+            assert gzip.decompress(members[i]) == blocks[i] == out[i].tobytes()
+    ctx.set_stream(0)
+
+
 def test_config4_bwt_1024x256k(ctx, oracle):
     """1024 blocks x 256 KiB: forward then inverse; inverse(forward(x)) == x; samples == oracle (L, origin)."""
     import torch

@@ -186,3 +186,24 @@ def test_large_fixture_if_reference_present(oracle):
     assert len(out) == 6100000 and used == len(big)
     assert hashlib.sha256(out).hexdigest() == "94d8990947a4b4d878afa2509e1f6b08fb52906fd688204139c6b814e4b97014"
     assert oracle.adler32(out) == 0x82E12107
+
+
+def test_oracle_vs_derived_golden(oracle):
+    """The encoder side of the oracle (no reference-held vector exists for it) against the committed output of a SECOND,
+    independent restatement: tests/gen_derived_golden.py, plain Python written from SURVEY Appendix A, which imports nothing
+    from oracle/.  36 inputs (six generators x sizes 0 .. 262144) x LZ4 block encode, MTF, dc::encode_simple words and
+    contexts, ByteEncoder, the binary and the SumProxy coders."""
+    import derived
+    n = 0
+    for rec, data in derived.records():
+        derived.check(rec, "lz4_encode", oracle.lz4_encode_block(data))
+        derived.check(rec, "mtf_encode", oracle.mtf_encode(data))
+        words, ctx = oracle.dc_encode(data, with_ctx=True)
+        derived.check(rec, "dc_words", words.astype("<u4").tobytes())
+        derived.check(rec, "dc_ctx", derived.ctx_bytes(ctx))
+        derived.check(rec, "ari_byte", oracle.ari_byte_encode(data))
+        derived.check(rec, "ari_bin5", oracle.ari_binary_encode(data, 5))
+        derived.check(rec, "ari_proxy", oracle.ari_proxy_encode(data))
+        n += 1
+    assert n == 36
+
