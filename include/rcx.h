@@ -260,6 +260,30 @@ int rcx_ctx_set_variant(rcx_ctx*, int codec, int variant);
 /* codec parameter for rcx_launch_dev (the *_batch entry points take it as an argument): the rate of RCX_ARI_BINARY_* */
 int rcx_ctx_set_param(rcx_ctx*, int codec, uint32_t value);
 
+/* ---- more than one device ---------------------------------
+ * Blocks are independent in every codec (reference: src/lz4.rs:445-456 one block per frame block, src/bwt/mod.rs:373-401 one
+ * record per block, src/entropy/ari/test.rs:52-89 self-terminating streams), so a batch shards by contiguous block ranges and
+ * needs no collective: range g runs on device g.  An rcx_multi owns one rcx_ctx per listed device (a device may be listed more
+ * than once: two ranges on one GPU).  Three layers, all without Python:
+ *   rcx_partition        the ranges: contiguous, balanced by `weights` (decoded bytes), bounds[parts + 1], bounds[0] = 0
+ *   rcx_multi_batch      a HOST-memory batch: every range is staged to its device, run and copied back by a host thread of its
+ *                        own (one context each: contexts are thread-compatible, not thread-safe); per-block results land in the
+ *                        caller's arrays exactly as the one-device entry point of that codec leaves them.  aux_in / aux_out /
+ *                        n_out: what that entry point takes beside the batch (origins in, origins / flags / checksums out,
+ *                        DC decode's lengths), or NULL.
+ *   rcx_multi_launch_dev DEVICE-resident ranges: per_device[g] (arrays in device g's HBM, or NULL for none) is enqueued on device
+ *                        g's context stream like rcx_launch_dev; rcx_multi_sync waits for every device. */
+typedef struct rcx_multi rcx_multi;
+int  rcx_multi_create(const int* device_ids, int n, rcx_multi** out);
+void rcx_multi_destroy(rcx_multi*);
+int  rcx_multi_count(const rcx_multi*);
+rcx_ctx* rcx_multi_ctx(rcx_multi*, int i);      /* device i's context: its stream, variant and parameter knobs, last error */
+void rcx_partition(const uint64_t* weights, uint32_t nblocks, uint32_t parts, uint32_t* bounds);
+int  rcx_multi_batch(rcx_multi*, int codec, const rcx_batch*, const uint32_t* aux_in, uint32_t* aux_out, const uint64_t* n_out);
+int  rcx_multi_launch_dev(rcx_multi*, int codec, const rcx_dev_batch* const* per_device, void* const* scratch, const uint64_t* scratch_bytes);
+int  rcx_multi_sync(rcx_multi*);
+const char* rcx_multi_last_error(const rcx_multi*);
+
 #ifdef __cplusplus
 }
 #endif

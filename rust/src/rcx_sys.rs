@@ -8,6 +8,11 @@ use std::os::raw::{c_char, c_int, c_void};
 pub struct rcx_ctx {
     _private: [u8; 0],
 }
+/// `struct rcx_multi` (opaque): one context per listed device.
+#[repr(C)]
+pub struct rcx_multi {
+    _private: [u8; 0],
+}
 
 /// `struct rcx_batch`: struct-of-arrays batch descriptor, host arrays (include/rcx.h).
 #[repr(C)]
@@ -157,4 +162,14 @@ extern "C" {
     pub fn rcx_launch_dev(ctx: *mut rcx_ctx, codec: c_int, b: *const rcx_dev_batch, scratch: *mut c_void, scratch_bytes: u64) -> c_int;
     pub fn rcx_ctx_set_variant(ctx: *mut rcx_ctx, codec: c_int, variant: c_int) -> c_int;
     pub fn rcx_ctx_set_param(ctx: *mut rcx_ctx, codec: c_int, value: u32) -> c_int;
+    // ---- more than one device: contiguous block ranges, one context per device, no collective (include/rcx.h)
+    pub fn rcx_multi_create(device_ids: *const c_int, n: c_int, out: *mut *mut rcx_multi) -> c_int;
+    pub fn rcx_multi_destroy(m: *mut rcx_multi);
+    pub fn rcx_multi_count(m: *const rcx_multi) -> c_int;
+    pub fn rcx_multi_ctx(m: *mut rcx_multi, i: c_int) -> *mut rcx_ctx;
+    pub fn rcx_partition(weights: *const u64, nblocks: u32, parts: u32, bounds: *mut u32);
+    pub fn rcx_multi_batch(m: *mut rcx_multi, codec: c_int, b: *const rcx_batch, aux_in: *const u32, aux_out: *mut u32, n_out: *const u64) -> c_int;
+    pub fn rcx_multi_launch_dev(m: *mut rcx_multi, codec: c_int, per_device: *const *const rcx_dev_batch, scratch: *const *mut c_void, scratch_bytes: *const u64) -> c_int;
+    pub fn rcx_multi_sync(m: *mut rcx_multi) -> c_int;
+    pub fn rcx_multi_last_error(m: *const rcx_multi) -> *const c_char;
 }

@@ -37,6 +37,8 @@ EXPORTS = [
     "rcx_ari_binary_encode_batch", "rcx_ari_binary_decode_batch", "rcx_ari_proxy_encode_batch", "rcx_ari_proxy_decode_batch",
     "rcx_ctx_set_param", "rcx_ari_apm_encode_batch", "rcx_ari_apm_decode_batch", "rcx_bwt_inverse_minimal_batch",
     "rcx_bwt_suffixes_batch", "rcx_bwt_inversion_table_batch",
+    "rcx_multi_create", "rcx_multi_destroy", "rcx_multi_count", "rcx_multi_ctx", "rcx_partition", "rcx_multi_batch",
+    "rcx_multi_launch_dev", "rcx_multi_sync", "rcx_multi_last_error",
 ]
 
 
@@ -102,5 +104,19 @@ def lib():
                      "rcx_bwt_inverse_batch", "rcx_bwt_inverse_minimal_batch", "rcx_dc_decode_batch", "rcx_dc_decode_ctx_batch",
                      "rcx_bwt_suffixes_batch", "rcx_bwt_inversion_table_batch"):
             getattr(L, name).argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p]
+        # more than one device (include/rcx.h: rcx_multi_*)
+        L.rcx_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+        L.rcx_multi_destroy.argtypes = [C.c_void_p]
+        L.rcx_multi_destroy.restype = None
+        L.rcx_multi_count.argtypes = [C.c_void_p]
+        L.rcx_multi_ctx.argtypes = [C.c_void_p, C.c_int]
+        L.rcx_multi_ctx.restype = C.c_void_p
+        L.rcx_partition.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.rcx_partition.restype = None
+        L.rcx_multi_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rcx_multi_launch_dev.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(DevBatch)), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.rcx_multi_sync.argtypes = [C.c_void_p]
+        L.rcx_multi_last_error.argtypes = [C.c_void_p]
+        L.rcx_multi_last_error.restype = C.c_char_p
         _lib = L
     return _lib

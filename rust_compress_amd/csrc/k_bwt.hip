@@ -396,20 +396,40 @@ static uint64_t bwt_forward_scratch_bytes(uint32_t nblocks, uint64_t max_block)
 
 // Page-locked words for the per-round read-backs (the counters of a round, the histogram): a copy into pageable memory goes
 // through the runtime's staging buffer and costs the host tens of microseconds more per round, with the GPU idle behind it.
-// One small allocation per host thread, kept for the life of the process (a context may be driven from any thread).
-static uint32_t* bwtf_pinned_words()
-{
-    static thread_local uint32_t* p = nullptr;
-    if (!p) { void* q = nullptr; if (hipHostMalloc(&q, 4 * (64 + BWS_NFLAG) + 4 * 264, hipHostMallocDefault) == hipSuccess) p = (uint32_t*)q; }
-    return p;
-}
+// (a pool, not one per host thread: a context may be driven from pool threads that come and go, and page-locked memory held per
+//  thread grew with every thread that ever sorted; the pool grows to the number of CONCURRENT callers and is kept for the life of
+//  the process -- nothing is handed back at exit, when the runtime may already be gone.)  When page-locked memory is not to be had
+// the read-backs land in ordinary memory: slower by the runtime's staging copy, not an error.
+#include <mutex>
+struct BwtfWords {
+    uint32_t* p = nullptr;
+    static std::mutex& mu() { static std::mutex m; return m; }
+    static std::vector<uint32_t*>& pool() { static std::vector<uint32_t*> v; return v; }
+    BwtfWords()
+    {
+        {
+            std::lock_guard<std::mutex> g(mu());
+            if (!pool().empty()) { p = pool().back(); pool().pop_back(); }
+        }
+        if (!p) {
+            const size_t bytes = 4 * (64 + BWS_NFLAG) + 4 * 264;
+            void* q = nullptr;
+            if (hipHostMalloc(&q, bytes, hipHostMallocDefault) == hipSuccess) p = (uint32_t*)q;
+            else { (void)hipGetLastError(); p = (uint32_t*)malloc(bytes); }
+        }
+    }
+    ~BwtfWords() { if (p) { std::lock_guard<std::mutex> g(mu()); pool().push_back(p); } }
+    BwtfWords(const BwtfWords&) = delete;
+    BwtfWords& operator=(const BwtfWords&) = delete;
+};
 
 static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::string& err, bool sa_words = false)
 {
     const uint32_t pass_blocks = variant > 0 ? (uint32_t)variant : 0xffffffffu;      // A/B knob: at most `variant` blocks per sorting pass
     const uint32_t nb_all = k.nblocks;
-    uint32_t* const pinned = bwtf_pinned_words();
-    if (!pinned) { err = "bwt forward: cannot allocate page-locked memory"; return RCX_RC_NO_MEMORY; }
+    BwtfWords words_;                                        // (back to the pool when the call returns)
+    uint32_t* const pinned = words_.p;
+    if (!pinned) { err = "bwt forward: cannot allocate the read-back words"; return RCX_RC_NO_MEMORY; }
     std::vector<uint64_t> h_len(nb_all);
     if (nb_all && (hipMemcpyAsync(h_len.data(), k.in_len, nb_all * 8ull, hipMemcpyDeviceToHost, s) != hipSuccess ||
                    hipStreamSynchronize(s) != hipSuccess)) { err = "bwt forward: cannot read in_len"; return RCX_RC_HIP_ERROR; }

@@ -242,15 +242,15 @@ __device__ __forceinline__ uint64_t rcx_inf_hops(uint32_t& q, uint32_t e, uint32
 #ifndef INF3_OCC
 #define INF3_OCC 6
 #endif
-template <int CB, bool SPEC = false>
-struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
+template <int CB, bool SPEC = false, bool ADLER = false>
+struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER> {
     // The kernel is bound by the latency of its dependent phases, so what it needs is waves: 12 / 16 / 18 / 20 / 24 waves per CU take
     // 18.5 / 14.3 / 13.1 / 12.4 / 11.6 ms for config 3.  24 waves = 6400 bytes of LDS each (handed out in 1280-byte granules) and
     // 80 VGPRs: 1024-byte batch output cap, 768 bytes of history in the window, NO staging of gathered matches (every byte goes
     // straight to its place), 320 literal bytes per batch, an 8-bit table for the distance code, and the code lengths of a block
     // header share the literal buffer (the batch is emitted before a header is read).  History / batch cap splits of the same
     // 1808 bytes (512 + 1280, 640 + 1152, 768 + 1024, 896 + 896) measure within 1 %.
-    typedef Lz4V4<CB, false, INF3_TCAP, INF3_H> B;
+    typedef Lz4V4<CB, false, INF3_TCAP, INF3_H, ADLER> B;
     static constexpr int LITCAP = INF3_LITCAP;       // literal bytes per batch
     static constexpr int LUTBITS = 9, LUTN = 1 << LUTBITS;     // lit/len table
     static constexpr int DBITS = 8, DLUTN = 1 << DBITS;        // distance (and code-length) table
@@ -1166,13 +1166,15 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB> {
 
 #define INF3_LDS_EXTRA (2 * 1024 + 2 * 288 + 2 * 32 + 352 + 4 * 80 + (1024 + 64) + 4 * 128)
 
-template <int CB, bool SPEC>
+// ADLER (zlib streams): the Adler-32 of the decoded bytes is summed while they leave the window (Lz4V4::flush and the wave-wide
+// copies) and lands in the first 4 * nblocks bytes of the scratch, where k_zlib_tail3 compares it with the stream's trailer.
+template <int CB, bool SPEC, bool ADLER>
 #ifndef INF3_VGPR
 #define INF3_VGPR 96
 #endif
 __global__ __launch_bounds__(64, INF3_OCC) void k_inflate3(rcx_kargs a, int zlib)
 {
-    typedef Inf3<CB, SPEC> S;
+    typedef Inf3<CB, SPEC, ADLER> S;
     __shared__ __align__(16) uint8_t s_cbuf[CB + 96];
     __shared__ __align__(16) uint8_t s_wbuf[S::WBUF5 + 16];     // + 16: lds_load16u reads one dword past the last staging slot
     __shared__ __align__(16) uint16_t s_lutL[512];
@@ -1194,6 +1196,13 @@ __global__ __launch_bounds__(64, INF3_OCC) void k_inflate3(rcx_kargs a, int zlib
     s.cbuf = s_cbuf; s.wb_ = s_wbuf; s.epos = nullptr; s.ring = nullptr;
     s.lutL = s_lutL; s.lutD = s_lutD; s.symL = s_symL; s.symD = s_symD; s.lens = s_lit; s.tab = s_tab; s.litbuf = s_lit; s.desc = s_desc;
     s.lmap = s_desc;                                             // (the descriptors are in registers while emit5 runs: its scratch)
+    if (ADLER) {
+        // the sums' two words: the last 8 bytes of the literal buffer's 64 bytes of slack (a literal load reads at most 36 bytes
+        // past the LITCAP literals, the code lengths end at byte 352)
+        static_assert(S::LITCAP + 36 <= S::LITCAP + 56 && 352 <= S::LITCAP + 56, "the literal buffer's last 8 bytes are free");
+        s.adp = (uint32_t*)(s_lit + S::LITCAP + 56);
+        if ((threadIdx.x & 63u) == 0) { s.adp[0] = 0; s.adp[1] = 0; }
+    }
     int32_t st; uint32_t olen, used, flags;
     s.run(zlib, &st, &olen, &used, &flags);
 #ifdef INF3_PROF
@@ -1207,10 +1216,11 @@ __global__ __launch_bounds__(64, INF3_OCC) void k_inflate3(rcx_kargs a, int zlib
         a.out_len[b] = olen;
         if (a.in_used) a.in_used[b] = used;
         if (a.aux) a.aux[b] = flags;
+        if (ADLER && a.scratch) ((uint32_t*)a.scratch)[b] = st ? 0u : s.ad_result(olen);
     }
 }
 
-// zlib trailer after the wave-per-stream decode: Adler-32 (computed by k_adler32 into `adler`) against the 4 big-endian
+// zlib trailer after the wave-per-stream decode: Adler-32 (summed by k_inflate3<.., true> on the way out, into `adler`) against the 4 big-endian
 // bytes after the DEFLATE stream (zlib.rs:108-118); a mismatch or a missing trailer goes to the exact kernel.
 __global__ void k_zlib_tail3(rcx_kargs a, const uint32_t* adler)
 {

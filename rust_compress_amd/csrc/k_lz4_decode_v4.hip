@@ -37,9 +37,52 @@
 #define LZ4P_T0() uint64_t t0_ = PROF ? (uint64_t)__builtin_readcyclecounter() : 0
 #define LZ4P_ADD(slot) do { if (PROF) { const uint64_t t1_ = (uint64_t)__builtin_readcyclecounter(); prof[slot] += t1_ - t0_; t0_ = t1_; } } while (0)
 
-template <int CB, bool PROF = false, int TC = 2560, int HH = 2048>
+// Sums of a 16-byte chunk for Adler-32 by position (zlib over the inflate front end, ADLER below): A = sum x_j, J = sum j * x_j
+#ifndef RCX_SAD_U8
+#define RCX_SAD_U8(a, c) __builtin_amdgcn_sad_u8((a), 0u, (c))                  // c + the four bytes of a
+#define RCX_UDOT4(a, w, c) __builtin_amdgcn_udot4((a), (w), (c), false)         // c + sum of a's bytes times w's bytes
+#endif
+__device__ __forceinline__ void rcx_adler_chunk(const rcx_u32x4 v, uint32_t rel, uint32_t& tA, uint32_t& tR)
+{
+    uint32_t A = RCX_SAD_U8(v[0], 0u); A = RCX_SAD_U8(v[1], A); A = RCX_SAD_U8(v[2], A); A = RCX_SAD_U8(v[3], A);
+    uint32_t J = RCX_UDOT4(v[0], 0x03020100u, 0u); J = RCX_UDOT4(v[1], 0x07060504u, J); J = RCX_UDOT4(v[2], 0x0b0a0908u, J); J = RCX_UDOT4(v[3], 0x0f0e0d0cu, J);
+    tA += A; tR += rel * A + J;
+}
+
+// ADLER (the inflate front end's zlib streams): every byte that leaves for global memory -- the window's drain, the wave-wide
+// copies -- is also summed for adler::State32 (src/checksum/adler.rs:29-44) on its way out, by POSITION:
+//   S0 = sum x_i,  S1 = sum i * x_i  (mod 65521)   =>   a = 1 + S0,  b = N + N * S0 - S1   for a stream of N bytes,
+// so that the chunks may arrive in any order and k_adler32's second pass over the output (a quarter of the launch's HBM traffic)
+// is not needed.  A lane sums its own chunks relative to the call's first byte (u32 is enough: a call moves a few KiB, or is
+// cut into such pieces), the call ends with two wave sums and scalar arithmetic on the wave-uniform S0 / S1.
+template <int CB, bool PROF = false, int TC = 2560, int HH = 2048, bool ADLER = false>
 struct Lz4V4 {
     uint64_t prof[16];
+    // ADLER: S0, S1 mod 65521 live in two words of LDS (`adp`, zeroed by the kernel), not in registers: the inflate kernel has
+    // neither a VGPR nor an SGPR to spare (80 + 106 at six waves per SIMD; two more wave-uniform values alive across the whole
+    // kernel spilled 44 dwords to scratch and config 3 went from 9.9 to 11.1 ms).  A wave's LDS operations are performed in order.
+    uint32_t* adp = nullptr;
+    __device__ __forceinline__ void ad_commit(uint32_t from0, uint32_t tA, uint32_t tR)
+    {
+        const uint32_t sA = RCX_U(__builtin_amdgcn_readlane(rcx_wave_incl_scan(tA), 63));
+        const uint32_t sR = RCX_U(__builtin_amdgcn_readlane(rcx_wave_incl_scan(tR), 63));
+        const uint32_t a = sA % 65521u;
+        const uint32_t s0 = adp[0], s1 = adp[1];
+        rcx_wave_sync();
+        if (lane == 0) {
+            adp[0] = (s0 + a) % 65521u;
+            adp[1] = (s1 + (from0 % 65521u) * a % 65521u + sR % 65521u) % 65521u;
+        }
+        rcx_wave_sync();
+    }
+    // Adler-32 of the `total` bytes that have left
+    __device__ __forceinline__ uint32_t ad_result(uint32_t total) const
+    {
+        const uint32_t N = total % 65521u, s0 = adp[0], s1 = adp[1];
+        const uint32_t a = (1u + s0) % 65521u;
+        const uint32_t b = (uint32_t)(((uint64_t)N + (uint64_t)N * s0 + 65521ull - s1) % 65521ull);
+        return (b << 16) | a;
+    }
     static constexpr int H = HH;                   // history kept when the window slides (2048 for LZ4)
     static constexpr int LCAP = 32, MCAP = 64;     // per-lane caps of a batched sequence
     static constexpr int WINMAX = 22 * (14 + MCAP);// most output one 64-byte token window can add (22 tokens)
@@ -154,22 +197,27 @@ struct Lz4V4 {
         uint32_t head = mis ? 16u - mis : 0u;
         if (head > to - from) head = final ? to - from : 0u;
         if (mis && head == 0 && !final) return;
+        const uint32_t from0 = from;
+        uint32_t tA = 0, tR = 0;                                   // ADLER: this lane's sums, positions relative to from0 (a drain is < 4 KiB)
         if (head) {
-            if (lane < head) out[from + lane] = wb_[(int32_t)(from + lane) - lbase];
+            if (lane < head) { const uint8_t x = wb_[(int32_t)(from + lane) - lbase]; out[from + lane] = x; if (ADLER) { tA += x; tR += lane * (uint32_t)x; } }
             from += head;
         }
         const uint32_t nch = (to - from) >> 4;
         #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
         for (uint32_t c = RCX_VGPR(lane); c < nch; c += 64) {      // (laundered: `out + 16 * lane` hoisted to the kernel's top is a spill)
             const uint32_t p = from + 16 * c;
-            *(rcx_u32x4*)(out + p) = *(const rcx_u32x4*)(wb_ + ((int32_t)p - lbase));
+            const rcx_u32x4 v = *(const rcx_u32x4*)(wb_ + ((int32_t)p - lbase));
+            *(rcx_u32x4*)(out + p) = v;
+            if (ADLER) rcx_adler_chunk(v, p - from0, tA, tR);
         }
         from += nch * 16;
         if (final) {
             const uint32_t tail = to - from;
-            if (lane < tail) out[from + lane] = wb_[(int32_t)(from + lane) - lbase];
+            if (lane < tail) { const uint8_t x = wb_[(int32_t)(from + lane) - lbase]; out[from + lane] = x; if (ADLER) { tA += x; tR += (from + lane - from0) * (uint32_t)x; } }
             from = to;
         }
+        if (ADLER) ad_commit(from0, tA, tR);
         gflush = RCX_U(from);
     }
 
@@ -190,13 +238,30 @@ struct Lz4V4 {
         const uint32_t mis = (uint32_t)((uintptr_t)d & 15u);
         uint32_t head = mis ? 16u - mis : 0u;
         if (head > len) head = len;
-        if (lane < head) d[lane] = s[lane];
+        uint32_t tA = 0, tR = 0;                                   // ADLER: relative to oend; the chunk loop commits every 2 KiB (u32 sums)
+        if (lane < head) { const uint8_t x = s[lane]; d[lane] = x; if (ADLER) { tA += x; tR += lane * (uint32_t)x; } }
+        if (ADLER) ad_commit(oend, tA, tR);
         const uint32_t nb = (len - head) >> 4;
-        #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-        for (uint32_t c = RCX_VGPR(lane); c < nb; c += 64)
-            *(rcx_u32x4*)(d + head + 16 * c) = *(const rcx_u32x4_u*)(s + head + 16 * c);
+        if (!ADLER) {
+            #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+            for (uint32_t c = RCX_VGPR(lane); c < nb; c += 64)
+                *(rcx_u32x4*)(d + head + 16 * c) = *(const rcx_u32x4_u*)(s + head + 16 * c);
+        } else {
+            #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+            for (uint32_t c0 = 0; c0 < nb; c0 += 128) {           // 128 chunks a step: two per lane, positions below 2 KiB
+                tA = 0; tR = 0;
+                for (uint32_t c = c0 + lane; c < nb && c < c0 + 128; c += 64) {
+                    const rcx_u32x4 v = *(const rcx_u32x4_u*)(s + head + 16 * c);
+                    *(rcx_u32x4*)(d + head + 16 * c) = v;
+                    rcx_adler_chunk(v, 16 * (c - c0), tA, tR);
+                }
+                ad_commit(oend + head + 16 * c0, tA, tR);
+            }
+        }
         const uint32_t done = head + nb * 16;
-        if (lane < len - done) d[done + lane] = s[done + lane];
+        tA = 0; tR = 0;
+        if (lane < len - done) { const uint8_t x = s[done + lane]; d[done + lane] = x; if (ADLER) { tA += x; tR += lane * (uint32_t)x; } }
+        if (ADLER) ad_commit(oend + done, tA, tR);
     }
 
     __device__ void wide_match(uint32_t off, uint32_t len)
@@ -206,11 +271,15 @@ struct Lz4V4 {
             uint32_t C = rem < e ? rem : e;
             if (C > 1024) C = 1024;
             const uint32_t i0 = 16 * RCX_VGPR(lane);
+            uint32_t tA = 0, tR = 0;                               // ADLER: relative to d, C <= 1024
             if (i0 + 16 <= C) {
-                *(rcx_u32x4_u*)(out + d + i0) = *(const rcx_u32x4_u*)(out + d - e + i0);
+                const rcx_u32x4 v = *(const rcx_u32x4_u*)(out + d - e + i0);
+                *(rcx_u32x4_u*)(out + d + i0) = v;
+                if (ADLER) rcx_adler_chunk(v, i0, tA, tR);
             } else if (i0 < C) {
-                for (uint32_t t = i0; t < C; t++) out[d + t] = out[d - e + t];
+                for (uint32_t t = i0; t < C; t++) { const uint8_t x = out[d - e + t]; out[d + t] = x; if (ADLER) { tA += x; tR += t * (uint32_t)x; } }
             }
+            if (ADLER) ad_commit(d, tA, tR);
             rcx_wave_sync();
             d += C; rem -= C;
             if (C == e && e < 1024) e *= 2;

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rcx_tu.h"
@@ -388,3 +389,120 @@ extern "C" int rcx_ari_apm_encode_batch(rcx_ctx* c, const rcx_batch* b) { return
 extern "C" int rcx_ari_apm_decode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_ARI_APM_DECODE, b, nullptr, nullptr, nullptr, true); }
 extern "C" int rcx_rle_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_RLE_ENCODE, b, nullptr, nullptr, nullptr, true); }
 extern "C" int rcx_rle_decode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_RLE_DECODE, b, nullptr, nullptr, nullptr, true); }
+
+// ---- more than one device -------------------------------------------------------------------------------------------------
+struct rcx_multi {
+    std::vector<rcx_ctx*> ctx;
+    std::string err;
+};
+
+extern "C" int rcx_multi_create(const int* device_ids, int n, rcx_multi** out)
+{
+    if (!out) return RCX_RC_BAD_ARG;
+    *out = nullptr;
+    if (!device_ids || n <= 0) return RCX_RC_BAD_ARG;
+    rcx_multi* m = new rcx_multi();
+    for (int i = 0; i < n; i++) {
+        rcx_ctx* c = nullptr;
+        const int rc = rcx_ctx_create(device_ids[i], &c);
+        if (rc != RCX_RC_OK) { for (rcx_ctx* d : m->ctx) rcx_ctx_destroy(d); delete m; return rc; }
+        m->ctx.push_back(c);
+    }
+    *out = m;
+    return RCX_RC_OK;
+}
+extern "C" void rcx_multi_destroy(rcx_multi* m) { if (!m) return; for (rcx_ctx* c : m->ctx) rcx_ctx_destroy(c); delete m; }
+extern "C" int rcx_multi_count(const rcx_multi* m) { return m ? (int)m->ctx.size() : 0; }
+extern "C" rcx_ctx* rcx_multi_ctx(rcx_multi* m, int i) { return (m && i >= 0 && (size_t)i < m->ctx.size()) ? m->ctx[(size_t)i] : nullptr; }
+extern "C" const char* rcx_multi_last_error(const rcx_multi* m) { return m ? m->err.c_str() : "null multi"; }
+
+// contiguous ranges balanced by weight: range g ends where the running sum first reaches g / parts of the total (what
+// rust_compress_amd/dist.py `partition` and host/compress.hpp `partition` compute)
+extern "C" void rcx_partition(const uint64_t* weights, uint32_t nblocks, uint32_t parts, uint32_t* bounds)
+{
+    if (!bounds || parts == 0) return;
+    for (uint32_t g = 0; g <= parts; g++) bounds[g] = nblocks;
+    bounds[0] = 0;
+    if (!weights || nblocks == 0) return;
+    long double total = 0, run = 0;
+    for (uint32_t i = 0; i < nblocks; i++) total += (long double)weights[i];
+    uint32_t g = 1;
+    for (uint32_t i = 0; i < nblocks && g < parts; i++) {
+        while (g < parts && run >= total * g / parts) bounds[g++] = i;
+        run += (long double)weights[i];
+    }
+}
+
+// one codec's host-descriptor entry point by its number (what rcx_multi_batch runs on a range)
+static int run_codec(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* aux_in, uint32_t* aux_out, const uint64_t* n_out)
+{
+    switch (codec) {
+    case RCX_ADLER32: case RCX_CRC32: return run_batch(c, codec, b, nullptr, aux_out, nullptr, false);
+    case RCX_DC_DECODE: if (!n_out) { c->err = "dc decode: n_out missing"; return RCX_RC_BAD_ARG; } return run_batch(c, codec, b, nullptr, nullptr, n_out, true);
+    case RCX_BWT_INVERSE: case RCX_BWT_INVERSE_MINIMAL: case RCX_BWT_INVERSION_TABLE:
+        if (!aux_in) { c->err = "bwt inverse: origins missing"; return RCX_RC_BAD_ARG; }
+        return run_batch(c, codec, b, aux_in, nullptr, nullptr, true);
+    default:
+        if (codec < 0 || codec >= RCX_CODEC_COUNT) { c->err = "unknown codec"; return RCX_RC_BAD_ARG; }
+        return run_batch(c, codec, b, nullptr, aux_out, nullptr, true);
+    }
+}
+
+extern "C" int rcx_multi_batch(rcx_multi* m, int codec, const rcx_batch* b, const uint32_t* aux_in, uint32_t* aux_out, const uint64_t* n_out)
+{
+    if (!m || m->ctx.empty()) return RCX_RC_BAD_ARG;
+    if (!b || (b->nblocks && (!b->in_off || !b->in_len || !b->status))) { m->err = "null descriptor array"; return RCX_RC_BAD_ARG; }
+    if (b->mem != RCX_MEM_HOST) { m->err = "rcx_multi_batch takes host-memory batches (device-resident ranges: rcx_multi_launch_dev)"; return RCX_RC_BAD_ARG; }
+    const uint32_t n = b->nblocks, G = (uint32_t)m->ctx.size();
+    if (n == 0) return RCX_RC_OK;
+    const bool has_out = b->out_off && b->out_cap;
+    std::vector<uint32_t> bounds(G + 1);
+    rcx_partition(has_out ? b->out_cap : b->in_len, n, G, bounds.data());
+    std::vector<int> rcs(G, RCX_RC_OK);
+    std::vector<std::thread> th;
+    for (uint32_t g = 0; g < G; g++) {
+        const uint32_t a0 = bounds[g], a1 = bounds[g + 1];
+        if (a1 <= a0) continue;
+        th.emplace_back([&, g, a0, a1] {
+            // the range's own view of the host buffers: offsets rebased to the range's first byte, so that only its span travels
+            const uint32_t k = a1 - a0;
+            uint64_t lo_in = ~0ull, lo_out = ~0ull;
+            for (uint32_t i = a0; i < a1; i++) { if (b->in_off[i] < lo_in) lo_in = b->in_off[i]; if (has_out && b->out_off[i] < lo_out) lo_out = b->out_off[i]; }
+            std::vector<uint64_t> io(k), oo(has_out ? k : 0);
+            for (uint32_t i = 0; i < k; i++) { io[i] = b->in_off[a0 + i] - lo_in; if (has_out) oo[i] = b->out_off[a0 + i] - lo_out; }
+            rcx_batch sb = *b;
+            sb.in_base = b->in_base ? b->in_base + lo_in : nullptr; sb.in_off = io.data(); sb.in_len = b->in_len + a0;
+            if (has_out) { sb.out_base = b->out_base ? b->out_base + lo_out : nullptr; sb.out_off = oo.data(); sb.out_cap = b->out_cap + a0; }
+            if (b->out_len) sb.out_len = b->out_len + a0;
+            if (b->in_used) sb.in_used = b->in_used + a0;
+            sb.status = b->status + a0;
+            sb.nblocks = k;
+            rcs[g] = run_codec(m->ctx[g], codec, &sb, aux_in ? aux_in + a0 : nullptr, aux_out ? aux_out + a0 : nullptr, n_out ? n_out + a0 : nullptr);
+        });
+    }
+    for (std::thread& t : th) t.join();
+    for (uint32_t g = 0; g < G; g++)
+        if (rcs[g] != RCX_RC_OK) { m->err = "device range " + std::to_string(g) + ": " + m->ctx[g]->err; return rcs[g]; }
+    return RCX_RC_OK;
+}
+
+extern "C" int rcx_multi_launch_dev(rcx_multi* m, int codec, const rcx_dev_batch* const* per_device, void* const* scratch, const uint64_t* scratch_bytes)
+{
+    if (!m || !per_device) return RCX_RC_BAD_ARG;
+    for (size_t g = 0; g < m->ctx.size(); g++) {
+        if (!per_device[g] || per_device[g]->nblocks == 0) continue;
+        const int rc = rcx_launch_dev(m->ctx[g], codec, per_device[g], scratch ? scratch[g] : nullptr, scratch_bytes ? scratch_bytes[g] : 0);
+        if (rc != RCX_RC_OK) { m->err = "device range " + std::to_string(g) + ": " + m->ctx[g]->err; return rc; }
+    }
+    return RCX_RC_OK;
+}
+
+extern "C" int rcx_multi_sync(rcx_multi* m)
+{
+    if (!m) return RCX_RC_BAD_ARG;
+    for (size_t g = 0; g < m->ctx.size(); g++) {
+        rcx_ctx* c = m->ctx[g];
+        if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { m->err = "device range " + std::to_string(g) + ": synchronize failed"; return RCX_RC_HIP_ERROR; }
+    }
+    return RCX_RC_OK;
+}

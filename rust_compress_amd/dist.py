@@ -51,8 +51,11 @@ def scatter_blocks(base, off, lens, bounds, root=0, device=None, with_desc=False
     (local_base tensor, local_off uint64, local_len uint64, bounds) -- and, with_desc, the int64 tensor [offsets | lengths] as it
     arrived on `device`, so that a device consumer need not upload the descriptors again.
     Two grouped exchanges: the descriptors (a fixed-size header broadcast, then one int64 tensor per peer), the payload bytes.
-    The root's own share is a VIEW of `base` (nothing is copied for the rank that already holds the bytes); a peer's buffer
-    has 64 bytes of slack behind it (16-byte loads of the last block)."""
+    The root's own share is a VIEW of `base` (nothing is copied for the rank that already holds the bytes).  ONE contract for every
+    rank: a share is exactly its blocks' bytes -- the decoders never read past `in_off + in_len` (16-byte loads are only issued
+    where 16 bytes of the block remain: k_lz4_decode_v8 stage8 / emit5's `lit16`, Inf3::stage; the wave simulator runs them
+    against exact-size buffers with a guard pattern behind).  A peer's receive buffer happens to be allocated 64 bytes longer
+    (a consumer with wider loads may use them); nothing here depends on it."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()

@@ -125,6 +125,8 @@ class BwtDcAri:
         self._sync()
         _need(nb == 0 or int(ar.status[: nb * S].abs().max()) == 0, "ari decode failed")
         _need(bool((ar.out_len[: nb * S].cpu().numpy().astype(np.int64) == praw.reshape(-1)).all()), "container piece length mismatch")
+        # the record buffer is not zeroed: a record's header may only be looked at when its first piece really covers it
+        _need(nb == 0 or bool((praw[:, 0] >= 4 * HDR_WORDS).all()), "container record: first piece shorter than the record header")
         rec32 = ar.out_base[: nb * slot].view(torch.int32).view(nb, slot // 4)
         hdr = rec32[:, :HDR_WORDS].cpu().numpy()
         n, origin, k = hdr[:, 0].astype(np.int64), hdr[:, 1].astype(np.uint32), hdr[:, 2].astype(np.int64)
@@ -204,8 +206,17 @@ class PipelineLanes:
                 for g in range(l, len(jobs), self.lanes):
                     res[g] = jobs[g](self.pipes[l])
                 self.streams[l].synchronize()
-        for f in [self.pool.submit(lane, l) for l in range(self.lanes)]:
-            f.result()
+        # every lane is waited for before an exception of one of them travels on: the lanes share the caller's buffers (safe
+        # across streams only because a lane synchronises its stream before it returns), and none may still be writing then
+        futs = [self.pool.submit(lane, l) for l in range(self.lanes)]
+        errs = []
+        for f in futs:
+            try:
+                f.result()
+            except BaseException as e:          # noqa: BLE001 (re-raised below)
+                errs.append(e)
+        if errs:
+            raise errs[0]
         return res
 
     def encode(self, raw, lens, keep_stages=False):

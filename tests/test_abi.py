@@ -54,3 +54,24 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 s = open(os.path.join(dp, f)).read()
                 assert not pat.search(s), f
+
+
+def test_partition_export_is_dist_partition():
+    """rcx_partition (the C-ABI's block ranges for more than one device) == rust_compress_amd.dist.partition, the ranges the
+    Python ranks use: contiguous, in order, balanced by weight, bounds[0] = 0, bounds[parts] = n."""
+    import ctypes as C
+    import numpy as np
+    from rust_compress_amd import _native as N, dist
+    L = C.CDLL(N.LIB_PATH)                       # (pure host arithmetic: no device needed)
+    L.rcx_partition.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.rcx_partition.restype = None
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 2, 7, 64, 1000):
+        for parts in (1, 2, 3, 8, 13):
+            for w in (np.ones(n, np.uint64), rng.integers(0, 70000, n).astype(np.uint64), np.zeros(n, np.uint64)):
+                b = np.zeros(parts + 1, np.uint32)
+                L.rcx_partition(w.ctypes.data, n, parts, b.ctypes.data)
+                assert b[0] == 0 and b[parts] == n and (np.diff(b.astype(np.int64)) >= 0).all()
+                if w.sum():
+                    assert b.tolist() == dist.partition(w, parts).tolist(), (n, parts)
+

@@ -121,3 +121,62 @@ def test_full_size_roundtrip_device_resident(ctx, oracle, kind):
         assert blob == oracle.lz4_encode_block(src)
         assert oracle.lz4_decode_block(blob, cap=BLOCK) == src
     ctx.set_stream(0)
+
+
+def test_multi_device_entry_points(ctx, oracle):
+    """include/rcx.h rcx_multi_*: a host-memory batch sharded over "devices" (the one GPU listed three times: three contexts,
+    three host threads, three ranges) returns block for block what one context returns -- LZ4 both ways, and BWT forward /
+    inverse for the aux arrays that travel with a range; device-resident ranges through rcx_multi_launch_dev."""
+    import ctypes as C
+    import torch
+    import rust_compress_amd as R
+    from rust_compress_amd import batch as B
+    L = N.lib()
+    raws = [synth.gen(("text", "runs", "rand")[i % 3], 1000 + 997 * (i % 23), 70 + i).tobytes() for i in range(101)] + [b"", b"x"]
+    devs = (C.c_int * 3)(0, 0, 0)
+    h = C.c_void_p()
+    assert L.rcx_multi_create(devs, 3, C.byref(h)) == 0 and L.rcx_multi_count(h) == 3 and L.rcx_multi_ctx(h, 2)
+    try:
+        def multi(codec, blobs, caps, aux_in=None, want_aux=False):
+            n = len(blobs)
+            base, off, lens = B.pack(blobs)
+            total, ooff, ocap = B.layout(caps)
+            out = np.zeros(total + 64, np.uint8)
+            out_len, in_used, status = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.full(n, -9, np.int32)
+            aux = np.zeros(n, np.uint32)
+            p = lambda a: a.ctypes.data
+            b = N.Batch(p(base), p(off), p(lens), p(out), p(ooff), p(ocap), p(out_len), p(in_used), p(status), n, N.MEM_HOST)
+            ai = np.ascontiguousarray(aux_in, dtype=np.uint32) if aux_in is not None else None
+            rc = L.rcx_multi_batch(h, codec, C.byref(b), p(ai) if ai is not None else None, p(aux) if want_aux else None, None)
+            assert rc == 0, L.rcx_multi_last_error(h)
+            assert not status.any()
+            return [bytes(out[int(o): int(o) + int(l)]) for o, l in zip(ooff, out_len)], aux
+        enc, _ = multi(N.LZ4_ENCODE, raws, [int(L.rcx_lz4_compression_bound(len(r))) for r in raws])
+        assert enc == ctx.lz4_encode_blocks(raws).check().outputs == [oracle.lz4_encode_block(r) for r in raws]
+        dec, _ = multi(N.LZ4_DECODE, enc, [len(r) for r in raws])
+        assert dec == raws
+        nz = [r for r in raws if r]
+        fw, origin = multi(N.BWT_FORWARD, nz, [len(r) for r in nz], want_aux=True)
+        one = ctx.bwt_forward(nz).check()
+        assert fw == one.outputs and origin.tolist() == [int(x) for x in one.aux]
+        back, _ = multi(N.BWT_INVERSE, fw, [len(r) for r in nz], aux_in=origin)
+        assert back == nz
+        # device-resident ranges: two DeviceBatches (both on device 0 here), enqueued on their contexts' streams, one sync
+        dev = torch.device("cuda", 0)
+        halves = [enc[:50], enc[50:]]
+        dbs = []
+        for part, rr in zip(halves, (raws[:50], raws[50:])):
+            base, off, lens = B.pack(part)
+            total, ooff, ocap = B.layout([len(r) for r in rr])
+            dbs.append(R.DeviceBatch.from_host(base, off, lens, total, ooff, ocap, dev))
+        torch.cuda.synchronize()
+        arr = (C.POINTER(N.DevBatch) * 3)(C.pointer(dbs[0].c), C.pointer(dbs[1].c), None)
+        assert L.rcx_multi_launch_dev(h, N.LZ4_DECODE, arr, None, None) == 0 and L.rcx_multi_sync(h) == 0
+        for db, rr in zip(dbs, (raws[:50], raws[50:])):
+            assert int(db.status[: len(rr)].abs().max()) == 0
+            got = db.out_base.cpu().numpy()
+            oo, ol = db.out_off.cpu().numpy(), db.out_len.cpu().numpy()
+            assert [bytes(got[int(o): int(o) + int(l)]) for o, l in zip(oo, ol)][: len(rr)] == rr
+    finally:
+        L.rcx_multi_destroy(h)
+

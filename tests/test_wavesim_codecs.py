@@ -167,6 +167,24 @@ def synth_dna(n):
     return synth.gen("dna4", n, 5).tobytes()
 
 
+def test_zlib_first_pass_sums_its_own_adler():
+    """The wave-per-stream decoder sums the Adler-32 of a zlib stream while the bytes leave (window drain, stored blocks, wave-wide
+    copies); a wrong sum would only send the stream to the exact second pass -- slower, still right, invisible to a parity test.
+    So the first pass ALONE (variants 12 / 10): every valid stream must come back OK from it, at any output alignment."""
+    import simrun
+    raws = corpus.small_corpus(sizes=(17, 1000, 40000)) + [synth_dna(120000), b"", b"x", b"ab" * 40000, bytes(100000)]
+    zs, exp = [], []
+    for r in raws:
+        for lvl in (0, 1, 6):                                   # level 0: stored blocks (the wave-wide literal copy), > 64 KiB of them
+            zs.append(zlib.compress(r, lvl)); exp.append(r)
+        c = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+        zs.append(c.compress(r) + c.flush()); exp.append(r)
+    sb = 12 * (len(zs) + 1) + 256
+    for variant, mis in ((12, 0), (12, 5), (10, 11)):
+        outs, _, used, st, _ = simrun.run(N.ZLIB_DECODE, variant, zs, [len(e) for e in exp], scratch_bytes=sb, out_misalign=mis)
+        assert not st.any() and outs == exp and list(used) == [len(z) for z in zs], (variant, mis)
+
+
 def test_inflate_zlib_adler(oracle, golden):
     import simrun
     txt = golden("test.txt")

@@ -312,6 +312,10 @@ static inline uint32_t ws_wave_incl_scan(uint32_t v)
 #define RCX_NO_INF_WALK_ASM 1          // Inf3::tile4's hand-written hop loop: the simulator walks with the portable hop4 alone
 #define RCX_NO_ROUNDS_ASM 1            // emit5's hand-written copy-round loop: the simulator runs the portable loop alone
 #define RCX_LDS_STORE16 ws_lds_store16
+static inline uint32_t ws_sad_u8(uint32_t a, uint32_t c) { return c + (a & 255u) + ((a >> 8) & 255u) + ((a >> 16) & 255u) + (a >> 24); }          // v_sad_u8 against 0
+static inline uint32_t ws_udot4(uint32_t a, uint32_t w, uint32_t c) { for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 255u) * ((w >> (8 * i)) & 255u); return c; }   // v_dot4_u32_u8
+#define RCX_SAD_U8(a, c) ws_sad_u8((a), (c))
+#define RCX_UDOT4(a, w, c) ws_udot4((a), (w), (c))
 #define RCX_INF_WALK ws_inf_walk
 #define BWS_PEERS ws_bws_peers
 #define RCX_WAIT_VMEM() ((void)0)
