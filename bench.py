@@ -80,13 +80,19 @@ class GpuEngine:
         dec, raw, cb, ob = make_workload(self.R, self.ctx, self.torch, self.dev, kind, nblocks, seed)
         return {"dec": dec, "raw": raw, "comp_bytes": cb, "out_bytes": ob, "nblocks": nblocks}
 
-    def check(self, wl):
+    def check(self, wl, reps=12):
+        """Parity, untimed: the decoded bytes == the synthetic source -- `reps` times over, each into an output buffer refilled
+        with a different byte first.  The decoder is two waves per block talking through an LDS ring under issue priorities:
+        a race would show as a run that differs, a stale byte as one that only passes over the previous run's output."""
         torch, dec, nb = self.torch, wl["dec"], wl["nblocks"]
-        self.ctx.launch_dev(self.N.LZ4_DECODE, dec)
-        torch.cuda.synchronize()
-        assert int(dec.status.abs().max()) == 0, "decode status != OK"
-        assert bool((dec.out_len[:nb] == BLOCK).all())
-        assert torch.equal(dec.out_base[: nb * BLOCK], wl["raw"][: nb * BLOCK]), "GPU decode != source"
+        for r in range(reps):
+            dec.out_base.fill_((0x5A + 37 * r) & 0xFF)
+            dec.status.fill_(-1)
+            self.ctx.launch_dev(self.N.LZ4_DECODE, dec)
+            torch.cuda.synchronize()
+            assert int(dec.status[:nb].abs().max()) == 0, "decode status != OK (run %d)" % r
+            assert bool((dec.out_len[:nb] == BLOCK).all())
+            assert torch.equal(dec.out_base[: nb * BLOCK], wl["raw"][: nb * BLOCK]), "GPU decode != source (run %d)" % r
 
     def decode(self, wl):
         self.ctx.launch_dev(self.N.LZ4_DECODE, wl["dec"])
@@ -462,6 +468,30 @@ def dry_sharded_pipeline(eng, dist, rank, world, nblocks=11, block=4096):
             "blocks": int(len(lens)), "block_ranges": np.diff(bounds).tolist(), "container_bytes": len(whole)}
 
 
+def summary_of(res):
+    """The line's key numbers once more, compact, as its last key (a log that keeps the last 2000 characters of the job's output
+    still holds every config's time): headline, the other distributions, configs 3 / 3g / 4 / 5, host path, CPU baseline."""
+    g = lambda d, *ks: (d.get(ks[0]) if len(ks) == 1 else g(d.get(ks[0]) or {}, *ks[1:])) if isinstance(d, dict) else None
+    out = {"lz4_decode_ms": res.get("ms_per_step"), "lz4_decode_GiB/s": res.get("value"), "roofline_frac": g(res, "roofline", "frac"),
+           "sustained_ms": g(res, "sustained", "kernel_ms_avg"), "runs_ms": g(res, "per_distribution", "G-runs", "ms_per_step"),
+           "rand_ms": g(res, "per_distribution", "G-rand", "ms_per_step"), "e2e_GiB/s": g(res, "end_to_end", "value"),
+           "host_path_GiB/s": g(res, "host_path", "GiB/s"), "cpu_GiB/s": g(res, "cpu_baseline", "value")}
+    for o in res.get("other_configs") or []:
+        if not isinstance(o, dict):
+            continue
+        c = o.get("config")
+        if "error" in o:
+            out["cfg_%s" % o.get("leg", c)] = "error"
+        elif c in (3, "3g"):
+            out["cfg%s_ms" % c] = o.get("ms"); out["cfg%s_frac" % c] = g(o, "roofline", "frac")
+        elif c == 4:
+            k = "text" if "G-text" in str(o.get("workload")) else "dna4"
+            out["cfg4_%s_fwd_ms" % k] = o.get("forward_ms"); out["cfg4_%s_inv_ms" % k] = o.get("inverse_ms")
+        elif c == 5:
+            out["cfg5_enc_s"] = o.get("encode_s"); out["cfg5_dec_s"] = o.get("decode_s")
+    return {k: v for k, v in out.items() if v is not None}
+
+
 # ------------------------------------------------------------------------------------------------ side legs
 class SideLegs:
     """Everything bench.py measures AFTER the headline (other distributions, end_to_end, configs 3-5, CPU baselines) runs
@@ -524,6 +554,7 @@ class SideLegs:
                     self.res["side_legs_failed"] = list(self.failed)
                 if note:
                     self.res["side_legs_note"] = note
+                self.res["summary"] = summary_of(self.res)      # the LAST key: a record that keeps only the line's tail keeps this
                 print(json.dumps(self.res), flush=True)
 
     def start_watchdog(self, seconds):

@@ -6,6 +6,7 @@
 //   Ari            : one LANE per stream (64 streams per wave): the coder is a chain of u32 divides with a
 //                    257-entry adaptive table per stream (LDS, lane-interleaved, 16-entry block sums)
 #include "rcx_dev.h"
+#include <type_traits>
 
 // =================================================================================================
 // MTF -- src/bwt/mtf.rs:63-90 with the stream codecs' identity start (:103-104, :141-142)
@@ -657,12 +658,101 @@ __global__ __launch_bounds__(64) void k_dcx_main(rcx_kargs a)
     if (lane == 0) { a.status[b] = RCX_OK; a.out_len[b] = 4ull * (256ull + rcl + 1u); if (a.in_used) a.in_used[b] = n; }
 }
 
+// The decoder's step (dc.rs:199-229) for the one-entry-per-lane list, as ISA (gfx950).  A step is a chain -- the next occurrence of
+// the second symbol (v_readlane) -> the run's end -> + the distance -> which rank fits (v_cmp, ballot, s_ff1) -> the list moves up
+// (DPP shift + selects) -> the next step's v_readlane -- and a block is ~50 000 of them, one after the other: the kernel's time IS
+// that chain (13.4 ms for 256 KiB blocks however many there are; both issue ports half idle, profiles/r04_ari_dc_sq_counters.txt).
+// hipcc's loop spends ~70 instructions and 14 branches on a step, with 64-bit compares and the window's refill logic in line:
+// ~590 cycles.  Here a step is 38 instructions and one taken branch; everything that is not the plain case -- the block's end, a
+// run of 64 bytes or more, a distance outside the 64 words held in `cur`, any error -- LEAVES with the state as it stood at the
+// top of that step, and the portable step below (which knows all the cases) takes it from there.
+//   sy, v: the list (lane r: the symbol at rank r and its next position); i: output position; di: index of the next distance
+//   cur: the distance words wbase .. wbase + 63 (a word a lane); maskA: lanes 1 .. A - 1
+// Hazards (gfx940+): two wait states between a VALU write of an SGPR pair and a VALU read of it, two between a VALU write of a
+// VGPR and a DPP read, one before a v_readlane of it: the instruction order below provides them.
+#ifndef RCX_NO_DC_STEPS_ASM
+__device__ __forceinline__ void rcx_dc_fast_steps(uint32_t& sy, uint32_t& v, uint32_t& i, uint32_t& di, uint32_t n, uint32_t nwords, uint32_t cur,
+                                                   uint32_t wbase, uint64_t maskA, uint32_t A, const uint8_t* out, uint32_t lane)
+{
+    uint32_t stop, sym, w, d, t, fut, rank, q, val, tmp, vsym, vval, ns, nv;
+    uint64_t m, ceq, cgt;
+    asm volatile(
+        "L_top_%=:\n\t"
+        "s_cmp_ge_u32 %[i], %[n]\n\t"
+        "s_cbranch_scc1 L_out_%=\n\t"
+        "v_readlane_b32 %[stop], %[v], 1\n\t"
+        "v_readlane_b32 %[sym], %[sy], 0\n\t"
+        "s_sub_u32 %[w], %[di], %[wbase]\n\t"
+        "s_cmp_gt_u32 %[w], 63\n\t"                              // the distance is not among the 64 words held (or before them)
+        "s_cbranch_scc1 L_out_%=\n\t"
+        "s_cmp_ge_u32 %[di], %[nwords]\n\t"
+        "s_cbranch_scc1 L_out_%=\n\t"
+        "v_readlane_b32 %[d], %[cur], %[w]\n\t"
+        "s_cmp_gt_u32 %[stop], %[n]\n\t"
+        "s_cbranch_scc1 L_out_%=\n\t"
+        "s_sub_u32 %[t], %[stop], %[i]\n\t"                      // the run: 0 .. 63 bytes here (a stop below i wraps: leaves too)
+        "s_cmp_gt_u32 %[t], 63\n\t"
+        "s_cbranch_scc1 L_out_%=\n\t"
+        "s_add_u32 %[fut], %[stop], %[d]\n\t"
+        "s_cbranch_scc1 L_out_%=\n\t"
+        "s_cmp_gt_u32 %[fut], %[n]\n\t"
+        "s_cbranch_scc1 L_out_%=\n\t"
+        // ---- the plain case: nothing below can fail
+        "v_add_u32_e32 %[tmp], %[fut], %[lane]\n\t"
+        "v_cmp_le_u32_e32 vcc, %[tmp], %[v]\n\t"                 // !(future + rank > next[rank])
+        "v_mov_b32_dpp %[ns], %[sy] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %[nv], %[v] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_and_b64 vcc, vcc, %[maskA]\n\t"
+        "s_ff1_i32_b64 %[rank], vcc\n\t"
+        "s_cmp_lg_u64 vcc, 0\n\t"
+        "s_cselect_b32 %[rank], %[rank], %[A]\n\t"
+        "s_sub_u32 %[q], %[rank], 1\n\t"
+        "s_add_u32 %[val], %[fut], %[q]\n\t"
+        "v_cmp_eq_u32_e64 %[ceq], %[q], %[lane]\n\t"
+        "v_cmp_gt_u32_e64 %[cgt], %[q], %[lane]\n\t"
+        // the run's bytes (behind the chain's compares: they fill the wait states)
+        "v_mov_b32_e32 %[vsym], %[sym]\n\t"
+        "v_mov_b32_e32 %[vval], %[val]\n\t"
+        "v_cndmask_b32_e64 %[sy], %[sy], %[vsym], %[ceq]\n\t"
+        "v_cndmask_b32_e64 %[v], %[v], %[vval], %[ceq]\n\t"
+        "v_cndmask_b32_e64 %[sy], %[sy], %[ns], %[cgt]\n\t"
+        "v_cndmask_b32_e64 %[v], %[v], %[nv], %[cgt]\n\t"
+        "s_bfm_b64 %[m], %[t], 0\n\t"
+        "v_add_u32_e32 %[tmp], %[i], %[lane]\n\t"
+        "s_mov_b64 exec, %[m]\n\t"
+        "global_store_byte %[tmp], %[vsym], %[out]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_mov_b32 %[i], %[stop]\n\t"
+        "s_add_u32 %[di], %[di], 1\n\t"
+        "s_branch L_top_%=\n\t"
+        "L_out_%=:\n\t"
+        : [sy] "+v"(sy), [v] "+v"(v), [i] "+s"(i), [di] "+s"(di), [stop] "=&s"(stop), [sym] "=&s"(sym), [w] "=&s"(w), [d] "=&s"(d), [t] "=&s"(t),
+          [fut] "=&s"(fut), [rank] "=&s"(rank), [q] "=&s"(q), [val] "=&s"(val), [m] "=&s"(m), [ceq] "=&s"(ceq), [cgt] "=&s"(cgt),
+          [tmp] "=&v"(tmp), [vsym] "=&v"(vsym), [vval] "=&v"(vval), [ns] "=&v"(ns), [nv] "=&v"(nv)
+        : [n] "s"(n), [nwords] "s"(nwords), [cur] "v"(cur), [wbase] "s"(wbase), [maskA] "s"(maskA), [A] "s"(A), [out] "s"(out), [lane] "v"(lane)
+        : "vcc", "scc", "memory");
+}
+#endif
+
 // dc.rs:199-229 driven as decode_simple :236-252; returns the status
 template <bool CTX, class LT>
 __device__ __forceinline__ int dc_decode_steps(LT& L, SeqWin<uint32_t>& wwin, uint32_t& i, uint32_t n, uint32_t A, uint32_t& di, uint32_t nwords, uint8_t* out, unsigned lane,
                                                uint32_t* ctxo = nullptr, uint8_t* ranks = nullptr)
 {
     while (i < n) {
+#ifndef RCX_NO_DC_STEPS_ASM
+        if constexpr (!CTX && std::is_same<LT, DcRegs1>::value) {
+            // as many plain steps as there are, hand-written; what it leaves at is taken by the portable step below (the distance
+            // window is moved there: wwin.get), and the loop comes back here
+            if (di >= 256u && di < nwords && n < 0xffffff00u) {        // (future + rank is computed in 32 bits there)
+                wwin.seek(di);
+                uint32_t ui = RCX_UNI(i), udi = RCX_UNI(di);
+                rcx_dc_fast_steps(L.sy, L.v, ui, udi, n, nwords, wwin.cur, RCX_UNI(wwin.base), A >= 64u ? ~1ull : ((1ull << A) - 2ull), A, out, lane);
+                i = ui; di = udi;
+                if (i >= n) break;
+            }
+        }
+#endif
         const uint32_t sym = L.sym_at(0);
         const uint32_t stop = L.val_at(1);
         if (stop > n) return RCX_E_MALFORMED;                  // output[i] index panic

@@ -24,6 +24,7 @@ static inline int hipStreamSynchronize(int) { return 0; }
 static inline int hipMemsetAsync(void* d, int v, size_t n, int) { memset(d, v, n); return 0; }
 #define hipHostMallocDefault 0
 static inline int hipHostMalloc(void** p, size_t n, int) { *p = malloc(n); return *p ? 0 : 1; }
+static inline int hipGetLastError() { return 0; }
 #include "../../rust_compress_amd/csrc/k_bwt_inverse.hip"
 #include "../../rust_compress_amd/csrc/k_bwt.hip"
 
