@@ -671,31 +671,32 @@ __global__ __launch_bounds__(64) void k_dcx_main(rcx_kargs a)
 // Hazards (gfx940+): two wait states between a VALU write of an SGPR pair and a VALU read of it, two between a VALU write of a
 // VGPR and a DPP read, one before a v_readlane of it: the instruction order below provides them.
 #ifndef RCX_NO_DC_STEPS_ASM
-__device__ __forceinline__ void rcx_dc_fast_steps(uint32_t& sy, uint32_t& v, uint32_t& i, uint32_t& di, uint32_t n, uint32_t nwords, uint32_t cur,
-                                                   uint32_t wbase, uint64_t maskA, uint32_t A, const uint8_t* out, uint32_t lane)
+// (second form: the CU's ONE scalar port -- SALU, v_readlane, v_cmp -- is what sixteen such chains share; the first form's 28 + 6
+//  scalar-port instructions a step measured 10.6 ms.  `lim` = min(nwords, wbase + 64) folds two exits into one, the distance's
+//  bound implies the stop's, a sentinel bit at rank A replaces the empty-ballot select, and the new entry is dropped into the
+//  shifted registers with v_writelane so that ONE compare moves the list.)
+//   lim: distances below this index are among the 64 words in `cur`; maskA: lanes 1 .. A - 1; bitA: 1 << A (A < 64)
+__device__ __forceinline__ void rcx_dc_fast_steps(uint32_t& sy, uint32_t& v, uint32_t& i, uint32_t& di, uint32_t n, uint32_t lim, uint32_t cur,
+                                                   uint32_t wbase, uint64_t maskA, uint64_t bitA, const uint8_t* out, uint32_t lane)
 {
-    uint32_t stop, sym, w, d, t, fut, rank, q, val, tmp, vsym, vval, ns, nv;
-    uint64_t m, ceq, cgt;
+    uint32_t stop, sym, w, d, t, fut, rank, q, val, tmp, vsym, ns, nv;
+    uint64_t m, cge;
     asm volatile(
         "L_top_%=:\n\t"
         "s_cmp_ge_u32 %[i], %[n]\n\t"
         "s_cbranch_scc1 L_out_%=\n\t"
+        "s_cmp_ge_u32 %[di], %[lim]\n\t"                         // the next distance is not among the 64 words held (or there is none)
+        "s_cbranch_scc1 L_out_%=\n\t"
         "v_readlane_b32 %[stop], %[v], 1\n\t"
         "v_readlane_b32 %[sym], %[sy], 0\n\t"
         "s_sub_u32 %[w], %[di], %[wbase]\n\t"
-        "s_cmp_gt_u32 %[w], 63\n\t"                              // the distance is not among the 64 words held (or before them)
-        "s_cbranch_scc1 L_out_%=\n\t"
-        "s_cmp_ge_u32 %[di], %[nwords]\n\t"
-        "s_cbranch_scc1 L_out_%=\n\t"
         "v_readlane_b32 %[d], %[cur], %[w]\n\t"
-        "s_cmp_gt_u32 %[stop], %[n]\n\t"
-        "s_cbranch_scc1 L_out_%=\n\t"
         "s_sub_u32 %[t], %[stop], %[i]\n\t"                      // the run: 0 .. 63 bytes here (a stop below i wraps: leaves too)
         "s_cmp_gt_u32 %[t], 63\n\t"
         "s_cbranch_scc1 L_out_%=\n\t"
         "s_add_u32 %[fut], %[stop], %[d]\n\t"
         "s_cbranch_scc1 L_out_%=\n\t"
-        "s_cmp_gt_u32 %[fut], %[n]\n\t"
+        "s_cmp_gt_u32 %[fut], %[n]\n\t"                          // (future <= n implies stop <= n)
         "s_cbranch_scc1 L_out_%=\n\t"
         // ---- the plain case: nothing below can fail
         "v_add_u32_e32 %[tmp], %[fut], %[lane]\n\t"
@@ -703,34 +704,31 @@ __device__ __forceinline__ void rcx_dc_fast_steps(uint32_t& sy, uint32_t& v, uin
         "v_mov_b32_dpp %[ns], %[sy] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
         "v_mov_b32_dpp %[nv], %[v] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
         "s_and_b64 vcc, vcc, %[maskA]\n\t"
+        "s_or_b64 vcc, vcc, %[bitA]\n\t"                         // no rank fits: A
         "s_ff1_i32_b64 %[rank], vcc\n\t"
-        "s_cmp_lg_u64 vcc, 0\n\t"
-        "s_cselect_b32 %[rank], %[rank], %[A]\n\t"
         "s_sub_u32 %[q], %[rank], 1\n\t"
         "s_add_u32 %[val], %[fut], %[q]\n\t"
-        "v_cmp_eq_u32_e64 %[ceq], %[q], %[lane]\n\t"
-        "v_cmp_gt_u32_e64 %[cgt], %[q], %[lane]\n\t"
-        // the run's bytes (behind the chain's compares: they fill the wait states)
+        "s_mov_b32 m0, %[q]\n\t"                                 // (a lane select in m0 is not a second scalar operand)
+        "v_writelane_b32 %[ns], %[sym], m0\n\t"                  // entry q of the shifted list = (sym, future + rank - 1)
+        "v_writelane_b32 %[nv], %[val], m0\n\t"
+        "v_cmp_ge_u32_e64 %[cge], %[q], %[lane]\n\t"             // ranks 0 .. q change
         "v_mov_b32_e32 %[vsym], %[sym]\n\t"
-        "v_mov_b32_e32 %[vval], %[val]\n\t"
-        "v_cndmask_b32_e64 %[sy], %[sy], %[vsym], %[ceq]\n\t"
-        "v_cndmask_b32_e64 %[v], %[v], %[vval], %[ceq]\n\t"
-        "v_cndmask_b32_e64 %[sy], %[sy], %[ns], %[cgt]\n\t"
-        "v_cndmask_b32_e64 %[v], %[v], %[nv], %[cgt]\n\t"
         "s_bfm_b64 %[m], %[t], 0\n\t"
         "v_add_u32_e32 %[tmp], %[i], %[lane]\n\t"
+        "v_cndmask_b32_e64 %[sy], %[sy], %[ns], %[cge]\n\t"
+        "v_cndmask_b32_e64 %[v], %[v], %[nv], %[cge]\n\t"
         "s_mov_b64 exec, %[m]\n\t"
-        "global_store_byte %[tmp], %[vsym], %[out]\n\t"
+        "global_store_byte %[tmp], %[vsym], %[out]\n\t"          // the run's bytes
         "s_mov_b64 exec, -1\n\t"
         "s_mov_b32 %[i], %[stop]\n\t"
         "s_add_u32 %[di], %[di], 1\n\t"
         "s_branch L_top_%=\n\t"
         "L_out_%=:\n\t"
         : [sy] "+v"(sy), [v] "+v"(v), [i] "+s"(i), [di] "+s"(di), [stop] "=&s"(stop), [sym] "=&s"(sym), [w] "=&s"(w), [d] "=&s"(d), [t] "=&s"(t),
-          [fut] "=&s"(fut), [rank] "=&s"(rank), [q] "=&s"(q), [val] "=&s"(val), [m] "=&s"(m), [ceq] "=&s"(ceq), [cgt] "=&s"(cgt),
-          [tmp] "=&v"(tmp), [vsym] "=&v"(vsym), [vval] "=&v"(vval), [ns] "=&v"(ns), [nv] "=&v"(nv)
-        : [n] "s"(n), [nwords] "s"(nwords), [cur] "v"(cur), [wbase] "s"(wbase), [maskA] "s"(maskA), [A] "s"(A), [out] "s"(out), [lane] "v"(lane)
-        : "vcc", "scc", "memory");
+          [fut] "=&s"(fut), [rank] "=&s"(rank), [q] "=&s"(q), [val] "=&s"(val), [m] "=&s"(m), [cge] "=&s"(cge),
+          [tmp] "=&v"(tmp), [vsym] "=&v"(vsym), [ns] "=&v"(ns), [nv] "=&v"(nv)
+        : [n] "s"(n), [lim] "s"(lim), [cur] "v"(cur), [wbase] "s"(wbase), [maskA] "s"(maskA), [bitA] "s"(bitA), [out] "s"(out), [lane] "v"(lane)
+        : "vcc", "scc", "m0", "memory");
 }
 #endif
 
@@ -744,10 +742,11 @@ __device__ __forceinline__ int dc_decode_steps(LT& L, SeqWin<uint32_t>& wwin, ui
         if constexpr (!CTX && std::is_same<LT, DcRegs1>::value) {
             // as many plain steps as there are, hand-written; what it leaves at is taken by the portable step below (the distance
             // window is moved there: wwin.get), and the loop comes back here
-            if (di >= 256u && di < nwords && n < 0xffffff00u) {        // (future + rank is computed in 32 bits there)
+            if (di >= 256u && di < nwords && n < 0xffffff00u && A < 64u) {        // (future + rank is computed in 32 bits there; rank A is a bit of the ballot)
                 wwin.seek(di);
                 uint32_t ui = RCX_UNI(i), udi = RCX_UNI(di);
-                rcx_dc_fast_steps(L.sy, L.v, ui, udi, n, nwords, wwin.cur, RCX_UNI(wwin.base), A >= 64u ? ~1ull : ((1ull << A) - 2ull), A, out, lane);
+                const uint32_t wb = RCX_UNI(wwin.base), lim = RCX_UNI(nwords < wb + 64u ? nwords : wb + 64u);
+                rcx_dc_fast_steps(L.sy, L.v, ui, udi, n, lim, wwin.cur, wb, (1ull << A) - 2ull, 1ull << A, out, lane);
                 i = ui; di = udi;
                 if (i >= n) break;
             }
