@@ -48,3 +48,25 @@ for pinned in (False, True):
     t = float(np.median(ts[1:]))
     print("host path (%s host buffers): %.2f ms per 4096 x 64 KiB  -> %.1f GiB/s decoded, PCIe-inclusive (%.0f MB in, %.0f MB out)"
           % ("pinned" if pinned else "pageable", t * 1e3, ob / t / 2**30, cb / 1e6, ob / 1e6))
+
+# the same blocks through rcx_multi_batch over the ONE device listed k times: k contexts, k host threads, each range's copy in, decode
+# and copy out under the others' (include/rcx.h)
+L = N.lib()
+inb = torch.from_numpy(in_base).pin_memory(); outb = torch.empty(nb * bench.BLOCK + 64, dtype=torch.uint8).pin_memory()
+for k in (1, 2, 3, 4):
+    devs = (C.c_int * k)(*([0] * k))
+    h = C.c_void_p()
+    assert L.rcx_multi_create(devs, k, C.byref(h)) == 0
+    out_len, in_used, status = np.zeros(nb, np.uint64), np.zeros(nb, np.uint64), np.zeros(nb, np.int32)
+    b = N.Batch(inb.data_ptr(), p(in_off), p(in_len), outb.data_ptr(), p(out_off), p(out_cap), p(out_len), p(in_used), p(status), nb, N.MEM_HOST)
+    ts = []
+    for it in range(6):
+        t0 = time.perf_counter()
+        rc = L.rcx_multi_batch(h, N.LZ4_DECODE, C.byref(b), None, None, None)
+        ts.append(time.perf_counter() - t0)
+    assert rc == 0 and not status.any()
+    assert np.array_equal(outb.numpy()[: nb * bench.BLOCK], raw.cpu().numpy()[: nb * bench.BLOCK])
+    t = float(np.median(ts[1:]))
+    print("rcx_multi_batch, device 0 listed %d x (pinned): %.2f ms -> %.1f GiB/s decoded, PCIe-inclusive" % (k, t * 1e3, ob / t / 2**30))
+    L.rcx_multi_destroy(h)
+
