@@ -675,21 +675,24 @@ __global__ __launch_bounds__(64) void k_dcx_main(rcx_kargs a)
 //  scalar-port instructions a step measured 10.6 ms.  `lim` = min(nwords, wbase + 64) folds two exits into one, the distance's
 //  bound implies the stop's, a sentinel bit at rank A replaces the empty-ballot select, and the new entry is dropped into the
 //  shifted registers with v_writelane so that ONE compare moves the list.)
-//   lim: distances below this index are among the 64 words in `cur`; maskA: lanes 1 .. A - 1; bitA: 1 << A (A < 64)
-__device__ __forceinline__ void rcx_dc_fast_steps(uint32_t& sy, uint32_t& v, uint32_t& i, uint32_t& di, uint32_t n, uint32_t lim, uint32_t cur,
-                                                   uint32_t wbase, uint64_t maskA, uint64_t bitA, const uint8_t* out, uint32_t lane)
+//  third form: the place in the word window is the loop variable, and the ballot shifted right by one gives rank - 1 at once --
+//  the lanes from A on hold 0xffffffff as their position, so every rank "fits" there and rank A needs no sentinel: 21 + 5.)
+__device__ __forceinline__ void rcx_dc_fast_steps(uint32_t& sy, uint32_t& v, uint32_t& i, uint32_t& w, uint32_t n, uint32_t wlim, uint32_t cur,
+                                                   uint64_t vmask, const uint8_t* out, uint32_t lane)
 {
-    uint32_t stop, sym, w, d, t, fut, rank, q, val, tmp, vsym, ns, nv;
+    // w: the next distance's place among the 64 words in `cur` (the caller keeps di = wbase + w); wlim: the first place that is not
+    // there (or behind the stream's last word); vmask: lanes 0 .. A - 1 (above them v is 0xffffffff: every rank "fits" there, so
+    // the ballot's lowest bit above rank 0 is the rank that fits or A itself)
+    uint32_t stop, sym, d, t, fut, q, val, tmp, vsym, ns, nv;
     uint64_t m, cge;
     asm volatile(
         "L_top_%=:\n\t"
         "s_cmp_ge_u32 %[i], %[n]\n\t"
         "s_cbranch_scc1 L_out_%=\n\t"
-        "s_cmp_ge_u32 %[di], %[lim]\n\t"                         // the next distance is not among the 64 words held (or there is none)
+        "s_cmp_ge_u32 %[w], %[wlim]\n\t"                         // the next distance is not among the 64 words held (or there is none)
         "s_cbranch_scc1 L_out_%=\n\t"
         "v_readlane_b32 %[stop], %[v], 1\n\t"
         "v_readlane_b32 %[sym], %[sy], 0\n\t"
-        "s_sub_u32 %[w], %[di], %[wbase]\n\t"
         "v_readlane_b32 %[d], %[cur], %[w]\n\t"
         "s_sub_u32 %[t], %[stop], %[i]\n\t"                      // the run: 0 .. 63 bytes here (a stop below i wraps: leaves too)
         "s_cmp_gt_u32 %[t], 63\n\t"
@@ -700,13 +703,11 @@ __device__ __forceinline__ void rcx_dc_fast_steps(uint32_t& sy, uint32_t& v, uin
         "s_cbranch_scc1 L_out_%=\n\t"
         // ---- the plain case: nothing below can fail
         "v_add_u32_e32 %[tmp], %[fut], %[lane]\n\t"
-        "v_cmp_le_u32_e32 vcc, %[tmp], %[v]\n\t"                 // !(future + rank > next[rank])
+        "v_cmp_le_u32_e32 vcc, %[tmp], %[v]\n\t"                 // !(future + rank > next[rank]); lanes >= A: always
         "v_mov_b32_dpp %[ns], %[sy] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
         "v_mov_b32_dpp %[nv], %[v] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-        "s_and_b64 vcc, vcc, %[maskA]\n\t"
-        "s_or_b64 vcc, vcc, %[bitA]\n\t"                         // no rank fits: A
-        "s_ff1_i32_b64 %[rank], vcc\n\t"
-        "s_sub_u32 %[q], %[rank], 1\n\t"
+        "s_lshr_b64 vcc, vcc, 1\n\t"                             // rank 0 does not count, and the lowest bit left is rank - 1
+        "s_ff1_i32_b64 %[q], vcc\n\t"
         "s_add_u32 %[val], %[fut], %[q]\n\t"
         "s_mov_b32 m0, %[q]\n\t"                                 // (a lane select in m0 is not a second scalar operand)
         "v_writelane_b32 %[ns], %[sym], m0\n\t"                  // entry q of the shifted list = (sym, future + rank - 1)
@@ -721,13 +722,13 @@ __device__ __forceinline__ void rcx_dc_fast_steps(uint32_t& sy, uint32_t& v, uin
         "global_store_byte %[tmp], %[vsym], %[out]\n\t"          // the run's bytes
         "s_mov_b64 exec, -1\n\t"
         "s_mov_b32 %[i], %[stop]\n\t"
-        "s_add_u32 %[di], %[di], 1\n\t"
+        "s_add_u32 %[w], %[w], 1\n\t"
         "s_branch L_top_%=\n\t"
         "L_out_%=:\n\t"
-        : [sy] "+v"(sy), [v] "+v"(v), [i] "+s"(i), [di] "+s"(di), [stop] "=&s"(stop), [sym] "=&s"(sym), [w] "=&s"(w), [d] "=&s"(d), [t] "=&s"(t),
-          [fut] "=&s"(fut), [rank] "=&s"(rank), [q] "=&s"(q), [val] "=&s"(val), [m] "=&s"(m), [cge] "=&s"(cge),
+        : [sy] "+v"(sy), [v] "+v"(v), [i] "+s"(i), [w] "+s"(w), [stop] "=&s"(stop), [sym] "=&s"(sym), [d] "=&s"(d), [t] "=&s"(t),
+          [fut] "=&s"(fut), [q] "=&s"(q), [val] "=&s"(val), [m] "=&s"(m), [cge] "=&s"(cge),
           [tmp] "=&v"(tmp), [vsym] "=&v"(vsym), [ns] "=&v"(ns), [nv] "=&v"(nv)
-        : [n] "s"(n), [lim] "s"(lim), [cur] "v"(cur), [wbase] "s"(wbase), [maskA] "s"(maskA), [bitA] "s"(bitA), [out] "s"(out), [lane] "v"(lane)
+        : [n] "s"(n), [wlim] "s"(wlim), [cur] "v"(cur), [vmask] "s"(vmask), [out] "s"(out), [lane] "v"(lane)
         : "vcc", "scc", "m0", "memory");
 }
 #endif
@@ -745,9 +746,10 @@ __device__ __forceinline__ int dc_decode_steps(LT& L, SeqWin<uint32_t>& wwin, ui
             if (di >= 256u && di < nwords && n < 0xffffff00u && A < 64u) {        // (future + rank is computed in 32 bits there; rank A is a bit of the ballot)
                 wwin.seek(di);
                 uint32_t ui = RCX_UNI(i), udi = RCX_UNI(di);
-                const uint32_t wb = RCX_UNI(wwin.base), lim = RCX_UNI(nwords < wb + 64u ? nwords : wb + 64u);
-                rcx_dc_fast_steps(L.sy, L.v, ui, udi, n, lim, wwin.cur, wb, (1ull << A) - 2ull, 1ull << A, out, lane);
-                i = ui; di = udi;
+                const uint32_t wb = RCX_UNI(wwin.base), wlim = RCX_UNI(nwords - wb < 64u ? nwords - wb : 64u);
+                uint32_t uw = RCX_UNI(udi - wb);
+                rcx_dc_fast_steps(L.sy, L.v, ui, uw, n, wlim, wwin.cur, (1ull << A) - 1ull, out, lane);
+                i = ui; di = wb + uw;
                 if (i >= n) break;
             }
         }
