@@ -376,6 +376,45 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
             const uint32_t hop = ((int)lane < bt.ns && !cont) ? 3u + L + (L >= 15u ? 1u : 0u) + (M >= 19u ? 1u : 0u) : 0u;
             const uint32_t w0 = p0 + rcx_wave_incl_scan(hop) - hop + 1u + (L >= 15u ? 1u : 0u);
             int lo = 0, e = 0;
+#if defined(RCX_DUMMY_SALU) || defined(RCX_DUMMY_VALU) || defined(RCX_DUMMY_VCMP) || defined(RCX_DUMMY_VCMPX) || defined(RCX_DUMMY_RL) || defined(RCX_DUMMY_SNOP) || defined(RCX_DUMMY_BR) || defined(RCX_DUMMY_LDS)
+            {   // port experiment (benchmarks/r5_lz4_ports.sh): N extra instructions a batch on one port, results untouched
+                uint32_t ds_ = 0, dv_ = this->lane;
+#ifdef RCX_DUMMY_SALU
+#pragma unroll
+                for (int k_ = 0; k_ < RCX_DUMMY_SALU; k_++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(ds_) : : "scc");
+#endif
+#ifdef RCX_DUMMY_VALU
+#pragma unroll
+                for (int k_ = 0; k_ < RCX_DUMMY_VALU; k_++) asm volatile("v_add_u32_e32 %0, 1, %0" : "+v"(dv_));
+#endif
+#ifdef RCX_DUMMY_VCMP
+#pragma unroll
+                for (int k_ = 0; k_ < RCX_DUMMY_VCMP; k_++) asm volatile("v_cmp_lt_u32_e32 vcc, %0, %0" : : "v"(dv_) : "vcc");
+#endif
+#ifdef RCX_DUMMY_VCMPX
+#pragma unroll
+                for (int k_ = 0; k_ < RCX_DUMMY_VCMPX; k_++) asm volatile("v_cmpx_le_u32_e32 vcc, %0, %0" : : "v"(dv_) : "vcc");   // (always true: exec stays)
+#endif
+#ifdef RCX_DUMMY_RL
+#pragma unroll
+                for (int k_ = 0; k_ < RCX_DUMMY_RL; k_++) asm volatile("v_readlane_b32 %0, %1, 0" : "=s"(ds_) : "v"(dv_));
+#endif
+#ifdef RCX_DUMMY_SNOP
+#pragma unroll
+                for (int k_ = 0; k_ < RCX_DUMMY_SNOP; k_++) asm volatile("s_nop 0");
+#endif
+#ifdef RCX_DUMMY_BR
+#pragma unroll
+                for (int k_ = 0; k_ < RCX_DUMMY_BR; k_++) asm volatile("s_cbranch_execz 1f\n1:");                                   // (exec is never zero here: not taken)
+#endif
+#ifdef RCX_DUMMY_LDS
+#pragma unroll
+                for (int k_ = 0; k_ < RCX_DUMMY_LDS; k_++) asm volatile("ds_read_b32 %0, %1" : "=v"(dv_) : "v"(0u) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                asm volatile("" : : "s"(ds_), "v"(dv_));
+            }
+#endif
             // CUT 8 (A/B): the executor only drains the ring -- what is left is the parser wave's instructions; 32: nor its own scan
             if (CUT & 8) { if (!(CUT & 32)) this->oend += RCX_U(__builtin_amdgcn_readlane(w0, 63)) & 1u; lo = bt.ns; }
             while (lo < bt.ns && !e) e = this->template emit5<false, PRED, CUT, (SPLIT ? SPLIT : 64)>(bt.ns, lo, w0, w1, nullptr, agey);
