@@ -46,6 +46,9 @@
 #ifndef RCX_AGE_PRIO
 #define RCX_AGE_PRIO 10
 #endif
+#ifndef RCX_DEGUARD
+#define RCX_DEGUARD 1                    /* 0: every section behind its ballot, as before round 5 (A/B) */
+#endif
 #ifndef RCX_AGE_SPLIT
 #define RCX_AGE_SPLIT 2                  /* age ranks below this are "old" */
 #endif
@@ -359,7 +362,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER> {
                     g1 = rcx_u32x4{x0, x1, x2, x3};
                 }
             }
-        } else if (!(CUT & 0x400) && __ballot(lit16)) {
+        } else if (!(CUT & 0x400) && (RCX_DEGUARD ? n >= 32u : __ballot(lit16) != 0)) {      // (RCX_DEGUARD: a ballot guard is a v_cmp, SALU and a branch -- four vector instructions each, DESIGN 3.1 -- around a load that nearly every batch issues anyway)
             // EVERY lane loads (a lane without such literals reads the block's first bytes -- there are >= 32 of them when any lane
             // has lit16 -- and its store below has length 0): no exec juggling, no zeroed registers for the lanes left out
             const uint32_t q = lit16 ? src : 0u;
@@ -370,7 +373,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER> {
         constexpr uint32_t FC = FARCAP < B::MCAP ? (uint32_t)FARCAP : (uint32_t)B::MCAP;
         const bool far16 = isfar && M <= FC && (uint64_t)slo + (uint32_t)B::MCAP <= (uint64_t)cap;      // (k_lz4_decode_v8 batches runs of up to 255 bytes: if one is ever outside the window, byte loads)
         const bool farb = isfar && !far16;
-        if (!(CUT & 0x200) && __ballot(far16)) {                     // the same: all lanes load, from the output's first 64 bytes where there is no far match
+        if (!(CUT & 0x200) && (RCX_DEGUARD ? cap >= 64u : __ballot(far16) != 0)) {   // the same: all lanes load, from the output's first 64 bytes where there is no far match
             const uint32_t q = far16 ? slo : 0u;
             f0 = *(const rcx_u32x4_u*)(out + q);
             if (FC > 16 && __ballot(far16 && M > 16)) f1 = *(const rcx_u32x4_u*)(out + q + 16);
@@ -383,7 +386,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER> {
         unsigned long long dep = 0;
         bool inb = M && !isfar && shi > oend0;
         uint32_t S = off;
-        if (!(CUT & 2) && __ballot(inb)) {
+        if (!(CUT & 2) && (RCX_DEGUARD || __ballot(inb))) {
             uint32_t ka, kb;
             if (LMOK && lmap != nullptr && !__ballot(act && len == 0u)) {       // (an empty entry shares its first byte with the next one: the search handles that)
                 uint8_t* const lcnt = (uint8_t*)(lmap + LMW);
@@ -433,13 +436,13 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER> {
 
         V5P_ADD(5);
         // ---- literals, then gathered matches: registers -> their place in the window
-        if (!(CUT & 4) && __ballot(L != 0)) {
+        if (!(CUT & 4) && (RCX_DEGUARD || __ballot(L != 0))) {
             RCX_LDS_STORE16(wb_ + li_o, g0[0], g0[1], g0[2], g0[3], lit16 ? (L < 16u ? L : 16u) : 0u);
             if (__ballot(lit16 && L > 16)) RCX_LDS_STORE16(wb_ + li_o + 16, g1[0], g1[1], g1[2], g1[3], (lit16 && L > 16u) ? L - 16u : 0u);
             for (uint32_t i = 0; __ballot(litb && i < L); i++)
                 if (litb && i < L) wb_[li_o + (int32_t)i] = in[src + i];
         }
-        if (!(CUT & 4) && __ballot(isfar)) {
+        if (!(CUT & 4) && (RCX_DEGUARD || __ballot(isfar))) {
             uint8_t* d = wb_ + li_m;
             const uint32_t mf = far16 ? M : 0u;
             if (SB != 0 && far16) { uint8_t* sl = wb_ + STAGE5 + SB * (int32_t)lane; *(rcx_u32x4*)sl = f0; if (SB == 32) *(rcx_u32x4*)(sl + 16) = f1; }
@@ -518,7 +521,8 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER> {
                     }
                 }
             };
-            if (CUT & 1) {} else if (__ballot(ovl0 && M > 16u)) rounds(std::true_type{}); else rounds(std::false_type{});
+            if (CUT & 1) {} else if (RCX_DEGUARD && !PROF5 && !(CUT & 64) && !__ballot(pending0)) {}      // (the hand-written loop left nothing: no second look)
+            else if (__ballot(ovl0 && M > 16u)) rounds(std::true_type{}); else rounds(std::false_type{});
             if (!LITLDS) RCX_SETPRIO_FLUSH(young); else if (RCX_INF_ROUNDS_PRIO) __builtin_amdgcn_s_setprio(0);
         }
         V5P_ADD(7);
