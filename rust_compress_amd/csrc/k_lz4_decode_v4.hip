@@ -193,6 +193,16 @@ struct Lz4V4 {
     {
         uint32_t from = gflush;
         if (to <= from) return;
+        if (!ADLER && !final && ((omis + from) & 15u) == 0u) {     // the usual drain: gflush is 16-byte aligned after the block's first one
+            const uint32_t nch = (to - from) >> 4;
+            #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+            for (uint32_t c = RCX_VGPR(lane); c < nch; c += 64) {
+                const uint32_t p = from + 16 * c;
+                *(rcx_u32x4*)(out + p) = *(const rcx_u32x4*)(wb_ + ((int32_t)p - lbase));
+            }
+            gflush = RCX_U(from + nch * 16);
+            return;
+        }
         const uint32_t mis = (uint32_t)((uintptr_t)(out + from) & 15u);
         uint32_t head = mis ? 16u - mis : 0u;
         if (head > to - from) head = final ? to - from : 0u;
@@ -634,6 +644,7 @@ struct Lz4V4 {
     __device__ __forceinline__ int after_batch(const Batch& bt, int& st)
     {
         int why = bt.why;
+        if (why == GO || why == STAGE_) return 0;              // (the usual batch: one test, not four)
         if (why == END_) return 1;
         if (why == ERR_) { st = bt.perr > 0 ? bt.perr : ((bt.gL > cap - oend) ? RCX_E_OUTPUT_TOO_SMALL : RCX_E_MALFORMED); return 1; }
         if (why == SOLO_) {

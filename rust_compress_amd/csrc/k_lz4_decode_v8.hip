@@ -360,9 +360,12 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
             rcx_wave_sync();
             const RCX_LDS_AS Slot8* sl = &ring->slot[tail % NSLOT8];
             typename B::Batch bt;
-            bt.ns = (int)RCX_U(sl->hdr[0]); bt.why = (int)RCX_U(sl->hdr[1]); bt.perr = (int)RCX_U(sl->hdr[2]);
-            bt.gL = RCX_U(sl->hdr[3]); bt.gM = RCX_U(sl->hdr[4]); bt.goff = RCX_U(sl->hdr[5]); bt.gsrc = RCX_U(sl->hdr[6]);
-            bt.gnext = 0;
+            bt.ns = (int)RCX_U(sl->hdr[0]); bt.why = (int)RCX_U(sl->hdr[1]);
+            bt.perr = 0; bt.gL = 0; bt.gM = 0; bt.goff = 0; bt.gsrc = 0; bt.gnext = 0;
+            if (bt.why != B::GO) {                        // the one long sequence / the error behind the batch: only then (five v_readfirstlane: scalar-port work)
+                bt.perr = (int)RCX_U(sl->hdr[2]);
+                bt.gL = RCX_U(sl->hdr[3]); bt.gM = RCX_U(sl->hdr[4]); bt.goff = RCX_U(sl->hdr[5]); bt.gsrc = RCX_U(sl->hdr[6]);
+            }
             const uint32_t p0 = RCX_U(sl->hdr[7]);
             uint32_t w1 = sl->d[lane];
             rcx_wave_sync();
