@@ -766,6 +766,25 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER> {
 #ifdef INF3_PROF
             pf[6] += 1;
 #endif
+#if defined(INF3_DUMMY_SALU) || defined(INF3_DUMMY_VALU) || defined(INF3_DUMMY_LDS)
+            {   // port experiment (benchmarks/r5_inflate_ports.sh): N extra instructions a chunk of 64 symbols on one port, results untouched
+                uint32_t ds_ = 0, dv_ = lane;
+#ifdef INF3_DUMMY_SALU
+#pragma unroll
+                for (int k_ = 0; k_ < INF3_DUMMY_SALU; k_++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(ds_) : : "scc");
+#endif
+#ifdef INF3_DUMMY_VALU
+#pragma unroll
+                for (int k_ = 0; k_ < INF3_DUMMY_VALU; k_++) asm volatile("v_add_u32_e32 %0, 1, %0" : "+v"(dv_));
+#endif
+#ifdef INF3_DUMMY_LDS
+#pragma unroll
+                for (int k_ = 0; k_ < INF3_DUMMY_LDS; k_++) asm volatile("ds_read_b32 %0, %1" : "=v"(dv_) : "v"(0u) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+                asm volatile("" : : "s"(ds_), "v"(dv_));
+            }
+#endif
             uint32_t j = 0;                                          // the lane whose map holds symbol `lane`: the number of lanes with incl <= lane
 #pragma unroll
             for (int step = 32; step >= 1; step >>= 1) {
