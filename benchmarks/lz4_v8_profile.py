@@ -23,4 +23,5 @@ print("kind %s, %d blocks: parser total %.0fK cycles, executor total %.0fK" % (k
 print("  cycles: " + "  ".join("%s %.0fK" % (names[i], p[i] / 1e3) for i in range(5)))
 print("  counts: " + "  ".join("%s %.1f" % (names[i], p[i]) for i in range(6, 10)))
 e = p[16:28]
+print("  executor: header+scan %.0fK  make_room %.0fK  after_batch %.0fK  | of the waiting, for the first batch: %.0fK" % (e[1] / 1e3, e[11] / 1e3, e[3] / 1e3, e[9] / 1e3))
 print("  executor: waiting for a batch %.0fK | scan+validate %.0fK  loads+chains %.0fK  lit/gather stores %.0fK  copy rounds %.0fK  flush %.0fK | rounds %.1f  emit calls %.1f  batches %.1f" % (e[0] / 1e3, e[4] / 1e3, e[5] / 1e3, e[6] / 1e3, e[7] / 1e3, e[8] / 1e3, e[9], e[10], e[2]))

@@ -57,6 +57,11 @@
 // bit 3: the older half drains one level down
 #define RCX_SETPRIO_FLUSH(young) do { if ((RCX_AGE_PRIO & 8) && !(young)) __builtin_amdgcn_s_setprio(RCX_FLUSH_PRIO - 1); else __builtin_amdgcn_s_setprio(RCX_FLUSH_PRIO); } while (0)
 #include <type_traits>
+#ifdef RCX_MARKS
+#define RCX_MARK(name) asm volatile("; MARK " name)
+#else
+#define RCX_MARK(name) do { } while (0)
+#endif
 
 // The copy rounds of emit5 as ISA (gfx950): every round, the lanes whose producers are done (no pending lane among `dep`) and
 // whose match does not overlap itself copy up to 16 bytes -- five aligned dword reads + v_alignbyte, the exec-narrowing byte
@@ -307,8 +312,11 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER> {
         const uint8_t* in = this->in; uint8_t* out = this->out; uint8_t* wb_ = this->wb_;
         const uint32_t cap = this->cap, n = this->n;
         uint64_t tq_ = PROF5 ? (uint64_t)__builtin_readcyclecounter() : 0;
-#define V5P_ADD(slot) do { if (PROF5) { const uint64_t t1_ = (uint64_t)__builtin_readcyclecounter(); pw[slot] += t1_ - tq_; tq_ = t1_; } } while (0)
+#define V5P_ADD(slot) do { RCX_MARK("emit5_" #slot); if (PROF5) { const uint64_t t1_ = (uint64_t)__builtin_readcyclecounter(); pw[slot] += t1_ - tq_; tq_ = t1_; } } while (0)
+        RCX_MARK("emit5_in");
         this->make_room(B::TCAP);
+        RCX_MARK("emit5_room");
+        V5P_ADD(11);
         const int lo0 = lo;
         bool act = (int)lane >= lo && (int)lane < ns;
         uint32_t L = act ? w1 & 0xffu : 0u, M = act ? (w1 >> 8) & 0xffu : 0u, off = act ? w1 >> 16 : 0u;
@@ -467,7 +475,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER> {
             bool pending0 = M != 0 && !farb && !(SB == 0 && far16);
             uint32_t prog0 = 0;
 #ifndef RCX_NO_ROUNDS_ASM
-            if (!PROF5 && !(CUT & 1) && !(CUT & 64)) {    // the hand-written loop takes every round the plain (non-overlapping) lanes can make
+            if (!(CUT & 1) && !(CUT & 64)) {    // the hand-written loop takes every round the plain (non-overlapping) lanes can make
                 if (CUT & 128) __builtin_amdgcn_s_setprio(1);
                 const uint32_t wa = (uint32_t)(uintptr_t)wb_;      // (low half of a generic LDS pointer = the LDS byte address)
                 uint64_t left;
@@ -521,7 +529,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER> {
                     }
                 }
             };
-            if (CUT & 1) {} else if (RCX_DEGUARD && !PROF5 && !(CUT & 64) && !__ballot(pending0)) {}      // (the hand-written loop left nothing: no second look)
+            if (CUT & 1) {} else if (RCX_DEGUARD && !(CUT & 64) && !__ballot(pending0)) {}      // (the hand-written loop left nothing: no second look)
             else if (__ballot(ovl0 && M > 16u)) rounds(std::true_type{}); else rounds(std::false_type{});
             if (!LITLDS) RCX_SETPRIO_FLUSH(young); else if (RCX_INF_ROUNDS_PRIO) __builtin_amdgcn_s_setprio(0);
         }

@@ -32,6 +32,27 @@
 #ifndef RCX_V8_ESLEEP
 #define RCX_V8_ESLEEP 4
 #endif
+#ifndef RCX_WALK_FORM
+#define RCX_WALK_FORM 0                  /* 0: eight bytes + a second read where needed (portable), 1: sixteen bytes, the step as ISA */
+#endif
+#ifndef RCX_WALK_PRIO
+#define RCX_WALK_PRIO RCX_PARSER_PRIO    /* issue priority while a chunk after the first is staged, walked and linked */
+#endif
+// RCX_V8_ADAPT: the parser's issue priority follows the ring.  The executors are the launch's critical waves and the parser idles
+// 40 % of its life, so the parser runs COLD while the executor has RCX_V8_LOW batches or more in front of it and HOT when the ring
+// runs low (the first chunk of a block, a chunk boundary the ring does not cover).
+#ifndef RCX_V8_ADAPT
+#define RCX_V8_ADAPT 0
+#endif
+#ifndef RCX_V8_LOW
+#define RCX_V8_LOW 3
+#endif
+#ifndef RCX_V8_HOT
+#define RCX_V8_HOT 3
+#endif
+#ifndef RCX_V8_COLD
+#define RCX_V8_COLD 1
+#endif
 #define V8P_T0() uint64_t t0_ = PROF8 ? (uint64_t)__builtin_readcyclecounter() : 0
 #define V8P_ADD(slot) do { if (PROF8) { const uint64_t t1_ = (uint64_t)__builtin_readcyclecounter(); pp[slot] += t1_ - t0_; t0_ = t1_; } } while (0)
 
@@ -113,26 +134,112 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
         }
         return q;
     }
-    // The same from the staged bytes: p lies in [cbase, chunk end) (the walk never leaves them), so token and extension byte are
-    // staged; long literal runs, longer extension chains and the last 20 bytes of the block go through next_tok.
-    __device__ __forceinline__ uint32_t next_tok_c(uint32_t p) const
+    // The same from the staged bytes: p lies in [cbase, chunk end) (the walk never leaves them).  ONE LDS round trip for nearly every
+    // token: three aligned dwords give the eight bytes from p on -- the token, the literal-length extension, and (79 % of a text's
+    // tokens have no literals) the match-length extension at p + 3; an extension byte further on is a second read.  A run of 255s
+    // (a literal run of 270 bytes or more, a match of 274), bytes that are not staged and the last 20 bytes of the block go
+    // through next_tok.  Round 5: the walk's step was the token byte, then the extension byte, and a call of next_tok whenever ANY of
+    // the 64 lanes met a literal run of 15 or more -- most steps; 970 cycles a step with the CU to itself, and the executor waited
+    // for its first batch and at chunk boundaries for 11 % of the kernel's time.
+    __device__ __forceinline__ uint32_t next_tok_c(uint32_t p, bool on = true) const
     {
         const uint32_t n = this->n;
-        const RCX_LDS_AS uint8_t* cb = (const RCX_LDS_AS uint8_t*)this->cbuf;
-        uint32_t q = 0;
         bool slow = n < 20u || p > n - 20u;
-        if (!slow) {
-            const int32_t i = (int32_t)p - this->cbase;
-            const uint32_t t = cb[i];
-            const uint32_t L = t >> 4;
-            q = p + 3u + L;
-            if (L == 15u) slow = true;
-            else if ((t & 15u) == 15u) {
-                const uint32_t x = cb[i + 3 + (int32_t)L];
+        const int32_t i = (on && !slow) ? (int32_t)p - this->cbase : 0;      // (a lane that is not walking reads the buffer's first bytes)
+        uint32_t q;
+#if RCX_WALK_FORM == 0
+        // eight bytes in one round trip (three aligned dwords), a second read where the match-length extension lies further on
+        q = 0;
+        if (on && !slow) {
+            const uint32_t* a = (const uint32_t*)(this->cbuf + (i & ~3));
+            const uint32_t sh = (uint32_t)i & 3u;
+            const uint32_t d0 = a[0], d1 = a[1], d2 = a[2];
+            const uint32_t w0 = RCX_ALIGNBYTE(d1, d0, sh), w1 = RCX_ALIGNBYTE(d2, d1, sh);      // bytes p .. p + 7
+            const uint32_t t = w0 & 0xffu, b1 = (w0 >> 8) & 0xffu;
+            uint32_t L = t >> 4, hop = 3u;                            // hop: token, literals, offset -- where the match-length extension would be
+            if (L == 15u) { L += b1; hop = 4u; if (b1 == 255u) slow = true; }
+            hop += L;
+            q = p + hop;
+            if (q >= n) slow = true;                                  // (only a long literal run gets there: p <= n - 20)
+            if ((t & 15u) == 15u && !slow) {
+                uint32_t x;
+                if (hop < 8u) x = ((hop < 4u ? w0 : w1) >> (8u * (hop & 3u))) & 0xffu;
+                else if (i + (int32_t)hop < CBUF8) x = ((const RCX_LDS_AS uint8_t*)this->cbuf)[i + (int32_t)hop];
+                else x = 255u;
                 if (x == 255u) slow = true; else q++;
             }
         }
-        return slow ? next_tok(p) : q;
+#elif !defined(RCX_NO_WALK_ASM)
+        // The step as ISA: hipcc turns every select and every `||` of the portable form below into an s_and_saveexec / branch pair
+        // (~100 instructions, 35 of them on the scalar port, a second LDS round trip wherever a lane needs byte 8 or later).  Here:
+        // five aligned dwords in one round trip, 29 vector instructions, 5 compares.  The byte at `hop` of sixteen is two v_perm
+        // (selector 13 = 0xff: a byte not among the sixteen reads as "the extension goes on" and the lane takes the slow path).
+        {
+            const uint32_t ad = (uint32_t)(uintptr_t)this->cbuf + (uint32_t)i;     // (low half of a generic LDS pointer = the LDS byte address)
+            const uint32_t a4 = ad & ~3u, sh = ad & 3u;
+            uint64_t d01, d23; uint32_t d4;
+            asm volatile("ds_read2_b32 %0, %3 offset1:1\n\tds_read2_b32 %1, %3 offset0:2 offset1:3\n\tds_read_b32 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(d01), "=&v"(d23), "=&v"(d4) : "v"(a4) : "memory");
+            const uint32_t d0 = (uint32_t)d01, d1 = (uint32_t)(d01 >> 32), d2 = (uint32_t)d23, d3 = (uint32_t)(d23 >> 32);
+            uint32_t w0, w1, w2, w3, L, t1, hop, tm, hop2, sel, xlo, xhi, inc;
+            uint64_t sA, sB, sm;
+            asm volatile(
+                "v_alignbyte_b32 %[w0], %[d1], %[d0], %[sh]\n\t"
+                "v_alignbyte_b32 %[w1], %[d2], %[d1], %[sh]\n\t"
+                "v_bfe_u32 %[L], %[w0], 4, 4\n\t"
+                "v_bfe_u32 %[t1], %[w0], 8, 8\n\t"
+                "v_cmp_eq_u32_e32 vcc, 15, %[L]\n\t"
+                "v_alignbyte_b32 %[w2], %[d3], %[d2], %[sh]\n\t"
+                "v_alignbyte_b32 %[w3], %[d4], %[d3], %[sh]\n\t"
+                "v_add_u32_e32 %[t1], 16, %[t1]\n\t"
+                "v_cndmask_b32_e32 %[hop], %[L], %[t1], vcc\n\t"          // 15 + the extension byte + one more byte in front of the offset
+                "v_add_u32_e32 %[hop], 3, %[hop]\n\t"
+                "v_and_b32_e32 %[tm], 15, %[w0]\n\t"
+                "v_add_u32_e32 %[q], %[p], %[hop]\n\t"
+                "v_cmp_gt_u32_e32 vcc, 8, %[hop]\n\t"
+                "v_add_u32_e32 %[hop2], -8, %[hop]\n\t"
+                "v_and_b32_e32 %[sel], 7, %[hop]\n\t"
+                "v_cmp_gt_u32_e64 %[sA], 8, %[hop2]\n\t"
+                "v_perm_b32 %[xlo], %[w1], %[w0], %[sel]\n\t"
+                "v_add_u32_e32 %[inc], 1, %[tm]\n\t"
+                "v_cndmask_b32_e64 %[sel], 13, %[hop2], %[sA]\n\t"
+                "v_perm_b32 %[xhi], %[w3], %[w2], %[sel]\n\t"
+                "v_cndmask_b32_e32 %[xlo], %[xhi], %[xlo], vcc\n\t"
+                "v_lshrrev_b32_e32 %[inc], 4, %[inc]\n\t"
+                "v_and_b32_e32 %[xlo], 0xff, %[xlo]\n\t"
+                "v_lshl_or_b32 %[xlo], %[tm], 8, %[xlo]\n\t"
+                "v_cmp_eq_u32_e32 vcc, 0xfff, %[xlo]\n\t"                // match length 15 and its extension 255 (or out of sight)
+                "v_cmp_ge_u32_e64 %[sA], %[q], %[n]\n\t"                 // (only a long literal run gets there: p <= n - 20)
+                "v_cmp_le_u32_e64 %[sB], %[k274], %[hop]\n\t"            // literal length 15 and its extension 255
+                "v_add_u32_e32 %[q], %[q], %[inc]\n\t"
+                "s_or_b64 vcc, vcc, %[sA]\n\t"
+                "s_or_b64 %[sm], vcc, %[sB]\n\t"
+                : [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [L] "=&v"(L), [t1] "=&v"(t1), [hop] "=&v"(hop), [tm] "=&v"(tm),
+                  [hop2] "=&v"(hop2), [sel] "=&v"(sel), [xlo] "=&v"(xlo), [xhi] "=&v"(xhi), [inc] "=&v"(inc), [q] "=&v"(q), [sA] "=&s"(sA), [sB] "=&s"(sB), [sm] "=&s"(sm)
+                : [d0] "v"(d0), [d1] "v"(d1), [d2] "v"(d2), [d3] "v"(d3), [d4] "v"(d4), [sh] "v"(sh), [p] "v"(p), [n] "s"(n), [k274] "s"(274u)
+                : "vcc", "scc");
+            slow = slow || RCX_INV_BALLOT(sm);
+        }
+#else
+        {
+            const uint32_t* a = (const uint32_t*)(this->cbuf + (i & ~3));
+            const uint32_t sh = (uint32_t)i & 3u;
+            const uint32_t d0 = a[0], d1 = a[1], d2 = a[2], d3 = a[3], d4 = a[4];
+            const uint32_t w0 = RCX_ALIGNBYTE(d1, d0, sh), w1 = RCX_ALIGNBYTE(d2, d1, sh), w2 = RCX_ALIGNBYTE(d3, d2, sh), w3 = RCX_ALIGNBYTE(d4, d3, sh);   // bytes p .. p + 15
+            const uint32_t t = w0 & 0xffu, b1 = (w0 >> 8) & 0xffu;
+            const bool l15 = (t >> 4) == 15u;
+            const uint32_t L = l15 ? 15u + b1 : t >> 4;
+            const uint32_t hop = L + (l15 ? 4u : 3u);                // token, extension, literals, offset: where the match-length extension would be
+            q = p + hop;
+            const bool m15 = (t & 15u) == 15u;
+            const uint32_t ws = hop < 8u ? (hop < 4u ? w0 : w1) : (hop < 12u ? w2 : w3);
+            const uint32_t x = (ws >> (8u * (hop & 3u))) & 0xffu;
+            slow = slow || (l15 && b1 == 255u) || q >= n || (m15 && (hop >= 16u || x == 255u));      // (q >= n: only a long run gets there, p <= n - 20)
+            q += m15 ? 1u : 0u;
+        }
+#endif
+        if (on && slow) q = next_tok(p);
+        return q;
     }
 
     // Stage [cs - PRE, cs + CH + CSLACK) of the input (what exists of it); (cs + the input's misalignment) is a multiple of 16.
@@ -223,6 +330,10 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
         }
     }
 
+    __device__ __forceinline__ void ring_prio(uint32_t head)
+    {
+        if (head - RCX_U(this->ring8->tail) < (uint32_t)RCX_V8_LOW) __builtin_amdgcn_s_setprio(RCX_V8_HOT); else __builtin_amdgcn_s_setprio(RCX_V8_COLD);
+    }
     // post one batch (p0: where its first token starts); returns false when the executor has given up
     // lane's token becomes entry `idx` (and idx + 1 when w1b != 0) of the batch, if `put`
     __device__ __forceinline__ bool post(uint32_t& head, int ns, int why, int perr, uint32_t gL, uint32_t gM, uint32_t goff, uint32_t gsrc, uint32_t p0, bool put, uint32_t idx, uint32_t w1, uint32_t w1b)
@@ -236,7 +347,8 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_sleep(RCX_V8_PSLEEP);
         }
-        if ((RCX_AGE_PRIO & 16) && this->agey) __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO + 1); else __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO);
+        if (RCX_V8_ADAPT) ring_prio(head);
+        else if ((RCX_AGE_PRIO & 16) && this->agey) __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO + 1); else __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO);
         rcx_wave_sync();
         RCX_LDS_AS Slot8* sl = &ring->slot[head % NSLOT8];
         if (put) { sl->d[idx] = w1; if (w1b) sl->d[idx + 1] = w1b; }
@@ -356,18 +468,21 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
         for (;;) {
             uint64_t te0 = PROF8 ? (uint64_t)__builtin_readcyclecounter() : 0;
             while (RCX_U(ring->head) == tail) __builtin_amdgcn_s_sleep(RCX_V8_ESLEEP);
-            if (PROF8) { this->pw[0] += (uint64_t)__builtin_readcyclecounter() - te0; this->pw[2] += 1; }
+            if (PROF8) { const uint64_t w_ = (uint64_t)__builtin_readcyclecounter() - te0; this->pw[0] += w_; this->pw[2] += 1; if (tail == 0) this->pw[9] = w_; }
+            uint64_t te1 = PROF8 ? (uint64_t)__builtin_readcyclecounter() : 0;
+            RCX_MARK("x8_polled");
             rcx_wave_sync();
             const RCX_LDS_AS Slot8* sl = &ring->slot[tail % NSLOT8];
             typename B::Batch bt;
-            bt.ns = (int)RCX_U(sl->hdr[0]); bt.why = (int)RCX_U(sl->hdr[1]);
+            const uint32_t h0_ = sl->hdr[0], h1_ = sl->hdr[1], h7_ = sl->hdr[7];      // (all of the slot's usual reads in one LDS round trip)
+            uint32_t w1 = sl->d[lane];
+            bt.ns = (int)RCX_U(h0_); bt.why = (int)RCX_U(h1_);
             bt.perr = 0; bt.gL = 0; bt.gM = 0; bt.goff = 0; bt.gsrc = 0; bt.gnext = 0;
             if (bt.why != B::GO) {                        // the one long sequence / the error behind the batch: only then (five v_readfirstlane: scalar-port work)
                 bt.perr = (int)RCX_U(sl->hdr[2]);
                 bt.gL = RCX_U(sl->hdr[3]); bt.gM = RCX_U(sl->hdr[4]); bt.goff = RCX_U(sl->hdr[5]); bt.gsrc = RCX_U(sl->hdr[6]);
             }
-            const uint32_t p0 = RCX_U(sl->hdr[7]);
-            uint32_t w1 = sl->d[lane];
+            const uint32_t p0 = RCX_U(h7_);
             rcx_wave_sync();
             tail++;
             if (lane == 0) ring->tail = tail;             // the slot is in registers: hand it back
@@ -379,6 +494,8 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
             const uint32_t hop = ((int)lane < bt.ns && !cont) ? 3u + L + (L >= 15u ? 1u : 0u) + (M >= 19u ? 1u : 0u) : 0u;
             const uint32_t w0 = p0 + rcx_wave_incl_scan(hop) - hop + 1u + (L >= 15u ? 1u : 0u);
             int lo = 0, e = 0;
+            RCX_MARK("x8_pre_emit");
+            if (PROF8) { const uint64_t t_ = (uint64_t)__builtin_readcyclecounter(); this->pw[1] += t_ - te1; te1 = t_; }
 #if defined(RCX_DUMMY_SALU) || defined(RCX_DUMMY_VALU) || defined(RCX_DUMMY_VCMP) || defined(RCX_DUMMY_VCMPX) || defined(RCX_DUMMY_RL) || defined(RCX_DUMMY_SNOP) || defined(RCX_DUMMY_BR) || defined(RCX_DUMMY_LDS)
             {   // port experiment (benchmarks/r5_lz4_ports.sh): N extra instructions a batch on one port, results untouched
                 uint32_t ds_ = 0, dv_ = this->lane;
@@ -421,8 +538,12 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
             // CUT 8 (A/B): the executor only drains the ring -- what is left is the parser wave's instructions; 32: nor its own scan
             if (CUT & 8) { if (!(CUT & 32)) this->oend += RCX_U(__builtin_amdgcn_readlane(w0, 63)) & 1u; lo = bt.ns; }
             while (lo < bt.ns && !e) e = this->template emit5<false, PRED, CUT, (SPLIT ? SPLIT : 64)>(bt.ns, lo, w0, w1, nullptr, agey);
+            RCX_MARK("x8_post_emit");
             if (e) { st = e; break; }
+            if (PROF8) te1 = (uint64_t)__builtin_readcyclecounter();
             if (this->after_batch(bt, st)) break;
+            if (PROF8) this->pw[3] += (uint64_t)__builtin_readcyclecounter() - te1;
+            RCX_MARK("x8_loop_end");
         }
         if (st && lane == 0) ring->abort_ = 1;
         if (!st) this->flush(this->oend, true);
@@ -442,7 +563,9 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
         uint32_t lcnt = 0;                                           // list entries carried over from the last chunk
         while (c < n) {
             V8P_T0();
-            if ((RCX_AGE_PRIO & 16) && this->agey) __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO + 1); else __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO);   // (the ring drains while a chunk is staged, walked and linked)
+            if (RCX_V8_ADAPT) ring_prio(head);
+            else if (c != 0 && RCX_WALK_PRIO != RCX_PARSER_PRIO) __builtin_amdgcn_s_setprio(RCX_WALK_PRIO);
+            else if ((RCX_AGE_PRIO & 16) && this->agey) __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO + 1); else __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO);   // (the ring drains while a chunk is staged, walked and linked)
             stage8(cs);
             const int nseg = ((int64_t)n - cs >= CH) ? NSEG : (int)(((int64_t)n - cs + SEGB - 1) / SEGB);
             const int k0 = (int)(((int32_t)c - cs) / SEGB);
@@ -457,17 +580,28 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
             int32_t p0 = s - PRE; p0 = p0 < 0 ? 0 : p0;
             uint32_t p = ((int)lane == k0) ? c : (uint32_t)p0;
             uint64_t map = (giant && (int)lane == k0) ? 1ull << (c - (uint32_t)s) : 0ull;
-            for (;;) {
+            RCX_MARK("p8_walk");
+            for (uint32_t wstep = 0;; wstep++) {
                 const bool go = mine && p < e;
                 if (!__ballot(go)) break;
                 if (PROF8) pp[7] += 1;
+                if (RCX_V8_ADAPT && (wstep & 3u) == 3u) ring_prio(head);
+#if RCX_WALK_FORM == 0
                 if (go) {
                     if ((int32_t)p >= s) map |= 1ull << (p - (uint32_t)s);
                     p = next_tok_c(p);
                 }
+#else
+                const uint32_t q = next_tok_c(p, go);                // (no branch around the step: every lane computes, the walking ones keep the result)
+                const uint64_t bit = (go && (int32_t)p >= s) ? 1ull << ((p - (uint32_t)s) & 63u) : 0ull;
+                map |= bit;
+                p = go ? q : p;
+#endif
             }
+            RCX_MARK("p8_walk_end");
             const uint32_t ex = p;                                   // where the segment's walk left it
             V8P_ADD(0);
+            if (RCX_V8_ADAPT) ring_prio(head);
             // ---- 2. link the segments.  Every lane first checks the usual case by itself: the walk of the segment before mine left
             // it at a byte my map has marked.  What is left -- a jump over a segment, walks that have not met -- is settled in
             // order by scalar code over the lanes' registers (and whatever that changes is checked again downstream).
@@ -521,6 +655,7 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
             // ---- 3. a lane per token: the maps unpacked into a position list (eight input bytes a lane), 64 entries a batch
             const int nwin = (nseg + LWIN - 1) / LWIN;
             for (int w = k0 / LWIN; w < nwin; w++) {
+                if (RCX_V8_ADAPT) ring_prio(head);
                 const int sl = LWIN * w + (int)(lane >> 3);                   // the segment whose map byte (lane & 7) this lane unpacks
                 const uint32_t mlo = (uint32_t)__builtin_amdgcn_ds_bpermute(sl << 2, (int)(uint32_t)map);
                 const uint32_t mhi = (uint32_t)__builtin_amdgcn_ds_bpermute(sl << 2, (int)(uint32_t)(map >> 32));

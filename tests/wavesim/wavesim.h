@@ -311,6 +311,7 @@ static inline uint32_t ws_wave_incl_scan(uint32_t v)
 #define RCX_RCPF(x) (1.0f / (x))       // v_rcp_f32: rcx_div_u13 is exact whatever the reciprocal's last bits are
 #define RCX_NO_INF_WALK_ASM 1          // Inf3::tile4's hand-written hop loop: the simulator walks with the portable hop4 alone
 #define RCX_NO_DC_STEPS_ASM 1          // k_dc_decode's hand-written step loop: the simulator runs the portable step alone
+#define RCX_NO_WALK_ASM 1              // Lz4V8::next_tok_c's hand-written step: the simulator runs the portable form
 #define RCX_NO_ROUNDS_ASM 1            // emit5's hand-written copy-round loop: the simulator runs the portable loop alone
 #define RCX_LDS_STORE16 ws_lds_store16
 static inline uint32_t ws_sad_u8(uint32_t a, uint32_t c) { return c + (a & 255u) + ((a >> 8) & 255u) + ((a >> 16) & 255u) + (a >> 24); }          // v_sad_u8 against 0
