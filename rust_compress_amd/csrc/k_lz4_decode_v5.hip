@@ -407,14 +407,14 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER> {
                 const uint32_t ex = rcx_wave_incl_scan(pc) - pc;
                 if (lane < (unsigned)LMW) lcnt[lane] = (uint8_t)ex;
                 rcx_wave_sync();
-                auto entry_of = [&](uint32_t x) -> uint32_t {                    // the active entry whose first byte is the last one <= x
-                    uint32_t r = x - oend0;
-                    r = r < (uint32_t)B::TCAP ? r : (uint32_t)B::TCAP;
-                    const uint32_t w = r >> 5;
-                    return (uint32_t)lo0 + (uint32_t)lcnt[w] + (uint32_t)__popc(lmap[w] & (0xffffffffu >> (31u - (r & 31u)))) - 1u;
-                };
-                ka = entry_of(slo > oend0 ? slo : oend0) & 63u;
-                kb = entry_of(shi > oend0 ? shi - 1 : oend0) & 63u;
+                // entry_of(x): the active entry whose first byte is the last one <= x = lo0 + lcnt[w] + popc(lmap[w] up to x's bit) - 1
+                // (both lookups' four reads in one LDS round trip: hipcc waits for the first pair before it asks for the second)
+                uint32_t ra = (slo > oend0 ? slo : oend0) - oend0, rb = (shi > oend0 ? shi - 1 : oend0) - oend0;
+                ra = ra < (uint32_t)B::TCAP ? ra : (uint32_t)B::TCAP; rb = rb < (uint32_t)B::TCAP ? rb : (uint32_t)B::TCAP;
+                uint32_t ca = lcnt[ra >> 5], ma = lmap[ra >> 5], cb2 = lcnt[rb >> 5], mb = lmap[rb >> 5];
+                RCX_SETTLE4(ca, ma, cb2, mb);
+                ka = ((uint32_t)lo0 + ca + (uint32_t)__popc(ma & (0xffffffffu >> (31u - (ra & 31u)))) - 1u) & 63u;
+                kb = ((uint32_t)lo0 + cb2 + (uint32_t)__popc(mb & (0xffffffffu >> (31u - (rb & 31u)))) - 1u) & 63u;
             } else {
                 ka = this->lane_of(ostart, slo > oend0 ? slo : oend0);
                 kb = this->lane_of(ostart, shi > oend0 ? shi - 1 : oend0);

@@ -41,17 +41,22 @@
 // RCX_V8_ADAPT: the parser's issue priority follows the ring.  The executors are the launch's critical waves and the parser idles
 // 40 % of its life, so the parser runs COLD while the executor has RCX_V8_LOW batches or more in front of it and HOT when the ring
 // runs low (the first chunk of a block, a chunk boundary the ring does not cover).
+// Measured on the headline (benchmarks/r5_lz4_flagcount.sh, one box, ms): fixed priority 2 (round 4) 0.5486 / 0.5451 | LOW 3 HOT 3 COLD 1
+// 0.556 | COLD 0: LOW 3 0.539-0.541, LOW 4 0.532, LOW 6 0.541, LOW 8 0.559 | LOW 4 HOT 2 COLD 0 0.545.
+#ifndef RCX_V8_PREFETCH
+#define RCX_V8_PREFETCH 0
+#endif
 #ifndef RCX_V8_ADAPT
-#define RCX_V8_ADAPT 0
+#define RCX_V8_ADAPT 1
 #endif
 #ifndef RCX_V8_LOW
-#define RCX_V8_LOW 3
+#define RCX_V8_LOW 4
 #endif
 #ifndef RCX_V8_HOT
 #define RCX_V8_HOT 3
 #endif
 #ifndef RCX_V8_COLD
-#define RCX_V8_COLD 1
+#define RCX_V8_COLD 0
 #endif
 #define V8P_T0() uint64_t t0_ = PROF8 ? (uint64_t)__builtin_readcyclecounter() : 0
 #define V8P_ADD(slot) do { if (PROF8) { const uint64_t t1_ = (uint64_t)__builtin_readcyclecounter(); pp[slot] += t1_ - t0_; t0_ = t1_; } } while (0)
@@ -567,6 +572,13 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
             else if (c != 0 && RCX_WALK_PRIO != RCX_PARSER_PRIO) __builtin_amdgcn_s_setprio(RCX_WALK_PRIO);
             else if ((RCX_AGE_PRIO & 16) && this->agey) __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO + 1); else __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO);   // (the ring drains while a chunk is staged, walked and linked)
             stage8(cs);
+#if RCX_V8_PREFETCH
+            {   // the next chunk's cache lines on their way to the L2 while this one is parsed (gfx950 has no prefetch instruction: a load
+                // nobody waits for -- the parser's next vector-memory wait is the next chunk's staging)
+                const int64_t q = (int64_t)cs + CH + CSLACK + 64 * (int64_t)lane;
+                if (q >= 0 && q + 4 <= (int64_t)n) { const uint32_t x = *(const rcx_u32_u*)(this->in + q); asm volatile("" : : "v"(x)); }
+            }
+#endif
             const int nseg = ((int64_t)n - cs >= CH) ? NSEG : (int)(((int64_t)n - cs + SEGB - 1) / SEGB);
             const int k0 = (int)(((int32_t)c - cs) / SEGB);
             // ---- 1. every segment walked at once (a lane each)

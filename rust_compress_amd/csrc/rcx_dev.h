@@ -178,6 +178,8 @@ __device__ __forceinline__ void rcx_lds_store16(uint8_t* p, uint32_t v0, uint32_
 #ifndef RCX_VGPR
 __device__ __forceinline__ uint32_t rcx_vgpr(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
 #define RCX_VGPR(x) rcx_vgpr(x)
+// "all of these have been requested before any is used": keeps hipcc from waiting for one load before it issues the next
+#define RCX_SETTLE4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 #endif
 
 // Cross-lane ordering inside one wave for traffic through LDS/global: hardware executes a wave's
