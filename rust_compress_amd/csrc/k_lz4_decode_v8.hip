@@ -52,6 +52,9 @@
 #ifndef RCX_V8_LOW
 #define RCX_V8_LOW 4
 #endif
+#ifndef RCX_V8_LOW_WALK
+#define RCX_V8_LOW_WALK RCX_V8_LOW       /* the same threshold while a chunk is staged, walked and linked (a long stretch without a batch) */
+#endif
 #ifndef RCX_V8_HOT
 #define RCX_V8_HOT 3
 #endif
@@ -335,9 +338,9 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
         }
     }
 
-    __device__ __forceinline__ void ring_prio(uint32_t head)
+    __device__ __forceinline__ void ring_prio(uint32_t head, uint32_t low = RCX_V8_LOW)
     {
-        if (head - RCX_U(this->ring8->tail) < (uint32_t)RCX_V8_LOW) __builtin_amdgcn_s_setprio(RCX_V8_HOT); else __builtin_amdgcn_s_setprio(RCX_V8_COLD);
+        if (head - RCX_U(this->ring8->tail) < low) __builtin_amdgcn_s_setprio(RCX_V8_HOT); else __builtin_amdgcn_s_setprio(RCX_V8_COLD);
     }
     // post one batch (p0: where its first token starts); returns false when the executor has given up
     // lane's token becomes entry `idx` (and idx + 1 when w1b != 0) of the batch, if `put`
@@ -568,7 +571,7 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
         uint32_t lcnt = 0;                                           // list entries carried over from the last chunk
         while (c < n) {
             V8P_T0();
-            if (RCX_V8_ADAPT) ring_prio(head);
+            if (RCX_V8_ADAPT) ring_prio(head, RCX_V8_LOW_WALK);
             else if (c != 0 && RCX_WALK_PRIO != RCX_PARSER_PRIO) __builtin_amdgcn_s_setprio(RCX_WALK_PRIO);
             else if ((RCX_AGE_PRIO & 16) && this->agey) __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO + 1); else __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO);   // (the ring drains while a chunk is staged, walked and linked)
             stage8(cs);
@@ -597,7 +600,7 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
                 const bool go = mine && p < e;
                 if (!__ballot(go)) break;
                 if (PROF8) pp[7] += 1;
-                if (RCX_V8_ADAPT && (wstep & 3u) == 3u) ring_prio(head);
+                if (RCX_V8_ADAPT && (wstep & 3u) == 3u) ring_prio(head, RCX_V8_LOW_WALK);
 #if RCX_WALK_FORM == 0
                 if (go) {
                     if ((int32_t)p >= s) map |= 1ull << (p - (uint32_t)s);
@@ -613,7 +616,7 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
             RCX_MARK("p8_walk_end");
             const uint32_t ex = p;                                   // where the segment's walk left it
             V8P_ADD(0);
-            if (RCX_V8_ADAPT) ring_prio(head);
+            if (RCX_V8_ADAPT) ring_prio(head, RCX_V8_LOW_WALK);
             // ---- 2. link the segments.  Every lane first checks the usual case by itself: the walk of the segment before mine left
             // it at a byte my map has marked.  What is left -- a jump over a segment, walks that have not met -- is settled in
             // order by scalar code over the lanes' registers (and whatever that changes is checked again downstream).
