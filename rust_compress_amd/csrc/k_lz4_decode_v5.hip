@@ -356,7 +356,8 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER> {
         const bool isfar = M && slo < re;                            // source drained and slid out of the window
 
         // ---- loads first: literals (parser staged them a moment ago: L2 hits) and old matches, 16 bytes each
-        rcx_u32x4 g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0};
+        rcx_u32x4 g0, g1;                                            // (RCX_NOINIT: not zeroed -- a register that was not loaded is stored with length 0; eight v_mov a batch each)
+        RCX_NOINIT4(g0); RCX_NOINIT4(g1);
         const bool lit16 = L && (LITLDS || (uint64_t)src + 32u <= (uint64_t)n);
         const bool litb = L && !lit16;                               // within 32 bytes of the block's end: byte loads
         if (LITLDS) {
@@ -377,7 +378,8 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER> {
             g0 = *(const rcx_u32x4_u*)(in + q);
             if (__ballot(lit16 && L > 16)) g1 = *(const rcx_u32x4_u*)(in + q + 16);
         }
-        rcx_u32x4 f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0}, f2 = {0, 0, 0, 0}, f3 = {0, 0, 0, 0};
+        rcx_u32x4 f0, f1, f2, f3;
+        RCX_NOINIT4(f0); RCX_NOINIT4(f1); RCX_NOINIT4(f2); RCX_NOINIT4(f3);
         constexpr uint32_t FC = FARCAP < B::MCAP ? (uint32_t)FARCAP : (uint32_t)B::MCAP;
         const bool far16 = isfar && M <= FC && (uint64_t)slo + (uint32_t)B::MCAP <= (uint64_t)cap;      // (k_lz4_decode_v8 batches runs of up to 255 bytes: if one is ever outside the window, byte loads)
         const bool farb = isfar && !far16;
