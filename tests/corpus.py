@@ -42,3 +42,55 @@ def mutate(blobs, count, seed, caps_choices):
         out.append(bytes(b))
         caps.append(int(rng.choice(caps_choices)))
     return out, caps
+
+
+
+def lz4_stream(seqs, tail):
+    """an LZ4 block from (literal bytes, match length, offset) triples and the last sequence's literals (lz4.rs:67-140's format)"""
+    out = bytearray()
+
+    def ext(v):
+        while v >= 255:
+            out.append(255); v -= 255
+        out.append(v)
+    for lit, m, off in seqs:
+        L, M = len(lit), m - 4
+        out.append((min(L, 15) << 4) | min(M, 15))
+        if L >= 15: ext(L - 15)
+        out += lit
+        out += bytes((off & 255, off >> 8))
+        if M >= 15: ext(M - 15)
+    L = len(tail)
+    out.append(min(L, 15) << 4)
+    if L >= 15: ext(L - 15)
+    out += tail
+    return bytes(out)
+
+
+def lz4_edge_streams(oracle, count, seed, max_out=180000):
+    """-> (blocks, their decoded bytes by the oracle): hand-built streams whose length extensions sit on both sides of every
+    boundary a decoder has -- literal runs and matches of 14..16, 269..271, 524..526 and 1000+ bytes among short tokens"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    edge_L = [0, 0, 0, 1, 2, 5, 12, 13, 14, 15, 16, 17, 31, 32, 33, 254, 255, 268, 269, 270, 271, 272, 300, 524, 525, 526, 1000, 4100]
+    edge_M = [4, 5, 8, 16, 17, 18, 19, 20, 32, 33, 64, 65, 272, 273, 274, 275, 276, 528, 529, 530, 2000]
+    blobs, raws = [], []
+    for it in range(count):
+        seqs, produced = [], 0
+        nseq = int(rng.integers(1, 1500))
+        for k in range(nseq):
+            rare = rng.random() < 0.08
+            L = int(rng.choice(edge_L)) if rare else int(rng.choice([0, 0, 0, 0, 1, 2, 3, 6]))
+            if produced == 0 and L == 0: L = 1
+            lit = rng.integers(0, 256, L, dtype=np.uint8).tobytes()
+            produced += L
+            M = int(rng.choice(edge_M)) if rng.random() < 0.08 else int(rng.integers(4, 19))
+            off = int(rng.integers(1, min(produced, 65535) + 1))
+            if rng.random() < 0.1: off = min(produced, int(rng.choice([1, 2, 3, 15, 16, 17, 31, 32, 33])))
+            seqs.append((lit, M, off)); produced += M
+            if produced > max_out: break
+        tail = rng.integers(0, 256, int(rng.choice([0, 1, 5, 12, 15, 19, 20, 21, 40, 270, 300])), dtype=np.uint8).tobytes()
+        b = lz4_stream(seqs, tail)
+        blobs.append(b); raws.append(oracle.lz4_decode_block(b, cap=produced + len(tail)))
+        assert len(raws[-1]) == produced + len(tail)
+    return blobs, raws

@@ -82,6 +82,37 @@ def test_decode_malformed_statuses(ctx, oracle, variant):
     ctx.set_variant(N.LZ4_DECODE, 0)
 
 
+@pytest.mark.parametrize("variant", N.LZ4_DECODE_VARIANTS[:2])
+def test_decode_long_runs_and_chunk_edges(ctx, oracle, variant):
+    """Length extensions on both sides of every boundary the parser has (k_lz4_decode_v8.hip, next_tok_c / fields): literal runs and
+    matches of 14..16, 269..271 (one extension byte, 254 / 255 / 255+0), 524..526 and 1000+ bytes, a text of short tokens
+    between them so that the long ones fall at every phase of the 4 KiB chunks and 64-byte segments, at many input alignments,
+    and within the last 20 bytes of the block (tests/corpus.py: lz4_edge_streams)."""
+    import corpus
+    rng = np.random.default_rng(78)
+    blobs, raws = corpus.lz4_edge_streams(oracle, 160, 77)
+    ctx.set_variant(N.LZ4_DECODE, variant)
+    try:
+        for rot in (0, 1, 2, 3):                       # (blocks are packed back to back: every rotation gives every block another input alignment)
+            bl, rw = blobs[rot:] + blobs[:rot], raws[rot:] + raws[:rot]
+            res = ctx.lz4_decode_blocks(bl, [len(r) for r in rw])
+            res.check()
+            assert res.outputs == rw, rot
+            assert list(res.in_used) == [len(b) for b in bl]
+        # the same streams cut short and with too little room: statuses as the reference's
+        cut = [b[: int(rng.integers(0, len(b)))] for b in blobs]
+        caps = [int(rng.integers(0, len(r) + 1)) for r in raws]
+        for bl, cp in ((cut, [len(r) for r in raws]), (blobs, caps)):
+            res = ctx.lz4_decode_blocks(bl, cp)
+            for i, (b, c) in enumerate(zip(bl, cp)):
+                eo, es = oracle.lz4_decode_block(b, cap=c, raise_on_error=False)
+                assert es == res.status[i], (i, es, res.status[i])
+                if es == 0:
+                    assert eo == res.outputs[i]
+    finally:
+        ctx.set_variant(N.LZ4_DECODE, 0)
+
+
 @pytest.mark.parametrize("kind", ["text", "mix", "runs", "rand"])
 def test_full_size_roundtrip_device_resident(ctx, oracle, kind):
     """BASELINE configs[1]: 4096 x 64 KiB, device-resident: decode(encode(x)) == x for every block, and a

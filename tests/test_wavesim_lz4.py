@@ -44,6 +44,26 @@ def test_decode_matches_oracle(oracle, golden, variant, mis):
     assert list(in_used) == [len(b) for b in blobs]
 
 
+@pytest.mark.parametrize("variant", [0, 15])
+def test_decode_long_runs_and_chunk_edges(oracle, variant):
+    """the hand-built streams of tests/corpus.py (length extensions at 15 / 270 / 525 / 1000+ on both sides, among short tokens), whole,
+    cut short and with too little room: bytes and statuses as the oracle's"""
+    import simrun, corpus
+    rng = np.random.default_rng(9)
+    blobs, raws = corpus.lz4_edge_streams(oracle, 24, 177, max_out=40000)
+    outs, out_len, in_used, st, _ = simrun.run(LZ4_DECODE, variant, blobs, [len(r) for r in raws], in_misalign=5)
+    assert not st.any() and outs == raws and list(in_used) == [len(b) for b in blobs]
+    cut = [b[: int(rng.integers(0, len(b)))] for b in blobs]
+    caps = [int(rng.integers(0, len(r) + 1)) for r in raws]
+    for bl, cp in ((cut, [len(r) for r in raws]), (blobs, caps)):
+        exp = [oracle.lz4_decode_block(b, cap=c, raise_on_error=False) for b, c in zip(bl, cp)]
+        outs, _, _, st, _ = simrun.run(LZ4_DECODE, variant, bl, cp)
+        for i, ((eo, es), s_, out) in enumerate(zip(exp, st, outs)):
+            assert es == s_, (i, es, s_)
+            if es == 0:
+                assert eo == out
+
+
 @pytest.mark.parametrize("variant", [1, 0, 15, 5, 6, 10, 17, 20])
 def test_decode_malformed_statuses_match_oracle(oracle, variant):
     import simrun
