@@ -33,7 +33,7 @@
 #define RCX_V8_ESLEEP 4
 #endif
 #ifndef RCX_WALK_FORM
-#define RCX_WALK_FORM 0                  /* 0: eight bytes + a second read where needed (portable), 1: sixteen bytes, the step as ISA */
+#define RCX_WALK_FORM 0                  /* 0: eight bytes + a second read where needed (portable), 1: sixteen bytes, the step as ISA, 2: form 0's whole loop as ISA */
 #endif
 #ifndef RCX_WALK_PRIO
 #define RCX_WALK_PRIO RCX_PARSER_PRIO    /* issue priority while a chunk after the first is staged, walked and linked */
@@ -142,6 +142,111 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
         }
         return q;
     }
+#if !defined(RCX_NO_WALK_ASM)
+    // The walk's LOOP as ISA (RCX_WALK_FORM 2): up to `steps` steps of every walking lane (mine, p < e) -- mark the token start if it lies
+    // in the lane's own segment, read eight bytes at p in one LDS round trip, form the next token's position as next_tok_c does, and
+    // read the match-length extension byte a second time only where it lies beyond the eight (a branch the wave takes when a lane
+    // needs it).  hipcc's loop for the portable form executes ~45 scalar, ~14 compare, ~10 branch and ~35 vector instructions a
+    // step (every `if` of the step an s_and_saveexec / s_cbranch pair); this is 8 + 10 + 4 and 28 -- at 324 steps a block the walk
+    // was a third of the kernel's scalar-port instructions.  Leaves with `slow` = the lanes whose token it does not decide (a run of
+    // 255s, bytes that are not staged, the block's last 20 bytes: marked, NOT advanced -- the caller takes next_tok for them), or
+    // with steps = ~0 when no lane walks any more.
+    __device__ __forceinline__ uint64_t walk_steps(uint32_t& p, uint32_t e, uint32_t sg, uint32_t& mlo, uint32_t& mhi, uint64_t mine, uint32_t& steps) const
+    {
+        const uint32_t adj = RCX_U((uint32_t)(uintptr_t)this->cbuf - (uint32_t)this->cbase);     // LDS byte address of input byte q = q + adj
+        const uint32_t cend = RCX_U((uint32_t)(uintptr_t)this->cbuf + (uint32_t)CBUF8);
+        const uint32_t n = this->n, n20 = n - 20u;
+        uint32_t ad, a4, sh, d0, d1, d2, w0, w1, L, t1, hop, tm, q, x, rel, bit, t2;
+        uint64_t slow = 0, sA, sB, sS;
+        asm volatile(
+            "L_top_%=:\n\t"
+            "v_cmp_lt_u32_e32 vcc, %[p], %[e]\n\t"
+            "s_and_b64 vcc, vcc, %[mine]\n\t"
+            "s_cbranch_vccz L_none_%=\n\t"
+            "s_mov_b64 exec, vcc\n\t"
+            "v_add_u32_e32 %[ad], %[adj], %[p]\n\t"
+            "v_and_b32_e32 %[a4], -4, %[ad]\n\t"
+            "ds_read_b32 %[d0], %[a4]\n\t"
+            "ds_read_b32 %[d1], %[a4] offset:4\n\t"
+            "ds_read_b32 %[d2], %[a4] offset:8\n\t"
+            "v_sub_u32_e32 %[rel], %[p], %[sg]\n\t"                     // the mark, while the bytes are on their way
+            "v_and_b32_e32 %[sh], 3, %[ad]\n\t"
+            "v_cmp_gt_u32_e32 vcc, 64, %[rel]\n\t"                     // (two steps in three are head start: no lane in its own segment yet)
+            "s_cbranch_vccz L_nomark_%=\n\t"
+            "v_bfm_b32 %[bit], 1, %[rel]\n\t"
+            "v_cmp_gt_u32_e32 vcc, 32, %[rel]\n\t"
+            "v_add_u32_e32 %[t2], -32, %[rel]\n\t"
+            "v_cmp_gt_u32_e64 %[sA], 32, %[t2]\n\t"
+            "v_cndmask_b32_e32 %[t1], 0, %[bit], vcc\n\t"
+            "v_or_b32_e32 %[mlo], %[mlo], %[t1]\n\t"
+            "s_nop 0\n\t"
+            "v_cndmask_b32_e64 %[t1], 0, %[bit], %[sA]\n\t"
+            "v_or_b32_e32 %[mhi], %[mhi], %[t1]\n\t"
+            "L_nomark_%=:\n\t"
+            "v_cmp_lt_u32_e64 %[sS], %[n20], %[p]\n\t"                  // the block's last 20 bytes
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_alignbyte_b32 %[w0], %[d1], %[d0], %[sh]\n\t"
+            "v_alignbyte_b32 %[w1], %[d2], %[d1], %[sh]\n\t"
+            "v_bfe_u32 %[L], %[w0], 4, 4\n\t"
+            "v_bfe_u32 %[t1], %[w0], 8, 8\n\t"
+            "v_cmp_eq_u32_e32 vcc, 15, %[L]\n\t"
+            "v_and_b32_e32 %[tm], 15, %[w0]\n\t"
+            "v_add_u32_e32 %[t1], 16, %[t1]\n\t"
+            "v_cndmask_b32_e32 %[hop], %[L], %[t1], vcc\n\t"            // 15 + the extension byte + one more byte in front of the offset
+            "v_add_u32_e32 %[hop], 3, %[hop]\n\t"
+            "v_cmp_eq_u32_e64 %[sA], 15, %[tm]\n\t"
+            "v_cmp_lt_u32_e32 vcc, 7, %[hop]\n\t"
+            "v_and_b32_e32 %[t2], 7, %[hop]\n\t"
+            "v_add_u32_e32 %[q], %[p], %[hop]\n\t"
+            "v_perm_b32 %[x], %[w1], %[w0], %[t2]\n\t"
+            "s_and_b64 vcc, vcc, %[sA]\n\t"                              // a match-length extension beyond the eight bytes in hand
+            "s_cbranch_vccz L_no2_%=\n\t"
+            "s_and_saveexec_b64 %[sB], vcc\n\t"
+            "v_add_u32_e32 %[t2], %[ad], %[hop]\n\t"
+            "v_mov_b32_e32 %[x], 0xff\n\t"                              // not staged: \"the extension goes on\" = the slow path
+            "v_cmp_gt_u32_e32 vcc, %[cend], %[t2]\n\t"
+            "s_mov_b64 exec, vcc\n\t"
+            "ds_read_u8 %[x], %[t2]\n\t"
+            "s_mov_b64 exec, %[sB]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "L_no2_%=:\n\t"
+            "v_and_b32_e32 %[x], 0xff, %[x]\n\t"
+            "v_add_u32_e32 %[t1], 1, %[tm]\n\t"
+            "v_lshl_or_b32 %[x], %[tm], 8, %[x]\n\t"
+            "v_cmp_ge_u32_e64 %[sA], %[q], %[n]\n\t"                     // (only a long literal run gets there: p <= n - 20)
+            "v_cmp_le_u32_e64 %[sB], %[k274], %[hop]\n\t"                // literal length 15 and its extension 255
+            "v_cmp_eq_u32_e32 vcc, 0xfff, %[x]\n\t"                     // match length 15 and its extension 255 (or out of sight)
+            "v_lshrrev_b32_e32 %[t1], 4, %[t1]\n\t"
+            "s_or_b64 %[sA], %[sA], %[sB]\n\t"
+            "s_or_b64 vcc, vcc, %[sS]\n\t"
+            "v_add_u32_e32 %[q], %[q], %[t1]\n\t"
+            "s_or_b64 vcc, vcc, %[sA]\n\t"
+            "s_cbranch_vccnz L_slow_%=\n\t"
+            "v_mov_b32_e32 %[p], %[q]\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            "s_sub_u32 %[steps], %[steps], 1\n\t"
+            "s_cmp_lg_u32 %[steps], 0\n\t"
+            "s_cbranch_scc1 L_top_%=\n\t"
+            "s_branch L_out_%=\n\t"
+            "L_slow_%=:\n\t"
+            "s_mov_b64 %[slow], vcc\n\t"
+            "s_andn2_b64 exec, exec, vcc\n\t"
+            "v_mov_b32_e32 %[p], %[q]\n\t"
+            "s_sub_u32 %[steps], %[steps], 1\n\t"
+            "s_branch L_out_%=\n\t"
+            "L_none_%=:\n\t"
+            "s_mov_b32 %[steps], -1\n\t"
+            "L_out_%=:\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            : [p] "+v"(p), [mlo] "+v"(mlo), [mhi] "+v"(mhi), [steps] "+s"(steps), [slow] "+s"(slow), [sA] "=&s"(sA), [sB] "=&s"(sB), [sS] "=&s"(sS),
+              [ad] "=&v"(ad), [a4] "=&v"(a4), [sh] "=&v"(sh), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [w0] "=&v"(w0), [w1] "=&v"(w1), [L] "=&v"(L),
+              [t1] "=&v"(t1), [hop] "=&v"(hop), [tm] "=&v"(tm), [q] "=&v"(q), [x] "=&v"(x), [rel] "=&v"(rel), [bit] "=&v"(bit), [t2] "=&v"(t2)
+            : [e] "v"(e), [sg] "v"(sg), [mine] "s"(mine), [adj] "s"(adj), [cend] "s"(cend), [n] "s"(n), [n20] "s"(n20), [k274] "s"(274u)
+            : "vcc", "scc", "memory");
+        return slow;
+    }
+#endif
+
     // The same from the staged bytes: p lies in [cbase, chunk end) (the walk never leaves them).  ONE LDS round trip for nearly every
     // token: three aligned dwords give the eight bytes from p on -- the token, the literal-length extension, and (79 % of a text's
     // tokens have no literals) the match-length extension at p + 3; an extension byte further on is a second read.  A run of 255s
@@ -596,6 +701,21 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
             uint32_t p = ((int)lane == k0) ? c : (uint32_t)p0;
             uint64_t map = (giant && (int)lane == k0) ? 1ull << (c - (uint32_t)s) : 0ull;
             RCX_MARK("p8_walk");
+#if RCX_WALK_FORM == 2 && !defined(RCX_NO_WALK_ASM)
+            if (n >= 20u) {
+                uint32_t mlo = (uint32_t)map, mhi = (uint32_t)(map >> 32);
+                const uint64_t minem = __ballot(mine);
+                for (;;) {
+                    uint32_t steps = 4;
+                    const uint64_t slow = walk_steps(p, e, (uint32_t)s, mlo, mhi, minem, steps);
+                    if (PROF8) pp[7] += steps == 0xffffffffu ? 0 : 4 - steps;
+                    if (slow) { if (RCX_INV_BALLOT(slow)) p = next_tok(p); }
+                    else if (steps == 0xffffffffu) break;
+                    if (RCX_V8_ADAPT) ring_prio(head, RCX_V8_LOW_WALK);
+                }
+                map = (uint64_t)mlo | ((uint64_t)mhi << 32);
+            } else
+#endif
             for (uint32_t wstep = 0;; wstep++) {
                 const bool go = mine && p < e;
                 if (!__ballot(go)) break;
