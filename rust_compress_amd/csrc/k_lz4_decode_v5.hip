@@ -65,7 +65,7 @@
 
 // The copy rounds of emit5 as ISA (gfx950): every round, the lanes whose producers are done (no pending lane among `dep`) and
 // whose match does not overlap itself copy up to 16 bytes -- five aligned dword reads + v_alignbyte, the exec-narrowing byte
-// stores of rcx_lds_store16 -- and the loop ends when no such lane is left (all done, or only self-overlapping matches: emit5's
+// stores of rcx_lds_store16 -- and the loop ends when no such lane is left (the caller keeps self-overlapping matches out of `pend`: emit5's
 // portable loop takes those).  hipcc's loop for the same source carries the lane sets as booleans through v_cndmask / v_cmp_ne
 // pairs and re-derives exec at every `if`: ~35 vector + ~25 scalar instructions a round around the stores; this is 17 + 9.
 // The pending set is ONE compiler-allocated SGPR pair (its halves are read through vcc): a first version named six SGPRs of its
@@ -74,7 +74,7 @@
 //   src_a / dst_a: LDS byte addresses of the lane's source and destination; mc: bytes to copy; prog: bytes done (in / out)
 // Returns the lanes still pending.
 #ifndef RCX_NO_ROUNDS_ASM
-__device__ __forceinline__ uint64_t rcx_lz4_rounds(uint32_t src_a, uint32_t dst_a, uint32_t mc, uint32_t dep_lo, uint32_t dep_hi, uint64_t pend, uint64_t ovl, uint32_t& prog)
+__device__ __forceinline__ uint64_t rcx_lz4_rounds(uint32_t src_a, uint32_t dst_a, uint32_t mc, uint32_t dep_lo, uint32_t dep_hi, uint64_t pend, uint32_t& prog)
 {
     uint32_t t0, t1, a, a4, nv, da, d0, d1, d2, d3, d4;
 #define RCX_RB4(V, O0, O1, O2, O3)                                         \
@@ -96,7 +96,6 @@ __device__ __forceinline__ uint64_t rcx_lz4_rounds(uint32_t src_a, uint32_t dst_
         "v_or_b32_e32 %[t0], %[t0], %[t1]\n\t"
         "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"
         "s_and_b64 vcc, vcc, %[pend]\n\t"
-        "s_andn2_b64 vcc, vcc, %[ovl]\n\t"
         "s_cbranch_vccz L_out_%=\n\t"
         "s_mov_b64 exec, vcc\n\t"
         "v_add_u32_e32 %[a], %[srca], %[prog]\n\t"
@@ -131,7 +130,7 @@ __device__ __forceinline__ uint64_t rcx_lz4_rounds(uint32_t src_a, uint32_t dst_
         "s_mov_b64 exec, -1\n\t"
         : [pend] "+s"(pend), [prog] "+v"(prog), [t0] "=&v"(t0), [t1] "=&v"(t1), [a] "=&v"(a), [a4] "=&v"(a4), [nv] "=&v"(nv), [da] "=&v"(da),
           [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4)
-        : [ovl] "s"(ovl), [srca] "v"(src_a), [dsta] "v"(dst_a), [mc] "v"(mc), [dlo] "v"(dep_lo), [dhi] "v"(dep_hi)
+        : [srca] "v"(src_a), [dsta] "v"(dst_a), [mc] "v"(mc), [dlo] "v"(dep_lo), [dhi] "v"(dep_hi)
         : "vcc", "scc", "memory");
 #undef RCX_RB4
     return pend;
@@ -392,6 +391,36 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER> {
         }
 
         if (!LITLDS) RCX_SETPRIO_ROUND(young); else if (RCX_INF_ROUNDS_PRIO) __builtin_amdgcn_s_setprio(RCX_ROUND_PRIO);   // (the inflate executor: the plain level)
+#if defined(RCX_DUMMY3_MOV) || defined(RCX_DUMMY3_ADD1) || defined(RCX_DUMMY3_ADD2) || defined(RCX_DUMMY3_ALIGN) || defined(RCX_DUMMY3_SALU) || defined(RCX_DUMMY3_ADD1I)
+        {   // port experiment, second site: N extra instructions a batch at the executor's HIGH priority (benchmarks/r5_lz4_ports2.sh)
+            uint32_t dv_ = this->lane, dw_ = this->lane ^ 5u, dx_ = this->lane + 9u, ds_ = 0;
+#ifdef RCX_DUMMY3_MOV
+#pragma unroll
+            for (int k_ = 0; k_ < RCX_DUMMY3_MOV; k_++) asm volatile("v_mov_b32_e32 %0, 0" : "=v"(dv_));
+#endif
+#ifdef RCX_DUMMY3_ADD1
+#pragma unroll
+            for (int k_ = 0; k_ < RCX_DUMMY3_ADD1; k_++) asm volatile("v_add_u32_e32 %0, 1, %0" : "+v"(dv_));
+#endif
+#ifdef RCX_DUMMY3_ADD1I
+#pragma unroll
+            for (int k_ = 0; k_ < RCX_DUMMY3_ADD1I; k_++) { if (k_ & 1) asm volatile("v_add_u32_e32 %0, 1, %0" : "+v"(dv_)); else asm volatile("v_add_u32_e32 %0, 1, %0" : "+v"(dw_)); }   // two independent chains
+#endif
+#ifdef RCX_DUMMY3_ADD2
+#pragma unroll
+            for (int k_ = 0; k_ < RCX_DUMMY3_ADD2; k_++) asm volatile("v_add_u32_e32 %0, %1, %0" : "+v"(dv_) : "v"(dw_));
+#endif
+#ifdef RCX_DUMMY3_ALIGN
+#pragma unroll
+            for (int k_ = 0; k_ < RCX_DUMMY3_ALIGN; k_++) asm volatile("v_alignbyte_b32 %0, %0, %1, %2" : "+v"(dv_) : "v"(dw_), "v"(dx_));
+#endif
+#ifdef RCX_DUMMY3_SALU
+#pragma unroll
+            for (int k_ = 0; k_ < RCX_DUMMY3_SALU; k_++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(ds_) : : "scc");
+#endif
+            asm volatile("" : : "v"(dv_), "v"(dw_), "v"(dx_), "s"(ds_));
+        }
+#endif
         // ---- producer lanes of [slo, shi) inside this batch, chains redirected (see Lz4V4::emit) while the loads fly
         unsigned long long dep = 0;
         bool inb = M && !isfar && shi > oend0;
@@ -426,17 +455,24 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER> {
                 const uint32_t pmd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ka << 2), (int)((isfar || off < M) ? 0xffffffffu : mdst));
                 prod = (inb && ka == kb && slo >= pmd && off >= M) ? ka : 64u;
             }
+            if (!NORED) {
+                // the lane's chain state as ONE word (producer | first << 7 | last << 13 | in-batch << 19) through the redirection rounds:
+                // two selects a round instead of an s_and_saveexec nest around five assignments (the executor's scalar instructions
+                // are its dearest)
+                uint32_t st = prod | (ka << 7) | (kb << 13) | ((uint32_t)inb << 19);
 #pragma unroll
-            for (int rr = 0; rr < (NORED ? 0 : B::RR); rr++) {
-                if (!__ballot(prod < 64u)) break;
-                const uint32_t j = prod < 64u ? prod : lane;
-                const uint32_t Sj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)S);
-                const uint32_t pk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)(prod | (ka << 7) | (kb << 13) | ((uint32_t)inb << 19)));
-                if (prod < 64u) {
-                    if (mdst - S - Sj >= re && S + Sj <= mdst) {
-                        S += Sj; prod = pk & 127u; ka = (pk >> 7) & 63u; kb = (pk >> 13) & 63u; inb = (pk >> 19) & 1u;
-                    } else prod = 64u;
+                for (int rr = 0; rr < B::RR; rr++) {
+                    const bool has = (st & 64u) == 0u;
+                    if (!__ballot(has)) break;
+                    const uint32_t j = has ? (st & 63u) : lane;
+                    const uint32_t Sj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)S);
+                    const uint32_t pk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)st);
+                    const uint32_t Sn = S + Sj;
+                    const bool ok = has && mdst - Sn >= re && Sn <= mdst;
+                    S = ok ? Sn : S;
+                    st = ok ? pk : (st | 64u);                        // (not shortened: no producer any more; the range stays)
                 }
+                ka = (st >> 7) & 63u; kb = (st >> 13) & 63u; inb = (st >> 19) & 1u;
             }
             if (inb) {
                 const unsigned long long upto = (kb >= 63) ? ~0ull : ((2ull << kb) - 1ull);
@@ -487,8 +523,11 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER> {
                     left = rcx_lz4_rounds_ovl(sa, ovl0 ? wa + (uint32_t)li_m - D : sa, ovl0 ? 0u : 0xffffffffu, ovl0 ? off : 16u, wa + (uint32_t)li_m, Mc,
                                               (uint32_t)dep, (uint32_t)(dep >> 32), __ballot(pending0), prog0);
                 } else
+                {   // (no self-overlapping lane in this batch -- the other loop takes those; only the A/B build without it has any: kept out here, the portable loop below copies them)
+                    const uint64_t hold = (CUT & 0x800) ? (__ballot(pending0) & __ballot(ovl0)) : 0ull;
                     left = rcx_lz4_rounds(wa + (uint32_t)sbase0, wa + (uint32_t)li_m, Mc, (uint32_t)dep, (uint32_t)(dep >> 32),
-                                          __ballot(pending0), __ballot(ovl0), prog0);
+                                          __ballot(pending0) & ~hold, prog0) | hold;
+                }
                 pending0 = RCX_INV_BALLOT(left);
             }
 #endif

@@ -590,7 +590,11 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
             const uint32_t h0_ = sl->hdr[0], h1_ = sl->hdr[1], h7_ = sl->hdr[7];      // (all of the slot's usual reads in one LDS round trip)
             uint32_t w1 = sl->d[lane];
             bt.ns = (int)RCX_U(h0_); bt.why = (int)RCX_U(h1_);
-            bt.perr = 0; bt.gL = 0; bt.gM = 0; bt.goff = 0; bt.gsrc = 0; bt.gnext = 0;
+            {   // (looked at only behind a batch with a reason: left undefined -- five s_mov a batch on the executor's chain)
+                uint32_t u_;
+                RCX_NOINIT_S(u_);
+                bt.perr = (int)u_; bt.gL = u_; bt.gM = u_; bt.goff = u_; bt.gsrc = u_; bt.gnext = 0;
+            }
             if (bt.why != B::GO) {                        // the one long sequence / the error behind the batch: only then (five v_readfirstlane: scalar-port work)
                 bt.perr = (int)RCX_U(sl->hdr[2]);
                 bt.gL = RCX_U(sl->hdr[3]); bt.gM = RCX_U(sl->hdr[4]); bt.goff = RCX_U(sl->hdr[5]); bt.gsrc = RCX_U(sl->hdr[6]);

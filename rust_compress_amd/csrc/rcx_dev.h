@@ -181,6 +181,7 @@ __device__ __forceinline__ uint32_t rcx_vgpr(uint32_t x) { asm volatile("" : "+v
 // "all of these have been requested before any is used": keeps hipcc from waiting for one load before it issues the next
 // a 16-byte register set that is deliberately not initialised: "defined" for the compiler by an empty asm, no instruction emitted
 #define RCX_NOINIT4(v) asm volatile("" : "=v"(v))
+#define RCX_NOINIT_S(x) asm volatile("" : "=s"(x))      /* a wave-uniform value, likewise */
 #define RCX_SETTLE4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 #endif
 

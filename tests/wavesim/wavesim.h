@@ -324,6 +324,7 @@ static inline uint32_t ws_udot4(uint32_t a, uint32_t w, uint32_t c) { for (int i
 #define RCX_VGPR(x) ((uint32_t)(x))
 #define RCX_SETTLE4(a, b, c, d) do { } while (0)
 #define RCX_NOINIT4(v) do { (v) = rcx_u32x4{0, 0, 0, 0}; } while (0)
+#define RCX_NOINIT_S(x) do { (x) = 0; } while (0)
 #define RCX_ALIGNBYTE(hi, lo, sh) ((uint32_t)(((((uint64_t)(hi)) << 32) | (uint32_t)(lo)) >> (8 * ((sh) & 3u))))
 #define RCX_INV_BALLOT(m) ((((m) >> (threadIdx.x & 63u)) & 1ull) != 0)
 #define RCX_HOP_WALK ws_hop_walk
