@@ -76,28 +76,32 @@
 #ifndef RCX_NO_ROUNDS_ASM
 __device__ __forceinline__ uint64_t rcx_lz4_rounds(uint32_t src_a, uint32_t dst_a, uint32_t mc, uint32_t dep_lo, uint32_t dep_hi, uint64_t pend, uint32_t& prog)
 {
+    // (round 5: the pending set lives in vcc for the whole loop -- every compare writes a scratch pair in its e64 form -- so a round
+    // has three scalar instructions where it had seven: no copy to vcc for the halves, exec straight from the readiness test, the
+    // lanes that finish collected in one pair and taken out once, which also sets the loop's condition.  A scalar instruction on the
+    // executor's chain costs it ~11 cycles)
     uint32_t t0, t1, a, a4, nv, da, d0, d1, d2, d3, d4;
+    uint64_t sT, sF;
 #define RCX_RB4(V, O0, O1, O2, O3)                                         \
-        "v_cmpx_lt_u32_e32 vcc, " #O0 ", %[nv]\n\t"                        \
+        "v_cmpx_lt_u32_e64 %[sT], " #O0 ", %[nv]\n\t"                      \
         "s_cbranch_execz L_sdone_%=\n\t"                                   \
         "ds_write_b8 %[da], %[" V "] offset:" #O0 "\n\t"                    \
-        "v_cmpx_lt_u32_e32 vcc, " #O1 ", %[nv]\n\t"                        \
+        "v_cmpx_lt_u32_e64 %[sT], " #O1 ", %[nv]\n\t"                      \
         "v_lshrrev_b32_e32 %[t0], 8, %[" V "]\n\t"                          \
         "ds_write_b8 %[da], %[t0] offset:" #O1 "\n\t"                       \
-        "v_cmpx_lt_u32_e32 vcc, " #O2 ", %[nv]\n\t"                        \
+        "v_cmpx_lt_u32_e64 %[sT], " #O2 ", %[nv]\n\t"                      \
         "ds_write_b8_d16_hi %[da], %[" V "] offset:" #O2 "\n\t"             \
-        "v_cmpx_lt_u32_e32 vcc, " #O3 ", %[nv]\n\t"                        \
+        "v_cmpx_lt_u32_e64 %[sT], " #O3 ", %[nv]\n\t"                      \
         "ds_write_b8_d16_hi %[da], %[t0] offset:" #O3 "\n\t"
     asm volatile(
-        "L_top_%=:\n\t"
         "s_mov_b64 vcc, %[pend]\n\t"
+        "L_top_%=:\n\t"
         "v_and_b32_e32 %[t0], vcc_lo, %[dlo]\n\t"
         "v_and_b32_e32 %[t1], vcc_hi, %[dhi]\n\t"
         "v_or_b32_e32 %[t0], %[t0], %[t1]\n\t"
-        "v_cmp_eq_u32_e32 vcc, 0, %[t0]\n\t"
-        "s_and_b64 vcc, vcc, %[pend]\n\t"
-        "s_cbranch_vccz L_out_%=\n\t"
-        "s_mov_b64 exec, vcc\n\t"
+        "v_cmp_eq_u32_e64 %[sT], 0, %[t0]\n\t"
+        "s_and_b64 exec, %[sT], vcc\n\t"                        // the ready lanes; scc: any
+        "s_cbranch_scc0 L_out_%=\n\t"
         "v_add_u32_e32 %[a], %[srca], %[prog]\n\t"
         "v_sub_u32_e32 %[nv], %[mc], %[prog]\n\t"
         "v_and_b32_e32 %[a4], -4, %[a]\n\t"
@@ -110,9 +114,7 @@ __device__ __forceinline__ uint64_t rcx_lz4_rounds(uint32_t src_a, uint32_t dst_
         "v_min_u32_e32 %[nv], 16, %[nv]\n\t"
         "v_add_u32_e32 %[da], %[dsta], %[prog]\n\t"
         "v_add_u32_e32 %[prog], %[prog], %[nv]\n\t"
-        "v_cmp_lt_u32_e32 vcc, %[prog], %[mc]\n\t"             // of this round's lanes, those with bytes left
-        "s_andn2_b64 %[pend], %[pend], exec\n\t"
-        "s_or_b64 %[pend], %[pend], vcc\n\t"
+        "v_cmp_ge_u32_e64 %[sF], %[prog], %[mc]\n\t"             // of this round's lanes, those that are done with it
         "s_waitcnt lgkmcnt(3)\n\t"
         "v_alignbyte_b32 %[d0], %[d1], %[d0], %[a]\n\t"
         "s_waitcnt lgkmcnt(2)\n\t"
@@ -124,12 +126,13 @@ __device__ __forceinline__ uint64_t rcx_lz4_rounds(uint32_t src_a, uint32_t dst_
         RCX_RB4("d0", 0, 1, 2, 3) RCX_RB4("d1", 4, 5, 6, 7) RCX_RB4("d2", 8, 9, 10, 11) RCX_RB4("d3", 12, 13, 14, 15)
         "L_sdone_%=:\n\t"
         "s_mov_b64 exec, -1\n\t"
-        "s_cmp_lg_u64 %[pend], 0\n\t"
+        "s_andn2_b64 vcc, vcc, %[sF]\n\t"                        // scc: a lane still pending
         "s_cbranch_scc1 L_top_%=\n\t"
         "L_out_%=:\n\t"
         "s_mov_b64 exec, -1\n\t"
+        "s_mov_b64 %[pend], vcc\n\t"
         : [pend] "+s"(pend), [prog] "+v"(prog), [t0] "=&v"(t0), [t1] "=&v"(t1), [a] "=&v"(a), [a4] "=&v"(a4), [nv] "=&v"(nv), [da] "=&v"(da),
-          [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4)
+          [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4), [sT] "=&s"(sT), [sF] "=&s"(sF)
         : [srca] "v"(src_a), [dsta] "v"(dst_a), [mc] "v"(mc), [dlo] "v"(dep_lo), [dhi] "v"(dep_hi)
         : "vcc", "scc", "memory");
 #undef RCX_RB4
@@ -485,8 +488,6 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER> {
         if (!(CUT & 4) && (RCX_DEGUARD || __ballot(L != 0))) {
             RCX_LDS_STORE16(wb_ + li_o, g0[0], g0[1], g0[2], g0[3], lit16 ? (L < 16u ? L : 16u) : 0u);
             if (__ballot(lit16 && L > 16)) RCX_LDS_STORE16(wb_ + li_o + 16, g1[0], g1[1], g1[2], g1[3], (lit16 && L > 16u) ? L - 16u : 0u);
-            for (uint32_t i = 0; __ballot(litb && i < L); i++)
-                if (litb && i < L) wb_[li_o + (int32_t)i] = in[src + i];
         }
         if (!(CUT & 4) && (RCX_DEGUARD || __ballot(isfar))) {
             uint8_t* d = wb_ + li_m;
@@ -496,6 +497,13 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER> {
             if (SB <= 16 && __ballot(mf > 16)) RCX_LDS_STORE16(d + 16, f1[0], f1[1], f1[2], f1[3], mf > 16u ? (mf < 32u ? mf - 16u : 16u) : 0u);
             if (FC > 32 && __ballot(mf > 32)) RCX_LDS_STORE16(d + 32, f2[0], f2[1], f2[2], f2[3], mf > 32u ? (mf < 48u ? mf - 32u : 16u) : 0u);
             if (FC > 48 && __ballot(mf > 48)) RCX_LDS_STORE16(d + 48, f3[0], f3[1], f3[2], f3[3], mf > 48u ? mf - 48u : 0u);
+        }
+        // the byte paths -- literals within 32 bytes of the block's end, a gathered match too long or too close to the end of the output
+        // for 16-byte loads -- behind ONE test (they write other bytes than the stores above: the order does not matter)
+        if (!(CUT & 4) && __ballot(litb || farb)) {
+            for (uint32_t i = 0; __ballot(litb && i < L); i++)
+                if (litb && i < L) wb_[li_o + (int32_t)i] = in[src + i];
+            uint8_t* d = wb_ + li_m;
             for (uint32_t i = 0; __ballot(farb && i < M); i++)
                 if (farb && i < M) d[i] = out[slo + i];
         }
