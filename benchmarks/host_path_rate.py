@@ -27,7 +27,12 @@ for i in range(nb):
 in_base = np.zeros(pos + 64, np.uint8)
 for i in range(nb):
     in_base[int(in_off[i]): int(in_off[i]) + int(in_len[i])] = slots[int(so[i]): int(so[i]) + int(in_len[i])]
-for pinned in (False, True):
+# RCX_HP_PIECES: block ranges of the page-locked call (rcx_ctx_set_param(ctx, RCX_LZ4_DECODE, pieces << 8); 0 = the library's choice), a list to sweep
+sweep = [int(x, 0) for x in os.environ.get("RCX_HP_PIECES", "0").split(",")]      # (values above 255: first-range divisor << 8 and growth in quarters << 16 ride along, rcx_api.hip)
+for pinned in [False] + [True] * len(sweep):
+    if pinned:
+        N.lib().rcx_ctx_set_param(ctx._h, N.LZ4_DECODE, sweep[0] << 8)
+        print("pieces", sweep.pop(0), end=": ")
     if pinned:
         inb = torch.from_numpy(in_base).pin_memory(); outb = torch.empty(nb * bench.BLOCK + 64, dtype=torch.uint8).pin_memory()
         ip, op = inb.data_ptr(), outb.data_ptr()
@@ -53,7 +58,7 @@ for pinned in (False, True):
 # and copy out under the others' (include/rcx.h)
 L = N.lib()
 inb = torch.from_numpy(in_base).pin_memory(); outb = torch.empty(nb * bench.BLOCK + 64, dtype=torch.uint8).pin_memory()
-for k in (1, 2, 3, 4):
+for k in (() if os.environ.get("RCX_HP_ONLY") else (1, 2, 3, 4)):      # (RCX_HP_ONLY: benchmarks/r5_hostpath_trace.sh -- the trace ends with the page-locked single-context call)
     devs = (C.c_int * k)(*([0] * k))
     h = C.c_void_p()
     assert L.rcx_multi_create(devs, k, C.byref(h)) == 0

@@ -3,6 +3,7 @@
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/hpt
+export RCX_HP_ONLY=1
 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/hpt -- python $REPO/benchmarks/host_path_rate.py > /tmp/hpt.log 2>&1
 tail -3 /tmp/hpt.log
 python - <<P
@@ -21,6 +22,6 @@ for i in range(1, len(ev)):
     if ev[i][0] - ev[i - 1][1] > 5_000_000: cut = i
 ev = ev[cut:]
 t0 = ev[0][0]
-for s, e, k in ev[:80]:
+for s, e, k in ev[:120]:
     print("%9.3f ms .. %9.3f ms  %8.1f us  %s" % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e3, k))
 P

@@ -124,7 +124,11 @@ typedef struct rcx_batch {
 } rcx_batch;
 
 /* ---- LZ4 -------------------------------------------------------------------- */
-/* reference: src/lz4.rs:602-611 decode_block() -> BlockDecoder::decode :67-110 */
+/* reference: src/lz4.rs:602-611 decode_block() -> BlockDecoder::decode :67-110
+ * RCX_MEM_HOST with a PAGE-LOCKED out_base (hipHostMalloc / hipHostRegister): the decoder stores the decoded bytes straight into
+ * the caller's buffer while it runs (nothing beyond out_len[i] of a block's slot is written) and, when in_base is page-locked
+ * too, the compressed bytes arrive in block ranges under the launch; with pageable buffers one copy each way around the launch.
+ * Same results either way.  rcx_ctx_set_param(ctx, RCX_LZ4_DECODE, 1) keeps the plain copies (A/B). */
 int rcx_lz4_decode_batch(rcx_ctx*, const rcx_batch*);
 /* reference: src/lz4.rs:616-627 encode_block() -> BlockEncoder::encode :226-310
  * (bit-exact: hash/skip/backtrack heuristics reproduced) */
@@ -257,7 +261,8 @@ uint64_t rcx_scratch_bytes(int codec, uint32_t nblocks, uint64_t max_block);
 int rcx_launch_dev(rcx_ctx*, int codec, const rcx_dev_batch*, void* scratch, uint64_t scratch_bytes);
 /* kernel variant knob for A/B measurements (0 = default/best). */
 int rcx_ctx_set_variant(rcx_ctx*, int codec, int variant);
-/* codec parameter for rcx_launch_dev (the *_batch entry points take it as an argument): the rate of RCX_ARI_BINARY_* */
+/* codec parameter for rcx_launch_dev (the *_batch entry points take it as an argument): the rate of RCX_ARI_BINARY_*;
+ * RCX_LZ4_DECODE: bit 0 = host-memory batches by plain copies (see rcx_lz4_decode_batch), bits 8-15 / 16-23 tuning of the ranges */
 int rcx_ctx_set_param(rcx_ctx*, int codec, uint32_t value);
 
 /* ---- more than one device ---------------------------------

@@ -55,7 +55,10 @@ __device__ __forceinline__ void rcx_adler_chunk(const rcx_u32x4 v, uint32_t rel,
 // so that the chunks may arrive in any order and k_adler32's second pass over the output (a quarter of the launch's HBM traffic)
 // is not needed.  A lane sums its own chunks relative to the call's first byte (u32 is enough: a call moves a few KiB, or is
 // cut into such pieces), the call ends with two wave sums and scalar arithmetic on the wave-uniform S0 / S1.
-template <int CB, bool PROF = false, int TC = 2560, int HH = 2048, bool ADLER = false>
+// MIRROR (the host-memory entry point of the LZ4 decoder, rcx_api.hip): every byte that leaves for global memory is stored a second
+// time at the same offset of `out2` -- the caller's page-locked host buffer, written over PCIe while the block is still being
+// decoded -- so that no device-to-host copy follows the launch.  The copy in HBM stays: old matches are gathered from it.
+template <int CB, bool PROF = false, int TC = 2560, int HH = 2048, bool ADLER = false, bool MIRROR = false>
 struct Lz4V4 {
     uint64_t prof[16];
     // ADLER: S0, S1 mod 65521 live in two words of LDS (`adp`, zeroed by the kernel), not in registers: the inflate kernel has
@@ -98,6 +101,8 @@ struct Lz4V4 {
     static_assert(SOLO <= TCAP && (CB % 1024) == 0 && RH >= 2 * MCAP && (STAGE % 16) == 0, "geometry");
 
     const uint8_t* in; uint8_t* out; uint32_t n, cap;
+    uint8_t* out2 = nullptr;               // MIRROR: same misalignment (mod 256) as `out`
+    uint32_t mflush = 0;                   // MIRROR: what has left for out2
     uint8_t* cbuf; uint8_t* wb_;          // wb_: [lin | slack | staging]
     uint32_t* epos;                        // token positions of the batch (LDS, 64 entries)
     int32_t cbase; uint32_t cend;
@@ -192,7 +197,7 @@ struct Lz4V4 {
     __device__ void flush(uint32_t to, bool final)
     {
         uint32_t from = gflush;
-        if (to <= from) return;
+        if (to <= from) { if (MIRROR && final) mirror_to(to, true); return; }
         if (!ADLER && !final && ((omis + from) & 15u) == 0u) {     // the usual drain: gflush is 16-byte aligned after the block's first one
             const uint32_t nch = (to - from) >> 4;
             #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
@@ -201,6 +206,7 @@ struct Lz4V4 {
                 *(rcx_u32x4*)(out + p) = *(const rcx_u32x4*)(wb_ + ((int32_t)p - lbase));
             }
             gflush = RCX_U(from + nch * 16);
+            if (MIRROR) mirror_to(gflush, false);
             return;
         }
         const uint32_t mis = (uint32_t)((uintptr_t)(out + from) & 15u);
@@ -229,6 +235,38 @@ struct Lz4V4 {
         }
         if (ADLER) ad_commit(from0, tA, tR);
         gflush = RCX_U(from);
+        if (MIRROR) mirror_to(final ? to : gflush, final);
+    }
+
+    // MIRROR: the drained bytes [mflush, to) once more, from the window to the caller's page-locked buffer -- in whole 256-byte lines of
+    // that buffer (a drain moves ~700 bytes from wherever the last one stopped: written as they come they cross PCIe as partial lines,
+    // 43 GB/s against the link's 55), the rest with the next drain: fewer than 256 bytes stay behind, and the window keeps H >= 768
+    // bytes of history.  final: everything, byte-exact (the block's end, or a wave-wide copy follows that writes both places itself).
+    __device__ void mirror_to(uint32_t to, bool final)
+    {
+        uint32_t from = mflush;
+        const uint32_t A = (uint32_t)((uintptr_t)out2 & 255u);
+        uint32_t lim = to;
+        if (!final) { const uint32_t al = (A + to) & ~255u; if (al <= A + from) return; lim = al - A; }
+        if (lim <= from) return;
+        uint32_t head = (0u - (A + from)) & 15u;
+        if (head > lim - from) head = lim - from;
+        if (head) {
+            if (lane < head) out2[from + lane] = wb_[(int32_t)(from + lane) - lbase];
+            from += head;
+        }
+        const uint32_t nch = (lim - from) >> 4;
+        #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+        for (uint32_t c = RCX_VGPR(lane); c < nch; c += 64) {
+            const uint32_t p = from + 16 * c;
+            *(rcx_u32x4*)(out2 + p) = *(const rcx_u32x4*)(wb_ + ((int32_t)p - lbase));
+        }
+        from += nch * 16;
+        if (lim > from) {                                          // (final only: a line is a multiple of 16)
+            if (lane < lim - from) out2[from + lane] = wb_[(int32_t)(from + lane) - lbase];
+            from = lim;
+        }
+        mflush = RCX_U(from);
     }
 
     __device__ void repair()
@@ -244,18 +282,21 @@ struct Lz4V4 {
     __device__ void wide_literals(uint32_t src, uint32_t len)
     {
         uint8_t* d = out + oend;
+        uint8_t* d2 = MIRROR ? out2 + oend : nullptr;
         const uint8_t* s = in + src;
         const uint32_t mis = (uint32_t)((uintptr_t)d & 15u);
         uint32_t head = mis ? 16u - mis : 0u;
         if (head > len) head = len;
         uint32_t tA = 0, tR = 0;                                   // ADLER: relative to oend; the chunk loop commits every 2 KiB (u32 sums)
-        if (lane < head) { const uint8_t x = s[lane]; d[lane] = x; if (ADLER) { tA += x; tR += lane * (uint32_t)x; } }
+        if (lane < head) { const uint8_t x = s[lane]; d[lane] = x; if (MIRROR) d2[lane] = x; if (ADLER) { tA += x; tR += lane * (uint32_t)x; } }
         if (ADLER) ad_commit(oend, tA, tR);
         const uint32_t nb = (len - head) >> 4;
         if (!ADLER) {
             #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-            for (uint32_t c = RCX_VGPR(lane); c < nb; c += 64)
-                *(rcx_u32x4*)(d + head + 16 * c) = *(const rcx_u32x4_u*)(s + head + 16 * c);
+            for (uint32_t c = RCX_VGPR(lane); c < nb; c += 64) {
+                if (MIRROR) { const rcx_u32x4 v = *(const rcx_u32x4_u*)(s + head + 16 * c); *(rcx_u32x4*)(d + head + 16 * c) = v; *(rcx_u32x4*)(d2 + head + 16 * c) = v; }
+                else *(rcx_u32x4*)(d + head + 16 * c) = *(const rcx_u32x4_u*)(s + head + 16 * c);
+            }
         } else {
             #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
             for (uint32_t c0 = 0; c0 < nb; c0 += 128) {           // 128 chunks a step: two per lane, positions below 2 KiB
@@ -263,6 +304,7 @@ struct Lz4V4 {
                 for (uint32_t c = c0 + lane; c < nb && c < c0 + 128; c += 64) {
                     const rcx_u32x4 v = *(const rcx_u32x4_u*)(s + head + 16 * c);
                     *(rcx_u32x4*)(d + head + 16 * c) = v;
+                    if (MIRROR) *(rcx_u32x4*)(d2 + head + 16 * c) = v;
                     rcx_adler_chunk(v, 16 * (c - c0), tA, tR);
                 }
                 ad_commit(oend + head + 16 * c0, tA, tR);
@@ -270,7 +312,7 @@ struct Lz4V4 {
         }
         const uint32_t done = head + nb * 16;
         tA = 0; tR = 0;
-        if (lane < len - done) { const uint8_t x = s[done + lane]; d[done + lane] = x; if (ADLER) { tA += x; tR += lane * (uint32_t)x; } }
+        if (lane < len - done) { const uint8_t x = s[done + lane]; d[done + lane] = x; if (MIRROR) d2[done + lane] = x; if (ADLER) { tA += x; tR += lane * (uint32_t)x; } }
         if (ADLER) ad_commit(oend + done, tA, tR);
     }
 
@@ -285,9 +327,10 @@ struct Lz4V4 {
             if (i0 + 16 <= C) {
                 const rcx_u32x4 v = *(const rcx_u32x4_u*)(out + d - e + i0);
                 *(rcx_u32x4_u*)(out + d + i0) = v;
+                if (MIRROR) *(rcx_u32x4_u*)(out2 + d + i0) = v;
                 if (ADLER) rcx_adler_chunk(v, i0, tA, tR);
             } else if (i0 < C) {
-                for (uint32_t t = i0; t < C; t++) { const uint8_t x = out[d - e + t]; out[d + t] = x; if (ADLER) { tA += x; tR += t * (uint32_t)x; } }
+                for (uint32_t t = i0; t < C; t++) { const uint8_t x = out[d - e + t]; out[d + t] = x; if (MIRROR) out2[d + t] = x; if (ADLER) { tA += x; tR += t * (uint32_t)x; } }
             }
             if (ADLER) ad_commit(d, tA, tR);
             rcx_wave_sync();
@@ -665,6 +708,7 @@ struct Lz4V4 {
             }
             oend = RCX_U(oend);
             gflush = oend;
+            if (MIRROR) mflush = oend;
             repair();
         }
         return 0;
@@ -673,7 +717,7 @@ struct Lz4V4 {
     __device__ void init_window()
     {
         omis = (uint32_t)((uintptr_t)out & 15u);
-        oend = 0; gflush = 0; rlo = 0;
+        oend = 0; gflush = 0; rlo = 0; mflush = 0;
         lbase = (int32_t)RCX_U(lbase_for(0));
     }
 

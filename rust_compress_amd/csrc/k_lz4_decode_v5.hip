@@ -222,10 +222,10 @@ __device__ __forceinline__ uint64_t rcx_lz4_rounds_ovl(uint32_t sa, uint32_t sco
 #endif
 
 // SB: bytes of a gathered (old) match that are staged per lane and ride the copy rounds; the rest is stored straight to its place
-template <int CB, int TC = 2560, int HH = 2048, bool PROF5 = false, int SB = 32, bool ADLER = false>
-struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER> {
+template <int CB, int TC = 2560, int HH = 2048, bool PROF5 = false, int SB = 32, bool ADLER = false, bool MIRROR = false>
+struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER, MIRROR> {
     static_assert(SB == 0 || SB == 16 || SB == 32, "staging slot");
-    typedef Lz4V4<CB, false, TC, HH, ADLER> B;
+    typedef Lz4V4<CB, false, TC, HH, ADLER, MIRROR> B;
     static constexpr int NSLOT = 3;
     struct Slot { uint32_t hdr[16]; uint32_t desc[64][2]; };
     struct Ring { Slot slot[NSLOT]; volatile uint32_t head, tail, abort_, pad; };

@@ -64,15 +64,15 @@
 #define V8P_T0() uint64_t t0_ = PROF8 ? (uint64_t)__builtin_readcyclecounter() : 0
 #define V8P_ADD(slot) do { if (PROF8) { const uint64_t t1_ = (uint64_t)__builtin_readcyclecounter(); pp[slot] += t1_ - t0_; t0_ = t1_; } } while (0)
 
-template <int TC = 1024, int HH = 1024, int SB = 16, bool PROF8 = false, int PRE_ = 128, int SPLIT_ = 32, bool PRED = false, int PRR = 2, int CUT = 0>
-struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
+template <int TC = 1024, int HH = 1024, int SB = 16, bool PROF8 = false, int PRE_ = 128, int SPLIT_ = 32, bool PRED = false, int PRR = 2, int CUT = 0, bool MIRROR = false>
+struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR> {
     // A match longer than SPLIT bytes is handed over as TWO entries -- (L, SPLIT, offset) and (0, M - SPLIT, offset): the same
     // bytes -- so that the executor's copy rounds, 16 bytes a lane and round, are paced by SPLIT and not by the 64-byte cap
     // (3.8 of its 4.6 rounds per batch of text were the long matches').  0: off.
     static constexpr int SPLIT = SPLIT_;
     static_assert(SPLIT_ == 0 || 2 * SPLIT_ >= 64, "two entries cover the 64-byte cap");
     bool agey = true;                             // RCX_AGE_PRIO (k_lz4_decode_v5.hip): this wave is in the younger half of its SIMD's (true: the plain levels)
-    typedef Lz4V5<1024, TC, HH, PROF8, SB> P5;
+    typedef Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR> P5;
     typedef typename P5::B B;
     static constexpr int SEGB = 64, NSEG = 64, CH = SEGB * NSEG;      // a chunk: 64 segments of 64 bytes, a lane each
     static constexpr int PRE = PRE_;                                  // head start of a guessing lane (staged in front of the chunk)
@@ -847,10 +847,10 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB> {
     }
 };
 
-template <int TC = 1024, int HH = 768, bool PROF8 = false, int PRE_ = 128, int SPLIT_ = 32, bool PRED = false, int PRR = 2, int CUT = 0>
+template <int TC = 1024, int HH = 768, bool PROF8 = false, int PRE_ = 128, int SPLIT_ = 32, bool PRED = false, int PRR = 2, int CUT = 0, bool MIRROR = false>
 __global__ __launch_bounds__(128, 8) void k_lz4_decode_v8(rcx_kargs a, int only_status = 0)
 {
-    typedef Lz4V8<TC, HH, 16, PROF8, PRE_, SPLIT_, PRED, PRR, CUT> S;
+    typedef Lz4V8<TC, HH, 16, PROF8, PRE_, SPLIT_, PRED, PRR, CUT, MIRROR> S;
     const uint64_t tk0 = PROF8 ? (uint64_t)__builtin_readcyclecounter() : 0;
     __shared__ __align__(16) uint8_t s_wbuf[S::WBUF5 + 16];
     __shared__ __align__(16) typename S::Ring8 s_ring;
@@ -860,6 +860,36 @@ __global__ __launch_bounds__(128, 8) void k_lz4_decode_v8(rcx_kargs a, int only_
     const uint32_t b = blockIdx.x;
     if (b >= a.nblocks) return;
     if (only_status && a.status[b] != only_status) return;
+    if (MIRROR && a.gate) {
+        // the block's compressed bytes may still be on their way in (rcx_api.hip: one launch, the input in ranges on a copy stream).
+        // Nothing of this block has been read yet -- no cache holds a line of it -- and the acquire behind the flag keeps it that way.
+        uint32_t r = 0;
+#pragma unroll
+        for (int i = 0; i < 15; i++) r += b >= a.gate_bnd[i] ? 1u : 0u;
+        if (r) {
+            if (threadIdx.x == 0) {
+                const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+                uint32_t ok = 1;
+                if (b == a.gate_bnd[r - 1]) {                       // the range's first block: the host's word, then everybody's
+                    while (__hip_atomic_load(a.gate_host + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != a.gate_seq) {
+                        __builtin_amdgcn_s_sleep(60);
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > (uint64_t)a.gate_ticks) { ok = 0; break; }
+                    }
+                    if (ok) __hip_atomic_store(a.gate + r, a.gate_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                while (ok && __hip_atomic_load(a.gate + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != a.gate_seq) {
+                    __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > (uint64_t)a.gate_ticks) ok = 0;
+                }
+                s_lmap[0] = ok;
+            }
+            __syncthreads();
+            const uint32_t ok = s_lmap[0];
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            __syncthreads();
+            if (!ok) { if (threadIdx.x == 0) a.status[b] = (int32_t)RCX_ST_GATE; return; }
+        }
+    }
     if (threadIdx.x == 0) { RCX_LDS_AS typename S::Ring8* r0 = (RCX_LDS_AS typename S::Ring8*)&s_ring; r0->head = 0; r0->tail = 0; r0->abort_ = 0; }
     __syncthreads();
     const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -867,6 +897,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_decode_v8(rcx_kargs a, int only_
     s.in = a.in_base + a.in_off[b];
     s.n = (uint32_t)a.in_len[b];
     s.out = a.out_base + a.out_off[b];
+    if (MIRROR) s.out2 = a.out_mirror + a.out_off[b];
     const uint64_t cap64 = a.out_cap[b];
     s.cap = cap64 > 0xffffffffull ? 0xffffffffu : (uint32_t)cap64;
     s.cbuf = s_cbuf;

@@ -36,6 +36,9 @@ struct rcx_ctx {
     DevBuf d_in, d_out, d_desc, d_scratch;
     DevBuf d_apm;                        // apm stretch table + gate bins (filled on first use)
     std::vector<uint8_t> h_desc;
+    hipStream_t copy_stream = nullptr;   // the host-memory LZ4 decode: compressed ranges on their way in under the launch that decodes them
+    std::vector<hipEvent_t> piece_ev;
+    DevBuf d_gate; uint32_t* h_gate = nullptr; uint32_t gate_seq = 0;      // "range r has arrived" words (device; their page-locked source)
 };
 
 #define HIPCHK(ctx, call)                                                                     \
@@ -70,6 +73,10 @@ extern "C" void rcx_ctx_destroy(rcx_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     c->d_in.release(); c->d_out.release(); c->d_desc.release(); c->d_scratch.release(); c->d_apm.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (hipEvent_t e : c->piece_ev) (void)hipEventDestroy(e);
+    c->d_gate.release();
+    if (c->h_gate) (void)hipHostFree(c->h_gate);
     delete c;
 }
 
@@ -235,7 +242,7 @@ extern "C" int rcx_launch_dev(rcx_ctx* c, int codec, const rcx_dev_batch* b, voi
     k.in_base = b->in_base; k.in_off = b->in_off; k.in_len = b->in_len;
     k.out_base = b->out_base; k.out_off = b->out_off; k.out_cap = b->out_cap;
     k.out_len = b->out_len; k.in_used = b->in_used; k.status = b->status; k.aux = b->aux;
-    k.n_out = nullptr; k.scratch = scratch; k.scratch_bytes = scratch_bytes; k.nblocks = b->nblocks;
+    k.n_out = nullptr; k.scratch = scratch; k.scratch_bytes = scratch_bytes; k.nblocks = b->nblocks; k.out_mirror = nullptr; k.gate = nullptr;
     if (codec == RCX_DC_DECODE) { c->err = "dc decode needs n_out: use rcx_dc_decode_batch"; return RCX_RC_BAD_ARG; }
     return launch_codec(c, codec, k);
 }
@@ -275,12 +282,36 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
     if ((in_span && !b->in_base) || (out_span && !b->out_base)) { c->err = "null data pointer"; return RCX_RC_BAD_ARG; }
     const uint8_t* d_in = b->in_base;
     uint8_t* d_out = b->out_base;
+    // LZ4 decode from host memory into a PAGE-LOCKED output buffer (hipHostMalloc / hipHostRegister: the device can address it):
+    // the decoder stores every byte that leaves its window a second time straight into that buffer (k_lz4_decode_v4.hip, MIRROR),
+    // so the decoded bytes cross PCIe while the launch runs and no device-to-host copy follows it; and the compressed bytes travel in
+    // as block ranges on a copy stream while the launch already decodes the ranges before them (below).  One copy
+    // each way (what every other codec and a pageable buffer get) costs in + kernel + out = 1.8 + 0.5 + 4.9 ms on the headline
+    // workload; this is the outbound 4.9 ms and little else.  rcx_ctx_set_param(ctx, RCX_LZ4_DECODE, 1) keeps the plain copies.
+    uint8_t* mirror = nullptr;
+    uint32_t pieces = 1;
+    if (b->mem == RCX_MEM_HOST && codec == RCX_LZ4_DECODE && out_span && c->variant[codec] == 0 && !(c->param[codec] & 1u)) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, b->out_base) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) {
+            mirror = (uint8_t*)at.devicePointer;
+            // (ranges only from page-locked INPUT: a pageable buffer is staged piece by piece, by copies that may need the compute
+            // units the waiting blocks would hold)
+            hipPointerAttribute_t ai;
+            if (in_span && hipPointerGetAttributes(&ai, b->in_base) == hipSuccess && ai.type == hipMemoryTypeHost) {
+                pieces = ((c->param[codec] >> 8) & 255u) ? ((c->param[codec] >> 8) & 255u) : 8u;
+                if (pieces > 16u) pieces = 16u;             // (the most; see below)
+                if (pieces > n / 128u) pieces = n / 128u ? n / 128u : 1u;
+            } else (void)hipGetLastError();
+        } else (void)hipGetLastError();
+    }
+    size_t out_shift = 0;
     if (b->mem == RCX_MEM_HOST) {
+        out_shift = mirror ? (size_t)((uintptr_t)mirror & 255u) : 0;           // the copy in HBM and the host buffer: the same alignment
         HIPCHK(c, c->d_in.reserve(in_span + 64));
-        HIPCHK(c, c->d_out.reserve(out_span + 64));
-        if (in_span) HIPCHK(c, hipMemcpyAsync(c->d_in.p, b->in_base, in_span, hipMemcpyHostToDevice, s));
+        HIPCHK(c, c->d_out.reserve(out_span + out_shift + 64));
+        if (in_span && pieces <= 1) HIPCHK(c, hipMemcpyAsync(c->d_in.p, b->in_base, in_span, hipMemcpyHostToDevice, s));
         d_in = (const uint8_t*)c->d_in.p;
-        d_out = (uint8_t*)c->d_out.p;
+        d_out = (uint8_t*)c->d_out.p + out_shift;
     } else if (b->mem != RCX_MEM_DEVICE) { c->err = "bad mem kind"; return RCX_RC_BAD_ARG; }
 
     const size_t N = n;
@@ -321,11 +352,98 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
         k.scratch = c->d_scratch.p; k.scratch_bytes = c->d_scratch.cap;
         if (codec == RCX_DC_ENCODE && !sb) { k.scratch = nullptr; k.scratch_bytes = 0; }
     }
-    int rc = launch_codec(c, codec, k, param_over);
-    if (rc) return rc;
+    k.out_mirror = mirror; k.gate = nullptr; k.gate_host = nullptr; k.gate_seq = 0; k.gate_ticks = 0;
+    for (int i = 0; i < 15; i++) k.gate_bnd[i] = 0xffffffffu;
+    bool gated = false;
+    if (pieces > 1) {
+        // ONE launch, the input in ranges: the first range (a sixteenth of the blocks) is all the launch waits for; the blocks of a later
+        // range start when this thread has seen the range's copy complete and said so in a page-locked word (k_lz4_decode_v8, `gate`).  A launch per range was built first and measured: each one ends with the link drained and begins with nothing to
+        // send, 5.9 ms for three growing ranges, 6.6 for eight equal ones, against 7.0 for one launch behind one copy.
+        // A range's compressed bytes are the span from its lowest to its highest input byte, widened to whole 256-byte lines of the
+        // staging buffer (a line two ranges share is complete the first time anybody reads it; what the widening copies early are the
+        // caller's own bytes).  Blocks that do not lie in index order make the spans overlap: more than a quarter of the input twice and
+        // the call goes back to one copy in front of the launch.  A block whose input does not arrive in gate_ticks gives up with
+        // RCX_ST_GATE and is decoded by a second launch below (the copies cannot be held up by the waiting blocks as long as a copy
+        // engine moves them; a copy done by a kernel could be, and then this is what ends the wait).
+        std::vector<uint32_t> bnd(1, 0);
+        const uint32_t fdiv = ((c->param[codec] >> 16) & 255u) ? ((c->param[codec] >> 16) & 255u) : 16u;       // (tuning)
+        const uint32_t first = n / fdiv > 128u ? n / fdiv : 128u;
+        for (uint32_t pc = 1; pc < pieces; pc++) {
+            const uint32_t at = first + (uint32_t)((uint64_t)(n - first) * (pc - 1) / (pieces - 1));
+            if (at > bnd.back() && at < n) bnd.push_back(at);
+        }
+        bnd.push_back(n);
+        pieces = (uint32_t)bnd.size() - 1;
+        std::vector<uint64_t> lo(pieces, ~0ull), hi(pieces, 0);
+        uint64_t moved = 0;
+        for (uint32_t pc = 0; pc < pieces; pc++) {
+            for (uint32_t i = bnd[pc]; i < bnd[pc + 1]; i++) {
+                if (!b->in_len[i]) continue;
+                if (b->in_off[i] < lo[pc]) lo[pc] = b->in_off[i];
+                if (b->in_off[i] + b->in_len[i] > hi[pc]) hi[pc] = b->in_off[i] + b->in_len[i];
+            }
+            if (hi[pc] > lo[pc]) {
+                lo[pc] &= ~255ull;
+                hi[pc] = (hi[pc] + 255ull) & ~255ull; if (hi[pc] > in_span) hi[pc] = in_span;
+                moved += hi[pc] - lo[pc];
+            }
+        }
+        if (pieces <= 1 || moved > in_span + in_span / 4) {
+            pieces = 1;
+            if (in_span) HIPCHK(c, hipMemcpyAsync(c->d_in.p, b->in_base, in_span, hipMemcpyHostToDevice, s));
+        } else {
+            if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+            while (c->piece_ev.size() < pieces) { hipEvent_t e; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->piece_ev.push_back(e); }
+            if (!c->h_gate) HIPCHK(c, hipHostMalloc((void**)&c->h_gate, 64, hipHostMallocDefault));
+            HIPCHK(c, c->d_gate.reserve(64));
+            const uint32_t seq = ++c->gate_seq ? c->gate_seq : ++c->gate_seq;       // (never 0: a fresh buffer)
+            {
+                hipPointerAttribute_t ga;
+                HIPCHK(c, hipPointerGetAttributes(&ga, c->h_gate));
+                k.gate_host = (const uint32_t*)ga.devicePointer;
+            }
+            k.gate = (uint32_t*)c->d_gate.p; k.gate_seq = seq;
+            for (uint32_t pc = 1; pc < pieces; pc++) k.gate_bnd[pc - 1] = bnd[pc];
+            const uint64_t ticks = 100000ull * (50 + in_span / 10000000ull);       // 50 ms + the input at a fifth of the link's rate
+            k.gate_ticks = ticks > 0xffffffffull ? 0xffffffffu : (uint32_t)ticks;
+            if (hi[0] > lo[0]) HIPCHK(c, hipMemcpyAsync((uint8_t*)c->d_in.p + lo[0], b->in_base + lo[0], hi[0] - lo[0], hipMemcpyHostToDevice, c->copy_stream));
+            HIPCHK(c, hipEventRecord(c->piece_ev[0], c->copy_stream));
+            HIPCHK(c, hipStreamWaitEvent(s, c->piece_ev[0], 0));
+            const int rcg = launch_codec(c, codec, k, param_over);
+            if (rcg) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamSynchronize(s); return rcg; }
+            for (uint32_t pc = 1; pc < pieces; pc++) {
+                if (hi[pc] > lo[pc]) HIPCHK(c, hipMemcpyAsync((uint8_t*)c->d_in.p + lo[pc], b->in_base + lo[pc], hi[pc] - lo[pc], hipMemcpyHostToDevice, c->copy_stream));
+                HIPCHK(c, hipEventRecord(c->piece_ev[pc], c->copy_stream));
+            }
+            // this thread tells the launch what has arrived (a word copied in behind each range would be the natural signal; such a small
+            // copy is done by a kernel, and a kernel does not run while every slot of the device holds a waiting block: built, measured --
+            // every gate ran into its time limit)
+            for (uint32_t pc = 1; pc < pieces; pc++) {
+                HIPCHK(c, hipEventSynchronize(c->piece_ev[pc]));
+                __atomic_store_n((volatile uint32_t*)(c->h_gate + pc), seq, __ATOMIC_RELEASE);
+            }
+            gated = true;
+        }
+    }
+    if (!gated) {
+        int rc = launch_codec(c, codec, k, param_over);
+        if (rc) return rc;
+    }
     HIPCHK(c, hipMemcpyAsync(h64 + 5 * N, d64 + 5 * N, 2 * N * 8 + 2 * N * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    if (b->mem == RCX_MEM_HOST && out_span) {
+    if (gated) {
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+        bool again = false;
+        for (size_t i = 0; i < N && !again; i++) again = h_status[i] == (int32_t)RCX_ST_GATE;
+        if (again) {
+            k.gate = nullptr;
+            rcx_tu_lz4_decode_mirror_again(s, k);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(h64 + 5 * N, d64 + 5 * N, 2 * N * 8 + 2 * N * 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+        }
+    }
+    if (b->mem == RCX_MEM_HOST && out_span && !mirror) {
         // only what was produced travels back: the span up to the last byte any block wrote, not the slots' capacity
         uint64_t used_span = 0;
         const uint64_t* ol = h64 + 5 * N;
@@ -333,7 +451,7 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
             const uint64_t l = ol[i] < b->out_cap[i] ? ol[i] : b->out_cap[i];
             if (l && b->out_off[i] + l > used_span) used_span = b->out_off[i] + l;
         }
-        if (used_span) HIPCHK(c, hipMemcpy(b->out_base, c->d_out.p, used_span, hipMemcpyDeviceToHost));
+        if (used_span) HIPCHK(c, hipMemcpy(b->out_base, d_out, used_span, hipMemcpyDeviceToHost));
     }
     if (b->out_len) memcpy(b->out_len, h64 + 5 * N, N * 8);
     if (b->in_used) memcpy(b->in_used, h64 + 6 * N, N * 8);

@@ -19,7 +19,16 @@ struct rcx_kargs {
     void* scratch;
     uint64_t scratch_bytes;
     uint32_t nblocks;
+    uint8_t* out_mirror; // LZ4 decode from host memory: the caller's page-locked output buffer as the device sees it (k_lz4_decode_v4.hip, MIRROR), else null
+    // ... and its input arrives WHILE the launch runs: blocks from gate_bnd[i - 1] on (range i = 1..15) start when gate[i] == gate_seq
+    // (rcx_api.hip), or give up after gate_ticks (100 MHz) with RCX_ST_GATE
+    uint32_t* gate;
+    const uint32_t* gate_host;   // the same words in page-locked host memory, set by the calling thread when a range's copy has completed: the
+                                 // range's FIRST block watches its word there (across PCIe) and passes it on to gate[i] for the others
+    uint32_t gate_seq, gate_ticks;
+    uint32_t gate_bnd[15];
 };
+#define RCX_ST_GATE 0x7ff00003               /* internal, never leaves the library: the block's input did not arrive in time, run it again */
 
 #define RCX_WAVE 64
 

@@ -11,6 +11,7 @@
 // tu_lz4.hip
 int rcx_tu_lz4_decode(hipStream_t s, rcx_kargs& k, int variant, std::string& err);
 int rcx_tu_lz4_encode(hipStream_t s, rcx_kargs& k, int variant, std::string& err);
+void rcx_tu_lz4_decode_mirror_again(hipStream_t s, rcx_kargs& k);
 uint64_t rcx_tu_lz4_encode_scratch(uint32_t nblocks);
 // tu_inflate.hip
 void rcx_tu_inflate(hipStream_t s, rcx_kargs& k, bool zlib, int variant);

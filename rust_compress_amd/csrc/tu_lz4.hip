@@ -27,7 +27,8 @@ uint64_t rcx_tu_lz4_encode_scratch(uint32_t nblocks) { return (uint64_t)(nblocks
 int rcx_tu_lz4_decode(hipStream_t s, rcx_kargs& k, int v, std::string& err)
 {
     const uint32_t n = k.nblocks;
-    if (v == 0 || v == 23) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768>), dim3(n), dim3(128), 0, s, k, 0);
+    if ((v == 0 || v == 23) && k.out_mirror) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 0, true>), dim3(n), dim3(128), 0, s, k, 0);   // + every byte to the caller's page-locked buffer
+    else if (v == 0 || v == 23) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768>), dim3(n), dim3(128), 0, s, k, 0);
     else if (v == 15) hipLaunchKernelGGL((k_lz4_decode_v5<2048, 1536, 2048>), dim3(n), dim3(128), 0, s, k, 0);
 #ifdef RCX_AB_VARIANTS
     else if (v == 11) hipLaunchKernelGGL((k_lz4_decode_v4<1024, 1>), dim3(n), dim3(64), 0, s, k);
@@ -77,6 +78,12 @@ int rcx_tu_lz4_decode(hipStream_t s, rcx_kargs& k, int v, std::string& err)
 #endif
     else { err = "lz4 decode: unknown kernel variant (A/B variants need a -DRCX_AB_VARIANTS build)"; return RCX_RC_BAD_ARG; }
     return RCX_RC_OK;
+}
+
+// the blocks a gated launch gave up on (RCX_ST_GATE: their input was late), once more -- the input is all there now
+void rcx_tu_lz4_decode_mirror_again(hipStream_t s, rcx_kargs& k)
+{
+    hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 0, true>), dim3(k.nblocks), dim3(128), 0, s, k, (int)RCX_ST_GATE);
 }
 
 int rcx_tu_lz4_encode(hipStream_t s, rcx_kargs& k, int v, std::string& err)

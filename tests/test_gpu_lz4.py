@@ -211,3 +211,83 @@ def test_multi_device_entry_points(ctx, oracle):
     finally:
         L.rcx_multi_destroy(h)
 
+
+
+def test_host_path_into_page_locked_output(ctx, oracle):
+    """rcx_lz4_decode_batch with RCX_MEM_HOST and a PAGE-LOCKED output buffer (rcx_api.hip: the decoder stores what leaves its window
+    straight into the caller's buffer, the compressed bytes travel in as block ranges under the launches before them) returns what
+    the plain copies return (rcx_ctx_set_param(ctx, RCX_LZ4_DECODE, 1)) and what the oracle returns: ragged and empty blocks, the
+    wave-wide paths (incompressible blocks, long runs), the reference's statuses on corrupted blocks among the good ones, output
+    slots at odd addresses with room to spare (not a byte beyond a block's decoded length is touched), blocks listed in reverse
+    input order (one range), and enough blocks for several ranges."""
+    import ctypes as C
+    import torch
+    import corpus
+    from rust_compress_amd import batch as B
+    L = N.lib()
+    rng = np.random.default_rng(2026)
+    kinds = ("text", "runs", "rand", "dna4", "mix")
+    raws = [synth.gen(kinds[i % 5], int(rng.choice([0, 1, 13, 700, 4096, 20000, 65536, 100000])) if i % 7 else 65536, 300 + i).tobytes() for i in range(700)]
+    blobs = [oracle.lz4_encode_block(r) for r in raws]
+    eb, er = corpus.lz4_edge_streams(oracle, 60, 91)
+    blobs += eb; raws += er
+    caps = [len(r) + int(rng.integers(0, 40)) for r in raws]
+    for i in range(0, len(blobs), 37):                    # corrupted / short of room among the good ones
+        b = bytearray(blobs[i])
+        if len(b) > 8 and i % 2: b[int(rng.integers(0, len(b)))] ^= 0x5a
+        elif len(b) > 8: b = b[: int(rng.integers(1, len(b)))]
+        blobs[i] = bytes(b)
+        if i % 3 == 0 and caps[i] > 10: caps[i] = caps[i] // 2
+    n = len(blobs)
+    want = [oracle.lz4_decode_block(b, cap=c, raise_on_error=False) for b, c in zip(blobs, caps)]
+
+    def run(order, plain, out_mis):
+        bl = [blobs[i] for i in order]
+        base, off, lens = B.pack(bl)
+        total, ooff, ocap = B.layout([caps[i] for i in order])
+        ooff = ooff + np.uint64(out_mis)
+        inb = torch.from_numpy(base).pin_memory()
+        outb = torch.full((int(total) + 256,), 0xAA, dtype=torch.uint8).pin_memory()
+        out_len, in_used, status = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.full(n, -9, np.int32)
+        p = lambda a: a.ctypes.data
+        b = N.Batch(inb.data_ptr(), p(off), p(lens), outb.data_ptr() + 3, p(ooff), p(ocap), p(out_len), p(in_used), p(status), n, N.MEM_HOST)
+        assert L.rcx_ctx_set_param(ctx._h, N.LZ4_DECODE, 1 if plain else 0) == 0
+        try:
+            assert L.rcx_lz4_decode_batch(ctx._h, C.byref(b)) == 0, L.rcx_last_error(ctx._h)
+        finally:
+            L.rcx_ctx_set_param(ctx._h, N.LZ4_DECODE, 0)
+        got = outb.numpy()[3:]
+        for j, i in enumerate(order):
+            eo, es = want[i]
+            assert es == status[j], (plain, i, es, status[j])
+            o = int(ooff[j])
+            if es == 0:
+                assert int(out_len[j]) == len(eo) and bytes(got[o: o + len(eo)]) == eo, (plain, i)
+                assert int(in_used[j]) == len(blobs[i])
+                if not plain:                             # (the plain path copies one span back: the room between the blocks comes with it)
+                    assert (got[o + len(eo): o + int(ocap[j])] == 0xAA).all(), (i, "bytes beyond the decoded length were written")
+        return status.copy(), out_len.copy()
+
+    fwd = list(range(n))
+    s0, l0 = run(fwd, True, 0)
+    s1, l1 = run(fwd, False, 0)
+    assert (s0 == s1).all() and (l0 == l1).all()
+    run(fwd, False, 5)
+    # blocks listed in reverse input order: the ranges' spans would overlap, the call takes one range
+    bl = [blobs[i] for i in fwd]
+    base, off, lens = B.pack(bl)
+    total, ooff, ocap = B.layout(caps)
+    inb = torch.from_numpy(base).pin_memory()
+    outb = torch.full((int(total) + 64,), 0xAA, dtype=torch.uint8).pin_memory()
+    rev = np.arange(n)[::-1].copy()
+    off_r, lens_r, ooff_r, ocap_r = (np.ascontiguousarray(a[rev]) for a in (off, lens, ooff, ocap))
+    out_len, in_used, status = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.full(n, -9, np.int32)
+    p = lambda a: a.ctypes.data
+    b = N.Batch(inb.data_ptr(), p(off_r), p(lens_r), outb.data_ptr(), p(ooff_r), p(ocap_r), p(out_len), p(in_used), p(status), n, N.MEM_HOST)
+    assert L.rcx_lz4_decode_batch(ctx._h, C.byref(b)) == 0
+    got = outb.numpy()
+    for j in range(n):
+        i = int(rev[j]); eo, es = want[i]
+        assert es == status[j]
+        if es == 0:
+            assert bytes(got[int(ooff[i]): int(ooff[i]) + len(eo)]) == eo
