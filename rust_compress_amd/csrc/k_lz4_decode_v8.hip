@@ -33,7 +33,14 @@
 #define RCX_V8_ESLEEP 4
 #endif
 #ifndef RCX_WALK_FORM
-#define RCX_WALK_FORM 0                  /* 0: eight bytes + a second read where needed (portable), 1: sixteen bytes, the step as ISA, 2: form 0's whole loop as ISA */
+#define RCX_WALK_FORM 3                  /* 0: eight bytes + a second read where needed (portable), 1: sixteen bytes, the step as ISA, 2: form 0's whole loop as ISA,
+                                            3: form 2 for a block's FIRST chunk, form 0 after it, 4: form 2 whenever the executor has fewer than RCX_WALK_ISA_LOW batches in front of it.
+                                            Form 2 shortens the walk's latency (fewer scalar instructions, no divergent branches) and costs 30 more vector instructions a
+                                            batch: a loss while the executors fill the vector ALU (0.534 against 0.528 ms), a gain before the block's first batch, when
+                                            nothing else runs on the SIMD (3: 0.5224; 4 with LOW 2 / 3 / 4 / 6: 0.5233 / 0.5220 / 0.5229 / 0.5240 -- no better than 3) */
+#endif
+#ifndef RCX_WALK_ISA_LOW
+#define RCX_WALK_ISA_LOW 3
 #endif
 #ifndef RCX_WALK_PRIO
 #define RCX_WALK_PRIO RCX_PARSER_PRIO    /* issue priority while a chunk after the first is staged, walked and linked */
@@ -260,7 +267,7 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR> {
         bool slow = n < 20u || p > n - 20u;
         const int32_t i = (on && !slow) ? (int32_t)p - this->cbase : 0;      // (a lane that is not walking reads the buffer's first bytes)
         uint32_t q;
-#if RCX_WALK_FORM == 0
+#if RCX_WALK_FORM == 0 || RCX_WALK_FORM >= 3
         // eight bytes in one round trip (three aligned dwords), a second read where the match-length extension lies further on
         q = 0;
         if (on && !slow) {
@@ -705,8 +712,8 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR> {
             uint32_t p = ((int)lane == k0) ? c : (uint32_t)p0;
             uint64_t map = (giant && (int)lane == k0) ? 1ull << (c - (uint32_t)s) : 0ull;
             RCX_MARK("p8_walk");
-#if RCX_WALK_FORM == 2 && !defined(RCX_NO_WALK_ASM)
-            if (n >= 20u) {
+#if (RCX_WALK_FORM >= 2) && !defined(RCX_NO_WALK_ASM)
+            if (n >= 20u && (RCX_WALK_FORM == 2 || head == 0 || (RCX_WALK_FORM == 4 && head - RCX_U(this->ring8->tail) < (uint32_t)RCX_WALK_ISA_LOW))) {
                 uint32_t mlo = (uint32_t)map, mhi = (uint32_t)(map >> 32);
                 const uint64_t minem = __ballot(mine);
                 for (;;) {
@@ -725,7 +732,7 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR> {
                 if (!__ballot(go)) break;
                 if (PROF8) pp[7] += 1;
                 if (RCX_V8_ADAPT && (wstep & 3u) == 3u) ring_prio(head, RCX_V8_LOW_WALK);
-#if RCX_WALK_FORM == 0
+#if RCX_WALK_FORM == 0 || RCX_WALK_FORM >= 3
                 if (go) {
                     if ((int32_t)p >= s) map |= 1ull << (p - (uint32_t)s);
                     p = next_tok_c(p);
