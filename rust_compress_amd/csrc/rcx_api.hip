@@ -38,6 +38,7 @@ struct rcx_ctx {
     std::vector<uint8_t> h_desc;
     hipStream_t copy_stream = nullptr;   // the host-memory LZ4 decode: compressed ranges on their way in under the launch that decodes them
     std::vector<hipEvent_t> piece_ev;
+    bool gate_bad = false;               // a gated launch ran into its time limit once (the copies did not run beside it): one copy in front of the launch from then on
     DevBuf d_gate; uint32_t* h_gate = nullptr; uint32_t gate_seq = 0;      // "range r has arrived" words (device; their page-locked source)
 };
 
@@ -297,7 +298,7 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
             // (ranges only from page-locked INPUT: a pageable buffer is staged piece by piece, by copies that may need the compute
             // units the waiting blocks would hold)
             hipPointerAttribute_t ai;
-            if (in_span && hipPointerGetAttributes(&ai, b->in_base) == hipSuccess && ai.type == hipMemoryTypeHost) {
+            if (in_span && !c->gate_bad && hipPointerGetAttributes(&ai, b->in_base) == hipSuccess && ai.type == hipMemoryTypeHost) {
                 pieces = ((c->param[codec] >> 8) & 255u) ? ((c->param[codec] >> 8) & 255u) : 8u;
                 if (pieces > 16u) pieces = 16u;             // (the most; see below)
                 if (pieces > n / 128u) pieces = n / 128u ? n / 128u : 1u;
@@ -392,7 +393,14 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
             pieces = 1;
             if (in_span) HIPCHK(c, hipMemcpyAsync(c->d_in.p, b->in_base, in_span, hipMemcpyHostToDevice, s));
         } else {
-            if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+            if (!c->copy_stream) {
+                // a stream of ANOTHER priority than the launch's: HIP hands its few hardware queues to the streams of one priority in
+                // turn, and a copy stream that shares the launch's queue stands behind the launch it is meant to feed (every gate ran into
+                // its limit for one context in two: 66 ms a call)
+                int least = 0, greatest = 0;
+                HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+                HIPCHK(c, hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, greatest));
+            }
             while (c->piece_ev.size() < pieces) { hipEvent_t e; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->piece_ev.push_back(e); }
             if (!c->h_gate) HIPCHK(c, hipHostMalloc((void**)&c->h_gate, 64, hipHostMallocDefault));
             HIPCHK(c, c->d_gate.reserve(64));
@@ -404,7 +412,7 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
             }
             k.gate = (uint32_t*)c->d_gate.p; k.gate_seq = seq;
             for (uint32_t pc = 1; pc < pieces; pc++) k.gate_bnd[pc - 1] = bnd[pc];
-            const uint64_t ticks = 100000ull * (50 + in_span / 10000000ull);       // 50 ms + the input at a fifth of the link's rate
+            const uint64_t ticks = 1000000ull + in_span / 50ull;                   // 10 ms + the input at 5 GB/s (100 MHz ticks)
             k.gate_ticks = ticks > 0xffffffffull ? 0xffffffffu : (uint32_t)ticks;
             if (hi[0] > lo[0]) HIPCHK(c, hipMemcpyAsync((uint8_t*)c->d_in.p + lo[0], b->in_base + lo[0], hi[0] - lo[0], hipMemcpyHostToDevice, c->copy_stream));
             HIPCHK(c, hipEventRecord(c->piece_ev[0], c->copy_stream));
@@ -436,6 +444,7 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
         bool again = false;
         for (size_t i = 0; i < N && !again; i++) again = h_status[i] == (int32_t)RCX_ST_GATE;
         if (again) {
+            c->gate_bad = true;
             k.gate = nullptr;
             rcx_tu_lz4_decode_mirror_again(s, k);
             HIPCHK(c, hipGetLastError());

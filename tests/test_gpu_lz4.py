@@ -291,3 +291,21 @@ def test_host_path_into_page_locked_output(ctx, oracle):
         assert es == status[j]
         if es == 0:
             assert bytes(got[int(ooff[i]): int(ooff[i]) + len(eo)]) == eo
+    # the same page-locked buffers through rcx_multi_batch (two contexts on the one device: two gated launches side by side)
+    h = C.c_void_p()
+    devs = (C.c_int * 2)(0, 0)
+    assert L.rcx_multi_create(devs, 2, C.byref(h)) == 0
+    try:
+        outb.fill_(0xAA)
+        out_len[:] = 0; in_used[:] = 0; status[:] = -9
+        b = N.Batch(inb.data_ptr(), p(off), p(lens), outb.data_ptr(), p(ooff), p(ocap), p(out_len), p(in_used), p(status), n, N.MEM_HOST)
+        for rep in range(2):
+            assert L.rcx_multi_batch(h, N.LZ4_DECODE, C.byref(b), None, None, None) == 0, L.rcx_multi_last_error(h)
+        got = outb.numpy()
+        for i in range(n):
+            eo, es = want[i]
+            assert es == status[i]
+            if es == 0:
+                assert int(out_len[i]) == len(eo) and bytes(got[int(ooff[i]): int(ooff[i]) + len(eo)]) == eo
+    finally:
+        L.rcx_multi_destroy(h)
