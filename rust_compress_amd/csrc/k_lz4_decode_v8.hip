@@ -873,11 +873,11 @@ __global__ __launch_bounds__(128, 8) void k_lz4_decode_v8(rcx_kargs a, int only_
         uint32_t r = 0;
 #pragma unroll
         for (int i = 0; i < 15; i++) r += b >= a.gate_bnd[i] ? 1u : 0u;
-        if (r) {
+        if (r || a.gate_all) {
             if (threadIdx.x == 0) {
                 const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
                 uint32_t ok = 1;
-                if (b == a.gate_bnd[r - 1]) {                       // the range's first block: the host's word, then everybody's
+                if (b == (r ? a.gate_bnd[r - 1] : 0u)) {                       // the range's first block: the host's word, then everybody's
                     while (__hip_atomic_load(a.gate_host + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != a.gate_seq) {
                         __builtin_amdgcn_s_sleep(60);
                         if (__builtin_amdgcn_s_memrealtime() - t0 > (uint64_t)a.gate_ticks) { ok = 0; break; }

@@ -35,7 +35,7 @@ struct rcx_ctx {
     uint32_t param[RCX_CODEC_COUNT] = {0};
     DevBuf d_in, d_out, d_desc, d_scratch;
     DevBuf d_apm;                        // apm stretch table + gate bins (filled on first use)
-    std::vector<uint8_t> h_desc;
+    uint8_t* h_desc = nullptr; size_t h_desc_cap = 0;      // page-locked: the descriptors' way in and the results' way out are small copies the call waits for
     hipStream_t copy_stream = nullptr;   // the host-memory LZ4 decode: compressed ranges on their way in under the launch that decodes them
     std::vector<hipEvent_t> piece_ev;
     bool gate_bad = false;               // a gated launch ran into its time limit once (the copies did not run beside it): one copy in front of the launch from then on
@@ -78,6 +78,7 @@ extern "C" void rcx_ctx_destroy(rcx_ctx* c)
     for (hipEvent_t e : c->piece_ev) (void)hipEventDestroy(e);
     c->d_gate.release();
     if (c->h_gate) (void)hipHostFree(c->h_gate);
+    if (c->h_desc) (void)hipHostFree(c->h_desc);
     delete c;
 }
 
@@ -243,7 +244,7 @@ extern "C" int rcx_launch_dev(rcx_ctx* c, int codec, const rcx_dev_batch* b, voi
     k.in_base = b->in_base; k.in_off = b->in_off; k.in_len = b->in_len;
     k.out_base = b->out_base; k.out_off = b->out_off; k.out_cap = b->out_cap;
     k.out_len = b->out_len; k.in_used = b->in_used; k.status = b->status; k.aux = b->aux;
-    k.n_out = nullptr; k.scratch = scratch; k.scratch_bytes = scratch_bytes; k.nblocks = b->nblocks; k.out_mirror = nullptr; k.gate = nullptr;
+    k.n_out = nullptr; k.scratch = scratch; k.scratch_bytes = scratch_bytes; k.nblocks = b->nblocks; k.out_mirror = nullptr; k.gate = nullptr; k.gate_all = 0;
     if (codec == RCX_DC_DECODE) { c->err = "dc decode needs n_out: use rcx_dc_decode_batch"; return RCX_RC_BAD_ARG; }
     return launch_codec(c, codec, k);
 }
@@ -299,7 +300,7 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
             // units the waiting blocks would hold)
             hipPointerAttribute_t ai;
             if (in_span && !c->gate_bad && hipPointerGetAttributes(&ai, b->in_base) == hipSuccess && ai.type == hipMemoryTypeHost) {
-                pieces = ((c->param[codec] >> 8) & 255u) ? ((c->param[codec] >> 8) & 255u) : 8u;
+                pieces = ((c->param[codec] >> 8) & 255u) ? ((c->param[codec] >> 8) & 255u) : 16u;
                 if (pieces > 16u) pieces = 16u;             // (the most; see below)
                 if (pieces > n / 128u) pieces = n / 128u ? n / 128u : 1u;
             } else (void)hipGetLastError();
@@ -320,8 +321,13 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
     const size_t res_words = 2 * N;                // u64
     const size_t desc_bytes = (in_words + res_words) * 8 + 2 * N * 4 + 64;
     HIPCHK(c, c->d_desc.reserve(desc_bytes));
-    c->h_desc.resize(desc_bytes);
-    uint64_t* h64 = (uint64_t*)c->h_desc.data();
+    if (desc_bytes > c->h_desc_cap) {
+        if (c->h_desc) (void)hipHostFree(c->h_desc);
+        c->h_desc = nullptr; c->h_desc_cap = 0;
+        HIPCHK(c, hipHostMalloc((void**)&c->h_desc, desc_bytes + desc_bytes / 4, hipHostMallocDefault));
+        c->h_desc_cap = desc_bytes + desc_bytes / 4;
+    }
+    uint64_t* h64 = (uint64_t*)c->h_desc;
     memcpy(h64 + 0 * N, b->in_off, N * 8);
     memcpy(h64 + 1 * N, b->in_len, N * 8);
     if (needs_out) { memcpy(h64 + 2 * N, b->out_off, N * 8); memcpy(h64 + 3 * N, b->out_cap, N * 8); }
@@ -332,7 +338,7 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
     for (size_t i = 0; i < N; i++) h_status[i] = RCX_E_MALFORMED;
     if (aux_in) memcpy(h_aux, aux_in, N * 4); else memset(h_aux, 0, N * 4);
     memset(h64 + 5 * N, 0, 2 * N * 8);
-    HIPCHK(c, hipMemcpyAsync(c->d_desc.p, c->h_desc.data(), (7 * N) * 8 + 2 * N * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->d_desc.p, c->h_desc, (7 * N) * 8 + 2 * N * 4, hipMemcpyHostToDevice, s));
     uint64_t* d64 = (uint64_t*)c->d_desc.p;
 
     rcx_kargs k;
@@ -353,12 +359,12 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
         k.scratch = c->d_scratch.p; k.scratch_bytes = c->d_scratch.cap;
         if (codec == RCX_DC_ENCODE && !sb) { k.scratch = nullptr; k.scratch_bytes = 0; }
     }
-    k.out_mirror = mirror; k.gate = nullptr; k.gate_host = nullptr; k.gate_seq = 0; k.gate_ticks = 0;
+    k.out_mirror = mirror; k.gate = nullptr; k.gate_host = nullptr; k.gate_seq = 0; k.gate_ticks = 0; k.gate_all = 0;
     for (int i = 0; i < 15; i++) k.gate_bnd[i] = 0xffffffffu;
     bool gated = false;
     if (pieces > 1) {
-        // ONE launch, the input in ranges: the first range (a sixteenth of the blocks) is all the launch waits for; the blocks of a later
-        // range start when this thread has seen the range's copy complete and said so in a page-locked word (k_lz4_decode_v8, `gate`).  A launch per range was built first and measured: each one ends with the link drained and begins with nothing to
+        // ONE launch, the input in ranges: the blocks of a
+        // range (the first one small: a sixty-fourth of the blocks) start when this thread has seen the range's copy complete and said so in a page-locked word (k_lz4_decode_v8, `gate`).  A launch per range was built first and measured: each one ends with the link drained and begins with nothing to
         // send, 5.9 ms for three growing ranges, 6.6 for eight equal ones, against 7.0 for one launch behind one copy.
         // A range's compressed bytes are the span from its lowest to its highest input byte, widened to whole 256-byte lines of the
         // staging buffer (a line two ranges share is complete the first time anybody reads it; what the widening copies early are the
@@ -367,8 +373,8 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
         // RCX_ST_GATE and is decoded by a second launch below (the copies cannot be held up by the waiting blocks as long as a copy
         // engine moves them; a copy done by a kernel could be, and then this is what ends the wait).
         std::vector<uint32_t> bnd(1, 0);
-        const uint32_t fdiv = ((c->param[codec] >> 16) & 255u) ? ((c->param[codec] >> 16) & 255u) : 16u;       // (tuning)
-        const uint32_t first = n / fdiv > 128u ? n / fdiv : 128u;
+        const uint32_t fdiv = ((c->param[codec] >> 16) & 255u) ? ((c->param[codec] >> 16) & 255u) : 64u;       // (tuning)
+        const uint32_t first = n / fdiv > 64u ? n / fdiv : 64u;
         for (uint32_t pc = 1; pc < pieces; pc++) {
             const uint32_t at = first + (uint32_t)((uint64_t)(n - first) * (pc - 1) / (pieces - 1));
             if (at > bnd.back() && at < n) bnd.push_back(at);
@@ -414,19 +420,20 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
             for (uint32_t pc = 1; pc < pieces; pc++) k.gate_bnd[pc - 1] = bnd[pc];
             const uint64_t ticks = 1000000ull + in_span / 50ull;                   // 10 ms + the input at 5 GB/s (100 MHz ticks)
             k.gate_ticks = ticks > 0xffffffffull ? 0xffffffffu : (uint32_t)ticks;
-            if (hi[0] > lo[0]) HIPCHK(c, hipMemcpyAsync((uint8_t*)c->d_in.p + lo[0], b->in_base + lo[0], hi[0] - lo[0], hipMemcpyHostToDevice, c->copy_stream));
-            HIPCHK(c, hipEventRecord(c->piece_ev[0], c->copy_stream));
-            HIPCHK(c, hipStreamWaitEvent(s, c->piece_ev[0], 0));
-            const int rcg = launch_codec(c, codec, k, param_over);
-            if (rcg) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamSynchronize(s); return rcg; }
-            for (uint32_t pc = 1; pc < pieces; pc++) {
+            // (range 0 waits at a gate like the others: the launch is on its way to the device while the first bytes are)
+            k.gate_all = 1;
+            for (uint32_t pc = 0; pc < pieces; pc++) {
                 if (hi[pc] > lo[pc]) HIPCHK(c, hipMemcpyAsync((uint8_t*)c->d_in.p + lo[pc], b->in_base + lo[pc], hi[pc] - lo[pc], hipMemcpyHostToDevice, c->copy_stream));
                 HIPCHK(c, hipEventRecord(c->piece_ev[pc], c->copy_stream));
+                if (pc == 0) {
+                    const int rcg = launch_codec(c, codec, k, param_over);
+                    if (rcg) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamSynchronize(s); return rcg; }
+                }
             }
             // this thread tells the launch what has arrived (a word copied in behind each range would be the natural signal; such a small
             // copy is done by a kernel, and a kernel does not run while every slot of the device holds a waiting block: built, measured --
             // every gate ran into its time limit)
-            for (uint32_t pc = 1; pc < pieces; pc++) {
+            for (uint32_t pc = 0; pc < pieces; pc++) {
                 HIPCHK(c, hipEventSynchronize(c->piece_ev[pc]));
                 __atomic_store_n((volatile uint32_t*)(c->h_gate + pc), seq, __ATOMIC_RELEASE);
             }

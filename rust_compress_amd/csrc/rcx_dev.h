@@ -26,6 +26,7 @@ struct rcx_kargs {
     const uint32_t* gate_host;   // the same words in page-locked host memory, set by the calling thread when a range's copy has completed: the
                                  // range's FIRST block watches its word there (across PCIe) and passes it on to gate[i] for the others
     uint32_t gate_seq, gate_ticks;
+    uint32_t gate_all;           // range 0 waits too (at gate[0]; its first block is block 0): the launch is enqueued before any input has arrived
     uint32_t gate_bnd[15];
 };
 #define RCX_ST_GATE 0x7ff00003               /* internal, never leaves the library: the block's input did not arrive in time, run it again */

@@ -91,3 +91,36 @@ def test_decode_malformed_statuses_match_oracle(oracle, variant):
         assert es == s, (i, es, s)
         if es == 0:
             assert eo == out
+
+
+@pytest.mark.parametrize("mis", [(0, 0), (3, 5), (0, 250)])
+def test_decode_mirror_and_gates(oracle, golden, mis):
+    """The host-memory decoder (k_lz4_decode_v8<..., MIRROR>, rcx_api.hip run_batch): what leaves the window is stored a second time,
+    in whole 256-byte lines of the caller's buffer, the rest with the next drain or at the block's end -- the second buffer holds
+    the decoded bytes of every block and not a byte more, at three alignments; blocks behind an open gate decode as ever, blocks
+    behind a gate that stays shut give up with the internal status and leave their slots alone."""
+    import simrun
+    raws = _raws() + [golden("test.txt")]
+    blobs = [oracle.lz4_encode_block(r) for r in raws]
+    caps = [len(r) + (i % 3) * 7 for i, r in enumerate(raws)]
+    outs, out_len, in_used, st, _ = simrun.run(LZ4_DECODE, 60, blobs, caps, in_misalign=mis[0], out_misalign=mis[1], mirror=True)
+    assert not st.any() and outs == raws and list(in_used) == [len(b) for b in blobs]
+    n = len(blobs)
+    outs, _, _, st, _ = simrun.run(LZ4_DECODE, 60, blobs, caps, out_misalign=mis[1], mirror=True, gate_bnd=[3, n // 2, n - 1], gates_open=True)
+    assert not st.any() and outs == raws
+    outs, _, _, st, _ = simrun.run(LZ4_DECODE, 60, blobs, caps, out_misalign=mis[1], mirror=True, gate_bnd=[n // 2], gates_open=False)
+    assert not st[: n // 2].any() and outs[: n // 2] == raws[: n // 2]
+    assert (st[n // 2:] == 0x7ff00003).all()
+    # too little room, and streams cut short, with the mirror: the reference's statuses
+    import corpus
+    rng = np.random.default_rng(19)
+    eb, er = corpus.lz4_edge_streams(oracle, 16, 23, max_out=30000)
+    cut = [b[: int(rng.integers(0, len(b)))] for b in eb]
+    small = [int(rng.integers(0, len(r) + 1)) for r in er]
+    for bl, cp in ((eb, [len(r) for r in er]), (cut, [len(r) for r in er]), (eb, small)):
+        exp = [oracle.lz4_decode_block(b, cap=c, raise_on_error=False) for b, c in zip(bl, cp)]
+        outs, _, _, st, _ = simrun.run(LZ4_DECODE, 60, bl, cp, out_misalign=mis[1], mirror=True)
+        for i, ((eo, es), s_, out) in enumerate(zip(exp, st, outs)):
+            assert es == s_, (i, es, s_)
+            if es == 0:
+                assert eo == out

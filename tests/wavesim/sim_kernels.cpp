@@ -49,6 +49,7 @@ extern "C" int sim_launch(int codec, int variant, const rcx_kargs* a)
         else if (variant == 23) ws::launch(dim3(k.nblocks), dim3(128), [&] { k_lz4_decode_v8<1024, 768>(k); });
         else if (variant == 20) ws::launch(dim3(k.nblocks), dim3(128), [&] { k_lz4_decode_v7<1024, 1008, 2048, 2048>(k); });
         else if (variant == 18) ws::launch(dim3(k.nblocks), dim3(512), [&] { k_lz4_decode_v6<8>(k); });      // no second pass: which blocks bail
+        else if (variant == 60) ws::launch(dim3(k.nblocks), dim3(128), [&] { k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 0, true>(k); });   // + the mirror (and the gates)
         else if (variant == 0) ws::launch(dim3(k.nblocks), dim3(128), [&] { k_lz4_decode_v8<1024, 768>(k); });
         else if (variant == 15) ws::launch(dim3(k.nblocks), dim3(128), [&] { k_lz4_decode_v5<2048, 1536, 2048>(k); });
         else ws::launch(dim3(k.nblocks), dim3(64), [&] { k_lz4_decode_v4<1024, 1>(k); });

@@ -224,6 +224,12 @@ static inline unsigned __byte_perm_(unsigned a, unsigned b, unsigned s) { (void)
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) ws::yield_()        // spin-wait loops let the other waves of the block run
 #define __builtin_amdgcn_s_setprio(n) ((void)0)
+// (the gate of the host-memory LZ4 decoder: a clock that advances with every look at it, plain loads and stores for the system-scope atomics)
+static inline unsigned long long ws_memrealtime_() { static unsigned long long t = 0; return t += 1000; }
+#define __builtin_amdgcn_s_memrealtime() ws_memrealtime_()
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#define __hip_atomic_load(p, order, scope) (*(volatile const uint32_t*)(p))
+#define __hip_atomic_store(p, v, order, scope) (*(volatile uint32_t*)(p) = (v))
 #define __builtin_amdgcn_s_getreg(n) (0u)              // (HW_ID: every wave in slot 0 here; only issue priorities depend on it)
 #define RCX_LDS_AS
 #define RCX_GLOBAL_AS
