@@ -68,6 +68,28 @@
 #ifndef RCX_V8_COLD
 #define RCX_V8_COLD 0
 #endif
+// RCX_AGE_DYN: which executors of a SIMD give way (RCX_AGE_PRIO, k_lz4_decode_v5.hip) follows their PROGRESS instead of their age.  A SIMD
+// issues the oldest wave first, the static rule (the older half one level down in rounds and drain) takes 2 % off that, and the blocks of
+// a launch still finish 20 % apart (benchmarks/r4_lz4_tail.py: 1.10 M .. 1.34 M ticks, an average block's slot busy 90 % of the launch)
+// while the launch ends with the last.  Every RCX_AGE_DYN-th batch an executor publishes the share of its input it has consumed in a
+// word per (SIMD, wave slot) of g_lz4_prog, looks at the eight words of its SIMD (read one period ago: nobody waits for the load) and
+// gives way when more running executors are behind it than ahead.  Parsers mark their slots, finished executors theirs.
+#ifndef RCX_AGE_DYN
+#define RCX_AGE_DYN 0
+#endif
+#define RCX_PROG_FIN 0xfffffffeu
+#define RCX_PROG_PARSER 0xffffffffu
+#define RCX_PROG_LIVE 0xffffff00u               /* running executors are below this */
+#if RCX_AGE_DYN
+__device__ uint32_t g_lz4_prog[65536 * 8];      // [XCC | SE | SH | CU | pipe | SIMD][wave slot]
+#else
+__device__ uint32_t g_lz4_prog[8];
+#endif
+// Measured (benchmarks/r5_lz4_flagcount.sh, one box): off 0.5189 / 0.5193 ms | every 8th batch 0.5231 | 4th 0.5254 | 2nd 0.556 | every batch 0.775
+// -- 13 vector and 16 scalar instructions more a batch even at a period of 8, and nothing back: one level of issue priority in the copy
+// rounds and the drain is too weak a lever to move a block's finishing time (the static rule bought 2 %), and a block that finishes early
+// does not leave its slot idle -- the others of its CU speed up (a block alone takes 0.49 ms).  Kept as a switch, off.
+
 #define V8P_T0() uint64_t t0_ = PROF8 ? (uint64_t)__builtin_readcyclecounter() : 0
 #define V8P_ADD(slot) do { if (PROF8) { const uint64_t t1_ = (uint64_t)__builtin_readcyclecounter(); pp[slot] += t1_ - t0_; t0_ = t1_; } } while (0)
 
@@ -78,6 +100,7 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR> {
     // (3.8 of its 4.6 rounds per batch of text were the long matches').  0: off.
     static constexpr int SPLIT = SPLIT_;
     static_assert(SPLIT_ == 0 || 2 * SPLIT_ >= 64, "two entries cover the 64-byte cap");
+    uint32_t* prog = nullptr; uint32_t wslot = 0;  // RCX_AGE_DYN: this SIMD's eight words, my wave slot
     bool agey = true;                             // RCX_AGE_PRIO (k_lz4_decode_v5.hip): this wave is in the younger half of its SIMD's (true: the plain levels)
     typedef Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR> P5;
     typedef typename P5::B B;
@@ -585,6 +608,9 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR> {
         int st = RCX_OK;
         uint32_t tail = 0;
         auto ring = this->ring8;
+        uint32_t dyn_pv = RCX_PROG_PARSER, dyn_mine = 0;
+        const uint32_t dyn_inv = RCX_AGE_DYN ? RCX_U(0xffffffffu / (this->n ? this->n : 1u)) : 0u;
+        if (RCX_AGE_DYN && lane == 0) __hip_atomic_store(prog + wslot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (;;) {
             uint64_t te0 = PROF8 ? (uint64_t)__builtin_readcyclecounter() : 0;
             while (RCX_U(ring->head) == tail) __builtin_amdgcn_s_sleep(RCX_V8_ESLEEP);
@@ -608,6 +634,17 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR> {
             }
             const uint32_t p0 = RCX_U(h7_);
             rcx_wave_sync();
+            if (RCX_AGE_DYN && (tail % (uint32_t)(RCX_AGE_DYN ? RCX_AGE_DYN : 1)) == 0u && bt.ns > 0) {
+                // decide on what was read a period ago, against where I stood then; publish where I stand now; ask again
+                const unsigned long long behind = __ballot(lane < 8u && dyn_pv < dyn_mine);
+                const unsigned long long ahead = __ballot(lane < 8u && dyn_pv > dyn_mine && dyn_pv < RCX_PROG_LIVE);
+                if (tail) agey = __popcll(behind) <= __popcll(ahead);
+                uint32_t mine = RCX_U(p0 * dyn_inv);
+                mine = mine < RCX_PROG_LIVE ? mine : RCX_PROG_LIVE - 1u;
+                if (lane == 0) __hip_atomic_store(prog + wslot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dyn_pv = __hip_atomic_load(prog + (lane & 7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dyn_mine = mine;
+            }
             tail++;
             if (lane == 0) ring->tail = tail;             // the slot is in registers: hand it back
             // where each entry's literals lie: behind its token, and the tokens follow one another (the second half of a split
@@ -670,6 +707,7 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR> {
             RCX_MARK("x8_loop_end");
         }
         if (st && lane == 0) ring->abort_ = 1;
+        if (RCX_AGE_DYN && lane == 0) __hip_atomic_store(prog + wslot, RCX_PROG_FIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!st) this->flush(this->oend, true);
         *st_out = st;
         *len_out = st ? 0u : this->oend;
@@ -914,7 +952,14 @@ __global__ __launch_bounds__(128, 8) void k_lz4_decode_v8(rcx_kargs a, int only_
     s.ring8 = (RCX_LDS_AS typename S::Ring8*)&s_ring;
     s.list = s_list;
     s.lmap = s_lmap;
+    if (RCX_AGE_DYN) {
+        const uint32_t hw = (uint32_t)__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);            // HW_ID[15:0]: wave, SIMD, pipe, CU, SH, SE
+        const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // XCC_ID
+        s.prog = g_lz4_prog + 8u * (((hw >> 4) & 0xfffu) | (xcc << 12));
+        s.wslot = hw & 7u;
+    }
     if (role == 0) {
+        if (RCX_AGE_DYN && (threadIdx.x & 63u) == 0) __hip_atomic_store(s.prog + s.wslot, RCX_PROG_PARSER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (RCX_AGE_PRIO & 16) s.agey = (((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) >> 1) & 7u) >= (uint32_t)RCX_AGE_SPLIT;
         s.run_parser8();
         if (PROF8 && a.scratch && (threadIdx.x & 63u) == 0) {          // [0..9] parser phases, [10] parser total

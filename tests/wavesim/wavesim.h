@@ -228,6 +228,7 @@ static inline unsigned __byte_perm_(unsigned a, unsigned b, unsigned s) { (void)
 static inline unsigned long long ws_memrealtime_() { static unsigned long long t = 0; return t += 1000; }
 #define __builtin_amdgcn_s_memrealtime() ws_memrealtime_()
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
+#define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(p, order, scope) (*(volatile const uint32_t*)(p))
 #define __hip_atomic_store(p, v, order, scope) (*(volatile uint32_t*)(p) = (v))
 #define __builtin_amdgcn_s_getreg(n) (0u)              // (HW_ID: every wave in slot 0 here; only issue priorities depend on it)
