@@ -289,6 +289,14 @@ int  rcx_multi_launch_dev(rcx_multi*, int codec, const rcx_dev_batch* const* per
 int  rcx_multi_sync(rcx_multi*);
 const char* rcx_multi_last_error(const rcx_multi*);
 
+/* ---- page-locked host memory (no counterpart in the reference: its Vec<u8> buffers are pageable) ----------------------------------
+ * rcx_lz4_decode_batch writes a page-locked output buffer directly and takes page-locked input in ranges under the launch (above).
+ * A host language without the HIP headers pins its own allocation with these: rcx_host_register(ptr, bytes) page-locks
+ * [ptr, ptr + bytes) for every device (hipHostRegister, portable + mapped; ~0.1 ms per MiB the first time), rcx_host_unregister
+ * undoes it before the memory is freed.  Return enum rcx_rc. */
+int rcx_host_register(void* ptr, uint64_t bytes);
+int rcx_host_unregister(void* ptr);
+
 #ifdef __cplusplus
 }
 #endif

@@ -172,4 +172,7 @@ extern "C" {
     pub fn rcx_multi_launch_dev(m: *mut rcx_multi, codec: c_int, per_device: *const *const rcx_dev_batch, scratch: *const *mut c_void, scratch_bytes: *const u64) -> c_int;
     pub fn rcx_multi_sync(m: *mut rcx_multi) -> c_int;
     pub fn rcx_multi_last_error(m: *const rcx_multi) -> *const c_char;
+    // ---- page-locked host memory: what lets rcx_lz4_decode_batch write the caller's buffer itself (include/rcx.h)
+    pub fn rcx_host_register(ptr: *mut c_void, bytes: u64) -> c_int;
+    pub fn rcx_host_unregister(ptr: *mut c_void) -> c_int;
 }

@@ -38,7 +38,7 @@ EXPORTS = [
     "rcx_ctx_set_param", "rcx_ari_apm_encode_batch", "rcx_ari_apm_decode_batch", "rcx_bwt_inverse_minimal_batch",
     "rcx_bwt_suffixes_batch", "rcx_bwt_inversion_table_batch",
     "rcx_multi_create", "rcx_multi_destroy", "rcx_multi_count", "rcx_multi_ctx", "rcx_partition", "rcx_multi_batch",
-    "rcx_multi_launch_dev", "rcx_multi_sync", "rcx_multi_last_error",
+    "rcx_multi_launch_dev", "rcx_multi_sync", "rcx_multi_last_error", "rcx_host_register", "rcx_host_unregister",
 ]
 
 
@@ -118,5 +118,7 @@ def lib():
         L.rcx_multi_sync.argtypes = [C.c_void_p]
         L.rcx_multi_last_error.argtypes = [C.c_void_p]
         L.rcx_multi_last_error.restype = C.c_char_p
+        L.rcx_host_register.argtypes = [C.c_void_p, C.c_uint64]
+        L.rcx_host_unregister.argtypes = [C.c_void_p]
         _lib = L
     return _lib

@@ -640,3 +640,21 @@ extern "C" int rcx_multi_sync(rcx_multi* m)
     }
     return RCX_RC_OK;
 }
+
+// ---- page-locking a caller's buffers (include/rcx.h) -----------------------------------------------------------------------------
+extern "C" int rcx_host_register(void* ptr, uint64_t bytes)
+{
+    if (!ptr || !bytes) return RCX_RC_BAD_ARG;
+    const hipError_t e = hipHostRegister(ptr, (size_t)bytes, hipHostRegisterPortable | hipHostRegisterMapped);
+    if (e == hipSuccess) return RCX_RC_OK;
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? RCX_RC_NO_MEMORY : e == hipErrorNoDevice ? RCX_RC_NO_DEVICE : RCX_RC_HIP_ERROR;
+}
+extern "C" int rcx_host_unregister(void* ptr)
+{
+    if (!ptr) return RCX_RC_BAD_ARG;
+    const hipError_t e = hipHostUnregister(ptr);
+    if (e == hipSuccess) return RCX_RC_OK;
+    (void)hipGetLastError();
+    return RCX_RC_HIP_ERROR;
+}

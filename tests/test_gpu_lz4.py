@@ -309,3 +309,21 @@ def test_host_path_into_page_locked_output(ctx, oracle):
                 assert int(out_len[i]) == len(eo) and bytes(got[int(ooff[i]): int(ooff[i]) + len(eo)]) == eo
     finally:
         L.rcx_multi_destroy(h)
+    # ordinary (pageable) allocations page-locked through the C-ABI, as a host language without the HIP headers pins a Vec's memory
+    # (include/rcx.h rcx_host_register): the mirrored path again, the same bytes
+    inn = np.ascontiguousarray(base)
+    outn = np.full(int(total) + 64, 0xAA, np.uint8)
+    assert L.rcx_host_register(inn.ctypes.data, inn.size) == 0 and L.rcx_host_register(outn.ctypes.data, outn.size) == 0
+    try:
+        out_len[:] = 0; in_used[:] = 0; status[:] = -9
+        b = N.Batch(p(inn), p(off), p(lens), p(outn), p(ooff), p(ocap), p(out_len), p(in_used), p(status), n, N.MEM_HOST)
+        assert L.rcx_lz4_decode_batch(ctx._h, C.byref(b)) == 0, L.rcx_last_error(ctx._h)
+        for i in range(n):
+            eo, es = want[i]
+            assert es == status[i]
+            if es == 0:
+                o = int(ooff[i])
+                assert int(out_len[i]) == len(eo) and bytes(outn[o: o + len(eo)]) == eo
+                assert (outn[o + len(eo): o + int(ocap[i])] == 0xAA).all()
+    finally:
+        assert L.rcx_host_unregister(outn.ctypes.data) == 0 and L.rcx_host_unregister(inn.ctypes.data) == 0
