@@ -363,9 +363,10 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
     for (int i = 0; i < 15; i++) k.gate_bnd[i] = 0xffffffffu;
     bool gated = false;
     if (pieces > 1) {
-        // ONE launch, the input in ranges: the blocks of a
-        // range (the first one small: a sixty-fourth of the blocks) start when this thread has seen the range's copy complete and said so in a page-locked word (k_lz4_decode_v8, `gate`).  A launch per range was built first and measured: each one ends with the link drained and begins with nothing to
-        // send, 5.9 ms for three growing ranges, 6.6 for eight equal ones, against 7.0 for one launch behind one copy.
+        // ONE launch, the input in ranges: the blocks of a range (the first one small: a sixty-fourth of the blocks) start when this
+        // thread has seen the range's copy complete and said so in a page-locked word (k_lz4_decode_v8, `gate`).  A launch per range
+        // was built first and measured: each one ends with the link drained and begins with nothing to send, 5.9 ms for three
+        // growing ranges, 6.6 for eight equal ones, against 7.0 for one launch behind one copy and 5.6 for this.
         // A range's compressed bytes are the span from its lowest to its highest input byte, widened to whole 256-byte lines of the
         // staging buffer (a line two ranges share is complete the first time anybody reads it; what the widening copies early are the
         // caller's own bytes).  Blocks that do not lie in index order make the spans overlap: more than a quarter of the input twice and
