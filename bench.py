@@ -230,10 +230,13 @@ def make_workload(R, ctx, torch, dev, kind, nblocks, seed):
 def time_steps(eng, wl, steps, warmup, dist):
     """W untimed steps, then exactly K steps between barrier + device sync on both sides; per-step device time from events
     recorded on the stream the kernels are launched on."""
+    # (a barrier among ONE rank waits for nobody and costs a collective's launch and host sync -- 0.1-0.45 ms inside a timed region of
+    # 10 ms, 1-4 % of ms_per_step at K = 20 -- so with world 1 the device syncs alone bracket the region)
+    peers = dist is not None and dist.get_world_size() > 1
     for _ in range(warmup):
         eng.decode(wl)
     eng.sync()
-    if dist is not None:
+    if peers:
         dist.barrier()
     eng.sync()
     evs = eng.events(steps + 1)
@@ -243,7 +246,7 @@ def time_steps(eng, wl, steps, warmup, dist):
         eng.decode(wl)
         evs[i + 1].record()
     eng.sync()
-    if dist is not None:
+    if peers:
         dist.barrier()
     eng.sync()
     wall = time.perf_counter() - t0
