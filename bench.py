@@ -498,6 +498,8 @@ def summary_of(res):
             out["cfg_%s" % o.get("leg", c)] = "error"
         elif c in (3, "3g"):
             out["cfg%s_ms" % c] = o.get("ms"); out["cfg%s_frac" % c] = g(o, "roofline", "frac")
+            if g(o, "host_path", "GiB/s") is not None:
+                out["cfg%s_host_GiB/s" % c] = g(o, "host_path", "GiB/s")
         elif c == 4:
             k = "text" if "G-text" in str(o.get("workload")) else "dna4"
             out["cfg4_%s_fwd_ms" % k] = o.get("forward_ms"); out["cfg4_%s_inv_ms" % k] = o.get("inverse_ms")

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_adler32(rcx_kargs a)
 #define INF3_OCC 6
 #endif
 template <int SPW, int LG, int MINW> __global__ __launch_bounds__(64, MINW) void k_inflate2(rcx_kargs a, int zlib);
-template <int CB, bool SPEC = false, bool ADLER = false> __global__ __launch_bounds__(64, INF3_OCC) void k_inflate3(rcx_kargs a, int zlib);
+template <int CB, bool SPEC = false, bool ADLER = false, bool MIRROR = false> __global__ __launch_bounds__(64, INF3_OCC) void k_inflate3(rcx_kargs a, int zlib);
 __global__ void k_zlib_tail3(rcx_kargs a, const uint32_t* adler);
 template <int WAVES> __global__ void k_adler32(rcx_kargs a);
 
@@ -376,7 +376,19 @@ static void launch_inflate2(hipStream_t s, rcx_kargs& k, int flags, int v)
 
 static constexpr uint32_t INF3_MAX_STREAMS = 0xffffffffu;   // every batch size measured (1024 .. 65536 streams) is faster wave-per-stream
 // scratch the default path wants: Adler-32 values (zlib) and a stand-in for a null in_used
-static uint64_t inflate_scratch_bytes(uint32_t nblocks) { return 12ull * nblocks + 256; }
+static uint64_t inflate_scratch_bytes(uint32_t nblocks) { return 13ull * nblocks + 512; }
+static uint64_t inflate_scratch_min(uint32_t nblocks) { return 12ull * nblocks + 256; }      // (without the marks of a mirrored launch: what rcx_scratch_bytes asked for before them)
+// ... and, for a mirrored launch, which streams the first pass handed back (their bytes reach the caller's buffer by a copy): a count
+// in the first word, a byte per stream from byte 64 on
+static uint64_t inflate_marks_offset(uint32_t nblocks) { return (12ull * nblocks + 256 + 63) & ~63ull; }
+__global__ void k_inflate_mark(const int32_t* status, uint32_t n, uint8_t* marks)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    const bool fb = status[b] == (int32_t)0x7ff00001;          // RCX_ST_FALLBACK (k_inflate3.hip)
+    marks[64 + b] = fb ? 1 : 0;
+    if (fb) atomicAdd((uint32_t*)marks, 1u);
+}
 
 // Variant 0: one wave per stream (k_inflate3), then k_inflate2 over the blocks it handed back (every error status and
 // every unusual stream comes from the kernel that reproduces the reference case by case).  Variants 1..8: k_inflate /
@@ -393,20 +405,29 @@ static void launch_inflate(hipStream_t s, rcx_kargs& k, bool zlib, int v)
     // 12.4 ms for config 3); 11 / 10: the window pass (Inf3::pass) with / without the second pass, 12: pass4 without it
     const bool spec = v == 0 || v == 12;
     const bool wave_per_stream = v == 10 || v == 11 || v == 12 || (v == 0 && n < INF3_MAX_STREAMS);
-    if (!wave_per_stream || k.scratch == nullptr || k.scratch_bytes < inflate_scratch_bytes(n)) { launch_inflate2(s, k, zlib ? 1 : 0, (v >= 9 && v <= 12) ? 0 : v); return; }
+    if (!wave_per_stream || k.scratch == nullptr || k.scratch_bytes < inflate_scratch_min(n)) { launch_inflate2(s, k, zlib ? 1 : 0, (v >= 9 && v <= 12) ? 0 : v); return; }
     rcx_kargs k3 = k;
     uint32_t* adler = (uint32_t*)k.scratch;
     if (!k3.in_used) k3.in_used = (uint64_t*)((uint8_t*)k.scratch + ((4ull * n + 63) & ~63ull));
     // zlib: the decoder sums the Adler-32 of what it writes itself (k_inflate3<.., true>; the separate k_adler32 pass over the
     // output was 1.08 of the launch's 4.4 GB of HBM traffic for config 3) and k_zlib_tail3 compares it with the trailer
+    const bool mirror = k.out_mirror != nullptr && spec && k.scratch_bytes >= inflate_scratch_bytes(n);      // (rcx_api.hip sizes the scratch for it)
+    if (!mirror) k3.out_mirror = nullptr;
     if (zlib) {
         k3.scratch = adler;                                    // (the kernel's slot array: 4 bytes a stream)
-        if (spec) hipLaunchKernelGGL((k_inflate3<1024, true, true>), dim3(n), dim3(64), 0, s, k3, 1);
+        if (mirror) hipLaunchKernelGGL((k_inflate3<1024, true, true, true>), dim3(n), dim3(64), 0, s, k3, 1);
+        else if (spec) hipLaunchKernelGGL((k_inflate3<1024, true, true>), dim3(n), dim3(64), 0, s, k3, 1);
         else hipLaunchKernelGGL((k_inflate3<1024, false, true>), dim3(n), dim3(64), 0, s, k3, 1);
         hipLaunchKernelGGL(k_zlib_tail3, dim3((n + 255) / 256), dim3(256), 0, s, k3, adler);
     } else {
-        if (spec) hipLaunchKernelGGL((k_inflate3<1024, true, false>), dim3(n), dim3(64), 0, s, k3, 0);
+        if (mirror) hipLaunchKernelGGL((k_inflate3<1024, true, false, true>), dim3(n), dim3(64), 0, s, k3, 0);
+        else if (spec) hipLaunchKernelGGL((k_inflate3<1024, true, false>), dim3(n), dim3(64), 0, s, k3, 0);
         else hipLaunchKernelGGL((k_inflate3<1024, false, false>), dim3(n), dim3(64), 0, s, k3, 0);
+    }
+    if (mirror) {
+        uint8_t* marks = (uint8_t*)k.scratch + inflate_marks_offset(n);
+        (void)hipMemsetAsync(marks, 0, 64, s);
+        hipLaunchKernelGGL(k_inflate_mark, dim3((n + 255) / 256), dim3(256), 0, s, k.status, n, marks);
     }
     if (v != 10 && v != 12) launch_inflate2(s, k, (zlib ? 1 : 0) | 2, 0);                      // 10: A/B, shows what the first pass handed back
 }

@@ -242,15 +242,15 @@ __device__ __forceinline__ uint64_t rcx_inf_hops(uint32_t& q, uint32_t e, uint32
 #ifndef INF3_OCC
 #define INF3_OCC 6
 #endif
-template <int CB, bool SPEC = false, bool ADLER = false>
-struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER> {
+template <int CB, bool SPEC = false, bool ADLER = false, bool MIRROR = false>
+struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER, MIRROR> {
     // The kernel is bound by the latency of its dependent phases, so what it needs is waves: 12 / 16 / 18 / 20 / 24 waves per CU take
     // 18.5 / 14.3 / 13.1 / 12.4 / 11.6 ms for config 3.  24 waves = 6400 bytes of LDS each (handed out in 1280-byte granules) and
     // 80 VGPRs: 1024-byte batch output cap, 768 bytes of history in the window, NO staging of gathered matches (every byte goes
     // straight to its place), 320 literal bytes per batch, an 8-bit table for the distance code, and the code lengths of a block
     // header share the literal buffer (the batch is emitted before a header is read).  History / batch cap splits of the same
     // 1808 bytes (512 + 1280, 640 + 1152, 768 + 1024, 896 + 896) measure within 1 %.
-    typedef Lz4V4<CB, false, INF3_TCAP, INF3_H, ADLER> B;
+    typedef Lz4V4<CB, false, INF3_TCAP, INF3_H, ADLER, MIRROR> B;
     static constexpr int LITCAP = INF3_LITCAP;       // literal bytes per batch
     static constexpr int LUTBITS = 9, LUTN = 1 << LUTBITS;     // lit/len table
     static constexpr int DBITS = 8, DLUTN = 1 << DBITS;        // distance (and code-length) table
@@ -1187,13 +1187,15 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER> {
 
 // ADLER (zlib streams): the Adler-32 of the decoded bytes is summed while they leave the window (Lz4V4::flush and the wave-wide
 // copies) and lands in the first 4 * nblocks bytes of the scratch, where k_zlib_tail3 compares it with the stream's trailer.
-template <int CB, bool SPEC, bool ADLER>
+// MIRROR: the host-memory entry points with a page-locked output buffer (rcx_api.hip): what leaves the window is stored a second time
+// in the caller's buffer (Lz4V4::mirror_to, the wave-wide copies); streams the first pass hands back are copied out behind the second.
+template <int CB, bool SPEC, bool ADLER, bool MIRROR>
 #ifndef INF3_VGPR
 #define INF3_VGPR 96
 #endif
 __global__ __launch_bounds__(64, INF3_OCC) void k_inflate3(rcx_kargs a, int zlib)
 {
-    typedef Inf3<CB, SPEC, ADLER> S;
+    typedef Inf3<CB, SPEC, ADLER, MIRROR> S;
     __shared__ __align__(16) uint8_t s_cbuf[CB + 96];
     __shared__ __align__(16) uint8_t s_wbuf[S::WBUF5 + 16];     // + 16: lds_load16u reads one dword past the last staging slot
     __shared__ __align__(16) uint16_t s_lutL[512];
@@ -1206,11 +1208,43 @@ __global__ __launch_bounds__(64, INF3_OCC) void k_inflate3(rcx_kargs a, int zlib
     __shared__ __align__(16) uint32_t s_desc[128];
     const uint32_t b = blockIdx.x;
     if (b >= a.nblocks) return;
+    if (MIRROR && a.gate) {
+        // the stream's compressed bytes may still be on their way in (rcx_api.hip: one launch, the input in ranges on a copy stream; the
+        // same gate as k_lz4_decode_v8's).  A stream that gives up leaves RCX_ST_GATE, which neither the trailer check nor the second
+        // pass looks at: the host decodes the batch again behind one copy.
+        uint32_t r = 0;
+#pragma unroll
+        for (int i = 0; i < 15; i++) r += b >= a.gate_bnd[i] ? 1u : 0u;
+        if (r || a.gate_all) {
+            if (threadIdx.x == 0) {
+                const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+                uint32_t ok = 1;
+                if (b == (r ? a.gate_bnd[r - 1] : 0u)) {
+                    while (__hip_atomic_load(a.gate_host + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != a.gate_seq) {
+                        __builtin_amdgcn_s_sleep(60);
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > (uint64_t)a.gate_ticks) { ok = 0; break; }
+                    }
+                    if (ok) __hip_atomic_store(a.gate + r, a.gate_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                while (ok && __hip_atomic_load(a.gate + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != a.gate_seq) {
+                    __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > (uint64_t)a.gate_ticks) ok = 0;
+                }
+                s_desc[0] = ok;
+            }
+            __syncthreads();
+            const uint32_t ok = s_desc[0];
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            __syncthreads();
+            if (!ok) { if (threadIdx.x == 0) { a.status[b] = (int32_t)RCX_ST_GATE; a.out_len[b] = 0; } return; }
+        }
+    }
     S s;
     s.in = a.in_base + a.in_off[b];
     const uint64_t n64 = a.in_len[b], cap64 = a.out_cap[b];
     s.n = n64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)n64;
     s.out = a.out_base + a.out_off[b];
+    if (MIRROR) s.out2 = a.out_mirror + a.out_off[b];
     s.cap = cap64 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)cap64;
     s.cbuf = s_cbuf; s.wb_ = s_wbuf; s.epos = nullptr; s.ring = nullptr;
     s.lutL = s_lutL; s.lutD = s_lutD; s.symL = s_symL; s.symD = s_symD; s.lens = s_lit; s.tab = s_tab; s.litbuf = s_lit; s.desc = s_desc;

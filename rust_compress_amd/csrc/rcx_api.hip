@@ -292,7 +292,9 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
     // workload; this is the outbound 4.9 ms and little else.  rcx_ctx_set_param(ctx, RCX_LZ4_DECODE, 1) keeps the plain copies.
     uint8_t* mirror = nullptr;
     uint32_t pieces = 1;
-    if (b->mem == RCX_MEM_HOST && codec == RCX_LZ4_DECODE && out_span && c->variant[codec] == 0 && !(c->param[codec] & 1u)) {
+    const bool inf_mirror = (codec == RCX_INFLATE || codec == RCX_ZLIB_DECODE) && !(c->param[codec] & 1u);    // (the inflate front end drains through the same window; the
+                                                                                                              //  streams its first pass hands back are copied out behind the second)
+    if (b->mem == RCX_MEM_HOST && (codec == RCX_LZ4_DECODE || inf_mirror) && out_span && c->variant[codec] == 0 && !(c->param[codec] & 1u)) {
         hipPointerAttribute_t at;
         if (hipPointerGetAttributes(&at, b->out_base) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) {
             mirror = (uint8_t*)at.devicePointer;
@@ -451,6 +453,10 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
         HIPCHK(c, hipStreamSynchronize(c->copy_stream));
         bool again = false;
         for (size_t i = 0; i < N && !again; i++) again = h_status[i] == (int32_t)RCX_ST_GATE;
+        if (again && codec != RCX_LZ4_DECODE) {                 // (the inflate path's second pass and trailer check passed these streams by: the whole batch again, behind one copy)
+            c->gate_bad = true;
+            return run_batch(c, codec, b, aux_in, aux_out, n_out, needs_out, param_over);
+        }
         if (again) {
             c->gate_bad = true;
             k.gate = nullptr;
@@ -458,6 +464,31 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipMemcpyAsync(h64 + 5 * N, d64 + 5 * N, 2 * N * 8 + 2 * N * 4, hipMemcpyDeviceToHost, s));
             HIPCHK(c, hipStreamSynchronize(s));
+        }
+    }
+    if (mirror && inf_mirror && k.scratch) {
+        // the streams the first pass handed back were decoded into HBM alone: a few, one copy each; many (a batch of corrupted streams), the span
+        const uint8_t* marks = (const uint8_t*)k.scratch + rcx_tu_inflate_marks_offset(n);
+        uint32_t nfb = 0;
+        HIPCHK(c, hipMemcpy(&nfb, marks, 4, hipMemcpyDeviceToHost));
+        if (nfb) {
+            const uint64_t* ol = h64 + 5 * N;
+            if (nfb > n / 8u + 16u) {
+                uint64_t used_span = 0;
+                for (uint32_t i = 0; i < n; i++) {
+                    const uint64_t l = ol[i] < b->out_cap[i] ? ol[i] : b->out_cap[i];
+                    if (l && b->out_off[i] + l > used_span) used_span = b->out_off[i] + l;
+                }
+                if (used_span) HIPCHK(c, hipMemcpy(b->out_base, d_out, used_span, hipMemcpyDeviceToHost));
+            } else {
+                std::vector<uint8_t> fb(n);
+                HIPCHK(c, hipMemcpy(fb.data(), marks + 64, n, hipMemcpyDeviceToHost));
+                for (uint32_t i = 0; i < n; i++) {
+                    const uint64_t l = ol[i] < b->out_cap[i] ? ol[i] : b->out_cap[i];
+                    if (fb[i] && l) HIPCHK(c, hipMemcpyAsync(b->out_base + b->out_off[i], d_out + b->out_off[i], l, hipMemcpyDeviceToHost, s));
+                }
+                HIPCHK(c, hipStreamSynchronize(s));
+            }
         }
     }
     if (b->mem == RCX_MEM_HOST && out_span && !mirror) {

@@ -335,3 +335,58 @@ def test_hip_vs_derived_golden(ctx):
         derived.check(rec, "ari_bin5", bn.outputs[i])
         derived.check(rec, "ari_proxy", px.outputs[i])
 
+
+
+def test_inflate_host_path_into_page_locked_output(ctx, oracle, golden):
+    """rcx_zlib_decode_batch / rcx_inflate_batch with RCX_MEM_HOST and a PAGE-LOCKED output buffer (rcx_api.hip: the wave-per-stream
+    decoder stores what leaves its window straight into the caller's buffer; streams its first pass hands back -- every corrupted or
+    unusual one -- are copied out behind the second pass, one by one when they are few, as one span when they are many): the bytes,
+    lengths, consumed counts, flags and statuses of the plain copies (rcx_ctx_set_param(ctx, codec, 1)) and of the oracle."""
+    import ctypes as C
+    import torch
+    from rust_compress_amd import batch as B, synth
+    L = N.lib()
+    rng = np.random.default_rng(77)
+    raws = [synth.gen(("text", "runs", "rand", "dna4")[i % 4], int(rng.choice([0, 1, 300, 5000, 16384, 70000])), 500 + i).tobytes() for i in range(400)]
+    good = []
+    for i, r in enumerate(raws):
+        co = zlib.compressobj([1, 6, 9, 6][i % 4], zlib.DEFLATED, 15, 8, zlib.Z_FIXED if i % 5 == 4 else zlib.Z_DEFAULT_STRATEGY)
+        good.append(co.compress(r) + co.flush())
+    good.append(golden("test.z.5"))
+    raws.append(zlib.decompress(good[-1]))
+    for few in (True, False):
+        blobs, caps = list(good), [len(r) + 9 for r in raws]
+        step = 41 if few else 3                                # a few corrupted streams among the good ones / a third of the batch
+        for i in range(0, len(blobs), step):
+            b = bytearray(blobs[i])
+            if len(b) > 12: b[int(rng.integers(2, len(b)))] ^= 0x11
+            blobs[i] = bytes(b)
+        n = len(blobs)
+        for codec, fn, strip in ((N.ZLIB_DECODE, "rcx_zlib_decode_batch", 0), (N.INFLATE, "rcx_inflate_batch", 2)):
+            bl = [x[strip:] for x in blobs]
+            base, off, lens = B.pack(bl)
+            total, ooff, ocap = B.layout(caps)
+            inb = torch.from_numpy(base).pin_memory()
+            res = {}
+            for plain in (True, False):
+                outb = torch.full((int(total) + 64,), 0xAA, dtype=torch.uint8).pin_memory()
+                out_len, in_used, status, flags = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.full(n, -9, np.int32), np.zeros(n, np.uint32)
+                p = lambda a: a.ctypes.data
+                b = N.Batch(inb.data_ptr(), p(off), p(lens), outb.data_ptr(), p(ooff), p(ocap), p(out_len), p(in_used), p(status), n, N.MEM_HOST)
+                assert L.rcx_ctx_set_param(ctx._h, codec, 1 if plain else 0) == 0
+                try:
+                    assert getattr(L, fn)(ctx._h, C.byref(b), C.c_void_p(p(flags))) == 0, L.rcx_last_error(ctx._h)
+                finally:
+                    L.rcx_ctx_set_param(ctx._h, codec, 0)
+                got = outb.numpy()
+                res[plain] = (status.copy(), out_len.copy(), in_used.copy(), flags.copy(),
+                              [bytes(got[int(o): int(o) + int(l)]) for o, l in zip(ooff, out_len)])
+            for k in range(4):
+                assert (res[True][k] == res[False][k]).all(), (few, codec, k)
+            assert res[True][4] == res[False][4], (few, codec)
+            dec = oracle.zlib_decode if codec == N.ZLIB_DECODE else oracle.inflate
+            for i in range(n):
+                eo, eu, _, es = dec(bl[i], cap=caps[i], raise_on_error=False)
+                assert es == res[False][0][i] and eu == res[False][2][i], (few, codec, i)
+                if es == 0:
+                    assert eo == res[False][4][i]

@@ -363,3 +363,38 @@ def test_crc32_gzip(golden):
     exp = [N.E_GZIP_MAGIC, N.E_GZIP_METHOD, N.E_GZIP_FLAGS, N.E_GZIP_CRC, N.E_GZIP_ISIZE, N.E_EOF, N.E_EOF, N.E_EOF]
     _, _, _, st, _ = simrun.run(N.GZIP_DECODE, 0, bad, [len(raws[4])] * len(bad), scratch_bytes=48 * len(bad) + 256)
     assert list(st) == exp
+
+
+def test_zlib_mirror_and_gates(oracle):
+    """The wave-per-stream inflate kernel with the caller's page-locked buffer as a second destination (k_inflate3<.., MIRROR>,
+    rcx_api.hip): valid streams come back OK from the FIRST pass with the second buffer holding exactly their decoded bytes (stored
+    blocks and long matches leave by the wave-wide copies, the rest through the window's drain in whole 256-byte lines), at three output
+    alignments; behind open gates the same; behind a gate that stays shut a stream gives up with the internal status that sends the
+    batch round again."""
+    import simrun
+    raws = corpus.small_corpus(sizes=(17, 1000, 40000)) + [synth_dna(70000), b"", b"x", b"ab" * 30000, bytes(70000)]
+    zs, exp = [], []
+    for r in raws:
+        for lvl in (0, 1, 6):
+            zs.append(zlib.compress(r, lvl)); exp.append(r)
+        c = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+        zs.append(c.compress(r) + c.flush()); exp.append(r)
+    n = len(zs)
+    sb = 13 * (n + 1) + 512
+    for mis in (0, 5, 250):
+        outs, _, used, st, _ = simrun.run(N.ZLIB_DECODE, 12, zs, [len(e) + 3 for e in exp], scratch_bytes=sb, out_misalign=mis, mirror=True)
+        assert not st.any() and outs == exp and list(used) == [len(z) for z in zs], mis
+    outs, _, _, st, _ = simrun.run(N.ZLIB_DECODE, 12, zs, [len(e) for e in exp], scratch_bytes=sb, mirror=True, gate_bnd=[2, n // 2], gates_open=True)
+    assert not st.any() and outs == exp
+    outs, _, _, st, _ = simrun.run(N.INFLATE, 12, [z[2:-4] for z in zs], [len(e) for e in exp], scratch_bytes=sb, mirror=True, gate_bnd=[n // 2], gates_open=False)
+    assert not st[: n // 2].any() and outs[: n // 2] == exp[: n // 2] and (st[n // 2:] == 0x7ff00003).all()
+    # corrupted streams with the mirror and both passes (variant 0): the reference's statuses; what the first pass handed back is marked
+    blobs, caps = corpus.mutate(zs[:40], 120, 2, [50, 3000, 50000])
+    ex = [oracle.zlib_decode(b, cap=c, raise_on_error=False) for b, c in zip(blobs, caps)]
+    keep = []
+    outs, _, used, st, _ = simrun.run(N.ZLIB_DECODE, 0, blobs, caps, scratch_bytes=13 * len(blobs) + 512, mirror=True, scratch_out=keep)
+    for i, e in enumerate(ex):
+        assert e[-1] == st[i] and e[1] == used[i] and (st[i] != 0 or e[0] == outs[i]), i
+    marks = keep[0][(12 * len(blobs) + 256 + 63) & ~63:]
+    nfb = int(np.frombuffer(marks[:4].tobytes(), np.uint32)[0])
+    assert nfb == int(marks[64: 64 + len(blobs)].sum()) and nfb >= sum(1 for e in ex if e[-1] != 0)

@@ -9,6 +9,7 @@
 #include "../../benchmarks/experiments/k_lz4_decode_v6.hip"
 #include "../../rust_compress_amd/csrc/k_lz4_encode.hip"
 #define hipStream_t int
+static inline int hipMemsetAsync(void* d, int v, size_t n, int) { memset(d, v, n); return 0; }
 #define hipLaunchKernelGGL(kern, grid, block, shm, stream, ...) ws::launch(grid, block, [&] { kern(__VA_ARGS__); })
 #include "../../rust_compress_amd/csrc/k_serial.hip"
 #include "../../rust_compress_amd/csrc/k_inflate.hip"
@@ -21,7 +22,6 @@
 static inline int hipMemcpyAsync(void* d, const void* s, size_t n, int, int) { memcpy(d, s, n); return 0; }
 static inline int hipStreamSynchronize(int) { return 0; }
 #define hipMemcpyHostToDevice 1
-static inline int hipMemsetAsync(void* d, int v, size_t n, int) { memset(d, v, n); return 0; }
 #define hipHostMallocDefault 0
 static inline int hipHostMalloc(void** p, size_t n, int) { *p = malloc(n); return *p ? 0 : 1; }
 static inline int hipGetLastError() { return 0; }
