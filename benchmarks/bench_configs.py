@@ -193,8 +193,8 @@ def config3(ctx, torch, dev, scale=1.0, gzip_framing=False, cpu=True, rank=0, wo
            "roofline": _roof(alg, t, None if gzip_framing else pmc_traffic(3))}
     if cliff is not None:
         res["fallback_cliff"] = cliff
-    if not gzip_framing and not once and rank == 0 and world == 1 and not nocheck and not os.environ.get("RCX_INFLATE_VARIANT"):
-        # PCIe-inclusive: the same members through rcx_zlib_decode_batch with page-locked host buffers -- the decoder stores what leaves
+    if not once and rank == 0 and world == 1 and not nocheck and not os.environ.get("RCX_INFLATE_VARIANT"):
+        # PCIe-inclusive: the same members through rcx_zlib_decode_batch / rcx_gzip_decode_batch with page-locked host buffers -- the decoder stores what leaves
         # its window straight into the caller's buffer (rcx_api.hip) -- beside one copy each way around the launch
         import ctypes as C
         inb = torch.from_numpy(base).pin_memory()
@@ -205,23 +205,23 @@ def config3(ctx, torch, dev, scale=1.0, gzip_framing=False, cpu=True, rank=0, wo
         hb = N.Batch(inb.data_ptr(), p(off), p(lens), outb.data_ptr(), p(ooff), p(ocap), p(out_len), p(in_used), p(status), nb, N.MEM_HOST)
         hp = {}
         for plain in (True, False):
-            N.lib().rcx_ctx_set_param(ctx._h, N.ZLIB_DECODE, 1 if plain else 0)
+            N.lib().rcx_ctx_set_param(ctx._h, codec, 1 if plain else 0)
             ts = []
             try:
                 for it in range(4):
                     if it == 3:
                         outb.zero_(); status[:] = -9
                     t0 = time.perf_counter()
-                    rc = N.lib().rcx_zlib_decode_batch(ctx._h, C.byref(hb), C.c_void_p(p(flags)))
+                    rc = (N.lib().rcx_gzip_decode_batch if gzip_framing else N.lib().rcx_zlib_decode_batch)(ctx._h, C.byref(hb), C.c_void_p(p(flags)))
                     ts.append(time.perf_counter() - t0)
                     assert rc == 0 and not status.any()
             finally:
-                N.lib().rcx_ctx_set_param(ctx._h, N.ZLIB_DECODE, 0)
+                N.lib().rcx_ctx_set_param(ctx._h, codec, 0)
             assert np.array_equal(outb.numpy()[: nb * BLOCK], raw_np)
             hp[plain] = float(np.median(ts[1:]))
         res["host_path"] = {"GiB/s": round(nb * BLOCK / hp[False] / 2**30, 2), "ms": round(hp[False] * 1e3, 2), "ms_plain_copies": round(hp[True] * 1e3, 2),
                             "bytes_in": int(lens.sum()), "bytes_out": nb * BLOCK, "verified": True,
-                            "what": "rcx_zlib_decode_batch, RCX_MEM_HOST, page-locked host buffers: decoded bytes stored straight into the caller's buffer by the launch"}
+                            "what": "%s, RCX_MEM_HOST, page-locked host buffers: decoded bytes stored straight into the caller's buffer by the launch" % ("rcx_gzip_decode_batch" if gzip_framing else "rcx_zlib_decode_batch")}
     if cpu and gzip_framing and rank == 0 and world == 1:
         # the reference crate has no gzip reader (an extension), so there is no oracle leg for this framing:
         # the CPU line is libz itself -- inflate + CRC-32 + ISIZE per member, every host core

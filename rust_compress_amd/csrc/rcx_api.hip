@@ -292,7 +292,7 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
     // workload; this is the outbound 4.9 ms and little else.  rcx_ctx_set_param(ctx, RCX_LZ4_DECODE, 1) keeps the plain copies.
     uint8_t* mirror = nullptr;
     uint32_t pieces = 1;
-    const bool inf_mirror = (codec == RCX_INFLATE || codec == RCX_ZLIB_DECODE) && !(c->param[codec] & 1u);    // (the inflate front end drains through the same window; the
+    const bool inf_mirror = (codec == RCX_INFLATE || codec == RCX_ZLIB_DECODE || codec == RCX_GZIP_DECODE) && !(c->param[codec] & 1u);    // (the inflate front end drains through the same window; the
                                                                                                               //  streams its first pass hands back are copied out behind the second)
     if (b->mem == RCX_MEM_HOST && (codec == RCX_LZ4_DECODE || inf_mirror) && out_span && c->variant[codec] == 0 && !(c->param[codec] & 1u)) {
         hipPointerAttribute_t at;
@@ -301,7 +301,8 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
             // (ranges only from page-locked INPUT: a pageable buffer is staged piece by piece, by copies that may need the compute
             // units the waiting blocks would hold)
             hipPointerAttribute_t ai;
-            if (in_span && !c->gate_bad && hipPointerGetAttributes(&ai, b->in_base) == hipSuccess && ai.type == hipMemoryTypeHost) {
+            // (gzip members: their headers are parsed by a kernel of its own in front of the decoder, which wants every member there)
+            if (codec != RCX_GZIP_DECODE && in_span && !c->gate_bad && hipPointerGetAttributes(&ai, b->in_base) == hipSuccess && ai.type == hipMemoryTypeHost) {
                 pieces = ((c->param[codec] >> 8) & 255u) ? ((c->param[codec] >> 8) & 255u) : 16u;
                 if (pieces > 16u) pieces = 16u;             // (the most; see below)
                 if (pieces > n / 128u) pieces = n / 128u ? n / 128u : 1u;
@@ -468,7 +469,7 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
     }
     if (mirror && inf_mirror && k.scratch) {
         // the streams the first pass handed back were decoded into HBM alone: a few, one copy each; many (a batch of corrupted streams), the span
-        const uint8_t* marks = (const uint8_t*)k.scratch + rcx_tu_inflate_marks_offset(n);
+        const uint8_t* marks = (const uint8_t*)k.scratch + (codec == RCX_GZIP_DECODE ? rcx_tu_gzip_marks_offset(n) : rcx_tu_inflate_marks_offset(n));
         uint32_t nfb = 0;
         HIPCHK(c, hipMemcpy(&nfb, marks, 4, hipMemcpyDeviceToHost));
         if (nfb) {

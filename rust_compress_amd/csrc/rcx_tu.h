@@ -21,6 +21,7 @@ void rcx_tu_gzip_decode(hipStream_t s, rcx_kargs& k, int variant);
 uint64_t rcx_tu_inflate_scratch(uint32_t nblocks);
 uint64_t rcx_tu_inflate_marks_offset(uint32_t nblocks);      // a mirrored launch: [count | 60 bytes | a byte per stream the first pass handed back]
 uint64_t rcx_tu_gzip_scratch(uint32_t nblocks);
+uint64_t rcx_tu_gzip_marks_offset(uint32_t nblocks);
 // tu_bwt.hip
 int rcx_tu_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::string& err, bool sa_words);
 int rcx_tu_bwt_inversion_table(hipStream_t s, rcx_kargs& k);

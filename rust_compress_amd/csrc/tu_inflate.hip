@@ -15,3 +15,4 @@ void rcx_tu_gzip_decode(hipStream_t s, rcx_kargs& k, int variant) { launch_gzip_
 uint64_t rcx_tu_inflate_scratch(uint32_t nblocks) { return inflate_scratch_bytes(nblocks); }
 uint64_t rcx_tu_inflate_marks_offset(uint32_t nblocks) { return inflate_marks_offset(nblocks); }
 uint64_t rcx_tu_gzip_scratch(uint32_t nblocks) { return gzip_scratch_bytes(nblocks); }
+uint64_t rcx_tu_gzip_marks_offset(uint32_t nblocks) { return ((gzip_scratch_bytes(nblocks) + 255) & ~255ull) + inflate_marks_offset(nblocks); }   // (launch_gzip_decode: the inflate path's own scratch behind the gzip arrays)

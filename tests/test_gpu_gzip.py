@@ -62,3 +62,48 @@ def test_gzip_reader_api(ctx):
     assert d.read_to_end() == b"".join(parts) and d.members == 3 and d.consumed == len(stream)
     c = cz.Crc32(); c.feed(b"abc"); c.feed(b"def")
     assert c.result() == zlib.crc32(b"abcdef")
+
+
+def test_gzip_host_path_into_page_locked_output(ctx, golden):
+    """rcx_gzip_decode_batch with RCX_MEM_HOST and a PAGE-LOCKED output buffer (rcx_api.hip: the inflate kernel stores the decoded bytes
+    in the caller's buffer itself; members its first pass hands back are copied out behind the second pass): statuses, lengths,
+    consumed counts and bytes of the plain copies (rcx_ctx_set_param(ctx, RCX_GZIP_DECODE, 1)), and Python's gzip for the good ones."""
+    import ctypes as C
+    import torch
+    from rust_compress_amd import batch as B, synth
+    L = N.lib()
+    rng = np.random.default_rng(12)
+    raws = [synth.gen(("text", "runs", "rand")[i % 3], int(rng.choice([0, 1, 900, 16384, 50000])), 900 + i).tobytes() for i in range(300)] + [golden("test.txt")]
+    gz = _gzip_members(raws)
+    for step in (47, 2):                                        # a few corrupted members / every other one
+        blobs = list(gz)
+        for i in range(0, len(blobs), step):
+            b = bytearray(blobs[i])
+            if len(b) > 30: b[int(rng.integers(12, len(b) - 8))] ^= 0x21
+            blobs[i] = bytes(b)
+        n = len(blobs)
+        base, off, lens = B.pack(blobs)
+        total, ooff, ocap = B.layout([len(r) + 5 for r in raws])
+        inb = torch.from_numpy(base).pin_memory()
+        res = {}
+        for plain in (True, False):
+            outb = torch.full((int(total) + 64,), 0xAA, dtype=torch.uint8).pin_memory()
+            out_len, in_used, status, flags = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.full(n, -9, np.int32), np.zeros(n, np.uint32)
+            p = lambda a: a.ctypes.data
+            b = N.Batch(inb.data_ptr(), p(off), p(lens), outb.data_ptr(), p(ooff), p(ocap), p(out_len), p(in_used), p(status), n, N.MEM_HOST)
+            assert L.rcx_ctx_set_param(ctx._h, N.GZIP_DECODE, 1 if plain else 0) == 0
+            try:
+                assert L.rcx_gzip_decode_batch(ctx._h, C.byref(b), C.c_void_p(p(flags))) == 0, L.rcx_last_error(ctx._h)
+            finally:
+                L.rcx_ctx_set_param(ctx._h, N.GZIP_DECODE, 0)
+            got = outb.numpy()
+            res[plain] = (status.copy(), out_len.copy(), in_used.copy(), [bytes(got[int(o): int(o) + int(l)]) for o, l in zip(ooff, out_len)])
+        for k in range(3):
+            assert (res[True][k] == res[False][k]).all(), (step, k)
+        assert res[True][3] == res[False][3], step
+        good = 0
+        for i in range(n):
+            if res[False][0][i] == 0:
+                good += 1
+                assert res[False][3][i] == gzip.decompress(blobs[i])
+        assert good >= n - (n + step - 1) // step
