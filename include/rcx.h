@@ -138,7 +138,10 @@ uint64_t rcx_lz4_compression_bound(uint64_t in_len);
 
 /* ---- DEFLATE / zlib / Adler-32 ---------------------------------------------- */
 /* reference: src/flate.rs:195-206,237-246,262-341,343-450 (one RFC-1951 stream
- * per block, decoded to BFINAL). flags may be NULL. */
+ * per block, decoded to BFINAL). flags may be NULL.
+ * RCX_MEM_HOST with a PAGE-LOCKED out_base: as rcx_lz4_decode_batch -- rcx_inflate_batch, rcx_zlib_decode_batch and rcx_gzip_decode_batch
+ * store the decoded bytes straight into the caller's buffer while the launch runs (streams the fast kernel hands to the exact one
+ * arrive by a copy behind it); same results as with pageable buffers.  rcx_ctx_set_param(ctx, <codec>, 1) keeps the plain copies. */
 int rcx_inflate_batch(rcx_ctx*, const rcx_batch*, uint32_t* flags);
 /* reference: src/zlib.rs:55-126 (header checks, inflate, Adler-32 BE trailer) */
 int rcx_zlib_decode_batch(rcx_ctx*, const rcx_batch*, uint32_t* flags);
