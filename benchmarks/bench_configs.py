@@ -59,12 +59,13 @@ def timeit_ranks(fn, torch, dist, reps=5, warm=1):
 
 
 def source_hash():
-    """sha256 over every kernel source: a PMC traffic figure is only quoted for the code it was measured on"""
+    """sha256 over every kernel source (the host-side files -- rcx_api.hip, the C-ABI and its staging, and rcx_tu.h -- hold no device
+    code): a PMC traffic figure is only quoted for the code it was measured on"""
     import hashlib
     d = os.path.join(ROOT, "rust_compress_amd", "csrc")
     h = hashlib.sha256()
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
+        if f.endswith((".hip", ".h")) and f not in ("rcx_api.hip", "rcx_tu.h"):
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -406,10 +406,11 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
             if (!c->copy_stream) {
                 // a stream of ANOTHER priority than the launch's: HIP hands its few hardware queues to the streams of one priority in
                 // turn, and a copy stream that shares the launch's queue stands behind the launch it is meant to feed (every gate ran into
-                // its limit for one context in two: 66 ms a call)
+                // its limit for one context in two: 66 ms a call).  The LOWEST priority: it carries copy-engine work only, and the
+                // high-priority queues stay with whoever uses them for kernels (pipeline.PipelineLanes keeps its two lanes apart that way)
                 int least = 0, greatest = 0;
                 HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-                HIPCHK(c, hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, greatest));
+                HIPCHK(c, hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, least));
             }
             while (c->piece_ev.size() < pieces) { hipEvent_t e; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->piece_ev.push_back(e); }
             if (!c->h_gate) HIPCHK(c, hipHostMalloc((void**)&c->h_gate, 64, hipHostMallocDefault));
