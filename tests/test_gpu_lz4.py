@@ -327,3 +327,40 @@ def test_host_path_into_page_locked_output(ctx, oracle):
                 assert (outn[o + len(eo): o + int(ocap[i])] == 0xAA).all()
     finally:
         assert L.rcx_host_unregister(outn.ctypes.data) == 0 and L.rcx_host_unregister(inn.ctypes.data) == 0
+
+
+def test_host_path_ranges_see_fresh_input(ctx, oracle):
+    """The gated launch reads input that lands in the staging buffer WHILE it runs: a line of that buffer still cached from the call
+    before would be a stale read nobody notices as long as every call carries the same bytes.  So: two different sets of blocks of
+    the same total size, alternately through one context (the same staging buffer, the same offsets, other bytes), page-locked
+    in and out, three rounds -- LZ4 blocks and zlib members."""
+    import ctypes as C
+    import zlib
+    import torch
+    from rust_compress_amd import batch as B
+    L = N.lib()
+    sets = []
+    for s in (0, 1):
+        raws = [synth.gen(("text", "runs", "dna4")[(i + s) % 3], 20000 + 64 * ((i * 7 + s * 13) % 50), 4000 + 1000 * s + i).tobytes() for i in range(600)]
+        sets.append(raws)
+    for codec, fn, enc in ((N.LZ4_DECODE, "rcx_lz4_decode_batch", oracle.lz4_encode_block), (N.ZLIB_DECODE, "rcx_zlib_decode_batch", lambda r: zlib.compress(r, 1))):
+        packed = []
+        for raws in sets:
+            blobs = [enc(r) for r in raws]
+            base, off, lens = B.pack(blobs)
+            total, ooff, ocap = B.layout([len(r) for r in raws])
+            packed.append((torch.from_numpy(base).pin_memory(), off, lens, int(total), ooff, ocap, raws))
+        n = 600
+        outb = torch.zeros(max(p[3] for p in packed) + 64, dtype=torch.uint8).pin_memory()
+        for rnd in range(3):
+            for inb, off, lens, total, ooff, ocap, raws in packed:
+                outb.fill_(0x33 + rnd)
+                out_len, in_used, status, flags = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.full(n, -9, np.int32), np.zeros(n, np.uint32)
+                p = lambda a: a.ctypes.data
+                b = N.Batch(inb.data_ptr(), p(off), p(lens), outb.data_ptr(), p(ooff), p(ocap), p(out_len), p(in_used), p(status), n, N.MEM_HOST)
+                args = (ctx._h, C.byref(b)) if codec == N.LZ4_DECODE else (ctx._h, C.byref(b), C.c_void_p(p(flags)))
+                assert getattr(L, fn)(*args) == 0, L.rcx_last_error(ctx._h)
+                assert not status.any(), (codec, rnd, np.nonzero(status)[0][:5], status[status != 0][:5])
+                got = outb.numpy()
+                for i in range(n):
+                    assert bytes(got[int(ooff[i]): int(ooff[i]) + int(out_len[i])]) == raws[i], (codec, rnd, i)
