@@ -242,6 +242,9 @@ __device__ __forceinline__ uint64_t rcx_inf_hops(uint32_t& q, uint32_t e, uint32
 #ifndef INF3_OCC
 #define INF3_OCC 6
 #endif
+#ifndef INF3_OWNER_SCAN
+#define INF3_OWNER_SCAN 1                  /* 0: the owner of a symbol rank by binary search over the inclusive counts (A/B) */
+#endif
 template <int CB, bool SPEC = false, bool ADLER = false, bool MIRROR = false>
 struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER, MIRROR> {
     // The kernel is bound by the latency of its dependent phases, so what it needs is waves: 12 / 16 / 18 / 20 / 24 waves per CU take
@@ -786,11 +789,33 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER, MIRROR> {
             }
 #endif
             uint32_t j = 0;                                          // the lane whose map holds symbol `lane`: the number of lanes with incl <= lane
+#if INF3_OWNER_SCAN
+            {   // ... = the last lane with symbols whose first one has a rank <= lane: every such lane leaves its number at its first rank
+                // (64 bytes: the histogram words of the table builds, free between them), a running maximum fills the ranks between --
+                // one LDS round trip and six DPP steps where the binary search over `incl` was six dependent ds_bpermute round trips
+                uint8_t* const own = (uint8_t*)(tab + 64);
+                if (lane < 16u) ((uint32_t*)own)[lane] = 0u;
+                rcx_wave_sync();
+                const uint32_t excl = incl - cnt;
+                if (cnt && excl < 64u) own[excl] = (uint8_t)lane;
+                rcx_wave_sync();
+                uint32_t v = own[lane], t;
+                t = RCX_DPP0(v, 0x111, 0xf); v = t > v ? t : v;
+                t = RCX_DPP0(v, 0x112, 0xf); v = t > v ? t : v;
+                t = RCX_DPP0(v, 0x114, 0xf); v = t > v ? t : v;
+                t = RCX_DPP0(v, 0x118, 0xf); v = t > v ? t : v;
+                t = RCX_DPP0(v, 0x142, 0xa); v = t > v ? t : v;
+                t = RCX_DPP0(v, 0x143, 0xc); v = t > v ? t : v;
+                j = v;
+                rcx_wave_sync();
+            }
+#else
 #pragma unroll
             for (int step = 32; step >= 1; step >>= 1) {
                 const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((j + (uint32_t)step - 1u) << 2), (int)incl);
                 j = v <= lane ? j + (uint32_t)step : j;
             }
+#endif
             const uint32_t jj = j < 63u ? j : 63u;
             uint32_t r = lane - (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jj << 2), (int)(incl - cnt));
             const uint32_t m0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(jj << 2), (int)(uint32_t)tmap.lo);
