@@ -36,6 +36,22 @@ def test_bounds_and_strings():
     assert lib.rcx_status_string(24) == b"invalid checksum on zlib stream"
 
 
+def test_host_register_argument_checks():
+    """rcx_host_register / rcx_host_unregister (page-locking a caller's buffers, include/rcx.h): null or empty ranges are the caller's
+    error before any device is looked at; without a device a real range is an error too, never a crash."""
+    import numpy as np
+    import torch
+    from rust_compress_amd import _native
+    lib = _native.lib()
+    assert lib.rcx_host_register(None, 4096) == _native.RC_BAD_ARG
+    buf = np.zeros(1 << 16, np.uint8)
+    assert lib.rcx_host_register(buf.ctypes.data, 0) == _native.RC_BAD_ARG
+    assert lib.rcx_host_unregister(None) == _native.RC_BAD_ARG
+    if not torch.cuda.is_available():
+        assert lib.rcx_host_register(buf.ctypes.data, buf.size) != _native.RC_OK
+        assert lib.rcx_host_unregister(buf.ctypes.data) != _native.RC_OK
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():
