@@ -58,15 +58,24 @@ def timeit_ranks(fn, torch, dist, reps=5, warm=1):
     return float(t.item())
 
 
-def source_hash():
-    """sha256 over every kernel source (the host-side files -- rcx_api.hip, the C-ABI and its staging, and rcx_tu.h -- hold no device
-    code): a PMC traffic figure is only quoted for the code it was measured on"""
+CONFIG_SOURCES = {      # the device sources a config's kernels are compiled from (the translation units of rust_compress_amd/csrc/tu_*.hip)
+    "3": ["k_inflate.hip", "k_inflate2.hip", "k_inflate3.hip", "k_lz4_decode_v4.hip", "k_lz4_decode_v5.hip", "k_crc32.hip", "k_gzip.hip", "tu_inflate.hip", "rcx_dev.h"],
+    "4": ["k_bwt.hip", "k_bwt_sort.hip", "k_bwt_inverse.hip", "tu_bwt.hip", "rcx_dev.h"],
+    "5": ["k_serial.hip", "tu_serial.hip", "k_bwt.hip", "k_bwt_sort.hip", "k_bwt_inverse.hip", "tu_bwt.hip", "rcx_dev.h"],
+}
+
+
+def source_hash(cfg=None):
+    """sha256 over the device sources of a config's kernels (all of them when cfg is None; the host-side files -- rcx_api.hip, the C-ABI
+    and its staging, and rcx_tu.h -- hold no device code): a PMC traffic figure is only quoted for the code it was measured on"""
     import hashlib
     d = os.path.join(ROOT, "rust_compress_amd", "csrc")
     h = hashlib.sha256()
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")) and f not in ("rcx_api.hip", "rcx_tu.h"):
-            h.update(open(os.path.join(d, f), "rb").read())
+    files = CONFIG_SOURCES.get(str(cfg)[:1]) if cfg is not None else None
+    if files is None:
+        files = [f for f in sorted(os.listdir(d)) if f.endswith((".hip", ".h")) and f not in ("rcx_api.hip", "rcx_tu.h")]
+    for f in sorted(files):
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -76,7 +85,7 @@ def pmc_traffic(cfg, key=None):
     f = os.path.join(ROOT, "profiles", "pmc_cfg%s.json" % cfg)
     try:
         j = json.load(open(f))
-        if j.get("kernel_source_hash") != source_hash():
+        if j.get("kernel_source_hash") != source_hash(cfg):
             return None
         j = j[key] if key else j
         return {"hbm_bytes_per_launch": j["hbm_bytes_per_launch"], "file": "profiles/pmc_cfg%s.json" % cfg}

@@ -77,6 +77,9 @@
 #ifndef RCX_AGE_DYN
 #define RCX_AGE_DYN 0
 #endif
+#ifndef RCX_RUNSPLIT
+#define RCX_RUNSPLIT 1                   /* a run longer than SPLIT bytes as pieces that copy side by side (post()); 0: one lane fills it (A/B) */
+#endif
 #define RCX_PROG_FIN 0xfffffffeu
 #define RCX_PROG_PARSER 0xffffffffu
 #define RCX_PROG_LIVE 0xffffff00u               /* running executors are below this */
@@ -479,7 +482,8 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR> {
     }
     // post one batch (p0: where its first token starts); returns false when the executor has given up
     // lane's token becomes entry `idx` (and idx + 1 when w1b != 0) of the batch, if `put`
-    __device__ __forceinline__ bool post(uint32_t& head, int ns, int why, int perr, uint32_t gL, uint32_t gM, uint32_t goff, uint32_t gsrc, uint32_t p0, bool put, uint32_t idx, uint32_t w1, uint32_t w1b)
+    __device__ __forceinline__ bool post(uint32_t& head, int ns, int why, int perr, uint32_t gL, uint32_t gM, uint32_t goff, uint32_t gsrc, uint32_t p0, bool put, uint32_t idx, uint32_t w1, uint32_t w1b,
+                                         uint32_t runM = 0, uint32_t runoff = 1)
     {
         const unsigned lane = this->lane;
         auto ring = this->ring8;
@@ -495,6 +499,20 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR> {
         rcx_wave_sync();
         RCX_LDS_AS Slot8* sl = &ring->slot[head % NSLOT8];
         if (put) { sl->d[idx] = w1; if (w1b) sl->d[idx + 1] = w1b; }
+        if (RCX_RUNSPLIT && SPLIT && __ballot(put && runM != 0u)) {
+            // a RUN (a match that overlaps itself: offset < 16 and < its length) longer than SPLIT bytes: pieces of SPLIT bytes, and every piece
+            // after the first copies from a whole number of periods back that lands in what the FIRST piece (and the period in front of
+            // it) wrote -- byte x of a run equals byte x - m * offset for every m that stays behind the run's start -- so the pieces wait
+            // for the first one only and copy side by side, where one lane filled the run 16 bytes a round (G-runs: 7.6 rounds an emit call)
+            if (put && runM != 0u) {
+                const uint32_t cnt = (runM + (uint32_t)SPLIT - 1u) / (uint32_t)SPLIT;
+                for (uint32_t k = 1; k < cnt; k++) {
+                    const uint32_t back = (((uint32_t)SPLIT * k + runoff - 1u) / runoff) * runoff;       // in [SPLIT k, SPLIT k + offset)
+                    const uint32_t lk = runM - (uint32_t)SPLIT * k < (uint32_t)SPLIT ? runM - (uint32_t)SPLIT * k : (uint32_t)SPLIT;
+                    sl->d[idx + k] = 0x80u | (lk << 8) | (back << 16);
+                }
+            }
+        }
         if (PRED) {
             // Match chains are shortened HERE, by the wave that has the time: an entry whose whole source lies in the match
             // bytes of ONE earlier entry of the batch copies from that entry's source instead (Lz4V4::emit's redirection),
@@ -571,8 +589,12 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR> {
         int g = -1;
         if (stop) { g = __ffsll(stop) - 1; nt = g; }
         // entries: one per token, two for a match longer than SPLIT; at most 64 a batch
-        const bool two = SPLIT && (int)lane < nt && M > (uint32_t)SPLIT && off >= 16u;      // (a short period copies itself: its halves would only wait for each other)
-        const uint32_t ecnt = (int)lane < nt ? (two ? 2u : 1u) : 0u;
+        // (a short period copies itself: halves with the same offset would only wait for each other, so a RUN's pieces copy from whole periods
+        // back, post(); a token in the batch with M > MCAP is a run of <= 255 bytes, see `stop`, and SPLIT < M <= 2 SPLIT makes two pieces either way)
+        const bool big = SPLIT && (int)lane < nt && M > (uint32_t)SPLIT;
+        const bool two = big && off >= 16u;
+        const bool rs = RCX_RUNSPLIT && big && off < 16u;
+        const uint32_t ecnt = (int)lane < nt ? (RCX_RUNSPLIT ? (big ? (M + (uint32_t)SPLIT - 1u) / (uint32_t)SPLIT : 1u) : (two ? 2u : 1u)) : 0u;
         const uint32_t eincl = SPLIT ? rcx_wave_incl_scan(ecnt) : (uint32_t)lane + ecnt;
         uint32_t ne = (uint32_t)nt;
         if (SPLIT) {
@@ -591,9 +613,9 @@ struct Lz4V8 : Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR> {
             else why = (gL + gM <= (uint32_t)B::SOLO) ? B::SOLO_ : B::WIDE_;
         }
         const bool put = (int)lane < nt;
-        const uint32_t M1 = two ? (uint32_t)SPLIT : M;
+        const uint32_t M1 = (RCX_RUNSPLIT ? big : two) ? (uint32_t)SPLIT : M;
         if (!post(head, (int)ne, why, gerr, gL, gM, goff, gsrc, RCX_U(tp), put, eincl - ecnt, L | (M1 << 8) | (off << 16),
-                  (put && two) ? (0x80u | ((M - (uint32_t)SPLIT) << 8) | (off << 16)) : 0u)) return -1;
+                  (put && two) ? (0x80u | ((M - (uint32_t)SPLIT) << 8) | (off << 16)) : 0u, (put && rs) ? M : 0u, off ? off : 1u)) return -1;
         V8P_ADD(4);
         if (PROF8) pp[9] += 1;
         if (why == B::ERR_) return -1;
