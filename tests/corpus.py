@@ -94,3 +94,26 @@ def lz4_edge_streams(oracle, count, seed, max_out=180000):
         blobs.append(b); raws.append(oracle.lz4_decode_block(b, cap=produced + len(tail)))
         assert len(raws[-1]) == produced + len(tail)
     return blobs, raws
+
+
+def lz4_run_streams(oracle, seed=5):
+    """-> (blocks, their decoded bytes by the oracle): runs -- matches that overlap themselves -- of every offset 1..15 (and 16, 17: not
+    runs) with lengths on both sides of the parser's piece boundaries (k_lz4_decode_v8.hip, RCX_RUNSPLIT: 32 / 64 / ... / 255, and the
+    256+ that leave the batch), with 0..3 literals between them, back to back and at the start of a block."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    lens = [4, 15, 16, 17, 31, 32, 33, 34, 47, 48, 63, 64, 65, 66, 95, 96, 97, 127, 128, 129, 191, 192, 193, 223, 224, 225, 254, 255, 256, 257, 300, 1100]
+    blobs, raws = [], []
+    for off0 in range(1, 18):
+        for variant in range(3):
+            seqs, produced = [], 0
+            for M in (lens if variant < 2 else list(rng.permutation(lens))):
+                L = off0 if not seqs else int(rng.integers(0, 4)) if variant else 0
+                lit = rng.integers(0, 256, L, dtype=np.uint8).tobytes()
+                produced += L
+                off = min(off0 if variant != 1 else int(rng.integers(1, 18)), produced)
+                seqs.append((lit, int(M), off)); produced += int(M)
+            b = lz4_stream(seqs, rng.integers(0, 256, 7, dtype=np.uint8).tobytes())
+            blobs.append(b); raws.append(oracle.lz4_decode_block(b, cap=produced + 7))
+            assert len(raws[-1]) == produced + 7
+    return blobs, raws

@@ -83,6 +83,33 @@ def test_decode_malformed_statuses(ctx, oracle, variant):
 
 
 @pytest.mark.parametrize("variant", N.LZ4_DECODE_VARIANTS[:2])
+def test_decode_runs_of_every_offset_and_length(ctx, oracle, variant):
+    """Runs (matches that overlap themselves) of every offset 1..15 and lengths on both sides of the parser's piece boundaries
+    (tests/corpus.py: lz4_run_streams): the parser hands a run over as pieces whose offsets are whole periods back (k_lz4_decode_v8.hip,
+    RCX_RUNSPLIT); whole, cut short and with too little room -- bytes and statuses as the oracle's."""
+    import corpus
+    rng = np.random.default_rng(3)
+    blobs, raws = corpus.lz4_run_streams(oracle)
+    ctx.set_variant(N.LZ4_DECODE, variant)
+    try:
+        for rot in (0, 1, 2):
+            bl, rw = blobs[rot:] + blobs[:rot], raws[rot:] + raws[:rot]
+            res = ctx.lz4_decode_blocks(bl, [len(r) for r in rw]).check()
+            assert res.outputs == rw and list(res.in_used) == [len(b) for b in bl], rot
+        cut = [b[: int(rng.integers(0, len(b)))] for b in blobs]
+        caps = [int(rng.integers(0, len(r) + 1)) for r in raws]
+        for bl, cp in ((cut, [len(r) for r in raws]), (blobs, caps)):
+            res = ctx.lz4_decode_blocks(bl, cp)
+            for i, (b, c) in enumerate(zip(bl, cp)):
+                eo, es = oracle.lz4_decode_block(b, cap=c, raise_on_error=False)
+                assert es == res.status[i], (i, es, res.status[i])
+                if es == 0:
+                    assert eo == res.outputs[i]
+    finally:
+        ctx.set_variant(N.LZ4_DECODE, 0)
+
+
+@pytest.mark.parametrize("variant", N.LZ4_DECODE_VARIANTS[:2])
 def test_decode_long_runs_and_chunk_edges(ctx, oracle, variant):
     """Length extensions on both sides of every boundary the parser has (k_lz4_decode_v8.hip, next_tok_c / fields): literal runs and
     matches of 14..16, 269..271 (one extension byte, 254 / 255 / 255+0), 524..526 and 1000+ bytes, a text of short tokens

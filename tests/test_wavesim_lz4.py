@@ -124,3 +124,21 @@ def test_decode_mirror_and_gates(oracle, golden, mis):
             assert es == s_, (i, es, s_)
             if es == 0:
                 assert eo == out
+
+
+@pytest.mark.parametrize("variant", [0, 15])
+def test_decode_runs_of_every_offset_and_length(oracle, variant):
+    """runs of every offset 1..15 with lengths on both sides of the parser's piece boundaries (tests/corpus.py: lz4_run_streams), whole and
+    with too little room: bytes and statuses as the oracle's"""
+    import simrun, corpus
+    rng = np.random.default_rng(4)
+    blobs, raws = corpus.lz4_run_streams(oracle)
+    outs, _, in_used, st, _ = simrun.run(LZ4_DECODE, variant, blobs, [len(r) for r in raws], in_misalign=3, out_misalign=1)
+    assert not st.any() and outs == raws and list(in_used) == [len(b) for b in blobs]
+    caps = [int(rng.integers(0, len(r) + 1)) for r in raws]
+    exp = [oracle.lz4_decode_block(b, cap=c, raise_on_error=False) for b, c in zip(blobs, caps)]
+    outs, _, _, st, _ = simrun.run(LZ4_DECODE, variant, blobs, caps)
+    for i, ((eo, es), s_, out) in enumerate(zip(exp, st, outs)):
+        assert es == s_, (i, es, s_)
+        if es == 0:
+            assert eo == out
