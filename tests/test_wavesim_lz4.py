@@ -142,3 +142,36 @@ def test_decode_runs_of_every_offset_and_length(oracle, variant):
         assert es == s_, (i, es, s_)
         if es == 0:
             assert eo == out
+
+
+def test_plain_batches_take_the_straight_line_executor(oracle):
+    """Round 6: a batch the parser calls plain goes through Lz4V8::emit6 (frames of aligned dwords stored under masks) and everything else
+    through emit5 -- both must give the oracle's bytes at every misalignment of input and output (a frame's shift is the destination's
+    misalignment), and a text must not fall back to emit5 for more than a fifth of its batches."""
+    import ctypes as C
+    import simrun
+    lib = simrun.lib()
+    lib.sim_stats.restype = C.POINTER(C.c_ulonglong)
+    st = lib.sim_stats()
+    for kind in ("text", "dna4", "mix"):
+        raws = [synth.gen(kind, 65536, 21).tobytes(), synth.gen(kind, 20000, 22).tobytes()]
+        blobs = [oracle.lz4_encode_block(r) for r in raws]
+        st[8] = 0; st[9] = 0
+        for mis in ((0, 0), (1, 1), (2, 7), (3, 14), (13, 3)):
+            outs, _, in_used, status, _ = simrun.run(LZ4_DECODE, 0, blobs, [len(r) for r in raws], in_misalign=mis[0], out_misalign=mis[1])
+            assert not status.any() and outs == raws and list(in_used) == [len(b) for b in blobs]
+        assert st[8] > 0
+        if kind != "mix":
+            assert st[8] >= 4 * st[9], (kind, st[8], st[9])
+    # too little room / cut short: the plain path must hand over to emit5 and give the oracle's statuses
+    rng = np.random.default_rng(5)
+    raw = synth.gen("text", 30000, 23).tobytes()
+    blob = oracle.lz4_encode_block(raw)
+    cuts = [blob[: int(rng.integers(40, len(blob)))] for _ in range(6)] + [blob] * 6
+    caps = [len(raw)] * 6 + [int(rng.integers(0, len(raw))) for _ in range(6)]
+    exp = [oracle.lz4_decode_block(b, cap=c, raise_on_error=False) for b, c in zip(cuts, caps)]
+    outs, _, _, status, _ = simrun.run(LZ4_DECODE, 0, cuts, caps)
+    for i, ((eo, es), s_, out) in enumerate(zip(exp, status, outs)):
+        assert es == s_, (i, es, s_)
+        if es == 0:
+            assert eo == out

@@ -241,6 +241,7 @@ static inline unsigned long long ws_memrealtime_() { static unsigned long long t
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 namespace ws { extern unsigned long long g_stat[16]; }
 #define RCX_V7_STAT(slot, v) (ws::g_stat[slot] += (unsigned long long)(v))
+#define RCX_V8_STAT(slot, v) (ws::g_stat[slot] += (unsigned long long)(v))
 // portable version of rcx_dev.h's hand-scheduled LZ4 token walk (the product uses inline gfx950 asm)
 static inline void ws_hop_walk(uint32_t dv, uint32_t& rel, uint64_t& vis)
 {
@@ -319,6 +320,7 @@ static inline uint32_t ws_wave_incl_scan(uint32_t v)
 #define RCX_NO_INF_WALK_ASM 1          // Inf3::tile4's hand-written hop loop: the simulator walks with the portable hop4 alone
 #define RCX_NO_DC_STEPS_ASM 1          // k_dc_decode's hand-written step loop: the simulator runs the portable step alone
 #define RCX_NO_WALK_ASM 1              // Lz4V8::next_tok_c's hand-written step: the simulator runs the portable form
+#define RCX_NO_MSKOR_ASM 1             // Lz4V8::store_frame's ds_mskor_b32 stores: byte stores here
 #define RCX_NO_ROUNDS_ASM 1            // emit5's hand-written copy-round loop: the simulator runs the portable loop alone
 #define RCX_LDS_STORE16 ws_lds_store16
 static inline uint32_t ws_sad_u8(uint32_t a, uint32_t c) { return c + (a & 255u) + ((a >> 8) & 255u) + ((a >> 16) & 255u) + (a >> 24); }          // v_sad_u8 against 0
