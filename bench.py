@@ -12,7 +12,8 @@ RANK / LOCAL_RANK / WORLD_SIZE as given.  Besides the kernel-only headline value
   * `end_to_end`: the same job when the compressed blocks live on rank 0 -- root scatter of the compressed ranges,
     decode, root gather of the decoded ranges (RCCL grouped send/recv, rust_compress_amd/dist.py), timed per phase;
   * `other_configs` (N=1): BASELINE configs 3, 4, 5 from the same process (benchmarks/bench_configs.py);
-  * `hbm_ceiling_measured`: a device-to-device copy, next to the 8 TB/s spec peak the roofline uses;
+  * `hbm_ceiling_measured`: a device-to-device copy (the library's own 16-bytes-a-lane kernel), next to the 8 TB/s spec peak the roofline uses;
+  * `single_stream` (N=1): one LZ4 block / one 1 MiB DEFLATE stream / one BWT block alone on the GPU, batches of 1..4096, break-even sizes;
   * `cpu_baseline` (N=1): the oracle on the host cores.
 Inputs are synthetic (rust_compress_amd.synth) and are compressed on the GPU by the product's own bit-exact LZ4 encoder;
 the oracle is used only for the cpu_baseline leg (and its parity check).
@@ -420,7 +421,9 @@ def sustained(eng, wl, seconds=2.0):
             "GiB/s": round(wl["out_bytes"] / (float(ms.mean()) * 1e-3) / 2**30, 2), "roofline_frac": round(alg / (float(ms.mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
 
 
-def hbm_ceiling(torch, dev, nbytes=1 << 30, reps=10):
+def hbm_ceiling(torch, dev, ctx=None, nbytes=1 << 30, reps=10):
+    """What a plain copy reaches on this device, two ways: the library's own kernel (rcx_hbm_copy_probe: 16 bytes a lane, four loads in
+    flight a thread, nontemporal) -- the figure quoted as "achievable" -- and torch's copy_ (rocm's blit kernel), which reads ~20 % lower."""
     a = torch.empty(nbytes, dtype=torch.uint8, device=dev).fill_(1)
     b = torch.empty_like(a)
     b.copy_(a); torch.cuda.synchronize()
@@ -430,7 +433,18 @@ def hbm_ceiling(torch, dev, nbytes=1 << 30, reps=10):
         b.copy_(a)
     e1.record(); torch.cuda.synchronize()
     t = e0.elapsed_time(e1) * 1e-3 / reps
-    return {"GB/s": round(2 * nbytes / t / 1e9, 1), "what": "device-to-device copy of 1 GiB (read + write bytes / time)", "spec_peak_GB/s": HBM_PEAK_GBS}
+    del a, b
+    torch.cuda.empty_cache()
+    res = {"GB/s": round(2 * nbytes / t / 1e9, 1), "what": "device-to-device copy of 1 GiB (read + write bytes / time), torch copy_", "spec_peak_GB/s": HBM_PEAK_GBS}
+    if ctx is not None:
+        from rust_compress_amd import _native as N
+        g = C.c_double(0)
+        rc = N.lib().rcx_hbm_copy_probe(ctx._h, nbytes, reps, C.byref(g))
+        if rc == 0:
+            res["torch_copy_GB/s"] = res["GB/s"]
+            res["GB/s"] = round(g.value, 1)
+            res["what"] = "device-to-device copy of 1 GiB (read + write bytes / time): rcx_hbm_copy_probe, the library's own 16-bytes-a-lane kernel; torch copy_ beside it"
+    return res
 
 
 def dry_sharded_pipeline(eng, dist, rank, world, nblocks=11, block=4096):
@@ -489,7 +503,9 @@ def summary_of(res):
     out = {"lz4_decode_ms": res.get("ms_per_step"), "lz4_decode_GiB/s": res.get("value"), "roofline_frac": g(res, "roofline", "frac"),
            "sustained_ms": g(res, "sustained", "kernel_ms_avg"), "runs_ms": g(res, "per_distribution", "G-runs", "ms_per_step"),
            "rand_ms": g(res, "per_distribution", "G-rand", "ms_per_step"), "e2e_GiB/s": g(res, "end_to_end", "value"),
-           "host_path_GiB/s": g(res, "host_path", "GiB/s"), "cpu_GiB/s": g(res, "cpu_baseline", "value")}
+           "host_path_GiB/s": g(res, "host_path", "GiB/s"), "cpu_GiB/s": g(res, "cpu_baseline", "value"),
+           "one_lz4_block_us": g(res, "single_stream", "lz4_block_64KiB", "host_us"), "one_deflate_MiB_us": g(res, "single_stream", "deflate_stream_1MiB", "host_us"),
+           "one_bwt_block_fwd_us": g(res, "single_stream", "bwt_block_256KiB", "forward_host_us"), "hbm_copy_GB/s": g(res, "hbm_ceiling_measured", "GB/s")}
     for o in res.get("other_configs") or []:
         if not isinstance(o, dict):
             continue
@@ -785,6 +801,14 @@ def main():
         res["host_path"] = legs.run("host_path", lambda: host_path(eng, wl), collective=False)
     if rank == 0 and world == 1 and not args.no_cpu and not args.dry_gloo:
         res["cpu_baseline"] = legs.run("cpu_baseline", lambda: cpu_baseline(wl["dec"], wl["raw"], torch, args.nblocks), collective=False)
+    if rank == 0 and world == 1 and not args.no_others and not args.dry_gloo:
+        # batch of ONE and the batch-size sweep (benchmarks/single_stream.py): what a caller with a single stream gets, and from which
+        # batch size the GPU path beats the host -- its oracle timings are a cpu_baseline leg like the one above (skipped with --no-cpu)
+        def leg_single():
+            sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
+            import single_stream as SS
+            return SS.single_stream(eng.ctx, torch, eng.dev, cpu=not args.no_cpu)
+        res["single_stream"] = legs.run("single_stream", leg_single, collective=False)
     # ---- BASELINE configs 3, 4, 5 on the same ranks: 3 and 4 weak (every rank its own members / blocks), 5 ONE stream sharded
     if not args.no_others:
         others = []
@@ -815,7 +839,7 @@ def main():
 
     if rank == 0:
         if world == 1 and not args.no_others and not args.dry_gloo:
-            res["hbm_ceiling_measured"] = legs.run("hbm_ceiling", lambda: hbm_ceiling(torch, eng.dev), collective=False)
+            res["hbm_ceiling_measured"] = legs.run("hbm_ceiling", lambda: hbm_ceiling(torch, eng.dev, eng.ctx), collective=False)
         if args.extras and world == 1 and not args.dry_gloo:
             def leg_extras():
                 N = eng.N

@@ -126,7 +126,9 @@ typedef struct rcx_batch {
 /* ---- LZ4 -------------------------------------------------------------------- */
 /* reference: src/lz4.rs:602-611 decode_block() -> BlockDecoder::decode :67-110
  * RCX_MEM_HOST with a PAGE-LOCKED out_base (hipHostMalloc / hipHostRegister): the decoder stores the decoded bytes straight into
- * the caller's buffer while it runs (nothing beyond out_len[i] of a block's slot is written) and, when in_base is page-locked
+ * the caller's buffer while it runs (nothing beyond out_len[i] of a block's slot is written for a block that decodes; a block that
+ * fails, or one whose late input made the library decode it a second time, may leave bytes of its first attempt anywhere in its
+ * slot -- never outside it) and, when in_base is page-locked
  * too, the compressed bytes arrive in block ranges under the launch; with pageable buffers one copy each way around the launch.
  * Same results either way.  rcx_ctx_set_param(ctx, RCX_LZ4_DECODE, 1) keeps the plain copies (A/B). */
 int rcx_lz4_decode_batch(rcx_ctx*, const rcx_batch*);
@@ -233,7 +235,11 @@ uint64_t rcx_rle_encode_bound(uint64_t in_len);
 /* ---- device-resident descriptors (benchmark / pipeline use) ------------------ */
 /* Same kernels, but every array (offsets, lengths, status, ...) already lives
  * in HBM, nothing is copied and nothing is synchronised: the call enqueues on
- * the ctx stream and returns. This is what bench.py times. */
+ * the ctx stream and returns. This is what bench.py times.
+ * ONE exception: RCX_BWT_FORWARD / RCX_BWT_SUFFIXES read in_len back and wait once per prefix-doubling round for a few counter words
+ * (the host decides which of the sorter's kernels the next round needs, csrc/k_bwt.hip) -- the call returns when the last round has been
+ * enqueued, with the transform's final kernels still running.  A caller that overlaps BWT batches gives each its own context and
+ * thread (pipeline.PipelineLanes does). */
 typedef struct rcx_dev_batch {
     const uint8_t*  in_base;
     const uint64_t* in_off;
@@ -262,6 +268,10 @@ enum rcx_codec {
  * rcx_launch_dev falls back to the lane-per-stream kernel (same results, slower on small batches). */
 uint64_t rcx_scratch_bytes(int codec, uint32_t nblocks, uint64_t max_block);
 int rcx_launch_dev(rcx_ctx*, int codec, const rcx_dev_batch*, void* scratch, uint64_t scratch_bytes);
+/* Measurement aid (no counterpart in the reference): what a plain copy reaches on this device -- `bytes` read and `bytes` written per
+ * pass by a kernel that moves 16 bytes a lane, `reps` passes timed with events on the ctx stream; *gb_per_s = 2 * bytes / time.  The
+ * "achievable" line next to the 8 TB/s spec peak in bench.py's roofline (rocm's own copy kernels, torch copy_, read 20 % lower). */
+int rcx_hbm_copy_probe(rcx_ctx*, uint64_t bytes, int reps, double* gb_per_s);
 /* kernel variant knob for A/B measurements (0 = default/best). */
 int rcx_ctx_set_variant(rcx_ctx*, int codec, int variant);
 /* codec parameter for rcx_launch_dev (the *_batch entry points take it as an argument): the rate of RCX_ARI_BINARY_*;
@@ -280,7 +290,19 @@ int rcx_ctx_set_param(rcx_ctx*, int codec, uint32_t value);
  *                        n_out: what that entry point takes beside the batch (origins in, origins / flags / checksums out,
  *                        DC decode's lengths), or NULL.
  *   rcx_multi_launch_dev DEVICE-resident ranges: per_device[g] (arrays in device g's HBM, or NULL for none) is enqueued on device
- *                        g's context stream like rcx_launch_dev; rcx_multi_sync waits for every device. */
+ *                        g's context stream like rcx_launch_dev; rcx_multi_sync waits for every device.
+ *   rcx_multi_scatter_dev / rcx_multi_gather_dev   the batch sits in the HBM of ONE device of the set (`root`): contiguous byte
+ *                        ranges travel to the devices that work on them and the results come back DEVICE TO DEVICE, no host staging
+ *                        ("RCCL only to scatter inputs and gather outputs").  range_off[g] .. range_off[g + 1] are device
+ *                        g's bytes in root_buf (count + 1 host words; an empty range is skipped); peer_buf[g] is device g's buffer,
+ *                        range-relative (its byte 0 is root_buf[range_off[g]]); peer_buf[root] may be NULL: that range stays where it
+ *                        is.  Both calls only enqueue, each transfer ordered on the streams of the two contexts it connects:
+ *                        scatter -> rcx_multi_launch_dev -> gather -> rcx_multi_sync needs no wait in between.
+ *                        Transport: RCCL -- grouped ncclSend / ncclRecv, one communicator per device under ncclCommInitAll, librccl
+ *                        loaded on first use -- when the set's devices are distinct; a set that lists a device twice (what a one-GPU
+ *                        box can test), a host without librccl, or RCX_MULTI_TRANSPORT=peer in the environment use
+ *                        hipMemcpyPeerAsync between the contexts' streams (events order it).  rcx_multi_transport() names the one
+ *                        in use ("rccl" / "peer"; "" before the first transfer).  Measured on one device only: see DESIGN.md 4. */
 typedef struct rcx_multi rcx_multi;
 int  rcx_multi_create(const int* device_ids, int n, rcx_multi** out);
 void rcx_multi_destroy(rcx_multi*);
@@ -288,6 +310,9 @@ int  rcx_multi_count(const rcx_multi*);
 rcx_ctx* rcx_multi_ctx(rcx_multi*, int i);      /* device i's context: its stream, variant and parameter knobs, last error */
 void rcx_partition(const uint64_t* weights, uint32_t nblocks, uint32_t parts, uint32_t* bounds);
 int  rcx_multi_batch(rcx_multi*, int codec, const rcx_batch*, const uint32_t* aux_in, uint32_t* aux_out, const uint64_t* n_out);
+int  rcx_multi_scatter_dev(rcx_multi*, int root, const uint8_t* root_buf, const uint64_t* range_off, uint8_t* const* peer_buf);
+int  rcx_multi_gather_dev(rcx_multi*, int root, uint8_t* root_buf, const uint64_t* range_off, const uint8_t* const* peer_buf);
+const char* rcx_multi_transport(const rcx_multi*);
 int  rcx_multi_launch_dev(rcx_multi*, int codec, const rcx_dev_batch* const* per_device, void* const* scratch, const uint64_t* scratch_bytes);
 int  rcx_multi_sync(rcx_multi*);
 const char* rcx_multi_last_error(const rcx_multi*);

@@ -172,7 +172,13 @@ extern "C" {
     pub fn rcx_multi_launch_dev(m: *mut rcx_multi, codec: c_int, per_device: *const *const rcx_dev_batch, scratch: *const *mut c_void, scratch_bytes: *const u64) -> c_int;
     pub fn rcx_multi_sync(m: *mut rcx_multi) -> c_int;
     pub fn rcx_multi_last_error(m: *const rcx_multi) -> *const c_char;
+    // the batch on ONE device of the set: ranges out to their devices and the results back, device to device (RCCL, or peer copies)
+    pub fn rcx_multi_scatter_dev(m: *mut rcx_multi, root: c_int, root_buf: *const u8, range_off: *const u64, peer_buf: *const *mut u8) -> c_int;
+    pub fn rcx_multi_gather_dev(m: *mut rcx_multi, root: c_int, root_buf: *mut u8, range_off: *const u64, peer_buf: *const *const u8) -> c_int;
+    pub fn rcx_multi_transport(m: *const rcx_multi) -> *const c_char;
     // ---- page-locked host memory: what lets rcx_lz4_decode_batch write the caller's buffer itself (include/rcx.h)
     pub fn rcx_host_register(ptr: *mut c_void, bytes: u64) -> c_int;
     pub fn rcx_host_unregister(ptr: *mut c_void) -> c_int;
+    // ---- measurement aid: the device's own copy rate (GB/s, read + written)
+    pub fn rcx_hbm_copy_probe(ctx: *mut rcx_ctx, bytes: u64, reps: c_int, gb_per_s: *mut f64) -> c_int;
 }

@@ -39,6 +39,7 @@ EXPORTS = [
     "rcx_bwt_suffixes_batch", "rcx_bwt_inversion_table_batch",
     "rcx_multi_create", "rcx_multi_destroy", "rcx_multi_count", "rcx_multi_ctx", "rcx_partition", "rcx_multi_batch",
     "rcx_multi_launch_dev", "rcx_multi_sync", "rcx_multi_last_error", "rcx_host_register", "rcx_host_unregister",
+    "rcx_hbm_copy_probe", "rcx_multi_scatter_dev", "rcx_multi_gather_dev", "rcx_multi_transport",
 ]
 
 
@@ -120,5 +121,10 @@ def lib():
         L.rcx_multi_last_error.restype = C.c_char_p
         L.rcx_host_register.argtypes = [C.c_void_p, C.c_uint64]
         L.rcx_host_unregister.argtypes = [C.c_void_p]
+        L.rcx_hbm_copy_probe.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
+        L.rcx_multi_scatter_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)]
+        L.rcx_multi_gather_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)]
+        L.rcx_multi_transport.argtypes = [C.c_void_p]
+        L.rcx_multi_transport.restype = C.c_char_p
         _lib = L
     return _lib

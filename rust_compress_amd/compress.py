@@ -173,6 +173,40 @@ class _BufferedDecoder:
     unwrap = finish
 
 
+def _decode_many(cls, readers, call, first_cap):
+    """Several streams of one kind through ONE batch call (and a second one for the slots that were too small): what a caller with many
+    `Decoder`s uses instead of reading them one by one -- a stream alone on the GPU takes longer than on one host thread, a batch of
+    eight or more does not ("how large a batch has to be").  `readers`: objects with .read(); -> the decoders, each
+    already decoded (read() / finish() serve from memory), in order.  The first stream that fails raises what its Decoder would raise."""
+    decs = [cls(r) for r in readers]
+    raws = []
+    for d in decs:
+        d.consumed = None
+        d._raw = d.r.read(-1)
+        raws.append(d._raw)
+    if not decs:
+        return decs
+    caps = [first_cap(x) for x in raws]
+    res = call(raws, caps)
+    outs, status, used, aux = list(res.outputs), [int(x) for x in res.status], [int(x) for x in res.in_used], list(res.aux) if res.aux is not None else [0] * len(raws)
+    redo = [i for i, st in enumerate(status) if st == N.E_OUTPUT_TOO_SMALL]
+    cap = max(caps) if caps else 0
+    while redo and cap < MAX_BLOCK:                    # the slots that did not fit, eight times larger, together
+        cap = min(cap * 8, MAX_BLOCK)
+        r2 = call([raws[i] for i in redo], [cap] * len(redo))
+        for j, i in enumerate(redo):
+            outs[i], status[i], used[i] = r2.outputs[j], int(r2.status[j]), int(r2.in_used[j])
+            if r2.aux is not None:
+                aux[i] = r2.aux[j]
+        redo = [i for i in redo if status[i] == N.E_OUTPUT_TOO_SMALL]
+    for d, o, st, u, a in zip(decs, outs, status, used, aux):
+        _raise(st)
+        d._out, d._pos, d.consumed, d.flags = o, 0, u, int(a)
+        d.r.unread(d._raw[u:])
+        d._raw = d._raw[:u]
+    return decs
+
+
 # ------------------------------------------------------------------------------------------------ lz4
 class lz4:
     MAGIC = 0x184D2204
@@ -203,7 +237,8 @@ class lz4:
     class Decoder(_BufferedDecoder):                  # lz4.rs:316-500 (frame reader)
         MAX_SIZES = [0, 0, 0, 0, 64 << 10, 256 << 10, 1 << 20, 4 << 20]
 
-        def _decode_all(self, data):
+        def _parse(self, data):
+            """host framing: -> [(stored?, payload)], self.consumed, self.max_block_size"""
             p, n = 0, len(data)
             if n - p < 4:
                 raise UnexpectedEof(1)
@@ -244,22 +279,51 @@ class lz4:
                         raise UnexpectedEof(1)
                     p += 4
             self.consumed = p                                                  # content checksum is never read
+            return parts
+
+        @staticmethod
+        def _decode_blocks(comp, caps):
+            """every compressed block of one or MANY frames: ONE batch call; a conforming frame's blocks decode to at most max_block_size
+            bytes, only the blocks that do not fit get a second, larger slot (the reference would simply grow its Vec, :148-161)"""
+            if not comp:
+                return []
+            res = context().lz4_decode_blocks(comp, caps)
+            outl = list(res.outputs)
+            redo = [i for i, st in enumerate(res.status) if st == N.E_OUTPUT_TOO_SMALL]
+            for i in redo:
+                outl[i] = _check(_grow_caps(lambda cap, d=comp[i]: context().lz4_decode_blocks([d], [cap]), 8 * caps[i])).outputs[0]
+            for i, st in enumerate(res.status):
+                if i not in redo:
+                    _raise(int(st))
+            return outl
+
+        def _decode_all(self, data):
+            parts = self._parse(data)
             comp = [d for stored, d in parts if not stored]
-            outs = iter(())
-            if comp:                                                           # ONE batch call for every compressed block
-                # a conforming frame's blocks decode to at most max_block_size bytes; only the blocks that do not fit get a second,
-                # larger slot (the reference would simply grow its Vec, :148-161)
-                mb = max(self.max_block_size, 1 << 16)
-                res = context().lz4_decode_blocks(comp, [mb] * len(comp))
-                outl = list(res.outputs)
-                redo = [i for i, st in enumerate(res.status) if st == N.E_OUTPUT_TOO_SMALL]
-                for i in redo:
-                    outl[i] = _check(_grow_caps(lambda cap, d=comp[i]: context().lz4_decode_blocks([d], [cap]), 8 * mb)).outputs[0]
-                for i, st in enumerate(res.status):
-                    if i not in redo:
-                        _raise(int(st))
-                outs = iter(outl)
+            outs = iter(self._decode_blocks(comp, [max(self.max_block_size, 1 << 16)] * len(comp)))
             return b"".join(d if stored else next(outs) for stored, d in parts)
+
+    @staticmethod
+    def decode_many(readers):
+        """-> [lz4.Decoder]: the frames of all readers parsed on the host, EVERY compressed block of EVERY frame in one batch call
+        (one 64 KiB block alone on the GPU takes six times what one host thread needs; eight or more together take less: INTEGRATION.md)."""
+        decs = [lz4.Decoder(r) for r in readers]
+        frames, comp, caps = [], [], []
+        for d in decs:
+            d.consumed = None
+            d._raw = d.r.read(-1)
+            parts = d._parse(d._raw)
+            frames.append(parts)
+            for stored, blk in parts:
+                if not stored:
+                    comp.append(blk); caps.append(max(d.max_block_size, 1 << 16))
+        outs = iter(lz4.Decoder._decode_blocks(comp, caps))
+        for d, parts in zip(decs, frames):
+            d._out = b"".join(blk if stored else next(outs) for stored, blk in parts)
+            d._pos = 0
+            d.r.unread(d._raw[d.consumed:])
+            d._raw = d._raw[:d.consumed]
+        return decs
 
     class Encoder:                                     # lz4.rs:505-597: stored blocks only (compress() is false)
         def __init__(self, w):
@@ -305,6 +369,12 @@ class flate:
             self.flags = int(res.aux[0])
             return res.outputs[0]
 
+    @staticmethod
+    def decode_many(readers):
+        """-> [flate.Decoder], every stream decoded by ONE batch call (the reference decodes one deflate block per read(), flate.rs:468-488:
+        one stream is one wave's work here -- hand over many)."""
+        return _decode_many(flate.Decoder, readers, lambda raws, caps: context().inflate(raws, caps), lambda x: max(1 << 16, 4 * len(x)))
+
 
 class zlib:
     class Decoder(_BufferedDecoder):                   # zlib.rs:32-127
@@ -312,6 +382,11 @@ class zlib:
             res = _check(_grow_caps(lambda cap: context().zlib_decode([data], [cap]), max(1 << 16, 4 * len(data))))
             self.consumed = int(res.in_used[0])
             return res.outputs[0]
+
+    @staticmethod
+    def decode_many(readers):
+        """-> [zlib.Decoder], every member decoded (and its Adler-32 checked) by ONE batch call"""
+        return _decode_many(zlib.Decoder, readers, lambda raws, caps: context().zlib_decode(raws, caps), lambda x: max(1 << 16, 4 * len(x)))
 
 
 class gzip:

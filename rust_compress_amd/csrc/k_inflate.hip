@@ -405,14 +405,16 @@ static void launch_inflate(hipStream_t s, rcx_kargs& k, bool zlib, int v)
     // 12.4 ms for config 3); 11 / 10: the window pass (Inf3::pass) with / without the second pass, 12: pass4 without it
     const bool spec = v == 0 || v == 12;
     const bool wave_per_stream = v == 10 || v == 11 || v == 12 || (v == 0 && n < INF3_MAX_STREAMS);
-    if (!wave_per_stream || k.scratch == nullptr || k.scratch_bytes < inflate_scratch_min(n)) { launch_inflate2(s, k, zlib ? 1 : 0, (v >= 9 && v <= 12) ? 0 : v); return; }
+    // (k.out_mirror tells the caller what happened: cleared wherever the launch did NOT store into the caller's buffer, so that the plain
+    //  copy follows -- rcx_api.hip asks inflate_mirrors() before it cuts the input into gated ranges, which only the mirroring kernel honours)
+    if (!wave_per_stream || k.scratch == nullptr || k.scratch_bytes < inflate_scratch_min(n)) { k.out_mirror = nullptr; launch_inflate2(s, k, zlib ? 1 : 0, (v >= 9 && v <= 12) ? 0 : v); return; }
     rcx_kargs k3 = k;
     uint32_t* adler = (uint32_t*)k.scratch;
     if (!k3.in_used) k3.in_used = (uint64_t*)((uint8_t*)k.scratch + ((4ull * n + 63) & ~63ull));
     // zlib: the decoder sums the Adler-32 of what it writes itself (k_inflate3<.., true>; the separate k_adler32 pass over the
     // output was 1.08 of the launch's 4.4 GB of HBM traffic for config 3) and k_zlib_tail3 compares it with the trailer
     const bool mirror = k.out_mirror != nullptr && spec && k.scratch_bytes >= inflate_scratch_bytes(n);      // (rcx_api.hip sizes the scratch for it)
-    if (!mirror) k3.out_mirror = nullptr;
+    if (!mirror) { k3.out_mirror = nullptr; k.out_mirror = nullptr; }
     if (zlib) {
         k3.scratch = adler;                                    // (the kernel's slot array: 4 bytes a stream)
         if (mirror) hipLaunchKernelGGL((k_inflate3<1024, true, true, true>), dim3(n), dim3(64), 0, s, k3, 1);
@@ -431,6 +433,8 @@ static void launch_inflate(hipStream_t s, rcx_kargs& k, bool zlib, int v)
     }
     if (v != 10 && v != 12) launch_inflate2(s, k, (zlib ? 1 : 0) | 2, 0);                      // 10: A/B, shows what the first pass handed back
 }
+// will launch_inflate(variant v) over n streams store into a page-locked output buffer (given the scratch rcx_scratch_bytes asks for)?
+static bool inflate_mirrors(uint32_t n, int v) { return (v == 0 && n < INF3_MAX_STREAMS) || v == 12; }
 static void launch_adler32(hipStream_t s, rcx_kargs& k)
 {
     hipLaunchKernelGGL((k_adler32<4>), dim3((k.nblocks + 3) / 4), dim3(256), 0, s, k);

@@ -38,7 +38,8 @@ struct rcx_ctx {
     uint8_t* h_desc = nullptr; size_t h_desc_cap = 0;      // page-locked: the descriptors' way in and the results' way out are small copies the call waits for
     hipStream_t copy_stream = nullptr;   // the host-memory LZ4 decode: compressed ranges on their way in under the launch that decodes them
     std::vector<hipEvent_t> piece_ev;
-    bool gate_bad = false;               // a gated launch ran into its time limit once (the copies did not run beside it): one copy in front of the launch from then on
+    bool gate_bad = false;               // a gated launch ran into its time limit (the copies did not run beside it): one copy in front of the launch for the next GATE_RETRY calls, then ranges are tried again
+    uint32_t gate_bad_calls = 0;         // calls left before the next try (rcx_ctx_set_param(ctx, codec, 0) of either decoder clears it at once)
     DevBuf d_gate; uint32_t* h_gate = nullptr; uint32_t gate_seq = 0;      // "range r has arrived" words (device; their page-locked source)
 };
 
@@ -100,6 +101,7 @@ extern "C" int rcx_ctx_set_param(rcx_ctx* c, int codec, uint32_t value)
 {
     if (!c || codec < 0 || codec >= RCX_CODEC_COUNT) return RCX_RC_BAD_ARG;
     c->param[codec] = value;
+    if (codec == RCX_LZ4_DECODE || codec == RCX_INFLATE || codec == RCX_ZLIB_DECODE) { c->gate_bad = false; c->gate_bad_calls = 0; }   // (setting a decoder's host-path knobs also ends the back-off a late gate started)
     return RCX_RC_OK;
 }
 
@@ -252,6 +254,7 @@ extern "C" int rcx_launch_dev(rcx_ctx* c, int codec, const rcx_dev_batch* b, voi
 // ---- host-descriptor batch path -------------------------------------------------------------------
 // Descriptor block layout in HBM (all 8-byte aligned):
 //   in_off[n] in_len[n] out_off[n] out_cap[n] n_out[n] | out_len[n] in_used[n] | status[n] aux[n]
+static const uint32_t GATE_RETRY = 64;      // calls that go back to one copy in front of the launch after a gate ran into its limit (one descheduling of the calling thread is enough for that)
 static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* aux_in, uint32_t* aux_out,
                      const uint64_t* n_out, bool needs_out, int param_over = -1)
 {
@@ -294,15 +297,25 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
     uint32_t pieces = 1;
     const bool inf_mirror = (codec == RCX_INFLATE || codec == RCX_ZLIB_DECODE || codec == RCX_GZIP_DECODE) && !(c->param[codec] & 1u);    // (the inflate front end drains through the same window; the
                                                                                                               //  streams its first pass hands back are copied out behind the second)
-    if (b->mem == RCX_MEM_HOST && (codec == RCX_LZ4_DECODE || inf_mirror) && out_span && c->variant[codec] == 0 && !(c->param[codec] & 1u)) {
+    if (b->mem == RCX_MEM_HOST && (codec == RCX_LZ4_DECODE || (inf_mirror && rcx_tu_inflate_mirrors(n, 0))) && out_span && c->variant[codec] == 0 && !(c->param[codec] & 1u)) {
         hipPointerAttribute_t at;
-        if (hipPointerGetAttributes(&at, b->out_base) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) {
+        // (the WHOLE span must be page-locked and mapped as one range: a buffer registered only in part would take the kernel's stores
+        //  into unmapped addresses -- the last byte's attributes must continue the first's)
+        auto covered = [](const void* base, uint64_t span, hipPointerAttribute_t& first) {
+            hipPointerAttribute_t last;
+            if (hipPointerGetAttributes(&first, base) != hipSuccess || first.type != hipMemoryTypeHost || !first.devicePointer) return false;
+            if (span <= 1) return true;
+            if (hipPointerGetAttributes(&last, (const uint8_t*)base + span - 1) != hipSuccess || last.type != hipMemoryTypeHost || !last.devicePointer) return false;
+            return (const uint8_t*)last.devicePointer == (const uint8_t*)first.devicePointer + (span - 1);
+        };
+        if (c->gate_bad && c->gate_bad_calls && --c->gate_bad_calls == 0) c->gate_bad = false;
+        if (covered(b->out_base, out_span, at)) {
             mirror = (uint8_t*)at.devicePointer;
             // (ranges only from page-locked INPUT: a pageable buffer is staged piece by piece, by copies that may need the compute
             // units the waiting blocks would hold)
             hipPointerAttribute_t ai;
             // (gzip members: their headers are parsed by a kernel of its own in front of the decoder, which wants every member there)
-            if (codec != RCX_GZIP_DECODE && in_span && !c->gate_bad && hipPointerGetAttributes(&ai, b->in_base) == hipSuccess && ai.type == hipMemoryTypeHost) {
+            if (codec != RCX_GZIP_DECODE && in_span && !c->gate_bad && covered(b->in_base, in_span, ai)) {
                 pieces = ((c->param[codec] >> 8) & 255u) ? ((c->param[codec] >> 8) & 255u) : 16u;
                 if (pieces > 16u) pieces = 16u;             // (the most; see below)
                 if (pieces > n / 128u) pieces = n / 128u ? n / 128u : 1u;
@@ -413,9 +426,13 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
                 HIPCHK(c, hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, least));
             }
             while (c->piece_ev.size() < pieces) { hipEvent_t e; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->piece_ev.push_back(e); }
+            const uint32_t seq = ++c->gate_seq ? c->gate_seq : ++c->gate_seq;       // (never 0)
             if (!c->h_gate) HIPCHK(c, hipHostMalloc((void**)&c->h_gate, 64, hipHostMallocDefault));
+            // the gate words hold anything BUT this call's number before the launch: recycled page-locked or device memory is not zero, and a
+            // stale word that happened to equal `seq` would let a range's blocks read input that has not arrived
+            for (int w = 0; w < 16; w++) __atomic_store_n((volatile uint32_t*)(c->h_gate + w), seq - 1u, __ATOMIC_RELAXED);
             HIPCHK(c, c->d_gate.reserve(64));
-            const uint32_t seq = ++c->gate_seq ? c->gate_seq : ++c->gate_seq;       // (never 0: a fresh buffer)
+            HIPCHK(c, hipMemsetAsync(c->d_gate.p, 0, 64, s));                        // (0 is never a call's number; in front of the launch on its stream)
             {
                 hipPointerAttribute_t ga;
                 HIPCHK(c, hipPointerGetAttributes(&ga, c->h_gate));
@@ -427,19 +444,33 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
             k.gate_ticks = ticks > 0xffffffffull ? 0xffffffffu : (uint32_t)ticks;
             // (range 0 waits at a gate like the others: the launch is on its way to the device while the first bytes are)
             k.gate_all = 1;
+            // a failure behind the launch must not leave it spinning at its gates under the next call's copies: open every gate (the blocks
+            // decode whatever has arrived; the call fails anyway), drain both streams, then return
+            bool launched = false;
+            auto bail = [&](hipError_t e, const char* what) {
+                c->err = std::string(what) + ": " + hipGetErrorString(e);
+                (void)hipGetLastError();
+                if (launched) for (int w = 0; w < 16; w++) __atomic_store_n((volatile uint32_t*)(c->h_gate + w), seq, __ATOMIC_RELEASE);
+                (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamSynchronize(s);
+                return RCX_RC_HIP_ERROR;
+            };
             for (uint32_t pc = 0; pc < pieces; pc++) {
-                if (hi[pc] > lo[pc]) HIPCHK(c, hipMemcpyAsync((uint8_t*)c->d_in.p + lo[pc], b->in_base + lo[pc], hi[pc] - lo[pc], hipMemcpyHostToDevice, c->copy_stream));
-                HIPCHK(c, hipEventRecord(c->piece_ev[pc], c->copy_stream));
+                hipError_t e = hipSuccess;
+                if (hi[pc] > lo[pc]) e = hipMemcpyAsync((uint8_t*)c->d_in.p + lo[pc], b->in_base + lo[pc], hi[pc] - lo[pc], hipMemcpyHostToDevice, c->copy_stream);
+                if (e != hipSuccess) return bail(e, "host path: range copy");
+                if ((e = hipEventRecord(c->piece_ev[pc], c->copy_stream)) != hipSuccess) return bail(e, "host path: event record");
                 if (pc == 0) {
                     const int rcg = launch_codec(c, codec, k, param_over);
                     if (rcg) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamSynchronize(s); return rcg; }
+                    launched = true;
                 }
             }
             // this thread tells the launch what has arrived (a word copied in behind each range would be the natural signal; such a small
             // copy is done by a kernel, and a kernel does not run while every slot of the device holds a waiting block: built, measured --
             // every gate ran into its time limit)
             for (uint32_t pc = 0; pc < pieces; pc++) {
-                HIPCHK(c, hipEventSynchronize(c->piece_ev[pc]));
+                const hipError_t e = hipEventSynchronize(c->piece_ev[pc]);
+                if (e != hipSuccess) return bail(e, "host path: event wait");
                 __atomic_store_n((volatile uint32_t*)(c->h_gate + pc), seq, __ATOMIC_RELEASE);
             }
             gated = true;
@@ -449,6 +480,7 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
         int rc = launch_codec(c, codec, k, param_over);
         if (rc) return rc;
     }
+    if (mirror && !k.out_mirror) mirror = nullptr;                      // the launch says it did not store into the caller's buffer after all: the plain copy below
     HIPCHK(c, hipMemcpyAsync(h64 + 5 * N, d64 + 5 * N, 2 * N * 8 + 2 * N * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (gated) {
@@ -456,11 +488,11 @@ static int run_batch(rcx_ctx* c, int codec, const rcx_batch* b, const uint32_t* 
         bool again = false;
         for (size_t i = 0; i < N && !again; i++) again = h_status[i] == (int32_t)RCX_ST_GATE;
         if (again && codec != RCX_LZ4_DECODE) {                 // (the inflate path's second pass and trailer check passed these streams by: the whole batch again, behind one copy)
-            c->gate_bad = true;
+            c->gate_bad = true; c->gate_bad_calls = GATE_RETRY;
             return run_batch(c, codec, b, aux_in, aux_out, n_out, needs_out, param_over);
         }
         if (again) {
-            c->gate_bad = true;
+            c->gate_bad = true; c->gate_bad_calls = GATE_RETRY;
             k.gate = nullptr;
             rcx_tu_lz4_decode_mirror_again(s, k);
             HIPCHK(c, hipGetLastError());
@@ -559,9 +591,48 @@ extern "C" int rcx_rle_encode_batch(rcx_ctx* c, const rcx_batch* b) { return run
 extern "C" int rcx_rle_decode_batch(rcx_ctx* c, const rcx_batch* b) { return run_batch(c, RCX_RLE_DECODE, b, nullptr, nullptr, nullptr, true); }
 
 // ---- more than one device -------------------------------------------------------------------------------------------------
+// RCCL, loaded on first use (librcx.so itself does not link it: the library loads wherever HIP does, and a process that has torch's RCCL
+// mapped already gets that one -- same SONAME).  Only what a grouped point-to-point exchange needs.
+#include <dlfcn.h>
+struct RcclApi {
+    typedef void* comm_t;
+    int (*CommInitAll)(comm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    static RcclApi& get()
+    {
+        static RcclApi a = [] {
+            RcclApi r;
+            void* h = nullptr;
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+            if (!h) return r;
+            r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
+            r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+            r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
+            r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
+            r.Send = (decltype(r.Send))dlsym(h, "ncclSend");
+            r.Recv = (decltype(r.Recv))dlsym(h, "ncclRecv");
+            r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+            r.ok = r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv;
+            return r;
+        }();
+        return a;
+    }
+};
+static const int RCCL_UINT8 = 1;                 // ncclUint8 (nccl.h: ncclInt8 = 0, ncclUint8 = 1)
+
 struct rcx_multi {
     std::vector<rcx_ctx*> ctx;
     std::string err;
+    // the device-to-device shard path (rcx_multi_scatter_dev / rcx_multi_gather_dev)
+    int transport = 0;                           // 0: not chosen yet, 1: RCCL, 2: peer copies
+    std::vector<RcclApi::comm_t> comm;
+    std::vector<hipEvent_t> ev;                  // peer copies: one event per context
 };
 
 extern "C" int rcx_multi_create(const int* device_ids, int n, rcx_multi** out)
@@ -579,7 +650,114 @@ extern "C" int rcx_multi_create(const int* device_ids, int n, rcx_multi** out)
     *out = m;
     return RCX_RC_OK;
 }
-extern "C" void rcx_multi_destroy(rcx_multi* m) { if (!m) return; for (rcx_ctx* c : m->ctx) rcx_ctx_destroy(c); delete m; }
+extern "C" void rcx_multi_destroy(rcx_multi* m)
+{
+    if (!m) return;
+    for (RcclApi::comm_t q : m->comm) if (q) (void)RcclApi::get().CommDestroy(q);
+    for (size_t g = 0; g < m->ev.size(); g++) if (m->ev[g]) { (void)hipSetDevice(m->ctx[g]->device); (void)hipEventDestroy(m->ev[g]); }
+    for (rcx_ctx* c : m->ctx) rcx_ctx_destroy(c);
+    delete m;
+}
+extern "C" const char* rcx_multi_transport(const rcx_multi* m) { return !m ? "" : m->transport == 1 ? "rccl" : m->transport == 2 ? "peer" : ""; }
+
+// choose and set up the transport once per set
+static int multi_transport_init(rcx_multi* m)
+{
+    if (m->transport) return RCX_RC_OK;
+    const size_t G = m->ctx.size();
+    bool distinct = true;
+    for (size_t a = 0; a < G; a++) for (size_t b = a + 1; b < G; b++) if (m->ctx[a]->device == m->ctx[b]->device) distinct = false;
+    const char* want = getenv("RCX_MULTI_TRANSPORT");
+    const bool force_peer = want && !strcmp(want, "peer"), force_rccl = want && !strcmp(want, "rccl");
+    if (!force_peer && distinct && RcclApi::get().ok) {
+        std::vector<int> devs(G);
+        for (size_t g = 0; g < G; g++) devs[g] = m->ctx[g]->device;
+        m->comm.assign(G, nullptr);
+        const int e = RcclApi::get().CommInitAll(m->comm.data(), (int)G, devs.data());
+        if (e == 0) { m->transport = 1; return RCX_RC_OK; }
+        m->comm.clear();
+        if (force_rccl) { m->err = std::string("ncclCommInitAll: ") + (RcclApi::get().GetErrorString ? RcclApi::get().GetErrorString(e) : "failed"); return RCX_RC_HIP_ERROR; }
+    } else if (force_rccl) { m->err = distinct ? "RCX_MULTI_TRANSPORT=rccl: librccl could not be loaded" : "RCX_MULTI_TRANSPORT=rccl: the set lists a device more than once (RCCL wants one rank per device)"; return RCX_RC_BAD_ARG; }
+    // peer copies: every device reads / writes every other's memory where the hardware allows (xGMI within a node); where it does not,
+    // hipMemcpyPeerAsync stages through the host by itself
+    for (size_t a = 0; a < G; a++) {
+        if (hipSetDevice(m->ctx[a]->device) != hipSuccess) { (void)hipGetLastError(); m->err = "hipSetDevice failed"; return RCX_RC_HIP_ERROR; }
+        for (size_t b = 0; b < G; b++) {
+            if (m->ctx[a]->device == m->ctx[b]->device) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, m->ctx[a]->device, m->ctx[b]->device) == hipSuccess && can) {
+                const hipError_t e = hipDeviceEnablePeerAccess(m->ctx[b]->device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                else (void)hipGetLastError();
+            } else (void)hipGetLastError();
+        }
+    }
+    m->ev.assign(G, nullptr);
+    for (size_t g = 0; g < G; g++) {
+        if (hipSetDevice(m->ctx[g]->device) != hipSuccess || hipEventCreateWithFlags(&m->ev[g], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); m->err = "cannot create an event"; return RCX_RC_HIP_ERROR; }
+    }
+    m->transport = 2;
+    return RCX_RC_OK;
+}
+
+// ranges root -> peers (scatter) or peers -> root (gather); see include/rcx.h
+static int multi_move(rcx_multi* m, int root, uint8_t* root_buf, const uint64_t* range_off, uint8_t* const* peer_buf, bool scatter)
+{
+    if (!m || m->ctx.empty()) return RCX_RC_BAD_ARG;
+    m->err.clear();
+    const int G = (int)m->ctx.size();
+    if (root < 0 || root >= G || !range_off || !peer_buf) { m->err = "bad root / null range table"; return RCX_RC_BAD_ARG; }
+    for (int g = 0; g < G; g++) {
+        if (range_off[g + 1] < range_off[g]) { m->err = "ranges must not decrease"; return RCX_RC_BAD_ARG; }
+        if (range_off[g + 1] > range_off[g] && (!root_buf || (!peer_buf[g] && g != root))) { m->err = "null buffer for a non-empty range"; return RCX_RC_BAD_ARG; }
+    }
+    const int rc = multi_transport_init(m);
+    if (rc != RCX_RC_OK) return rc;
+    rcx_ctx* R = m->ctx[(size_t)root];
+    if (m->transport == 1) {
+        RcclApi& N = RcclApi::get();
+        int e = N.GroupStart();
+        for (int g = 0; g < G && e == 0; g++) {
+            const uint64_t bytes = range_off[g + 1] - range_off[g];
+            if (!bytes || (g == root && !peer_buf[g])) continue;
+            uint8_t* rp = root_buf + range_off[g];
+            rcx_ctx* P = m->ctx[(size_t)g];
+            if (scatter) { e = N.Send(rp, bytes, RCCL_UINT8, g, m->comm[(size_t)root], R->stream); if (!e) e = N.Recv(peer_buf[g], bytes, RCCL_UINT8, root, m->comm[(size_t)g], P->stream); }
+            else { e = N.Send(peer_buf[g], bytes, RCCL_UINT8, root, m->comm[(size_t)g], P->stream); if (!e) e = N.Recv(rp, bytes, RCCL_UINT8, g, m->comm[(size_t)root], R->stream); }
+        }
+        const int e2 = N.GroupEnd();
+        if (e || e2) { m->err = std::string(scatter ? "scatter" : "gather") + ": " + (N.GetErrorString ? N.GetErrorString(e ? e : e2) : "RCCL error"); return RCX_RC_HIP_ERROR; }
+        return RCX_RC_OK;
+    }
+    // peer copies.  scatter: every receiving stream waits for what the root's stream has produced so far, then copies its range in;
+    // gather: every sending stream copies its range out behind its own launches, and the root's stream waits for all of them.
+#define MCHK(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) { (void)hipGetLastError(); m->err = std::string(#call) + ": " + hipGetErrorString(e_); return RCX_RC_HIP_ERROR; } } while (0)
+    if (scatter) { MCHK(hipSetDevice(R->device)); MCHK(hipEventRecord(m->ev[(size_t)root], R->stream)); }
+    for (int g = 0; g < G; g++) {
+        const uint64_t bytes = range_off[g + 1] - range_off[g];
+        if (!bytes || (g == root && !peer_buf[g])) continue;
+        uint8_t* rp = root_buf + range_off[g];
+        rcx_ctx* P = m->ctx[(size_t)g];
+        MCHK(hipSetDevice(P->device));
+        if (scatter) {
+            if (g != root) MCHK(hipStreamWaitEvent(P->stream, m->ev[(size_t)root], 0));
+            MCHK(hipMemcpyPeerAsync(peer_buf[g], P->device, rp, R->device, bytes, P->stream));
+        } else {
+            MCHK(hipMemcpyPeerAsync(rp, R->device, peer_buf[g], P->device, bytes, P->stream));
+            if (g != root) { MCHK(hipEventRecord(m->ev[(size_t)g], P->stream)); MCHK(hipSetDevice(R->device)); MCHK(hipStreamWaitEvent(R->stream, m->ev[(size_t)g], 0)); }
+        }
+    }
+#undef MCHK
+    return RCX_RC_OK;
+}
+extern "C" int rcx_multi_scatter_dev(rcx_multi* m, int root, const uint8_t* root_buf, const uint64_t* range_off, uint8_t* const* peer_buf)
+{
+    return multi_move(m, root, const_cast<uint8_t*>(root_buf), range_off, peer_buf, true);
+}
+extern "C" int rcx_multi_gather_dev(rcx_multi* m, int root, uint8_t* root_buf, const uint64_t* range_off, const uint8_t* const* peer_buf)
+{
+    return multi_move(m, root, root_buf, range_off, const_cast<uint8_t* const*>(reinterpret_cast<const uint8_t* const*>(peer_buf)), false);
+}
 extern "C" int rcx_multi_count(const rcx_multi* m) { return m ? (int)m->ctx.size() : 0; }
 extern "C" rcx_ctx* rcx_multi_ctx(rcx_multi* m, int i) { return (m && i >= 0 && (size_t)i < m->ctx.size()) ? m->ctx[(size_t)i] : nullptr; }
 extern "C" const char* rcx_multi_last_error(const rcx_multi* m) { return m ? m->err.c_str() : "null multi"; }
@@ -624,14 +802,17 @@ extern "C" int rcx_multi_batch(rcx_multi* m, int codec, const rcx_batch* b, cons
     const uint32_t n = b->nblocks, G = (uint32_t)m->ctx.size();
     if (n == 0) return RCX_RC_OK;
     const bool has_out = b->out_off && b->out_cap;
-    std::vector<uint32_t> bounds(G + 1);
+    m->err.clear();
+    std::vector<uint32_t> bounds; std::vector<int> rcs; std::vector<std::thread> th;
+    try { bounds.resize(G + 1); rcs.assign(G, RCX_RC_OK); th.reserve(G); } catch (...) { m->err = "out of memory"; return RCX_RC_NO_MEMORY; }
     rcx_partition(has_out ? b->out_cap : b->in_len, n, G, bounds.data());
-    std::vector<int> rcs(G, RCX_RC_OK);
-    std::vector<std::thread> th;
-    for (uint32_t g = 0; g < G; g++) {
+    int spawn_rc = RCX_RC_OK;
+    for (uint32_t g = 0; g < G && spawn_rc == RCX_RC_OK; g++) {
         const uint32_t a0 = bounds[g], a1 = bounds[g + 1];
         if (a1 <= a0) continue;
+        try {
         th.emplace_back([&, g, a0, a1] {
+          try {
             // the range's own view of the host buffers: offsets rebased to the range's first byte, so that only its span travels
             const uint32_t k = a1 - a0;
             uint64_t lo_in = ~0ull, lo_out = ~0ull;
@@ -646,9 +827,13 @@ extern "C" int rcx_multi_batch(rcx_multi* m, int codec, const rcx_batch* b, cons
             sb.status = b->status + a0;
             sb.nblocks = k;
             rcs[g] = run_codec(m->ctx[g], codec, &sb, aux_in ? aux_in + a0 : nullptr, aux_out ? aux_out + a0 : nullptr, n_out ? n_out + a0 : nullptr);
+          } catch (const std::bad_alloc&) { m->ctx[g]->err = "out of memory"; rcs[g] = RCX_RC_NO_MEMORY; }
+            catch (...) { m->ctx[g]->err = "unexpected exception"; rcs[g] = RCX_RC_HIP_ERROR; }
         });
+        } catch (...) { spawn_rc = RCX_RC_NO_MEMORY; }                       // (std::system_error: no thread to be had; the ones started are joined below)
     }
     for (std::thread& t : th) t.join();
+    if (spawn_rc != RCX_RC_OK) { m->err = "cannot start a worker thread"; return spawn_rc; }
     for (uint32_t g = 0; g < G; g++)
         if (rcs[g] != RCX_RC_OK) { m->err = "device range " + std::to_string(g) + ": " + m->ctx[g]->err; return rcs[g]; }
     return RCX_RC_OK;
@@ -657,6 +842,7 @@ extern "C" int rcx_multi_batch(rcx_multi* m, int codec, const rcx_batch* b, cons
 extern "C" int rcx_multi_launch_dev(rcx_multi* m, int codec, const rcx_dev_batch* const* per_device, void* const* scratch, const uint64_t* scratch_bytes)
 {
     if (!m || !per_device) return RCX_RC_BAD_ARG;
+    m->err.clear();
     for (size_t g = 0; g < m->ctx.size(); g++) {
         if (!per_device[g] || per_device[g]->nblocks == 0) continue;
         const int rc = rcx_launch_dev(m->ctx[g], codec, per_device[g], scratch ? scratch[g] : nullptr, scratch_bytes ? scratch_bytes[g] : 0);
@@ -673,6 +859,50 @@ extern "C" int rcx_multi_sync(rcx_multi* m)
         if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { m->err = "device range " + std::to_string(g) + ": synchronize failed"; return RCX_RC_HIP_ERROR; }
     }
     return RCX_RC_OK;
+}
+
+// ---- measurement aid: the device's own copy rate (include/rcx.h) ------------------------------------------------------------------
+// 16 bytes a lane, four independent loads in flight per thread, a grid of 16 workgroups per CU that strides over the buffer:
+// /opt/skills/guides/MI355X_MICROARCH.md measures 6.3 TB/s this way where torch's copy_ reads 5.1.
+__global__ __launch_bounds__(256) void k_hbm_copy(const rcx_u32x4* __restrict__ src, rcx_u32x4* __restrict__ dst, uint64_t n16)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const rcx_u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        const rcx_u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
+        __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    }
+    for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+extern "C" int rcx_hbm_copy_probe(rcx_ctx* c, uint64_t bytes, int reps, double* gb_per_s)
+{
+    if (!c || !gb_per_s || bytes < 4096 || reps < 1) return RCX_RC_BAD_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t n16 = bytes / 16;
+    void *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = RCX_RC_OK;
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+    const uint32_t grid = (uint32_t)prop.multiProcessorCount * 16u;
+    float ms = 0;
+    if (hipMalloc(&a, n16 * 16) != hipSuccess || hipMalloc(&b, n16 * 16) != hipSuccess) { (void)hipGetLastError(); c->err = "copy probe: out of device memory"; rc = RCX_RC_NO_MEMORY; }
+    else if (hipMemsetAsync(a, 0x5a, n16 * 16, c->stream) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); c->err = "copy probe: setup failed"; rc = RCX_RC_HIP_ERROR; }
+    else {
+        hipLaunchKernelGGL(k_hbm_copy, dim3(grid), dim3(256), 0, c->stream, (const rcx_u32x4*)a, (rcx_u32x4*)b, n16);      // warm-up
+        (void)hipEventRecord(e0, c->stream);
+        for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_hbm_copy, dim3(grid), dim3(256), 0, c->stream, (const rcx_u32x4*)a, (rcx_u32x4*)b, n16);
+        (void)hipEventRecord(e1, c->stream);
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || ms <= 0) { (void)hipGetLastError(); c->err = "copy probe: timing failed"; rc = RCX_RC_HIP_ERROR; }
+        else *gb_per_s = 2.0 * (double)(n16 * 16) * reps / ((double)ms * 1e-3) / 1e9;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    return rc;
 }
 
 // ---- page-locking a caller's buffers (include/rcx.h) -----------------------------------------------------------------------------

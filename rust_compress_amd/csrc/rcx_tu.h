@@ -19,6 +19,7 @@ void rcx_tu_adler32(hipStream_t s, rcx_kargs& k);
 void rcx_tu_crc32(hipStream_t s, rcx_kargs& k);
 void rcx_tu_gzip_decode(hipStream_t s, rcx_kargs& k, int variant);
 uint64_t rcx_tu_inflate_scratch(uint32_t nblocks);
+bool rcx_tu_inflate_mirrors(uint32_t nblocks, int variant);     // would the launch store into a page-locked output buffer itself?
 uint64_t rcx_tu_inflate_marks_offset(uint32_t nblocks);      // a mirrored launch: [count | 60 bytes | a byte per stream the first pass handed back]
 uint64_t rcx_tu_gzip_scratch(uint32_t nblocks);
 uint64_t rcx_tu_gzip_marks_offset(uint32_t nblocks);

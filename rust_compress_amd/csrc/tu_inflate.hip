@@ -13,6 +13,7 @@ void rcx_tu_adler32(hipStream_t s, rcx_kargs& k) { launch_adler32(s, k); }
 void rcx_tu_crc32(hipStream_t s, rcx_kargs& k) { launch_crc32(s, k); }
 void rcx_tu_gzip_decode(hipStream_t s, rcx_kargs& k, int variant) { launch_gzip_decode(s, k, variant); }
 uint64_t rcx_tu_inflate_scratch(uint32_t nblocks) { return inflate_scratch_bytes(nblocks); }
+bool rcx_tu_inflate_mirrors(uint32_t nblocks, int variant) { return inflate_mirrors(nblocks, variant); }
 uint64_t rcx_tu_inflate_marks_offset(uint32_t nblocks) { return inflate_marks_offset(nblocks); }
 uint64_t rcx_tu_gzip_scratch(uint32_t nblocks) { return gzip_scratch_bytes(nblocks); }
 uint64_t rcx_tu_gzip_marks_offset(uint32_t nblocks) { return ((gzip_scratch_bytes(nblocks) + 255) & ~255ull) + inflate_marks_offset(nblocks); }   // (launch_gzip_decode: the inflate path's own scratch behind the gzip arrays)

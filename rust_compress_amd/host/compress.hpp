@@ -266,55 +266,82 @@ inline size_t encode_block(const std::vector<uint8_t>& input, std::vector<uint8_
     output.insert(output.end(), r.out[0].begin(), r.out[0].end());
     return r.out[0].size();
 }
+}  // namespace lz4
+namespace detail {
+struct Lz4Frame { std::vector<std::pair<bool, std::vector<uint8_t>>> parts; size_t consumed = 0, max_block = 0; };   // (stored?, payload)
+inline Lz4Frame lz4_parse_frame(const std::vector<uint8_t>& d)                       // the host framing of lz4.rs:316-500
+{
+    Lz4Frame f;
+    size_t p = 0; const size_t n = d.size();
+    auto need = [&](size_t k) { if (n - p < k) raise_status(RCX_E_EOF); };
+    need(4);
+    if (le32(&d[p]) != 0x184d2204u) throw io_error(ErrorKind::InvalidInput, RCX_E_LZ4_MAGIC, "");   // :365-367
+    p += 4;
+    uint8_t flg = p < n ? d[p] : 0, bd = p + 1 < n ? d[p + 1] : 0;               // :369-372
+    p = p + 2 < n ? p + 2 : n;
+    if ((flg >> 6) != 1) throw io_error(ErrorKind::InvalidInput, RCX_E_LZ4_VERSION, "");           // :375-377
+    const bool blk_ck = flg & 0x10, ssize = flg & 0x08, preset = flg & 0x01;
+    static const size_t MAXS[8] = {0, 0, 0, 0, 64u << 10, 256u << 10, 1u << 20, 4u << 20};
+    f.max_block = MAXS[(bd >> 4) & 7];
+    if (ssize) { need(8); p += 8; }
+    if (preset) raise_status(RCX_E_MALFORMED);                                    // :407 assert!
+    need(1); p += 1;                                                              // header checksum ignored, :417
+    for (;;) {
+        need(4);
+        const uint32_t v = le32(&d[p]); p += 4;
+        if (v == 0) break;
+        const size_t amt = v & 0x7fffffffu;
+        need(amt);
+        f.parts.emplace_back((v & 0x80000000u) != 0, std::vector<uint8_t>(d.begin() + p, d.begin() + p + amt));
+        p += amt;
+        if (blk_ck) { need(4); p += 4; }
+    }
+    f.consumed = p;                                                               // (the content checksum is never read)
+    return f;
+}
+// a conforming frame's blocks decode to at most max_block bytes: that is every block's slot; only a block that does not
+// fit is decoded again with a larger one (the reference would grow its Vec)
+inline std::vector<std::vector<uint8_t>> lz4_decode_frames(const std::vector<const Lz4Frame*>& fs)
+{
+    std::vector<std::vector<uint8_t>> comp; std::vector<uint64_t> caps;
+    for (const Lz4Frame* f : fs) for (auto& pr : f->parts) if (!pr.first) { comp.push_back(pr.second); caps.push_back(std::max<size_t>(f->max_block, 1u << 16)); }
+    BatchResult r;
+    if (!comp.empty()) {
+        r = run_batch(comp, caps, [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_lz4_decode_batch(c, b); });
+        for (size_t i = 0; i < comp.size(); i++)
+            if (r.status[i] == RCX_E_OUTPUT_TOO_SMALL) { std::vector<uint8_t> o; lz4::decode_block(comp[i], o); r.out[i] = std::move(o); r.status[i] = RCX_OK; }
+        check(r);
+    }
+    std::vector<std::vector<uint8_t>> outs(fs.size());
+    size_t ci = 0;
+    for (size_t k = 0; k < fs.size(); k++)
+        for (auto& pr : fs[k]->parts) { const auto& src = pr.first ? pr.second : r.out[ci++]; outs[k].insert(outs[k].end(), src.begin(), src.end()); }
+    return outs;
+}
+}  // namespace detail
+namespace lz4 {
 template <class R>
 class Decoder : public BufferedDecoder<R, Decoder<R>> {                              // lz4.rs:316-500
 public:
     using BufferedDecoder<R, Decoder<R>>::BufferedDecoder;
     std::vector<uint8_t> decode_all(const std::vector<uint8_t>& d)
     {
-        size_t p = 0; const size_t n = d.size();
-        auto need = [&](size_t k) { if (n - p < k) raise_status(RCX_E_EOF); };
-        need(4);
-        if (le32(&d[p]) != 0x184d2204u) throw io_error(ErrorKind::InvalidInput, RCX_E_LZ4_MAGIC, "");   // :365-367
-        p += 4;
-        uint8_t flg = p < n ? d[p] : 0, bd = p + 1 < n ? d[p + 1] : 0;               // :369-372
-        p = p + 2 < n ? p + 2 : n;
-        if ((flg >> 6) != 1) throw io_error(ErrorKind::InvalidInput, RCX_E_LZ4_VERSION, "");           // :375-377
-        const bool blk_ck = flg & 0x10, ssize = flg & 0x08, preset = flg & 0x01;
-        static const size_t MAXS[8] = {0, 0, 0, 0, 64u << 10, 256u << 10, 1u << 20, 4u << 20};
-        const size_t max_block = MAXS[(bd >> 4) & 7];
-        if (ssize) { need(8); p += 8; }
-        if (preset) raise_status(RCX_E_MALFORMED);                                    // :407 assert!
-        need(1); p += 1;                                                              // header checksum ignored, :417
-        std::vector<std::pair<bool, std::vector<uint8_t>>> parts;
-        for (;;) {
-            need(4);
-            const uint32_t v = le32(&d[p]); p += 4;
-            if (v == 0) break;
-            const size_t amt = v & 0x7fffffffu;
-            need(amt);
-            parts.emplace_back((v & 0x80000000u) != 0, std::vector<uint8_t>(d.begin() + p, d.begin() + p + amt));
-            p += amt;
-            if (blk_ck) { need(4); p += 4; }
-        }
-        this->consumed = p;
-        std::vector<std::vector<uint8_t>> comp; std::vector<uint64_t> caps;
-        // a conforming frame's blocks decode to at most max_block bytes: that is every block's slot; only a block that does not
-        // fit is decoded again with a larger one (the reference would grow its Vec)
-        const uint64_t mb = std::max<size_t>(max_block, 1u << 16);
-        for (auto& pr : parts) if (!pr.first) { comp.push_back(pr.second); caps.push_back(mb); }
-        BatchResult r;
-        if (!comp.empty()) {
-            r = run_batch(comp, caps, [](rcx_ctx* c, rcx_batch* b, uint32_t*) { return rcx_lz4_decode_batch(c, b); });
-            for (size_t i = 0; i < comp.size(); i++)
-                if (r.status[i] == RCX_E_OUTPUT_TOO_SMALL) { std::vector<uint8_t> o; decode_block(comp[i], o); r.out[i] = std::move(o); r.status[i] = RCX_OK; }
-            check(r);
-        }
-        std::vector<uint8_t> out; size_t ci = 0;
-        for (auto& pr : parts) { const auto& src = pr.first ? pr.second : r.out[ci++]; out.insert(out.end(), src.begin(), src.end()); }
-        return out;
+        detail::Lz4Frame f = detail::lz4_parse_frame(d);
+        this->consumed = f.consumed;
+        std::vector<std::vector<uint8_t>> outs = detail::lz4_decode_frames({&f});
+        return std::move(outs[0]);
     }
 };
+// Several frames, ONE batch call for every compressed block of every frame (a single 64 KiB block alone on the GPU takes six times what
+// one host thread needs, eight or more together take less: INTEGRATION.md).  -> the decoded frames; consumed[i]: bytes frame i used.
+inline std::vector<std::vector<uint8_t>> decode_many(const std::vector<std::vector<uint8_t>>& frames, std::vector<size_t>* consumed = nullptr)
+{
+    std::vector<detail::Lz4Frame> fs; fs.reserve(frames.size());
+    for (const auto& d : frames) fs.push_back(detail::lz4_parse_frame(d));
+    std::vector<const detail::Lz4Frame*> ps; for (auto& f : fs) ps.push_back(&f);
+    if (consumed) { consumed->clear(); for (auto& f : fs) consumed->push_back(f.consumed); }
+    return detail::lz4_decode_frames(ps);
+}
 template <class W>
 class Encoder {                                                                       // lz4.rs:505-597 (stored blocks)
 public:
@@ -350,8 +377,43 @@ template <class Fn> std::vector<uint8_t> grow_decode(const std::vector<uint8_t>&
         return r.out[0];
     }
 }
+// several streams of one kind through ONE batch call; the slots that were too small once more, eight times larger, together
+struct ManyResult { std::vector<std::vector<uint8_t>> out; std::vector<size_t> consumed; std::vector<uint32_t> flags; };
+template <class Fn> ManyResult decode_many(const std::vector<std::vector<uint8_t>>& streams, Fn fn)
+{
+    ManyResult m;
+    const size_t n = streams.size();
+    m.out.resize(n); m.consumed.assign(n, 0); m.flags.assign(n, 0);
+    if (!n) return m;
+    std::vector<size_t> idx(n);
+    uint64_t cap = 1u << 16;
+    for (size_t i = 0; i < n; i++) { idx[i] = i; cap = std::max<uint64_t>(cap, 4 * streams[i].size()); }
+    cap = std::min<uint64_t>(cap, MAX_BLOCK);
+    std::vector<int> status(n, RCX_OK);
+    for (;;) {
+        std::vector<std::vector<uint8_t>> blobs; std::vector<uint64_t> caps(idx.size(), cap);
+        for (size_t i : idx) blobs.push_back(streams[i]);
+        auto r = run_batch(blobs, caps, fn);
+        std::vector<size_t> redo;
+        for (size_t j = 0; j < idx.size(); j++) {
+            const size_t i = idx[j];
+            status[i] = r.status[j];
+            if (r.status[j] == RCX_E_OUTPUT_TOO_SMALL && cap < MAX_BLOCK) { redo.push_back(i); continue; }
+            m.out[i] = std::move(r.out[j]); m.consumed[i] = r.in_used[j]; m.flags[i] = r.aux[j];
+        }
+        if (redo.empty()) break;
+        idx.swap(redo);
+        cap = std::min<uint64_t>(cap * 8, MAX_BLOCK);
+    }
+    for (int st : status) raise_status(st);                                       // the first stream that failed, as its own Decoder would
+    return m;
+}
 }  // namespace detail
 namespace flate {
+// many raw DEFLATE streams, ONE batch call (the reference decodes one deflate block per read(), flate.rs:468-488: a stream is one wave's work
+// on the GPU -- a caller with many streams hands them over together)
+inline detail::ManyResult decode_many(const std::vector<std::vector<uint8_t>>& streams)
+{ return detail::decode_many(streams, [](rcx_ctx* c, rcx_batch* b, uint32_t* f) { return rcx_inflate_batch(c, b, f); }); }
 template <class R>
 class Decoder : public BufferedDecoder<R, Decoder<R>> {                              // flate.rs:164-488
 public:
@@ -362,6 +424,8 @@ public:
 };
 }  // namespace flate
 namespace zlib {
+inline detail::ManyResult decode_many(const std::vector<std::vector<uint8_t>>& members)      // every member's Adler-32 checked on the device
+{ return detail::decode_many(members, [](rcx_ctx* c, rcx_batch* b, uint32_t* f) { return rcx_zlib_decode_batch(c, b, f); }); }
 template <class R>
 class Decoder : public BufferedDecoder<R, Decoder<R>> {                              // zlib.rs:32-127
 public:

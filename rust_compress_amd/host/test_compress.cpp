@@ -55,6 +55,23 @@ int main(int argc, char** argv)
     CHECK(!lz4::compression_bound(0x7e000001u).has_value() && *lz4::compression_bound(100) == 120);
     try { Bytes bad = B("\x01\x02\x03\x04zzzz"); lz4::Decoder<SliceReader> d{SliceReader(bad)}; d.read_to_end(); CHECK(false); }
     catch (const io_error& e) { CHECK(e.kind == ErrorKind::InvalidInput && std::string(e.what()).empty()); }
+    // ---- decode_many: the frames / members of many readers through one batch call == the single decoders
+    {
+        std::vector<Bytes> frames; std::vector<size_t> used;
+        for (int i = 1; i <= 9; i++) frames.push_back(file("test.lz4." + std::to_string(i)));
+        auto outs = lz4::decode_many(frames, &used);
+        CHECK(outs.size() == 9 && used.size() == 9);
+        for (size_t i = 0; i < 9; i++) { lz4::Decoder<SliceReader> d{SliceReader(frames[i])}; CHECK(outs[i] == txt && d.read_to_end() == txt && d.consumed == used[i]); }
+        std::vector<Bytes> zs; for (int i = 0; i < 10; i++) zs.push_back(file("test.z." + std::to_string(i)));
+        auto zr = zlib::decode_many(zs);
+        for (size_t i = 0; i < 10; i++) CHECK(zr.out[i] == txt && zr.consumed[i] == zs[i].size());
+        Bytes bad = zs[3]; bad.back() ^= 0x55;
+        int st_one = 0, st_many = 0;
+        try { zlib::Decoder<SliceReader> d{SliceReader(bad)}; d.read_to_end(); } catch (const io_error& e) { st_one = e.status; }
+        try { zlib::decode_many({zs[0], bad, zs[1]}); } catch (const io_error& e) { st_many = e.status; }
+        CHECK(st_one != 0 && st_one == st_many);
+        CHECK(flate::decode_many({}).out.empty());
+    }
     // ---- a batch sharded over several contexts (here: the one GPU, named three times): block for block what one context returns
     {
         std::vector<Bytes> raws, encs; std::vector<uint64_t> caps;

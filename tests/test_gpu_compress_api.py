@@ -273,3 +273,43 @@ def test_rle_encoder_streaming_writes_like_the_reference():
             e.write(c[1]) if c[0] == "w" else e.flush()
         e.finish()
         assert w.getvalue() == _ref_rle_stream(calls), (trial, calls)
+
+
+def test_decode_many_is_the_single_decoders_together(golden, oracle):
+    """decode_many (round 6): the frames / streams / members of many readers through ONE batch call -- every decoder must then read what it
+    would have read alone (the reference's fixtures lz4.rs:647-659, flate.rs:528-582, zlib.rs:151-203 all at once), leave its reader
+    exactly behind its stream, and the first bad stream must raise what its own Decoder raises."""
+    import zlib as pz
+    ref = golden("test.txt")
+    tail = b"TAIL-BYTES"
+    # lz4: the nine reference frames + a frame of stored blocks, each with bytes behind it
+    w = io.BytesIO(); e = C.lz4.Encoder(w); e.write(ref * 3); e.finish()
+    frames = [golden("test.lz4.%d" % i) for i in range(1, 10)] + [w.getvalue()]
+    readers = [io.BytesIO(f + tail) for f in frames]
+    decs = C.lz4.decode_many(readers)
+    assert [d.read_to_end() for d in decs] == [ref] * 9 + [ref * 3]
+    for d, f in zip(decs, frames):                       # (the reference never reads a frame's content checksum: it stays in the reader)
+        alone = C.lz4.Decoder(io.BytesIO(f + tail))
+        alone.read_to_end()
+        left = d.finish().read(-1)
+        assert left == alone.finish().read(-1) and left.endswith(tail)
+    assert _one_byte_at_a_time(C.lz4.decode_many([io.BytesIO(frames[0])])[0]) == ref
+    # zlib: the ten reference members; flate: raw streams of several sizes (one of them larger than the first slot)
+    zs = [golden("test.z.%d" % i) for i in range(10)]
+    decs = C.zlib.decode_many([io.BytesIO(z + tail) for z in zs])
+    assert [d.read_to_end() for d in decs] == [ref] * 10 and all(d.finish().read(-1) == tail for d in decs)
+    raws = [ref, ref * 40, b"", b"x" * 300000, bytes(range(256)) * 9]
+    def raw_deflate(r, lvl):
+        c = pz.compressobj(lvl, pz.DEFLATED, -15)
+        return c.compress(r) + c.flush()
+    streams = [raw_deflate(r, (1, 6, 9)[i % 3]) for i, r in enumerate(raws)]
+    decs = C.flate.decode_many([io.BytesIO(s + tail) for s in streams])
+    assert [d.read_to_end() for d in decs] == raws and all(d.finish().read(-1) == tail for d in decs)
+    assert [d.read_to_end() for d in C.flate.decode_many([])] == []
+    # a bad member among good ones raises like its own decoder
+    bad = bytearray(zs[3]); bad[-1] ^= 0x55
+    with pytest.raises(C.CompressError) as one:
+        C.zlib.Decoder(io.BytesIO(bytes(bad))).read_to_end()
+    with pytest.raises(C.CompressError) as many:
+        C.zlib.decode_many([io.BytesIO(zs[0]), io.BytesIO(bytes(bad)), io.BytesIO(zs[1])])
+    assert type(many.value) is type(one.value) and many.value.status == one.value.status

@@ -239,6 +239,81 @@ def test_multi_device_entry_points(ctx, oracle):
         L.rcx_multi_destroy(h)
 
 
+def test_multi_device_to_device_shard_path(ctx, oracle):
+    """rcx_multi_scatter_dev / rcx_multi_gather_dev (include/rcx.h): the whole batch sits on ONE device; the compressed ranges travel to
+    the devices that decode them and the decoded ranges come back, device to device.  On this box the set lists the one GPU three
+    times (three contexts, three streams; transport "peer": RCCL wants one rank per device) -- the result must be the one-context
+    result, block for block, with nothing waited for between scatter, launch and gather.  And a set of ONE device with
+    RCX_MULTI_TRANSPORT=rccl sends its range to itself through a grouped ncclSend / ncclRecv: librccl loaded, communicator built,
+    group issued."""
+    import ctypes as C
+    import os
+    import torch
+    import rust_compress_amd as R
+    from rust_compress_amd import batch as B
+    L = N.lib()
+    dev = torch.device("cuda", 0)
+    raws = [synth.gen(("text", "runs", "rand", "mix")[i % 4], 3000 + 1013 * (i % 29), 170 + i).tobytes() for i in range(150)]
+    enc = ctx.lz4_encode_blocks(raws).check().outputs
+    base, off, lens = B.pack(enc)
+    caps = [len(r) for r in raws]
+    total, ooff, ocap = B.layout(caps)
+    root_in = torch.from_numpy(base).to(dev)
+    root_out = torch.zeros(total + 64, dtype=torch.uint8, device=dev)
+
+    def run(devices, env):
+        G = len(devices)
+        old = os.environ.get("RCX_MULTI_TRANSPORT")
+        if env is None:
+            os.environ.pop("RCX_MULTI_TRANSPORT", None)
+        else:
+            os.environ["RCX_MULTI_TRANSPORT"] = env
+        h = C.c_void_p()
+        assert L.rcx_multi_create((C.c_int * G)(*devices), G, C.byref(h)) == 0
+        try:
+            bounds = (C.c_uint32 * (G + 1))()
+            w = np.ascontiguousarray(ocap, dtype=np.uint64)
+            L.rcx_partition(w.ctypes.data, len(enc), G, bounds)
+            bnd = list(bounds)
+            in_end = [int(off[b]) if b < len(enc) else int(off[-1] + ((lens[-1] + 15) // 16) * 16) for b in bnd]
+            out_end = [int(ooff[b]) if b < len(enc) else total for b in bnd]
+            r_in = (C.c_uint64 * (G + 1))(*in_end); r_out = (C.c_uint64 * (G + 1))(*out_end)
+            # every range gets buffers of its own on "its" device (range-relative), the root's range too: the copy is exercised for all
+            pin = [torch.zeros(max(in_end[g + 1] - in_end[g], 16) + 64, dtype=torch.uint8, device=dev) for g in range(G)]
+            pout = [torch.zeros(max(out_end[g + 1] - out_end[g], 16) + 64, dtype=torch.uint8, device=dev) for g in range(G)]
+            dbs = []
+            i64 = lambda a: torch.tensor(np.asarray(a, dtype=np.int64), dtype=torch.int64, device=dev)
+            for g in range(G):
+                a0, a1 = bnd[g], bnd[g + 1]
+                dbs.append(R.DeviceBatch(pin[g], i64(off[a0:a1].astype(np.int64) - in_end[g]), i64(lens[a0:a1].astype(np.int64)),
+                                         pout[g], i64(ooff[a0:a1].astype(np.int64) - out_end[g]), i64(ocap[a0:a1].astype(np.int64))) if a1 > a0 else None)
+            root_out.zero_()
+            torch.cuda.synchronize()
+            pi = (C.c_void_p * G)(*[t.data_ptr() for t in pin]); po = (C.c_void_p * G)(*[t.data_ptr() for t in pout])
+            arr = (C.POINTER(N.DevBatch) * G)(*[C.pointer(d.c) if d is not None else None for d in dbs])
+            assert L.rcx_multi_scatter_dev(h, 0, root_in.data_ptr(), r_in, pi) == 0, L.rcx_multi_last_error(h)
+            assert L.rcx_multi_launch_dev(h, N.LZ4_DECODE, arr, None, None) == 0, L.rcx_multi_last_error(h)
+            assert L.rcx_multi_gather_dev(h, 0, root_out.data_ptr(), r_out, po) == 0, L.rcx_multi_last_error(h)
+            assert L.rcx_multi_sync(h) == 0
+            name = L.rcx_multi_transport(h).decode()
+            for d in dbs:
+                if d is not None:
+                    assert int(d.status[: d.n].abs().max()) == 0
+            got = root_out.cpu().numpy()
+            assert [bytes(got[int(o): int(o) + c]) for o, c in zip(ooff, caps)] == raws
+            return name
+        finally:
+            L.rcx_multi_destroy(h)
+            if old is None:
+                os.environ.pop("RCX_MULTI_TRANSPORT", None)
+            else:
+                os.environ["RCX_MULTI_TRANSPORT"] = old
+
+    assert run([0, 0, 0], None) == "peer"
+    assert run([0, 0], "peer") == "peer"
+    assert run([0], "rccl") == "rccl"                    # (a send to oneself inside a group: the transport an N-device node takes)
+
+
 
 def test_host_path_into_page_locked_output(ctx, oracle):
     """rcx_lz4_decode_batch with RCX_MEM_HOST and a PAGE-LOCKED output buffer (rcx_api.hip: the decoder stores what leaves its window
