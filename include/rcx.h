@@ -76,7 +76,11 @@ enum rcx_status {
     RCX_E_GZIP_METHOD = 51,         /* CM != 8 */
     RCX_E_GZIP_FLAGS = 52,          /* reserved FLG bits set */
     RCX_E_GZIP_CRC = 53,            /* CRC32 trailer mismatch */
-    RCX_E_GZIP_ISIZE = 54           /* ISIZE trailer mismatch */
+    RCX_E_GZIP_ISIZE = 54,          /* ISIZE trailer mismatch */
+    /* a limit of this implementation, not of the format: bwt::Encoder::new(w, block_size) takes any usize (bwt/mod.rs:451), the suffix
+     * sorter keeps four flag bits beside a suffix index -- a block of 2^28 bytes or more gets this status (out_len 0) and the rest of
+     * the batch is transformed.  The host mirrors turn it into io::ErrorKind::InvalidInput. */
+    RCX_E_BWT_BLOCK_TOO_LARGE = 60  /* "bwt block of 2^28 bytes or more" */
 };
 
 /* ---- batch-level return codes --------------------------------------------- */

@@ -1,7 +1,7 @@
 //! RFC 1951 decoder (reference: src/flate.rs:164-193, 453-488).  Batch semantics: the stream is decoded to BFINAL in one
 //! call; `flags & RCX_W_EMPTY_BLOCK_MIDSTREAM` reports the reference's `Ok(0)` quirk (:474-476) instead of acting it out.
 use crate::rcx_sys::*;
-use crate::{grow_decode, Buffered, TailReader};
+use crate::{decode_many_with, grow_decode, Buffered, TailReader};
 use std::io::{self, Read};
 
 pub struct Decoder<R: Read> {
@@ -35,4 +35,11 @@ impl<R: Read> Read for Decoder<R> {
         })?;
         Ok(self.buf.serve(dst))
     }
+}
+
+/// Many raw DEFLATE streams through ONE batch call (the reference decodes one deflate block per `read()`, flate.rs:468-488: on the
+/// GPU a stream is one wave's work, so a caller with many streams hands them over together).  -> per stream (decoded bytes, input
+/// bytes used, flags); the first stream that fails returns what its `Decoder` would.
+pub fn decode_many(streams: &[&[u8]]) -> io::Result<Vec<(Vec<u8>, usize, u32)>> {
+    decode_many_with(streams, |c, b, f| unsafe { rcx_inflate_batch(c, b, f) })
 }

@@ -7,14 +7,23 @@
 //! There is no CPU fallback: without a HIP device `ctx()` panics.
 pub mod rcx_sys;
 
+// the reference's feature gates (src/lib.rs:19-50), module for module
+#[cfg(feature = "bwt")]
 pub mod bwt;
+#[cfg(feature = "checksum")]
 pub mod checksum;
+#[cfg(feature = "entropy")]
 pub mod entropy;
+#[cfg(feature = "flate")]
 pub mod flate;
+#[cfg(feature = "lz4")]
 pub mod lz4;
+#[cfg(feature = "rle")]
 pub mod rle;
+#[cfg(feature = "zlib")]
 pub mod zlib;
 
+#[cfg(feature = "checksum")]
 pub use checksum::adler::State32 as Adler32; // lib.rs:21
 
 use rcx_sys::*;
@@ -125,6 +134,50 @@ where
     }
 }
 
+/// Several blobs of one kind through ONE batch call; the slots that were too small once more, eight times larger, together
+/// (compress.hpp detail::decode_many).  A single stream alone on the GPU takes longer than on one host thread, a batch of eight or
+/// more does not: a caller with many `Decoder`s uses the codec's `decode_many` instead of reading them one by one.
+/// -> per blob (decoded bytes, input bytes used, aux word); the first blob that failed returns its Decoder's error.
+pub(crate) fn decode_many_with<F>(blobs: &[&[u8]], call: F) -> io::Result<Vec<(Vec<u8>, usize, u32)>>
+where
+    F: Fn(*mut rcx_ctx, *const rcx_batch, *mut u32) -> i32,
+{
+    const MAX_BLOCK: u64 = 0xFFFF_FFFF;
+    let n = blobs.len();
+    let mut res: Vec<(Vec<u8>, usize, u32)> = vec![(Vec::new(), 0, 0); n];
+    let mut status = vec![RCX_OK; n];
+    if n == 0 {
+        return Ok(res);
+    }
+    let mut cap = blobs.iter().map(|b| 4 * b.len() as u64).max().unwrap_or(0).max(1 << 16).min(MAX_BLOCK);
+    let mut idx: Vec<usize> = (0..n).collect();
+    loop {
+        let part: Vec<&[u8]> = idx.iter().map(|&i| blobs[i]).collect();
+        let caps = vec![cap; idx.len()];
+        let r = run_batch(&part, &caps, &call);
+        let mut redo = Vec::new();
+        for (j, &i) in idx.iter().enumerate() {
+            status[i] = r.status[j];
+            if r.status[j] == RCX_E_OUTPUT_TOO_SMALL && cap < MAX_BLOCK {
+                redo.push(i);
+            } else {
+                res[i] = (r.out[j].clone(), r.in_used[j] as usize, r.aux[j]);
+            }
+        }
+        if redo.is_empty() {
+            break;
+        }
+        idx = redo;
+        cap = (cap * 8).min(MAX_BLOCK);
+    }
+    for &st in &status {
+        if st != RCX_OK {
+            return Err(status_to_io(st));
+        }
+    }
+    Ok(res)
+}
+
 /// A reader that takes bytes back.  The batch decoders have to read ahead (a stream's end is only known once it is decoded);
 /// the reference's decoders stop reading exactly at the end of their stream (flate.rs:250-260 reads byte by byte,
 /// ari/mod.rs:289-292 `finish`) and its tests rely on the reader being left there (ari/test.rs:52-89).  Every Decoder keeps
@@ -170,9 +223,6 @@ impl<R: Read> TailReader<R> {
         t.extend_from_slice(&self.tail[self.tpos..]);
         self.tail = t;
         self.tpos = 0;
-    }
-    pub fn into_inner(self) -> R {
-        self.inner
     }
 }
 

@@ -51,7 +51,8 @@ impl<R: Read> Decoder<R> {
     }
 }
 
-fn decode_frame(d: &[u8], max_block_size: &mut usize) -> io::Result<(Vec<u8>, Option<usize>)> {
+/// the host framing of lz4.rs:316-500: -> ((stored?, payload) parts, bytes the frame used)
+fn parse_frame<'a>(d: &'a [u8], max_block_size: &mut usize) -> io::Result<(Vec<(bool, &'a [u8])>, usize)> {
     let n = d.len();
     let mut p = 0usize;
     if n - p < 4 {
@@ -104,13 +105,22 @@ fn decode_frame(d: &[u8], max_block_size: &mut usize) -> io::Result<(Vec<u8>, Op
             p += 4;
         }
     }
-    // ONE batch call for every compressed block; a conforming frame's blocks decode to at most max_block_size bytes, and only
-    // a block that does not fit is decoded again with a larger slot (the reference would grow its Vec, :148-161)
-    let comp: Vec<&[u8]> = parts.iter().filter(|p| !p.0).map(|p| p.1).collect();
-    let mb = (*max_block_size).max(1 << 16) as u64;
+    Ok((parts, p))
+}
+
+/// ONE batch call for every compressed block of one or MANY frames; a conforming frame's blocks decode to at most max_block_size
+/// bytes, and only a block that does not fit is decoded again with a larger slot (the reference would grow its Vec, :148-161)
+fn decode_frames(frames: &[(Vec<(bool, &[u8])>, usize)]) -> io::Result<Vec<Vec<u8>>> {
+    let mut comp: Vec<&[u8]> = Vec::new();
+    let mut caps: Vec<u64> = Vec::new();
+    for (parts, mbs) in frames {
+        for part in parts.iter().filter(|p| !p.0) {
+            comp.push(part.1);
+            caps.push((*mbs).max(1 << 16) as u64);
+        }
+    }
     let mut outs: Vec<Vec<u8>> = Vec::new();
     if !comp.is_empty() {
-        let caps = vec![mb; comp.len()];
         let mut r = run_batch(&comp, &caps, |c, b, _| unsafe { rcx_lz4_decode_batch(c, b) });
         for i in 0..comp.len() {
             if r.status[i] == RCX_E_OUTPUT_TOO_SMALL {
@@ -122,17 +132,41 @@ fn decode_frame(d: &[u8], max_block_size: &mut usize) -> io::Result<(Vec<u8>, Op
         }
         outs = r.check()?.out;
     }
-    let mut out = Vec::new();
     let mut ci = 0;
-    for (stored, data) in parts {
-        if stored {
-            out.extend_from_slice(data);
-        } else {
-            out.extend_from_slice(&outs[ci]);
-            ci += 1;
+    let mut res = Vec::with_capacity(frames.len());
+    for (parts, _) in frames {
+        let mut out = Vec::new();
+        for (stored, data) in parts {
+            if *stored {
+                out.extend_from_slice(data);
+            } else {
+                out.extend_from_slice(&outs[ci]);
+                ci += 1;
+            }
         }
+        res.push(out);
     }
-    Ok((out, Some(p)))
+    Ok(res)
+}
+
+fn decode_frame(d: &[u8], max_block_size: &mut usize) -> io::Result<(Vec<u8>, Option<usize>)> {
+    let (parts, used) = parse_frame(d, max_block_size)?;
+    let mut outs = decode_frames(&[(parts, *max_block_size)])?;
+    Ok((outs.remove(0), Some(used)))
+}
+
+/// Many frames, EVERY compressed block of EVERY frame in one batch call (one 64 KiB block alone on the GPU takes six times what one
+/// host thread needs; eight or more together take less: INTEGRATION.md).  -> per frame (decoded bytes, bytes of the input it used).
+pub fn decode_many(frames: &[&[u8]]) -> io::Result<Vec<(Vec<u8>, usize)>> {
+    let mut parsed = Vec::with_capacity(frames.len());
+    let mut used = Vec::with_capacity(frames.len());
+    for d in frames {
+        let mut mbs = 0usize;
+        let (parts, u) = parse_frame(d, &mut mbs)?;
+        parsed.push((parts, mbs));
+        used.push(u);
+    }
+    Ok(decode_frames(&parsed)?.into_iter().zip(used).collect())
 }
 
 impl<R: Read> Read for Decoder<R> {

@@ -68,6 +68,7 @@ pub const RCX_E_RLE_LONG_RUN: i32 = 30;
 pub const RCX_E_LZ4_MAGIC: i32 = 40;
 pub const RCX_E_LZ4_VERSION: i32 = 41;
 pub const RCX_E_LZ4_INPUT_TOO_LARGE: i32 = 42;
+pub const RCX_E_BWT_BLOCK_TOO_LARGE: i32 = 60; // a block of 2^28 bytes or more: this implementation's limit (bwt/mod.rs:451 takes any usize)
 pub const RCX_E_GZIP_MAGIC: i32 = 50;
 pub const RCX_E_GZIP_METHOD: i32 = 51;
 pub const RCX_E_GZIP_FLAGS: i32 = 52;

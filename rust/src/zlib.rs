@@ -1,6 +1,6 @@
 //! RFC 1950 decoder (reference: src/zlib.rs:32-127): CMF/FLG checks, DEFLATE, Adler-32 trailer -- all on the device.
 use crate::rcx_sys::*;
-use crate::{grow_decode, Buffered, TailReader};
+use crate::{decode_many_with, grow_decode, Buffered, TailReader};
 use std::io::{self, Read};
 
 pub struct Decoder<R: Read> {
@@ -27,4 +27,10 @@ impl<R: Read> Read for Decoder<R> {
         })?;
         Ok(self.buf.serve(dst))
     }
+}
+
+/// Many zlib members through ONE batch call, every member's Adler-32 checked on the device.  -> per member (decoded bytes, input
+/// bytes used); the first member that fails returns what its `Decoder` would.
+pub fn decode_many(members: &[&[u8]]) -> io::Result<Vec<(Vec<u8>, usize)>> {
+    Ok(decode_many_with(members, |c, b, f| unsafe { rcx_zlib_decode_batch(c, b, f) })?.into_iter().map(|(o, u, _)| (o, u)).collect())
 }

@@ -25,6 +25,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 # enum rcx_status (the ones Python code names; include/rcx.h has them all)
 E_EOF, E_OUTPUT_TOO_SMALL, E_MALFORMED = 1, 2, 3
 E_GZIP_MAGIC, E_GZIP_METHOD, E_GZIP_FLAGS, E_GZIP_CRC, E_GZIP_ISIZE = 50, 51, 52, 53, 54
+E_BWT_BLOCK_TOO_LARGE = 60
 RC_OK, RC_BAD_ARG, RC_NO_DEVICE, RC_HIP_ERROR, RC_NO_MEMORY = 0, -1, -2, -3, -4
 
 EXPORTS = [

@@ -423,6 +423,11 @@ struct BwtfWords {
     BwtfWords& operator=(const BwtfWords&) = delete;
 };
 
+__global__ void k_bwtf_too_large(int32_t* status, uint64_t* out_len, uint64_t* in_used, uint32_t* aux)
+{
+    if (threadIdx.x == 0) { *status = RCX_E_BWT_BLOCK_TOO_LARGE; *out_len = 0; if (in_used) *in_used = 0; if (aux) *aux = 0; }
+}
+
 static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::string& err, bool sa_words = false)
 {
     const uint32_t pass_blocks = variant > 0 ? (uint32_t)variant : 0xffffffffu;      // A/B knob: at most `variant` blocks per sorting pass
@@ -437,7 +442,13 @@ static int launch_bwt_forward(hipStream_t s, rcx_kargs& k, int variant, std::str
         // the next pass: as many blocks as stay below BWTF_MAXN suffixes
         uint32_t nb = 0; uint64_t N64 = 0, maxn = 0;
         while (lo + nb < nb_all && nb < pass_blocks && N64 + h_len[lo + nb] <= (uint64_t)(nb ? BWTF_PASSN : BWTF_MAXN)) { N64 += h_len[lo + nb]; if (h_len[lo + nb] > maxn) maxn = h_len[lo + nb]; nb++; }
-        if (nb == 0) { err = "bwt forward: a block of 2^28 bytes or more"; return RCX_RC_BAD_ARG; }
+        if (nb == 0) {
+            // a block of 2^28 bytes or more: a limit of this sorter (an SA word keeps four flag bits beside the suffix index), not of the
+            // format -- the block gets RCX_E_BWT_BLOCK_TOO_LARGE (include/rcx.h), the rest of the batch is transformed
+            hipLaunchKernelGGL(k_bwtf_too_large, dim3(1), dim3(64), 0, s, k.status + lo, k.out_len + lo, k.in_used ? k.in_used + lo : nullptr, k.aux ? k.aux + lo : nullptr);
+            lo += 1;
+            continue;
+        }
         rcx_kargs kk = k;
         kk.in_off += lo; kk.in_len += lo; kk.out_off += lo; kk.out_cap += lo; kk.out_len += lo; kk.status += lo;
         if (kk.in_used) kk.in_used += lo;

@@ -131,6 +131,7 @@ extern "C" const char* rcx_status_string(int s)
     case RCX_E_LZ4_MAGIC: return "";
     case RCX_E_LZ4_VERSION: return "";
     case RCX_E_LZ4_INPUT_TOO_LARGE: return "input too large";
+    case RCX_E_BWT_BLOCK_TOO_LARGE: return "bwt block of 2^28 bytes or more";
     case RCX_E_GZIP_MAGIC: return "not a gzip member";
     case RCX_E_GZIP_METHOD: return "unsupported gzip compression method";
     case RCX_E_GZIP_FLAGS: return "reserved gzip flags set";

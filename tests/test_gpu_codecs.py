@@ -390,3 +390,31 @@ def test_inflate_host_path_into_page_locked_output(ctx, oracle, golden):
                 assert es == res[False][0][i] and eu == res[False][2][i], (few, codec, i)
                 if es == 0:
                     assert eo == res[False][4][i]
+
+
+def test_bwt_block_over_the_sorters_limit_gets_its_own_status(ctx):
+    """bwt::Encoder::new(w, block_size) takes any usize (bwt/mod.rs:451); the suffix sorter keeps four flag bits beside a suffix index, so a
+    block of 2^28 bytes or more cannot be sorted here.  It must cost exactly that block: RCX_E_BWT_BLOCK_TOO_LARGE on it (include/rcx.h),
+    the other blocks of the batch transformed as ever."""
+    import torch
+    import rust_compress_amd as R
+    from rust_compress_amd import synth
+    dev = torch.device("cuda", 0)
+    small = synth.gen("text", 5000, 3).tobytes()
+    big = 1 << 28
+    inb = torch.zeros(big + 8192 + 64, dtype=torch.uint8, device=dev)
+    inb[:5000] = torch.frombuffer(bytearray(small), dtype=torch.uint8).to(dev)
+    inb[big + 8192 - 5000: big + 8192] = inb[:5000]
+    i64 = lambda a: torch.tensor(a, dtype=torch.int64, device=dev)
+    # block 0: 5000 bytes; block 1: 2^28 bytes (zeros, never read); block 2: the 5000 bytes again
+    db = R.DeviceBatch(inb, i64([0, 5008, big + 8192 - 5000]), i64([5000, big, 5000]),
+                       torch.zeros(3 * 8192, dtype=torch.uint8, device=dev), i64([0, 8192, 16384]), i64([8192, 8192, 8192]))
+    sc = torch.empty(ctx.scratch_bytes(N.BWT_FORWARD, 3, 8192) + 256, dtype=torch.uint8, device=dev)
+    ctx.launch_dev(N.BWT_FORWARD, db, sc)
+    torch.cuda.synchronize()
+    one = ctx.bwt_forward([small]).check()
+    assert db.status.tolist() == [0, N.E_BWT_BLOCK_TOO_LARGE, 0] and db.out_len.tolist() == [5000, 0, 5000]
+    got = db.out_base.cpu().numpy()
+    assert bytes(got[:5000]) == one.outputs[0] == bytes(got[16384: 16384 + 5000])
+    assert int(db.aux[0]) == int(one.aux[0]) == int(db.aux[2])
+    assert N.lib().rcx_status_string(N.E_BWT_BLOCK_TOO_LARGE).decode() == "bwt block of 2^28 bytes or more"

@@ -134,3 +134,39 @@ def test_shim_modules_only_call_declared_exports_and_cover_the_crates_surface():
     for f, t in text.items():
         t2 = re.sub(r'"(?:\\.|[^"\\])*"', '""', re.sub(r"//[^\n]*", "", t))
         assert t2.count("{") == t2.count("}") and t2.count("(") == t2.count(")"), f
+
+
+def test_the_crate_is_complete_on_paper():
+    """What cannot be compiled here must at least be all there: the reference's feature table and [[bin]] (Cargo.toml:11-24), its module
+    gates (src/lib.rs:19-50), the test application (src/main.rs) with the archive format and the passes of rust_compress_amd/cli.py,
+    and the many-streams entry points of round 6."""
+    ref = {"default": ["bwt", "checksum", "entropy", "flate", "lz4", "zlib", "rle"], "bwt": [], "checksum": [], "entropy": [], "flate": [], "lz4": [],
+           "zlib": ["flate", "checksum"], "rle": [], "unstable": []}
+    cargo = open(os.path.join(ROOT, "rust", "Cargo.toml")).read()
+    feat = re.search(r"^\[features\]\n(.*?)(?=^\[|\Z)", cargo, flags=re.S | re.M).group(1)
+    got = {m.group(1): re.findall(r'"([a-z0-9_]+)"', m.group(2)) for m in re.finditer(r"^([a-z0-9_]+)\s*=\s*\[(.*?)\]", feat, flags=re.M)}
+    assert got == ref
+    if os.path.exists("/root/reference/Cargo.toml"):                      # (the build container only: the reference's own table, parsed the same way)
+        rc = open("/root/reference/Cargo.toml").read()
+        rfeat = re.search(r"^\[features\]\n(.*?)(?=^\[|\Z)", rc, flags=re.S | re.M).group(1)
+        assert got == {m.group(1): re.findall(r'"([a-z0-9_]+)"', m.group(2)) for m in re.finditer(r"^([a-z0-9_]+)\s*=\s*\[(.*?)\]", rfeat, flags=re.M)}
+    binsec = re.search(r"^\[\[bin\]\]\n(.*?)(?=^\[|\Z)", cargo, flags=re.S | re.M).group(1)
+    assert 'name = "compress"' in binsec and "doc = false" in binsec and 'path = "src/main.rs"' in binsec
+    lib = open(os.path.join(ROOT, "rust", "src", "lib.rs")).read()
+    for feature, item in (("bwt", "pub mod bwt;"), ("checksum", "pub mod checksum;"), ("entropy", "pub mod entropy;"), ("flate", "pub mod flate;"), ("lz4", "pub mod lz4;"),
+                          ("rle", "pub mod rle;"), ("zlib", "pub mod zlib;"), ("checksum", "pub use checksum::adler::State32 as Adler32;")):
+        assert re.search(r'#\[cfg\(feature\s*=\s*"%s"\)\]\s*\n%s' % (feature, re.escape(item)), lib), (feature, item)
+    assert lib.count("pub fn into_inner") == 1                             # (two methods of one name do not compile)
+    main = open(os.path.join(ROOT, "rust", "src", "main.rs")).read()
+    from rust_compress_amd import cli
+    assert "0x7363_2172" in main and cli.MAGIC == 0x73632172
+    for name, (_, _, info) in cli.PASSES.items():
+        assert '("%s", "%s")' % (name, info) in main, name
+    for need in ("fn parse_args", "fn encode_pass", "fn decode_pass", "fn read_header", '"-block<N>"', "cfg.methods.iter().rev()", "Decompression methods are set in stone",
+                 "Input is not a rust-compress archive", "bwt::Decoder::new(src, true)", "bwt::Encoder::new(Vec::new(), cfg.block_size)"):
+        assert need in main, need
+    t2 = re.sub(r'"(?:\\.|[^"\\])*"', '""', re.sub(r"//[^\n]*", "", main))
+    assert t2.count("{") == t2.count("}") and t2.count("(") == t2.count(")")
+    src = lambda f: open(os.path.join(ROOT, "rust", "src", f)).read()
+    assert "pub fn decode_many(frames: &[&[u8]])" in src("lz4.rs") and "pub fn decode_many(streams: &[&[u8]])" in src("flate.rs") and "pub fn decode_many(members: &[&[u8]])" in src("zlib.rs")
+    assert "pub(crate) fn decode_many_with" in lib
