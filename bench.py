@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 BLOCK = 65536
 NBLOCKS = 4096
-HEADLINE_KERNEL_SOURCES = ["k_lz4_decode_v4.hip", "k_lz4_decode_v5.hip", "k_lz4_decode_v8.hip", "rcx_dev.h"]
+HEADLINE_KERNEL_SOURCES = ["k_lz4_decode_v4.hip", "k_lz4_decode_v5.hip", "k_lz4_emit6.hip", "k_lz4_decode_v8.hip", "rcx_dev.h"]
 
 
 def kernel_source_hash():
