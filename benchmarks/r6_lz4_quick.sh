@@ -3,7 +3,7 @@
 # bash benchmarks/r6_lz4_quick.sh [tag]
 T=${1:-quick}
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_lz4.py -x -q 2>&1 | tail -5 > gpurun_out/r6_${T}_tests.log
+timeout 900 python -m pytest tests/test_gpu_lz4.py -x -q 2>&1 | grep -E "passed|failed|error" | tail -3 > gpurun_out/r6_${T}_tests.log
 for i in 1 2; do
 timeout 300 python bench.py --no-cpu --no-e2e --no-others --steps 40 --warmup 20 2>/dev/null | python -c "
 import sys, json

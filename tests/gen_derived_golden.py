@@ -16,6 +16,7 @@ oracle with these files; tests/test_gpu_codecs.py compares the HIP path with the
 
     python tests/gen_derived_golden.py            # ~10 min of pure Python; rewrites the directory
     python tests/gen_derived_golden.py --self     # only the Appendix-B known answers (seconds)
+    python tests/gen_derived_golden.py --bins     # the small inputs' .bin files again, checked against the committed manifest (seconds)
 """
 import hashlib
 import json
@@ -332,10 +333,31 @@ def inputs():
             yield "%s_%d" % (kind, n), kind, n, seed, synth.gen(kind, n, seed).tobytes()
 
 
+def bins_only():
+    """the expected bytes of the small inputs once more (seconds), each checked against the committed manifest before it is written"""
+    man = json.load(open(os.path.join(OUT, "manifest.json")))
+    recs = {r["input"]: r for r in man["records"]}
+    wrote = 0
+    for name, kind, n, seed, data in inputs():
+        if n > SMALL:
+            continue
+        assert hashlib.sha256(data).hexdigest() == recs[name]["input_sha256"], name
+        for cname, fn in CODECS.items():
+            out = fn(data)
+            e = recs[name]["expect"][cname]
+            assert len(out) == e["len"] and hashlib.sha256(out).hexdigest() == e["sha256"], (name, cname)
+            with open(os.path.join(OUT, "%s.%s.bin" % (name, cname)), "wb") as fh:
+                fh.write(out)
+            wrote += 1
+    print("wrote %d vectors to %s" % (wrote, OUT))
+
+
 def main():
     self_check()
     if "--self" in sys.argv:
         return
+    if "--bins" in sys.argv:
+        return bins_only()
     os.makedirs(OUT, exist_ok=True)
     for f in os.listdir(OUT):
         os.remove(os.path.join(OUT, f))
