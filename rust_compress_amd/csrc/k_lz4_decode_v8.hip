@@ -31,7 +31,7 @@
 #define RCX_V8_PSLEEP 16
 #endif
 #ifndef RCX_V8_ESLEEP
-#define RCX_V8_ESLEEP 4
+#define RCX_V8_ESLEEP 2                     /* (round 6, with emit6: 4 -> 2 and RCX_V8_LOW 4 -> 6: 0.508 -> 0.497 ms, benchmarks/r6_modes.sh) */
 #endif
 #ifndef RCX_WALK_FORM
 #define RCX_WALK_FORM 3                  /* 0: eight bytes + a second read where needed (portable), 1: sixteen bytes, the step as ISA, 2: form 0's whole loop as ISA,
@@ -58,7 +58,7 @@
 #define RCX_V8_ADAPT 1
 #endif
 #ifndef RCX_V8_LOW
-#define RCX_V8_LOW 4
+#define RCX_V8_LOW 6                        /* round 6: the executor's batch is shorter with emit6 -- 3 / 4 / 6 / 8: 0.513 / 0.508 / 0.498 / 0.501 ms */
 #endif
 #ifndef RCX_V8_LOW_WALK
 #define RCX_V8_LOW_WALK RCX_V8_LOW       /* the same threshold while a chunk is staged, walked and linked (a long stretch without a batch) */
@@ -434,21 +434,25 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
         L = 0; M = 0; off = 0; src = p + 1; perr = 0;
         bool slow = on;
         const int32_t ci = (int32_t)p - this->cbase;
-        const bool fast = on && (uint64_t)p + 20u <= (uint64_t)n && ci >= 0 && ci + 20 <= CBUF8;
+        // Round 6: TWO dependent LDS reads, a lane per token, no loop -- the token and its literal-length extension, then (once the literal
+        // run's length is known) the offset and the first match-length extension behind it.  The first version read 16 bytes at once and
+        // took the byte-by-byte path below for every token with more than 12 literals: one token in forty, so four batches in five had a
+        // lane in that path, and it was a fifth of the parser's time (the parser, not the executor, is what bounds this kernel: 0.41 of the
+        // 0.50 ms with the executor switched off, benchmarks/pmc_insts.sh variant 45).  Left to the slow path: a run of 255s in either
+        // length, bytes that are not staged, the block's last 20 bytes.
+        const bool fast = on && (uint64_t)p + 20u <= (uint64_t)n && ci >= 0 && ci + 8 <= CBUF8;
         if (__ballot(fast)) {
-            uint32_t v0, v1, v2, v3;
-            B::lds_load16u(this->cbuf, fast ? ci : 0, v0, v1, v2, v3);
-            const uint32_t t = v0 & 0xffu, Ln = t >> 4;
-            if (fast && Ln <= 12u) {
-                const uint32_t i = 1u + Ln, q = i >> 2;
-                const uint32_t lo = q == 0 ? v0 : q == 1 ? v1 : q == 2 ? v2 : v3;
-                const uint32_t hi = q == 0 ? v1 : q == 1 ? v2 : v3;
-                const uint32_t w = RCX_ALIGNBYTE(hi, lo, i & 3u);            // offset lo, hi, first extension byte
-                const uint32_t x = (w >> 16) & 0xffu;
-                if ((t & 15u) != 15u || x != 255u) {
-                    L = Ln; off = w & 0xffffu; M = (t & 15u) + 4u + ((t & 15u) == 15u ? x : 0u);
-                    slow = false;
-                }
+            const uint32_t v0 = B::lds_load4u(this->cbuf, fast ? ci : 0);
+            const uint32_t t = v0 & 0xffu, Ln = t >> 4, Mn = t & 15u, b1 = (v0 >> 8) & 0xffu;
+            const uint32_t lx = Ln == 15u ? 1u : 0u;
+            const uint32_t Lf = Ln + (lx ? b1 : 0u);
+            const uint32_t i = 1u + lx + Lf;                            // where the offset lies, from the token
+            const bool in2 = fast && !(lx && b1 == 255u) && (uint64_t)p + i + 3u <= (uint64_t)n && ci + (int32_t)i + 8 <= CBUF8;
+            const uint32_t w = B::lds_load4u(this->cbuf, in2 ? ci + (int32_t)i : 0);      // offset lo, hi, first extension byte
+            const uint32_t x = (w >> 16) & 0xffu;
+            if (in2 && !(Mn == 15u && x == 255u)) {
+                L = Lf; off = w & 0xffffu; M = Mn + 4u + (Mn == 15u ? x : 0u); src = p + 1u + lx;
+                slow = false;
             }
         }
         if (__ballot(slow)) {
@@ -740,7 +744,7 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
             }
 #endif
             // CUT 8 (A/B): the executor only drains the ring -- what is left is the parser wave's instructions; 32: nor its own scan
-            if (CUT & 8) { if (!(CUT & 32)) this->oend += RCX_U(__builtin_amdgcn_readlane(w0, 63)) & 1u; lo = bt.ns; }
+            if (CUT & 8) { if (!(CUT & 32)) this->oend += RCX_U(__builtin_amdgcn_readlane(w0, 63)) & 1u; lo = bt.ns; if (bt.why == B::END_ || bt.why == B::ERR_) break; continue; }   // (nor the long sequence behind the batch: with no output its checks would end the block at once -- round 5's "parser share" measured a few batches per block)
             while (lo < bt.ns && !e) e = this->template emit5<false, PRED, CUT, (SPLIT ? SPLIT : 64)>(bt.ns, lo, w0, w1, nullptr, agey);
             RCX_MARK("x8_post_emit");
             if (e) { st = e; break; }
