@@ -94,6 +94,9 @@ __device__ uint32_t g_lz4_prog[8];
 // rounds and the drain is too weak a lever to move a block's finishing time (the static rule bought 2 %), and a block that finishes early
 // does not leave its slot idle -- the others of its CU speed up (a block alone takes 0.49 ms).  Kept as a switch, off.
 
+#ifndef RCX_X6_MAXRUNS
+#define RCX_X6_MAXRUNS 2
+#endif
 #ifndef RCX_V8_STAT
 #define RCX_V8_STAT(slot, v) ((void)0)                       /* the wave simulator counts batches through emit6 / emit5 here */
 #endif
@@ -624,12 +627,20 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
         }
         const bool put = (int)lane < nt;
         const uint32_t M1 = (RCX_RUNSPLIT ? big : two) ? (uint32_t)SPLIT : M;
-        // a PLAIN batch (the executor's emit6): every token with an offset, no match that overlaps itself, something
+        // a PLAIN batch (the executor's emit6): every token with an offset, something
         // to emit, >= 40 bytes in front of the block's end -- and the first one >= 3 bytes behind its start
         bool plain = false;
         if (X6 && SPLIT) {
-            const bool odd = (M != 0u && (off == 0u || (off < 16u && off < M))) || L + M == 0u || (uint64_t)tp + 40u > (uint64_t)this->n;
-            plain = nt > 0 && RCX_U(tp) >= 3u && !__ballot(put && odd);
+            const bool odd = (M != 0u && off == 0u) || L + M == 0u || (uint64_t)tp + 40u > (uint64_t)this->n;      // (runs stay: emit6 fills them by period doubling)
+            // (a batch with more than RCX_X6_MAXRUNS runs goes through emit5, whose round loop doubles all its runs side by side: emit6 fills its
+            //  runs one after the other as they become ready -- right for a text's one run in seven batches, slower for G-runs' several a batch)
+            plain = nt > 0 && RCX_U(tp) >= 3u && !__ballot(put && odd) && __popcll(__ballot(put && M != 0u && off < 16u && off < M)) <= RCX_X6_MAXRUNS;
+#ifdef RCX_V8_WHY_STATS                  /* (simulator only: why a batch is not plain) */
+            { const bool b0 = __ballot(put && M != 0u && off == 0u) != 0, b1 = __ballot(put && M != 0u && off < 16u && off < M && off > L) != 0, b2 = __ballot(put && L + M == 0u) != 0,
+                         b3 = __ballot(put && (uint64_t)tp + 40u > (uint64_t)this->n) != 0, b6 = __ballot(put && M != 0u && off < 16u && off < M && off <= L) != 0, b4 = RCX_U(tp) < 3u;
+              RCX_V8_STAT(0, lane == 0 && nt > 0 && b0); RCX_V8_STAT(1, lane == 0 && nt > 0 && b1); RCX_V8_STAT(2, lane == 0 && nt > 0 && b2); RCX_V8_STAT(3, lane == 0 && nt > 0 && b3);
+              RCX_V8_STAT(4, lane == 0 && nt > 0 && b4); RCX_V8_STAT(5, lane == 0 && nt > 0); RCX_V8_STAT(6, lane == 0 && nt > 0 && b6); }
+#endif
         }
         if (!post(head, (int)ne, why, gerr, gL, gM, goff, gsrc, RCX_U(tp), put, eincl - ecnt, L | (M1 << 8) | (off << 16),
                   (put && two) ? (0x80u | ((M - (uint32_t)SPLIT) << 8) | (off << 16)) : 0u, (put && rs) ? M : 0u, off ? off : 1u, plain)) return -1;
@@ -691,11 +702,13 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
             if (lane == 0) ring->tail = tail;             // the slot is in registers: hand it back
             // where each entry's literals lie: behind its token, and the tokens follow one another (the second half of a split
             // match, flagged 0x80, is no token)
+            if (X6 && plain6) { RCX_V8_STAT(10, lane == 0 && bt.why == B::SOLO_); RCX_V8_STAT(11, lane == 0 && bt.why == B::WIDE_); RCX_V8_STAT(12, lane == 0 ? (uint32_t)bt.ns : 0u); RCX_V8_STAT(13, lane == 0); }
             if (X6 && plain6 && this->emit6(bt.ns, w1, p0, agey)) {
                 if (this->after_batch(bt, st)) break;
                 continue;
             }
             RCX_V8_STAT(9, lane == 0 && bt.ns > 0);
+            RCX_V8_STAT(10, lane == 0 && bt.why == B::SOLO_); RCX_V8_STAT(11, lane == 0 && bt.why == B::WIDE_); RCX_V8_STAT(12, lane == 0 ? (uint32_t)bt.ns : 0u); RCX_V8_STAT(13, lane == 0);
             const bool cont = (w1 & 0x80u) != 0;
             if (cont) w1 &= ~0xffu;
             const uint32_t L = w1 & 0xffu, M = (w1 >> 8) & 0xffu;

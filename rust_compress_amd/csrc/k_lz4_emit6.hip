@@ -28,9 +28,10 @@
 // atomic under an empty mask would still take its turn at the dwords it shares with its neighbours.  24 vector + 4 scalar instructions a round
 // (hipcc's loop for the same source: 44 + 6, every lane at every LDS instruction).
 //   s0: LDS address of source - a; d4: LDS address of the destination's frame (4-byte aligned); mc: bytes to copy (0: none); tb: LDS address of
-//   the mask table + 32 a; fix: ~0 << 8 a.  No match overlaps itself: the loop ends with nothing pending.
+//   the mask table + 32 a; fix: ~0 << 8 a.  Returns the lanes still pending when no lane is ready: none, unless a lane was handed a dependency on
+//   itself (emit6 does that to a run, which it fills itself).
 #if !defined(RCX_NO_ROUNDS_ASM) && !defined(RCX_NO_MSKOR_ASM)
-__device__ __forceinline__ void rcx_lz4_rounds6(uint32_t s0, uint32_t d4, uint32_t mc, uint32_t dep_lo, uint32_t dep_hi, uint64_t pend, uint32_t tb, uint32_t fix)
+__device__ __forceinline__ uint64_t rcx_lz4_rounds6(uint32_t s0, uint32_t d4, uint32_t mc, uint32_t dep_lo, uint32_t dep_hi, uint64_t pend, uint32_t tb, uint32_t fix)
 {
     uint32_t t0, t1, nv, sa, sh, da, r0, r1, r2, r3, r4, r5, m0, m1, m2, m3, m4, prog = 0;
     uint64_t sT, sF;
@@ -94,11 +95,13 @@ __device__ __forceinline__ void rcx_lz4_rounds6(uint32_t s0, uint32_t d4, uint32
         "s_cbranch_scc1 L_top_%=\n\t"
         "L_out_%=:\n\t"
         "s_mov_b64 exec, -1\n\t"
-        : [prog] "+v"(prog), [t0] "=&v"(t0), [t1] "=&v"(t1), [nv] "=&v"(nv), [sa] "=&v"(sa), [sh] "=&v"(sh), [da] "=&v"(da),
+        "s_mov_b64 %[pend], vcc\n\t"
+        : [pend] "+s"(pend), [prog] "+v"(prog), [t0] "=&v"(t0), [t1] "=&v"(t1), [nv] "=&v"(nv), [sa] "=&v"(sa), [sh] "=&v"(sh), [da] "=&v"(da),
           [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [r4] "=&v"(r4), [r5] "=&v"(r5),
           [m0] "=&v"(m0), [m1] "=&v"(m1), [m2] "=&v"(m2), [m3] "=&v"(m3), [m4] "=&v"(m4), [sT] "=&s"(sT), [sF] "=&s"(sF)
-        : [pend] "s"(pend), [s0] "v"(s0), [d4] "v"(d4), [mc] "v"(mc), [dlo] "v"(dep_lo), [dhi] "v"(dep_hi), [tb] "v"(tb), [fix] "v"(fix)
+        : [s0] "v"(s0), [d4] "v"(d4), [mc] "v"(mc), [dlo] "v"(dep_lo), [dhi] "v"(dep_hi), [tb] "v"(tb), [fix] "v"(fix)
         : "vcc", "scc", "memory");
+    return pend;
 }
 #define RCX_HAVE_ROUNDS6 1
 #endif
@@ -270,25 +273,57 @@ struct Lz4X6 : Base {
         rcx_wave_sync();
         X6P_ADD(6);
 
-        // ---- window matches: copy rounds, 16 bytes per ready lane
+        // ---- window matches: copy rounds, 16 bytes per ready lane.  A RUN (a match that overlaps itself: offset < 16 and < its length; one
+        // batch in seven of a text holds one, and all of those went through emit5 at first) waits like any lane for the producers of its
+        // period -- the bytes [match - offset, match) -- and then fills itself in ONE go by period doubling: off, 2 off, 4 off ... (whole periods) up to 16
+        // bytes a step, a frame each, read from what the lane has just written (a lane's LDS operations are performed in order).  The
+        // hand-written loop never finds such a lane ready (it is handed a dependency on itself): it returns with the runs and whatever waits
+        // for them still pending, the runs whose periods stand are filled, and the loop goes on.
         {
             const int32_t dfr = li_m - (int32_t)a2;
+            const bool ovl = M != 0u && off < 16u && off < M;          // (never a gathered match: its source ends where it begins)
             const int32_t sfr = isfar ? dfr : (int32_t)(mdst - S) - lbase - (int32_t)a2;     // the source, as far back from a dword boundary as the destination (a gathered match reads itself: every lane reads)
             const uint32_t Mc = isfar ? 0u : M;
+            auto fill_run = [&]() __attribute__((always_inline)) {      // (called by the lanes of ready runs only: no collective inside)
+                uint32_t done = 0, back = off;                          // back: a whole number of periods, all of them standing behind the write position
+                while (done < M) {
+                    uint32_t c = back < M - done ? back : M - done;
+                    c = c < 16u ? c : 16u;
+                    const int32_t d = li_m + (int32_t)done;
+                    const uint32_t ar = (uint32_t)d & 3u;
+                    const int32_t sb = d - (int32_t)back - (int32_t)ar;
+                    const uint32_t* q = (const uint32_t*)(wb_ + (sb & ~3));
+                    const uint32_t sh = (uint32_t)sb & 3u;
+                    const uint32_t r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3], r4 = q[4], r5 = q[5];
+                    store_frame<5>(wb_ + (d - (int32_t)ar), RCX_ALIGNBYTE(r1, r0, sh), RCX_ALIGNBYTE(r2, r1, sh), RCX_ALIGNBYTE(r3, r2, sh),
+                                   RCX_ALIGNBYTE(r4, r3, sh), RCX_ALIGNBYTE(r5, r4, sh), ar, c);
+                    done += c;
+                    if (2u * back <= off + done) back *= 2u;
+                }
+            };
+            unsigned long long pm = __ballot(Mc != 0u);
 #ifdef RCX_HAVE_ROUNDS6
             if (RCX_X6_ROUNDS_ASM) {
                 const uint32_t wa = (uint32_t)(uintptr_t)wb_;      // (low half of a generic LDS pointer = the LDS byte address)
-                rcx_lz4_rounds6(wa + (uint32_t)sfr, wa + (uint32_t)dfr, Mc, (uint32_t)dep, (uint32_t)(dep >> 32), __ballot(Mc != 0u),
-                                (uint32_t)(uintptr_t)mtab + (a2 << 5), 0xffffffffu << (8u * a2));
+                const unsigned long long depx = dep | (ovl ? 1ull << lane : 0ull);
+                for (;;) {
+                    pm = rcx_lz4_rounds6(wa + (uint32_t)sfr, wa + (uint32_t)dfr, Mc, (uint32_t)depx, (uint32_t)(depx >> 32), pm,
+                                         (uint32_t)(uintptr_t)mtab + (a2 << 5), 0xffffffffu << (8u * a2));
+                    if (!pm) break;
+                    const bool fill = ovl && ((pm >> lane) & 1ull) && (pm & dep) == 0ull;
+                    if (fill) fill_run();
+                    rcx_wave_sync();
+                    pm &= ~__ballot(fill);
+                }
             } else
 #endif
             {
             uint32_t prog = 0;
-            unsigned long long pm = __ballot(Mc != 0u);
             while (pm) {
                 const bool ready = ((pm >> lane) & 1ull) && (pm & dep) == 0ull;
+                const bool fill = ready && ovl;
                 const uint32_t left = Mc - prog;
-                const uint32_t nv = ready ? (left < 16u ? left : 16u) : 0u;
+                const uint32_t nv = (ready && !ovl) ? (left < 16u ? left : 16u) : 0u;
                 const int32_t sb = sfr + (int32_t)prog;
                 const uint32_t* q = (const uint32_t*)(wb_ + (sb & ~3));
                 const uint32_t sh = (uint32_t)sb & 3u;
@@ -298,8 +333,9 @@ struct Lz4X6 : Base {
                 // (only the lanes that copy: an LDS atomic under an empty mask still takes its turn at the dwords it shares with its neighbours)
                 if (nv) store_frame<5>(wb_ + (dfr + (int32_t)prog), RCX_ALIGNBYTE(r1, r0, sh), RCX_ALIGNBYTE(r2, r1, sh), RCX_ALIGNBYTE(r3, r2, sh),
                                RCX_ALIGNBYTE(r4, r3, sh), RCX_ALIGNBYTE(r5, r4, sh), a2, nv);
+                if (fill) fill_run();                                  // (a ready run's period stands: nobody writes it any more, nobody reads the run yet)
                 rcx_wave_sync();
-                prog += nv;
+                prog += fill ? Mc : nv;
                 pm = __ballot(prog < Mc);
             }
             }

@@ -16,7 +16,7 @@ def build(force=False, sanitize=False):
         return OUT
     cmd = ["g++", "-std=c++17", "-O1", "-g"] + (["-DRCX_SIM_TRACE"] if os.environ.get("RCX_SIM_TRACE") else []) + \
           (["-fsanitize=address", "-fno-omit-frame-pointer"] if (sanitize or os.environ.get("RCX_SIM_ASAN")) else []) + [ "-fPIC", "-shared", "-x", "c++", "-include", os.path.join(HERE, "wavesim.h"),
-           "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-unused-variable", "-Wno-attributes",
+           "-Wall", "-DRCX_V8_WHY_STATS", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-unused-variable", "-Wno-attributes",
            "-o", OUT] + srcs
     subprocess.check_call(cmd)
     return OUT
