@@ -422,8 +422,8 @@ def sustained(eng, wl, seconds=2.0):
 
 
 def hbm_ceiling(torch, dev, ctx=None, nbytes=1 << 30, reps=10):
-    """What a plain copy reaches on this device, two ways: the library's own kernel (rcx_hbm_copy_probe: 16 bytes a lane, four loads in
-    flight a thread, nontemporal) -- the figure quoted as "achievable" -- and torch's copy_ (rocm's blit kernel), which reads ~20 % lower."""
+    """What a plain copy reaches on this device, two ways: the library's own kernel (rcx_hbm_copy_probe: 16 bytes a thread, a
+    workgroup per 4 KiB, one launch) -- the figure quoted as "achievable" -- and torch's copy_, which reads ~15 % lower."""
     a = torch.empty(nbytes, dtype=torch.uint8, device=dev).fill_(1)
     b = torch.empty_like(a)
     b.copy_(a); torch.cuda.synchronize()

@@ -273,8 +273,9 @@ enum rcx_codec {
 uint64_t rcx_scratch_bytes(int codec, uint32_t nblocks, uint64_t max_block);
 int rcx_launch_dev(rcx_ctx*, int codec, const rcx_dev_batch*, void* scratch, uint64_t scratch_bytes);
 /* Measurement aid (no counterpart in the reference): what a plain copy reaches on this device -- `bytes` read and `bytes` written per
- * pass by a kernel that moves 16 bytes a lane, `reps` passes timed with events on the ctx stream; *gb_per_s = 2 * bytes / time.  The
- * "achievable" line next to the 8 TB/s spec peak in bench.py's roofline (rocm's own copy kernels, torch copy_, read 20 % lower). */
+ * pass by a kernel that moves 16 bytes a thread (a workgroup per 4 KiB), `reps` passes timed with events on the ctx stream; *gb_per_s =
+ * 2 * bytes / time.  The "achievable" line next to the 8 TB/s spec peak in bench.py's roofline (hipMemcpy and torch's copy_ read 15-25 %
+ * lower: benchmarks/micro/hbm_copy.hip). */
 int rcx_hbm_copy_probe(rcx_ctx*, uint64_t bytes, int reps, double* gb_per_s);
 /* kernel variant knob for A/B measurements (0 = default/best). */
 int rcx_ctx_set_variant(rcx_ctx*, int codec, int variant);

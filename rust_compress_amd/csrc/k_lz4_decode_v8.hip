@@ -393,7 +393,11 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
             q += m15 ? 1u : 0u;
         }
 #endif
+#ifdef RCX_WALK_NOSLOW                    /* (instruction attribution of the parser-only build: results wrong on purpose) */
+        if (on && slow && q <= p) q = p + 3u;
+#else
         if (on && slow) q = next_tok(p);
+#endif
         return q;
     }
 
@@ -591,8 +595,10 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
         const uint32_t tp = (uint32_t)(cs + (on ? (int32_t)list[pos + lane] : 0));
         uint32_t L, M, off, src; int perr;
         V8P_T0();
+        RCX_MARK("p8_fields");
         fields(tp, on, L, M, off, src, perr);
         V8P_ADD(3);
+        RCX_MARK("p8_fields_end");
         // (a long match with a short period -- a run -- stays in the batch: its lane fills it 16 bytes a round from inside the window, where
         // a stop per run cut a batch of G-runs to ~14 sequences: 7 % of its runs are longer than 64 bytes)
         const bool longrun = M > (uint32_t)B::MCAP && M <= 255u && off != 0u && off < 16u;
@@ -645,6 +651,7 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
         if (!post(head, (int)ne, why, gerr, gL, gM, goff, gsrc, RCX_U(tp), put, eincl - ecnt, L | (M1 << 8) | (off << 16),
                   (put && two) ? (0x80u | ((M - (uint32_t)SPLIT) << 8) | (off << 16)) : 0u, (put && rs) ? M : 0u, off ? off : 1u, plain)) return -1;
         V8P_ADD(4);
+        RCX_MARK("p8_post_end");
         if (PROF8) pp[9] += 1;
         if (why == B::ERR_) return -1;
         return nt + (g >= 0 ? 1 : 0);
@@ -895,6 +902,7 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
             map &= ~((1ull << lowv) - 1ull);
             if (!mine && !giant) map = 0;
             V8P_ADD(1);
+            RCX_MARK("p8_link_end");
             if (PROF8) pp[6] += 1;
             // ---- 3. a lane per token: the maps unpacked into a position list (eight input bytes a lane), 64 entries a batch
             const int nwin = (nseg + LWIN - 1) / LWIN;
@@ -916,6 +924,7 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
                 lcnt += RCX_U(__builtin_amdgcn_readlane(incl, 63));
                 rcx_wave_sync();
                 V8P_ADD(2);
+                RCX_MARK("p8_list_end");
                 const bool last = (w + 1 == nwin) && c >= n;                  // the end of the block: nothing is carried over
                 uint32_t pos = 0;
                 while (lcnt - pos >= 64u || (last && lcnt > pos)) {

@@ -863,19 +863,14 @@ extern "C" int rcx_multi_sync(rcx_multi* m)
 }
 
 // ---- measurement aid: the device's own copy rate (include/rcx.h) ------------------------------------------------------------------
-// 16 bytes a lane, four independent loads in flight per thread, a grid of 16 workgroups per CU that strides over the buffer:
-// /opt/skills/guides/MI355X_MICROARCH.md measures 6.3 TB/s this way where torch's copy_ reads 5.1.
+// ONE 16-byte chunk a thread, a workgroup per 4 KiB, the whole buffer in one launch: 6.23 TB/s on the MI355X box, what
+// /opt/skills/guides/MI355X_MICROARCH.md measures with a float4 copy (6.29).  benchmarks/micro/hbm_copy.hip tried the shapes: grid-stride
+// loops (4 .. 32 workgroups a CU, 1 / 4 / 8 chunks in flight a thread, nontemporal or not) reach 4.3 - 5.5 TB/s, hipMemcpy 4.7, torch's
+// copy_ 5.4 -- more loads in flight per thread do not help a copy, more workgroups in flight do.
 __global__ __launch_bounds__(256) void k_hbm_copy(const rcx_u32x4* __restrict__ src, rcx_u32x4* __restrict__ dst, uint64_t n16)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * 256u;
-    uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const rcx_u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
-        const rcx_u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-        __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
-        __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
-    }
-    for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
 }
 extern "C" int rcx_hbm_copy_probe(rcx_ctx* c, uint64_t bytes, int reps, double* gb_per_s)
 {
@@ -885,9 +880,8 @@ extern "C" int rcx_hbm_copy_probe(rcx_ctx* c, uint64_t bytes, int reps, double* 
     void *a = nullptr, *b = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = RCX_RC_OK;
-    hipDeviceProp_t prop;
-    HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
-    const uint32_t grid = (uint32_t)prop.multiProcessorCount * 16u;
+    if ((n16 + 255) / 256 > 0x7fffffffull) { c->err = "copy probe: buffer too large"; return RCX_RC_BAD_ARG; }
+    const uint32_t grid = (uint32_t)((n16 + 255) / 256);
     float ms = 0;
     if (hipMalloc(&a, n16 * 16) != hipSuccess || hipMalloc(&b, n16 * 16) != hipSuccess) { (void)hipGetLastError(); c->err = "copy probe: out of device memory"; rc = RCX_RC_NO_MEMORY; }
     else if (hipMemsetAsync(a, 0x5a, n16 * 16, c->stream) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); c->err = "copy probe: setup failed"; rc = RCX_RC_HIP_ERROR; }

@@ -5,6 +5,9 @@
 // and chunk-centric experiments (v6, v7; benchmarks/experiments/), profiling and attribution instantiations -- is compiled only
 // with -DRCX_AB_VARIANTS into librcx_ab.so, for benchmarks/ and the A/B history in DESIGN.md.
 #include "rcx_tu.h"
+#ifndef RCX_V45_PRE
+#define RCX_V45_PRE 128                  /* (attribution: the parser-only variant with another head start) */
+#endif
 #ifdef RCX_AB_VARIANTS
 #include "../../benchmarks/experiments/k_lz4_decode_v1_v3.hip"
 #endif
@@ -68,7 +71,7 @@ int rcx_tu_lz4_decode(hipStream_t s, rcx_kargs& k, int v, std::string& err)
     else if (v == 42) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 3>), dim3(n), dim3(128), 0, s, k, 0);     // nor chain analysis
     else if (v == 43) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 7>), dim3(n), dim3(128), 0, s, k, 0);     // nor literal / gather stores
     else if (v == 44) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 23>), dim3(n), dim3(128), 0, s, k, 0);    // nor the drain
-    else if (v == 45) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 8>), dim3(n), dim3(128), 0, s, k, 0);     // executor only empties the ring: the parser wave's share
+    else if (v == 45) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, RCX_V45_PRE, 32, false, 2, 8>), dim3(n), dim3(128), 0, s, k, 0);     // executor only empties the ring: the parser wave's share
     else if (v == 46) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 64>), dim3(n), dim3(128), 0, s, k, 0);    // the compiled copy-round loop only (exact)
     else if (v == 47) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 128>), dim3(n), dim3(128), 0, s, k, 0);   // hand-written rounds at priority 1 (exact)
     else if (v == 48) hipLaunchKernelGGL((k_lz4_decode_v8<1024, 768, false, 128, 32, false, 2, 0x200>), dim3(n), dim3(128), 0, s, k, 0);   // no gathers of old matches (their latency)
