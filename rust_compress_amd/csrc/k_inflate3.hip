@@ -543,7 +543,11 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER, MIRROR> {
     Map tmap = {0, 0};
 #ifdef INF3_PROF
     uint64_t pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // cycles: [0] emit [1] wide copies [2] staging [3] block headers + tables [4] symbol passes in all [5] of them tile builds [6] chunks consumed [7] symbols booked
+#ifdef INF3_PROF_TILE
+#define INF3_T(slot, code) do { code; } while (0)
+#else
 #define INF3_T(slot, code) do { const uint64_t t0__ = __builtin_readcyclecounter(); code; pf[slot] += __builtin_readcyclecounter() - t0__; } while (0)
+#endif
 #else
 #define INF3_T(slot, code) do { code; } while (0)
 #endif
@@ -669,6 +673,10 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER, MIRROR> {
         uint32_t ex = 0;
         bool live = mine;
         for (;;) {
+#ifdef INF3_PROF_TILE                      /* (attribution: slots 0 / 1 / 2 = rounds of [ISA walk, portable step], cycles in the ISA walk, cycles in the portable step; 3 = tiles) */
+            const uint64_t tt0_ = __builtin_readcyclecounter();
+            pf[0] += 1;
+#endif
 #ifndef RCX_NO_INF_WALK_ASM
             {   // the hand-written loop walks until every lane is through or has stalled on a symbol it leaves to hop4 below
                 uint32_t m0 = (uint32_t)map.lo, m1 = (uint32_t)(map.lo >> 32), m2 = (uint32_t)map.hi, m3 = (uint32_t)(map.hi >> 32);
@@ -676,6 +684,10 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER, MIRROR> {
                                    RCX_U((uint32_t)(uintptr_t)lutD));
                 map.lo = (uint64_t)m0 | ((uint64_t)m1 << 32); map.hi = (uint64_t)m2 | ((uint64_t)m3 << 32);
             }
+#endif
+#ifdef INF3_PROF_TILE
+            const uint64_t tt1_ = __builtin_readcyclecounter();
+            pf[1] += tt1_ - tt0_;
 #endif
             const bool go = live && q < e;
             if (!__ballot(go)) break;
@@ -687,7 +699,13 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER, MIRROR> {
                 else if (kind == 4u) { ex = XGEN; live = false; }
                 else q += nb;
             }
+#ifdef INF3_PROF_TILE
+            pf[2] += __builtin_readcyclecounter() - tt1_;
+#endif
         }
+#ifdef INF3_PROF_TILE
+        pf[3] += 1;
+#endif
         if (live) ex = q;
         // link (see k_lz4_decode_v8.hip): the usual case lane by lane, the rest in order by scalar code over the lanes' registers
         uint32_t lowv = 0; bool clr = false;
@@ -944,7 +962,9 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER, MIRROR> {
                 }
                 ns = 0; litn = 0; runL = 0; runsrc = 0;
 #ifdef INF3_PROF
+#ifndef INF3_PROF_TILE
                 pf[0] += __builtin_readcyclecounter() - tfl0;
+#endif
 #endif
             }
             // ---- 2. a long match or a stored block: the wave-wide paths of the LZ4 decoder (the one after_batch site)
@@ -975,7 +995,9 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER, MIRROR> {
                     realign = false;
                 } else this->stage(p - ((bc + 7u) >> 3));              // from the byte of the next unread bit: pass() reads the bits from the buffer
 #ifdef INF3_PROF
+#ifndef INF3_PROF_TILE
                 pf[2] += __builtin_readcyclecounter() - tst0;
+#endif
 #endif
             }
             if (!staged(16)) { want_stage = true; continue; }          // every step below reads at most 12 bytes
@@ -1188,7 +1210,11 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER, MIRROR> {
 #ifdef INF3_PROF_CLENS                                         /* (attribution: the code-length decode counted apart, in the wide copies' slot) */
             pf[ph0 == P_SYMBOLS ? 4 : ph0 == P_CLENS ? 1 : 3] += __builtin_readcyclecounter() - tph0;
 #else
+#ifdef INF3_PROF_TILE
+            if (ph0 == P_SYMBOLS) pf[4] += __builtin_readcyclecounter() - tph0;
+#else
             pf[ph0 == P_SYMBOLS ? 4 : 3] += __builtin_readcyclecounter() - tph0;
+#endif
 #endif
 #endif
         }

@@ -132,7 +132,7 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
     // up to the per-lane caps each extension is a single byte), a wave scan on the executor's side.
     static constexpr int NSLOT8 = 8;
     struct Slot8 { uint32_t hdr[8]; uint32_t d[64]; };
-    struct Ring8 { Slot8 slot[NSLOT8]; volatile uint32_t head, tail, abort_, pad; };
+    struct Ring8 { Slot8 slot[NSLOT8]; volatile uint32_t tail, abort_, head, pad; };      // (tail | abort_: one aligned 64-bit read for the parser's look at the ring)
     RCX_LDS_AS Ring8* ring8;
     uint64_t pp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};          // PROF8 (A/B builds): cycles per parser phase, counts
 
@@ -504,14 +504,17 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
     {
         const unsigned lane = this->lane;
         auto ring = this->ring8;
+        uint32_t t;
         for (;;) {
-            const uint32_t t = RCX_U(ring->tail);
-            if (RCX_U(ring->abort_)) return false;
+            // (tail and abort in ONE read and one scalar move each way: the two words are neighbours, and the priority below follows the tail just read)
+            const uint64_t ta = *(const volatile RCX_LDS_AS uint64_t*)&ring->tail;
+            t = RCX_U((uint32_t)ta);
+            if (RCX_U((uint32_t)(ta >> 32))) return false;
             if (head - t < (uint32_t)NSLOT8) break;
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_sleep(RCX_V8_PSLEEP);
         }
-        if (RCX_V8_ADAPT) ring_prio(head);
+        if (RCX_V8_ADAPT) { if (head - t < (uint32_t)RCX_V8_LOW) __builtin_amdgcn_s_setprio(RCX_V8_HOT); else __builtin_amdgcn_s_setprio(RCX_V8_COLD); }
         else if ((RCX_AGE_PRIO & 16) && this->agey) __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO + 1); else __builtin_amdgcn_s_setprio(RCX_PARSER_PRIO);
         rcx_wave_sync();
         RCX_LDS_AS Slot8* sl = &ring->slot[head % NSLOT8];
@@ -577,8 +580,10 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
             if (why == B::SOLO_ || why == B::WIDE_) { const uint32_t r = po > (uint32_t)B::RH ? po - (uint32_t)B::RH : 0u; prlo = r > prlo ? r : prlo; }
         }
         if (lane == 0) {
-            sl->hdr[0] = (uint32_t)ns; sl->hdr[1] = (uint32_t)why | (plain ? 0x100u : 0u); sl->hdr[2] = (uint32_t)perr;
-            sl->hdr[3] = gL; sl->hdr[4] = gM; sl->hdr[5] = goff; sl->hdr[6] = gsrc; sl->hdr[7] = p0;
+            sl->hdr[0] = (uint32_t)ns; sl->hdr[1] = (uint32_t)why | (plain ? 0x100u : 0u); sl->hdr[7] = p0;
+            if (why != B::GO) {                                      // (the executor reads these behind a batch with a reason only)
+                sl->hdr[2] = (uint32_t)perr; sl->hdr[3] = gL; sl->hdr[4] = gM; sl->hdr[5] = goff; sl->hdr[6] = gsrc;
+            }
         }
         rcx_wave_sync();
         head++;
