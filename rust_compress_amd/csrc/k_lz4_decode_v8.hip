@@ -447,14 +447,15 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
         // lane in that path, and it was a fifth of the parser's time (the parser, not the executor, is what bounds this kernel: 0.41 of the
         // 0.50 ms with the executor switched off, benchmarks/pmc_insts.sh variant 45).  Left to the slow path: a run of 255s in either
         // length, bytes that are not staged, the block's last 20 bytes.
-        const bool fast = on && (uint64_t)p + 20u <= (uint64_t)n && ci >= 0 && ci + 8 <= CBUF8;
+        const bool nok = n >= 20u && n <= 0xfffffe00u;                // (uniform: 32-bit position arithmetic below cannot wrap)
+        const bool fast = on && nok && p <= n - 20u && ci >= 0 && ci + 8 <= CBUF8;
         if (__ballot(fast)) {
             const uint32_t v0 = B::lds_load4u(this->cbuf, fast ? ci : 0);
             const uint32_t t = v0 & 0xffu, Ln = t >> 4, Mn = t & 15u, b1 = (v0 >> 8) & 0xffu;
             const uint32_t lx = Ln == 15u ? 1u : 0u;
             const uint32_t Lf = Ln + (lx ? b1 : 0u);
             const uint32_t i = 1u + lx + Lf;                            // where the offset lies, from the token
-            const bool in2 = fast && !(lx && b1 == 255u) && (uint64_t)p + i + 3u <= (uint64_t)n && ci + (int32_t)i + 8 <= CBUF8;
+            const bool in2 = fast && !(lx && b1 == 255u) && p + i + 3u <= n && ci + (int32_t)i + 8 <= CBUF8;
             const uint32_t w = B::lds_load4u(this->cbuf, in2 ? ci + (int32_t)i : 0);      // offset lo, hi, first extension byte
             const uint32_t x = (w >> 16) & 0xffu;
             if (in2 && !(Mn == 15u && x == 255u)) {
@@ -642,7 +643,8 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
         // to emit, >= 40 bytes in front of the block's end -- and the first one >= 3 bytes behind its start
         bool plain = false;
         if (X6 && SPLIT) {
-            const bool odd = (M != 0u && off == 0u) || L + M == 0u || (uint64_t)tp + 40u > (uint64_t)this->n;      // (runs stay: emit6 fills them by period doubling)
+            const uint32_t n40 = this->n >= 40u ? this->n - 40u : 0u;
+            const bool odd = (M != 0u && off == 0u) || L + M == 0u || tp > n40;      // (runs stay: emit6 fills them by period doubling)
             // (a batch with more than RCX_X6_MAXRUNS runs goes through emit5, whose round loop doubles all its runs side by side: emit6 fills its
             //  runs one after the other as they become ready -- right for a text's one run in seven batches, slower for G-runs' several a batch)
             plain = nt > 0 && RCX_U(tp) >= 3u && !__ballot(put && odd) && __popcll(__ballot(put && M != 0u && off < 16u && off < M)) <= RCX_X6_MAXRUNS;
