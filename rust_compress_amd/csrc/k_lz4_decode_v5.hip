@@ -307,7 +307,9 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER, MIRROR> {
     // rounds, 2: chain analysis, 4: literal / gather stores, 16: window drain
     // FARCAP: the longest match that is gathered with 16-byte loads when its source has left the window (a longer one takes the
     // byte path): k_lz4_decode_v8 hands over matches of at most 32 bytes, so two of the four gathers and their stores are not compiled
-    template <bool LITLDS = false, bool NORED = false, int CUT = 0, int FARCAP = 64>
+    // FS (round 6): the derived executor that has Lz4X6's frame store (k_lz4_emit6.hip), or void -- with it (and no staging slots, SB = 0) a
+    // gathered match goes to its place as one or two masked frames loaded from `source - a` instead of two exec-narrowing byte stores
+    template <bool LITLDS = false, bool NORED = false, int CUT = 0, int FARCAP = 64, class FS = void>
     __device__ int emit5(int ns, int& lo, uint32_t w0, uint32_t w1, const uint8_t* litbuf = nullptr, bool young = true)   // young: RCX_AGE_PRIO (true: the plain levels)
     {
         const unsigned lane = this->lane;
@@ -383,12 +385,16 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER, MIRROR> {
         rcx_u32x4 f0, f1, f2, f3;
         RCX_NOINIT4(f0); RCX_NOINIT4(f1); RCX_NOINIT4(f2); RCX_NOINIT4(f3);
         constexpr uint32_t FC = FARCAP < B::MCAP ? (uint32_t)FARCAP : (uint32_t)B::MCAP;
-        const bool far16 = isfar && M <= FC && (uint64_t)slo + (uint32_t)B::MCAP <= (uint64_t)cap;      // (k_lz4_decode_v8 batches runs of up to 255 bytes: if one is ever outside the window, byte loads)
+        constexpr bool FR = !std::is_void<FS>::value && SB == 0 && FC <= 32;
+        const uint32_t af = FR ? (uint32_t)li_m & 3u : 0u;                                  // (FR: the frame's shift -- the window is 16-byte aligned)
+        const bool far16 = isfar && M <= FC && (uint64_t)slo + (uint32_t)B::MCAP <= (uint64_t)cap && (!FR || slo >= 4u);      // (k_lz4_decode_v8 batches runs of up to 255 bytes: if one is ever outside the window, byte loads)
         const bool farb = isfar && !far16;
+        uint32_t f2w = 0;
         if (!(CUT & 0x200) && (RCX_DEGUARD ? cap >= 64u : __ballot(far16) != 0)) {   // the same: all lanes load, from the output's first 64 bytes where there is no far match
-            const uint32_t q = far16 ? slo : 0u;
+            const uint32_t q = far16 ? slo - af : 0u;
             f0 = *(const rcx_u32x4_u*)(out + q);
-            if (FC > 16 && __ballot(far16 && M > 16)) f1 = *(const rcx_u32x4_u*)(out + q + 16);
+            if (FC > 16 && __ballot(far16 && af + M > 16)) f1 = *(const rcx_u32x4_u*)(out + q + 16);
+            if (FR && __ballot(far16 && af + M > 32)) f2w = *(const rcx_u32_u*)(out + q + 32);
             if (FC > 32 && __ballot(far16 && M > 32)) f2 = *(const rcx_u32x4_u*)(out + q + 32);
             if (FC > 48 && __ballot(far16 && M > 48)) f3 = *(const rcx_u32x4_u*)(out + q + 48);
         }
@@ -493,8 +499,14 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER, MIRROR> {
             uint8_t* d = wb_ + li_m;
             const uint32_t mf = far16 ? M : 0u;
             if (SB != 0 && far16) { uint8_t* sl = wb_ + STAGE5 + SB * (int32_t)lane; *(rcx_u32x4*)sl = f0; if (SB == 32) *(rcx_u32x4*)(sl + 16) = f1; }
-            if (SB == 0) RCX_LDS_STORE16(d, f0[0], f0[1], f0[2], f0[3], mf < 16u ? mf : 16u);     // no staging: every gathered byte goes straight to its place
-            if (SB <= 16 && __ballot(mf > 16)) RCX_LDS_STORE16(d + 16, f1[0], f1[1], f1[2], f1[3], mf > 16u ? (mf < 32u ? mf - 16u : 16u) : 0u);
+            if constexpr (FR) {
+                const uint32_t n1 = mf < 16u ? mf : 16u;
+                uint8_t* fp = d - (int32_t)af;
+                if (n1) static_cast<FS*>(this)->template store_frame<5>(fp, f0[0], f0[1], f0[2], f0[3], f1[0], af, n1);
+                if (mf > 16u) static_cast<FS*>(this)->template store_frame<5>(fp + 16, f1[0], f1[1], f1[2], f1[3], f2w, af, mf - n1);
+            }
+            if (!FR && SB == 0) RCX_LDS_STORE16(d, f0[0], f0[1], f0[2], f0[3], mf < 16u ? mf : 16u);     // no staging: every gathered byte goes straight to its place
+            if (!FR && SB <= 16 && __ballot(mf > 16)) RCX_LDS_STORE16(d + 16, f1[0], f1[1], f1[2], f1[3], mf > 16u ? (mf < 32u ? mf - 16u : 16u) : 0u);
             if (FC > 32 && __ballot(mf > 32)) RCX_LDS_STORE16(d + 32, f2[0], f2[1], f2[2], f2[3], mf > 32u ? (mf < 48u ? mf - 32u : 16u) : 0u);
             if (FC > 48 && __ballot(mf > 48)) RCX_LDS_STORE16(d + 48, f3[0], f3[1], f3[2], f3[3], mf > 48u ? mf - 48u : 0u);
         }

@@ -772,7 +772,7 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
 #endif
             // CUT 8 (A/B): the executor only drains the ring -- what is left is the parser wave's instructions; 32: nor its own scan
             if (CUT & 8) { if (!(CUT & 32)) this->oend += RCX_U(__builtin_amdgcn_readlane(w0, 63)) & 1u; lo = bt.ns; if (bt.why == B::END_ || bt.why == B::ERR_) break; continue; }   // (nor the long sequence behind the batch: with no output its checks would end the block at once -- round 5's "parser share" measured a few batches per block)
-            while (lo < bt.ns && !e) e = this->template emit5<false, PRED, CUT, (SPLIT ? SPLIT : 64)>(bt.ns, lo, w0, w1, nullptr, agey);
+            while (lo < bt.ns && !e) e = this->template emit5<false, PRED, CUT, (SPLIT ? SPLIT : 64), typename std::conditional<X6, Lz4V8, void>::type>(bt.ns, lo, w0, w1, nullptr, agey);
             RCX_MARK("x8_post_emit");
             if (e) { st = e; break; }
             if (PROF8) te1 = (uint64_t)__builtin_readcyclecounter();
