@@ -543,7 +543,7 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER, MIRROR> {
     Map tmap = {0, 0};
 #ifdef INF3_PROF
     uint64_t pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // cycles: [0] emit [1] wide copies [2] staging [3] block headers + tables [4] symbol passes in all [5] of them tile builds [6] chunks consumed [7] symbols booked
-#ifdef INF3_PROF_TILE
+#if defined(INF3_PROF_TILE) || defined(INF3_PROF_LINK)
 #define INF3_T(slot, code) do { code; } while (0)
 #else
 #define INF3_T(slot, code) do { const uint64_t t0__ = __builtin_readcyclecounter(); code; pf[slot] += __builtin_readcyclecounter() - t0__; } while (0)
@@ -707,7 +707,14 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER, MIRROR> {
         pf[3] += 1;
 #endif
         if (live) ex = q;
-        // link (see k_lz4_decode_v8.hip): the usual case lane by lane, the rest in order by scalar code over the lanes' registers
+#ifdef INF3_PROF_LINK                      /* (attribution: slots 0 / 1 / 2 / 3 = segments the link had to repair, cycles in the link, hops of the repairs, tiles) */
+        const uint64_t tl0_ = __builtin_readcyclecounter();
+#endif
+        // link (see k_lz4_decode_v8.hip): the usual case lane by lane, the rest in order by scalar code over the lanes' registers.
+        // (Round 6 measured it -- benchmarks/r6_inflate_tile.sh "" -DINF3_PROF_LINK=1: 79 of a member's 320 segments are repaired, 3.2 hops
+        // each, 290 K of a member's 1.57 M cycles -- and tried the repairs as a VECTOR pass, every failed segment walked again at once from
+        // the exit in front of it, repeated until the exits stand: failures come in runs, a run's later segments are walked again from
+        // entries that are themselves wrong, and the passes -- 14 a tile, 172 steps -- took three times the serial repairs: 27.6 ms.  Removed.)
         uint32_t lowv = 0; bool clr = false;
         const uint32_t eprev = (uint32_t)__shfl_up((int)ex, 1);
         const bool chk = mine && lane > 0;
@@ -723,6 +730,12 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER, MIRROR> {
                 cin = RCX_U(__builtin_amdgcn_readlane(ex, k - 1));
             }
             bad &= ~(1ull << k);
+#ifdef INF3_PROF_LINK
+            pf[0] += 1;
+#endif
+            // (the stream has ended, or left for the general path: every segment from here on is beyond it -- all of them at once, where each
+            //  took a turn of this loop: the last tile of every block has up to 63 of them)
+            if (cin >= XEOB) { if ((int)lane >= k) { clr = true; lowv = 0; } break; }
             const uint32_t sk = bp + SEGB4 * (uint32_t)k, ek = sk + SEGB4;
             const uint32_t exk = RCX_U(__builtin_amdgcn_readlane(ex, k));
             uint32_t X;
@@ -735,6 +748,9 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER, MIRROR> {
                     uint32_t q2 = cin, stop = 0;
                     while (q2 < ek && !mtest(mk, q2 - sk)) {
                         uint32_t kind, nb;
+#ifdef INF3_PROF_LINK
+                        pf[2] += 1;
+#endif
                         hop4(bits64(q2), kind, nb);
                         kind = RCX_U(kind); nb = RCX_U(nb);
                         mset(tm, q2 - sk);
@@ -756,6 +772,9 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER, MIRROR> {
         if (clr || !mine) { map.lo = 0; map.hi = 0; }
         mbelow(map, lowv);
         tmap = map;
+#ifdef INF3_PROF_LINK
+        pf[1] += __builtin_readcyclecounter() - tl0_; pf[3] += 1;
+#endif
     }
 
     __device__ __forceinline__ uint32_t pass4(uint32_t& flen, uint32_t& fdist)
@@ -962,7 +981,7 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER, MIRROR> {
                 }
                 ns = 0; litn = 0; runL = 0; runsrc = 0;
 #ifdef INF3_PROF
-#ifndef INF3_PROF_TILE
+#if !defined(INF3_PROF_TILE) && !defined(INF3_PROF_LINK)
                 pf[0] += __builtin_readcyclecounter() - tfl0;
 #endif
 #endif
@@ -995,7 +1014,7 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER, MIRROR> {
                     realign = false;
                 } else this->stage(p - ((bc + 7u) >> 3));              // from the byte of the next unread bit: pass() reads the bits from the buffer
 #ifdef INF3_PROF
-#ifndef INF3_PROF_TILE
+#if !defined(INF3_PROF_TILE) && !defined(INF3_PROF_LINK)
                 pf[2] += __builtin_readcyclecounter() - tst0;
 #endif
 #endif
@@ -1210,7 +1229,7 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER, MIRROR> {
 #ifdef INF3_PROF_CLENS                                         /* (attribution: the code-length decode counted apart, in the wide copies' slot) */
             pf[ph0 == P_SYMBOLS ? 4 : ph0 == P_CLENS ? 1 : 3] += __builtin_readcyclecounter() - tph0;
 #else
-#ifdef INF3_PROF_TILE
+#if defined(INF3_PROF_TILE) || defined(INF3_PROF_LINK)
             if (ph0 == P_SYMBOLS) pf[4] += __builtin_readcyclecounter() - tph0;
 #else
             pf[ph0 == P_SYMBOLS ? 4 : 3] += __builtin_readcyclecounter() - tph0;

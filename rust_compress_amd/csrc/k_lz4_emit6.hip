@@ -203,7 +203,11 @@ struct Lz4X6 : Base {
         if (lit2) g2 = *(const rcx_u32_u*)(in + ql + 32);
         rcx_u32x4 f0, f1; uint32_t f2;
         RCX_NOINIT4(f0); RCX_NOINIT4(f1); f2 = 0;
+#ifndef RCX_X6_NOFAR                     /* (attribution: no gathers -- wrong results on purpose) */
         if (re) {
+#else
+        if (false) {
+#endif
             const uint32_t qf = isfar ? slo - a2 : 0u;
             f0 = *(const rcx_u32x4_u*)(out + qf);
             f1 = *(const rcx_u32x4_u*)(out + qf + 16);
