@@ -33,8 +33,13 @@
 #ifndef RCX_V8_ESLEEP
 #define RCX_V8_ESLEEP 2                     /* (round 6, with emit6: 4 -> 2 and RCX_V8_LOW 4 -> 6: 0.508 -> 0.497 ms, benchmarks/r6_modes.sh) */
 #endif
+#ifndef RCX_FIELDS_ISA
+#define RCX_FIELDS_ISA 1                   /* fields(): the fast path as ISA (round 6) */
+#endif
 #ifndef RCX_WALK_FORM
-#define RCX_WALK_FORM 3                  /* 0: eight bytes + a second read where needed (portable), 1: sixteen bytes, the step as ISA, 2: form 0's whole loop as ISA,
+#define RCX_WALK_FORM 5                  /* 5 (round 6, the default): walk_steps2 -- the loop as ISA again, cheaper than hipcc's on BOTH ports (22 + 12 a step against
+                                            ~33 + ~45): parser alone 0.375 -> 0.326 ms, the launch 0.4755 -> 0.4634; the portable loop takes the block's last 20 bytes.
+                                            0: eight bytes + a second read where needed (portable), 1: sixteen bytes, the step as ISA, 2: form 0's whole loop as ISA,
                                             3: form 2 for a block's FIRST chunk, form 0 after it, 4: form 2 whenever the executor has fewer than RCX_WALK_ISA_LOW batches in front of it.
                                             Form 2 shortens the walk's latency (fewer scalar instructions, no divergent branches) and costs 30 more vector instructions a
                                             batch: a loss while the executors fill the vector ALU (0.534 against 0.528 ms), a gain before the block's first batch, when
@@ -287,6 +292,92 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
             : "vcc", "scc", "memory");
         return slow;
     }
+
+    // The loop again, cheaper on BOTH ports (RCX_WALK_FORM 5, round 6): the walking variable is the token's LDS ADDRESS (`ad`; the bound
+    // `ead` is the segment's end or the block's last 20 bytes, whichever comes first, 0 for a lane that does not walk -- the caller's
+    // portable loop takes what is left of the block's tail), the mark is one 64-bit shift and one 64-bit add under `exec`, the token's low nibble rides
+    // along in the v_perm that fetches the match-length extension byte (selector byte 1 = the token, bytes 2-3 = zero), the step to
+    // the next token is one v_addc (carry in = "match length 15"), and a token whose literals reach the block's end is not asked
+    // for -- such a lane leaves the loop past its bound, the caller clamps.  22 vector instructions a step + 2 where a mark is set,
+    // 12 on the scalar port with branches and waits (hipcc's loop: ~33 + ~45; walk_steps: 30 + 9 and ~22).  `exec` stays narrowed from
+    // step to step (a lane past its bound stays there).  Leaves with `slow` = the lanes whose token it does not decide (a run of
+    // 255s, an extension byte that is not staged), NOT advanced, or with steps = ~0 when no lane walks any more.
+    __device__ __forceinline__ uint64_t walk_steps2(uint32_t& ad, uint32_t ead, uint32_t sgad, uint64_t& m, uint32_t& steps) const
+    {
+        const uint32_t cend = RCX_U((uint32_t)(uintptr_t)this->cbuf + (uint32_t)CBUF8);
+        uint32_t a4, sh, d0, d1, d2, w0, w1, L, t1, hop, tm, x, rel, t2;
+        uint64_t slow = 0, sA, sB, sW, bit;
+        asm volatile(
+            "L_top_%=:\n\t"
+            "v_cmp_lt_u32_e32 vcc, %[ad], %[ead]\n\t"
+            "s_cbranch_vccz L_none_%=\n\t"
+            "s_mov_b64 exec, vcc\n\t"
+            "v_and_b32_e32 %[a4], -4, %[ad]\n\t"
+            "ds_read_b32 %[d0], %[a4]\n\t"
+            "ds_read_b32 %[d1], %[a4] offset:4\n\t"
+            "ds_read_b32 %[d2], %[a4] offset:8\n\t"
+            "v_sub_u32_e32 %[rel], %[ad], %[sgad]\n\t"                  // the mark, while the bytes are on their way
+            "v_and_b32_e32 %[sh], 3, %[ad]\n\t"
+            "v_cmp_gt_u32_e32 vcc, 64, %[rel]\n\t"                     // (two steps in three are head start: no lane in its own segment yet)
+            "s_cbranch_vccz L_nomark_%=\n\t"
+            "s_and_saveexec_b64 %[sW], vcc\n\t"
+            "v_lshlrev_b64 %[bit], %[rel], 1\n\t"
+            "v_lshl_add_u64 %[m], %[bit], 0, %[m]\n\t"                  // (a 64-bit OR the vector unit has not; a lane never marks a byte twice)
+            "s_mov_b64 exec, %[sW]\n\t"
+            "L_nomark_%=:\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_alignbyte_b32 %[w0], %[d1], %[d0], %[sh]\n\t"
+            "v_alignbyte_b32 %[w1], %[d2], %[d1], %[sh]\n\t"
+            "v_bfe_u32 %[L], %[w0], 4, 4\n\t"
+            "v_bfe_u32 %[t1], %[w0], 8, 8\n\t"
+            "v_cmp_eq_u32_e32 vcc, 15, %[L]\n\t"
+            "v_and_b32_e32 %[tm], 15, %[w0]\n\t"
+            "v_add_u32_e32 %[t1], 19, %[t1]\n\t"
+            "v_add_u32_e32 %[L], 3, %[L]\n\t"
+            "v_cndmask_b32_e32 %[hop], %[L], %[t1], vcc\n\t"            // token, (15 + the extension byte + that byte), literals, offset: where the match-length extension would be
+            "v_cmp_eq_u32_e64 %[sA], 15, %[tm]\n\t"
+            "v_cmp_lt_u32_e32 vcc, 7, %[hop]\n\t"
+            "v_and_or_b32 %[t2], %[hop], 7, %[ksel]\n\t"
+            "v_perm_b32 %[x], %[w1], %[w0], %[t2]\n\t"                  // token << 8 | the byte at `hop` of the eight in hand
+            "s_and_b64 vcc, vcc, %[sA]\n\t"                              // a match-length extension beyond the eight bytes
+            "s_cbranch_vccz L_no2_%=\n\t"
+            "s_and_saveexec_b64 %[sB], vcc\n\t"
+            "v_add_u32_e32 %[t2], %[ad], %[hop]\n\t"
+            "v_mov_b32_e32 %[x], 0xfff\n\t"                             // not staged: \"the extension goes on\" = the slow path
+            "v_cmp_gt_u32_e32 vcc, %[cend], %[t2]\n\t"
+            "s_mov_b64 exec, vcc\n\t"
+            "ds_read_u8 %[x], %[t2]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_or_b32_e32 %[x], 0xf00, %[x]\n\t"
+            "s_mov_b64 exec, %[sB]\n\t"
+            "L_no2_%=:\n\t"
+            "v_and_b32_e32 %[x], 0xfff, %[x]\n\t"
+            "v_cmp_le_u32_e64 %[sB], %[k274], %[hop]\n\t"                // literal length 15 and its extension 255
+            "v_cmp_eq_u32_e32 vcc, 0xfff, %[x]\n\t"                     // match length 15 and its extension 255 (or out of sight)
+            "v_addc_co_u32_e64 %[ad], %[sW], %[ad], %[hop], %[sA]\n\t"   // + 1 for a match-length extension byte
+            "s_or_b64 vcc, vcc, %[sB]\n\t"
+            "s_cbranch_vccnz L_slow_%=\n\t"
+            "s_sub_u32 %[steps], %[steps], 1\n\t"
+            "s_cmp_lg_u32 %[steps], 0\n\t"
+            "s_cbranch_scc1 L_top_%=\n\t"
+            "s_branch L_out_%=\n\t"
+            "L_slow_%=:\n\t"
+            "s_mov_b64 %[slow], vcc\n\t"
+            "s_mov_b64 exec, vcc\n\t"
+            "v_subb_co_u32_e64 %[ad], %[sW], %[ad], %[hop], %[sA]\n\t"   // the lanes the caller takes stay where they were
+            "s_sub_u32 %[steps], %[steps], 1\n\t"
+            "s_branch L_out_%=\n\t"
+            "L_none_%=:\n\t"
+            "s_mov_b32 %[steps], -1\n\t"
+            "L_out_%=:\n\t"
+            "s_mov_b64 exec, -1\n\t"
+            : [ad] "+v"(ad), [m] "+v"(m), [steps] "+s"(steps), [slow] "+s"(slow), [sA] "=&s"(sA), [sB] "=&s"(sB), [sW] "=&s"(sW),
+              [a4] "=&v"(a4), [sh] "=&v"(sh), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [w0] "=&v"(w0), [w1] "=&v"(w1), [L] "=&v"(L),
+              [t1] "=&v"(t1), [hop] "=&v"(hop), [tm] "=&v"(tm), [x] "=&v"(x), [rel] "=&v"(rel), [bit] "=&v"(bit), [t2] "=&v"(t2)
+            : [ead] "v"(ead), [sgad] "v"(sgad), [cend] "s"(cend), [k274] "s"(274u), [ksel] "s"(0x0c0c0000u)
+            : "vcc", "scc", "memory");
+        return slow;
+    }
 #endif
 
     // The same from the staged bytes: p lies in [cbase, chunk end) (the walk never leaves them).  ONE LDS round trip for nearly every
@@ -448,8 +539,78 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
         // 0.50 ms with the executor switched off, benchmarks/pmc_insts.sh variant 45).  Left to the slow path: a run of 255s in either
         // length, bytes that are not staged, the block's last 20 bytes.
         const bool nok = n >= 20u && n <= 0xfffffe00u;                // (uniform: 32-bit position arithmetic below cannot wrap)
+#if RCX_FIELDS_ISA && !defined(RCX_NO_WALK_ASM)
+        // The fast path as ISA (round 6): hipcc's code for the C++ below is ~75 vector and ~45 scalar instructions a batch -- every `&&`
+        // an s_and_saveexec / branch pair, every default a v_mov on each side of it; this is 30 + 14, straight down, `exec` narrowed
+        // twice (the lanes whose literal run is in sight, then the lanes whose match length is) and `done` = the lanes it decided.
+        if (nok) {
+            const uint32_t cb0 = RCX_U((uint32_t)(uintptr_t)this->cbuf);
+            uint32_t cix, ad, a4, sh, d0, d1, w0, Ln, b1, Mn, t, Lf, i, pe;
+            uint64_t sB, sL, sX, done = 0;
+            asm volatile(
+                "v_subrev_u32_e32 %[ci], %[cbase], %[p]\n\t"
+                "v_cmp_gt_u32_e32 vcc, %[k1], %[ci]\n\t"                 // staged: 0 <= ci, ci + 8 <= CBUF8
+                "v_cmp_ge_u32_e64 %[sB], %[n20], %[p]\n\t"               // not in the block's last 20 bytes
+                "s_and_b64 vcc, vcc, %[on]\n\t"
+                "s_and_b64 vcc, vcc, %[sB]\n\t"
+                "s_cbranch_vccz L_end_%=\n\t"
+                "s_mov_b64 exec, vcc\n\t"
+                "v_add_u32_e32 %[ad], %[cb0], %[ci]\n\t"
+                "v_and_b32_e32 %[a4], -4, %[ad]\n\t"
+                "ds_read_b32 %[d0], %[a4]\n\t"
+                "ds_read_b32 %[d1], %[a4] offset:4\n\t"
+                "v_and_b32_e32 %[sh], 3, %[ad]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_alignbyte_b32 %[w0], %[d1], %[d0], %[sh]\n\t"         // token, literal-length extension, ...
+                "v_bfe_u32 %[Ln], %[w0], 4, 4\n\t"
+                "v_bfe_u32 %[b1], %[w0], 8, 8\n\t"
+                "v_and_b32_e32 %[Mn], 15, %[w0]\n\t"
+                "v_cmp_eq_u32_e32 vcc, 15, %[Ln]\n\t"
+                "v_cndmask_b32_e32 %[t], 0, %[b1], vcc\n\t"
+                "s_mov_b64 %[sL], vcc\n\t"
+                "v_add_u32_e32 %[Lf], %[Ln], %[t]\n\t"
+                "v_addc_co_u32_e64 %[i], %[sX], %[Lf], 1, vcc\n\t"       // where the offset lies, from the token
+                "v_cmp_ne_u32_e64 %[sB], %[k270], %[Lf]\n\t"             // (15 + 255: the extension goes on)
+                "v_add3_u32 %[pe], %[p], %[i], 3\n\t"
+                "v_add_u32_e32 %[ad], %[ad], %[i]\n\t"
+                "v_cmp_ge_u32_e32 vcc, %[n], %[pe]\n\t"                  // offset and one extension byte lie in the block ...
+                "s_and_b64 %[sB], %[sB], vcc\n\t"
+                "v_cmp_gt_u32_e32 vcc, %[cend7], %[ad]\n\t"              // ... and are staged
+                "s_and_b64 %[sB], %[sB], vcc\n\t"
+                "s_and_b64 exec, exec, %[sB]\n\t"
+                "s_cbranch_execz L_end_%=\n\t"
+                "v_and_b32_e32 %[a4], -4, %[ad]\n\t"
+                "ds_read_b32 %[d0], %[a4]\n\t"
+                "ds_read_b32 %[d1], %[a4] offset:4\n\t"
+                "v_and_b32_e32 %[sh], 3, %[ad]\n\t"
+                "v_cmp_eq_u32_e32 vcc, 15, %[Mn]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_alignbyte_b32 %[w0], %[d1], %[d0], %[sh]\n\t"         // offset lo, hi, first match-length extension byte
+                "v_bfe_u32 %[t], %[w0], 16, 8\n\t"
+                "v_cndmask_b32_e32 %[t], 0, %[t], vcc\n\t"
+                "v_cmp_ne_u32_e64 %[sB], %[k255], %[t]\n\t"              // (255: the extension goes on)
+                "s_and_b64 exec, exec, %[sB]\n\t"
+                "v_mov_b32_e32 %[L], %[Lf]\n\t"
+                "v_and_b32_e32 %[off], 0xffff, %[w0]\n\t"
+                "v_add3_u32 %[M], %[Mn], %[t], 4\n\t"
+                "v_addc_co_u32_e64 %[src], %[sX], %[p], 1, %[sL]\n\t"
+                "s_mov_b64 %[done], exec\n\t"
+                "L_end_%=:\n\t"
+                "s_mov_b64 exec, -1\n\t"
+                : [L] "+v"(L), [M] "+v"(M), [off] "+v"(off), [src] "+v"(src), [done] "+s"(done), [sB] "=&s"(sB), [sL] "=&s"(sL), [sX] "=&s"(sX),
+                  [ci] "=&v"(cix), [ad] "=&v"(ad), [a4] "=&v"(a4), [sh] "=&v"(sh), [d0] "=&v"(d0), [d1] "=&v"(d1), [w0] "=&v"(w0), [Ln] "=&v"(Ln), [b1] "=&v"(b1),
+                  [Mn] "=&v"(Mn), [t] "=&v"(t), [Lf] "=&v"(Lf), [i] "=&v"(i), [pe] "=&v"(pe)
+                : [p] "v"(p), [on] "s"(__ballot(on)), [cbase] "s"((uint32_t)this->cbase), [k1] "s"((uint32_t)(CBUF8 - 7)), [n20] "s"(n - 20u), [cb0] "s"(cb0),
+                  [k270] "s"(270u), [k255] "s"(255u), [n] "s"(n), [cend7] "s"(cb0 + (uint32_t)(CBUF8 - 7))
+                : "vcc", "scc", "memory");
+            slow = on && !RCX_INV_BALLOT(done);
+        }
+        const bool fast = false;
+        if (false) {
+#else
         const bool fast = on && nok && p <= n - 20u && ci >= 0 && ci + 8 <= CBUF8;
         if (__ballot(fast)) {
+#endif
             const uint32_t v0 = B::lds_load4u(this->cbuf, fast ? ci : 0);
             const uint32_t t = v0 & 0xffu, Ln = t >> 4, Mn = t & 15u, b1 = (v0 >> 8) & 0xffu;
             const uint32_t lx = Ln == 15u ? 1u : 0u;
@@ -824,7 +985,23 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
             uint32_t p = ((int)lane == k0) ? c : (uint32_t)p0;
             uint64_t map = (giant && (int)lane == k0) ? 1ull << (c - (uint32_t)s) : 0ull;
             RCX_MARK("p8_walk");
-#if (RCX_WALK_FORM >= 2) && !defined(RCX_NO_WALK_ASM)
+#if (RCX_WALK_FORM == 5) && !defined(RCX_NO_WALK_ASM)
+            if (n >= 20u) {                                          // (the portable loop below takes what this one leaves: the block's last 20 bytes)
+                const uint32_t adj = RCX_U((uint32_t)(uintptr_t)this->cbuf - (uint32_t)this->cbase);     // LDS byte address of input byte q = q + adj
+                const uint32_t e20 = e < n - 19u ? e : n - 19u;
+                const uint32_t ead = mine ? e20 + adj : 0u, sgad = (uint32_t)s + adj;
+                uint32_t ad = p + adj;
+                for (;;) {
+                    uint32_t steps = 4;
+                    const uint64_t slow = walk_steps2(ad, ead, sgad, map, steps);
+                    if (PROF8) pp[7] += steps == 0xffffffffu ? 0 : 4 - steps;
+                    if (slow) { if (RCX_INV_BALLOT(slow)) ad = next_tok(ad - adj) + adj; }
+                    else if (steps == 0xffffffffu) break;
+                    if (RCX_V8_ADAPT) ring_prio(head, RCX_V8_LOW_WALK);
+                }
+                p = ad - adj; p = p < n ? p : n;
+            }
+#elif (RCX_WALK_FORM >= 2) && !defined(RCX_NO_WALK_ASM)
             if (n >= 20u && (RCX_WALK_FORM == 2 || head == 0 || (RCX_WALK_FORM == 4 && head - RCX_U(this->ring8->tail) < (uint32_t)RCX_WALK_ISA_LOW))) {
                 uint32_t mlo = (uint32_t)map, mhi = (uint32_t)(map >> 32);
                 const uint64_t minem = __ballot(mine);
