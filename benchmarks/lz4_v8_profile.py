@@ -17,7 +17,21 @@ ctx.set_variant(N.LZ4_DECODE, 24)
 sc = torch.zeros(nb * 256 + 64, dtype=torch.uint8, device=dev)
 for _ in range(2):
     ctx.launch_dev(N.LZ4_DECODE, dec, sc); torch.cuda.synchronize()
-p = sc[: nb * 256].view(torch.int64).view(nb, 32).cpu().numpy().astype(np.float64).mean(axis=0)
+allp = sc[: nb * 256].view(torch.int64).view(nb, 32).cpu().numpy().astype(np.float64)
+p = allp.mean(axis=0)
+if allp[:, 13].min() > 0:      # when each block started and ended (s_memrealtime, 10 ns ticks), against the first start
+    t0 = allp[:, 13].min(); st = (allp[:, 13] - t0) / 100.0; en = (allp[:, 14] - t0) / 100.0
+    q = lambda a: "  ".join("%d%% %.1f" % (k, np.percentile(a, k)) for k in (0, 10, 50, 90, 99, 100))
+    print("block start, us after the first:", q(st)); print("block end,   us after the first start:", q(en)); print("block life, us:", q(en - st))
+    raw = sc[: nb * 256].view(torch.int64).view(nb, 32).cpu().numpy()
+    hw = raw[:, 15] & 0xffffffff; xcc = (raw[:, 15] >> 32) & 0xf
+    cu = ((hw >> 8) & 0xf) | (((hw >> 12) & 0x1) << 4) | (((hw >> 13) & 0x7) << 5) | (xcc << 8)      # CU_ID[11:8], SH_ID[12], SE_ID[15:13], XCC
+    ids = np.unique(cu); print("CUs seen:", len(ids), " blocks a CU: min %d max %d" % (min((cu == i).sum() for i in ids), max((cu == i).sum() for i in ids)))
+    cend = np.array([en[cu == i].max() for i in ids]); cfirst = np.array([en[cu == i].min() for i in ids])
+    print("a CU's LAST block ends, us:", q(cend)); print("a CU's FIRST block ends, us:", q(cfirst))
+    rank = (hw & 0xf) >> 1
+    print("block end by the executor's age rank on its SIMD (wave slot >> 1), us: " + "  ".join("%d: %.1f (n %d)" % (r, en[rank == r].mean(), (rank == r).sum()) for r in np.unique(rank)))
+    xe = (allp[:, 11]); print("executor cycles per block: min %.0fK mean %.0fK max %.0fK" % (xe.min() / 1e3, xe.mean() / 1e3, xe.max() / 1e3))
 names = ["walk", "link", "list", "fields", "post(wait)", "-", "tiles", "walk steps", "repairs", "batches"]
 print("kind %s, %d blocks: parser total %.0fK cycles, executor total %.0fK" % (kind, nb, p[10] / 1e3, p[11] / 1e3))
 print("  cycles: " + "  ".join("%s %.0fK" % (names[i], p[i] / 1e3) for i in range(5)))

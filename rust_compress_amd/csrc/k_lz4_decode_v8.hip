@@ -45,6 +45,12 @@
                                             batch: a loss while the executors fill the vector ALU (0.534 against 0.528 ms), a gain before the block's first batch, when
                                             nothing else runs on the SIMD (3: 0.5224; 4 with LOW 2 / 3 / 4 / 6: 0.5233 / 0.5220 / 0.5229 / 0.5240 -- no better than 3) */
 #endif
+#ifndef RCX_V8_PRE
+#define RCX_V8_PRE 128                     /* the guessing lanes' head start, bytes (the kernel template's default) */
+#endif
+#ifndef RCX_WALK_STEPS
+#define RCX_WALK_STEPS 16                  /* steps of the ISA walk between two looks at the ring (ring_prio): 4 / 8 / 16 / 64: 0.4604 / 0.4587 / 0.4565 / 0.479 ms */
+#endif
 #ifndef RCX_WALK_ISA_LOW
 #define RCX_WALK_ISA_LOW 3
 #endif
@@ -83,6 +89,14 @@
 #ifndef RCX_AGE_DYN
 #define RCX_AGE_DYN 0
 #endif
+#ifndef RCX_AGE_DUTY
+#define RCX_AGE_DUTY 0x4200              /* 0: off (RCX_AGE_SPLIT alone).  Else a nibble per age rank (rank 0 = the oldest pair of waves on the SIMD, in bits 3:0): of every
+                                            four batches, how many the executor handles at the YOUNG half's priority levels -- 0x4400 is what RCX_AGE_SPLIT 2 does.
+                                            Round 6 (benchmarks/r6_age.sh: when each block ends, by rank): with 0x4400 the ranks end at 458 / 486 / 455 / 485 us -- the
+                                            boost of rank 2 is too strong, rank 1 has none -- and a CU's last block at 498; 0x4200: 437 / 467 / 472 / 480, the last at
+                                            489; 0.4562 -> 0.4505 ms, G-runs 0.714 -> 0.690.  0x4210 / 0x4310 / 0x3210 / 0x4211 within 0.5 % of it, 0x4320 best for
+                                            G-runs (0.669) and no gain for a text; lowering the old ranks' executor one more level (RCX_AGE_PRIO 42): 0.459 */
+#endif
 #ifndef RCX_RUNSPLIT
 #define RCX_RUNSPLIT 1                   /* a run longer than SPLIT bytes as pieces that copy side by side (post()); 0: one lane fills it (A/B) */
 #endif
@@ -118,6 +132,7 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
     static constexpr int SPLIT = SPLIT_;
     static_assert(SPLIT_ == 0 || 2 * SPLIT_ >= 64, "two entries cover the 64-byte cap");
     uint32_t* prog = nullptr; uint32_t wslot = 0;  // RCX_AGE_DYN: this SIMD's eight words, my wave slot
+    uint32_t agerank = 0;                         // RCX_AGE_DUTY: the executor's age rank among its SIMD's four
     bool agey = true;                             // RCX_AGE_PRIO (k_lz4_decode_v5.hip): this wave is in the younger half of its SIMD's (true: the plain levels)
     typedef Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR> P5;
     typedef typename P5::B B;
@@ -873,6 +888,7 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
                 dyn_pv = __hip_atomic_load(prog + (lane & 7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 dyn_mine = mine;
             }
+            if (RCX_AGE_DUTY) agey = (tail & 3u) < ((uint32_t)(RCX_AGE_DUTY >> (4u * agerank)) & 15u);
             tail++;
             if (lane == 0) ring->tail = tail;             // the slot is in registers: hand it back
             // where each entry's literals lie: behind its token, and the tokens follow one another (the second half of a split
@@ -992,9 +1008,9 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
                 const uint32_t ead = mine ? e20 + adj : 0u, sgad = (uint32_t)s + adj;
                 uint32_t ad = p + adj;
                 for (;;) {
-                    uint32_t steps = 4;
+                    uint32_t steps = RCX_WALK_STEPS;
                     const uint64_t slow = walk_steps2(ad, ead, sgad, map, steps);
-                    if (PROF8) pp[7] += steps == 0xffffffffu ? 0 : 4 - steps;
+                    if (PROF8) pp[7] += steps == 0xffffffffu ? 0 : RCX_WALK_STEPS - steps;
                     if (slow) { if (RCX_INV_BALLOT(slow)) ad = next_tok(ad - adj) + adj; }
                     else if (steps == 0xffffffffu) break;
                     if (RCX_V8_ADAPT) ring_prio(head, RCX_V8_LOW_WALK);
@@ -1147,13 +1163,14 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
 
 // X6: plain batches through emit6 (-1: wherever nothing else is being measured or cut out).  The mask table takes the place of the
 // gathered matches' staging slots (SB = 0: emit5 stores what it gathers straight to its place).
-template <int TC = 1024, int HH = 768, bool PROF8 = false, int PRE_ = 128, int SPLIT_ = 32, bool PRED = false, int PRR = 2, int CUT = 0, bool MIRROR = false, int X6_ = -1>
+template <int TC = 1024, int HH = 768, bool PROF8 = false, int PRE_ = RCX_V8_PRE, int SPLIT_ = 32, bool PRED = false, int PRR = 2, int CUT = 0, bool MIRROR = false, int X6_ = -1>
 __global__ __launch_bounds__(128, 8) void k_lz4_decode_v8(rcx_kargs a, int only_status = 0)
 {
     constexpr bool X6 = RCX_X6_MODE != 0 && (X6_ < 0 ? (CUT == 0 && !PRED && SPLIT_ != 0 && !MIRROR) : X6_ != 0);      // (MIRROR: the launch is bound by the PCIe link, and with emit6 inlined as well the kernel spills)
     typedef Lz4V8<TC, HH, X6 ? 0 : 16, PROF8, PRE_, SPLIT_, PRED, PRR, CUT, MIRROR, X6> S;
     __shared__ __align__(16) uint32_t s_mtab[X6 ? 160 : 4];
     const uint64_t tk0 = PROF8 ? (uint64_t)__builtin_readcyclecounter() : 0;
+    const uint64_t rt0 = PROF8 ? (uint64_t)__builtin_amdgcn_s_memrealtime() : 0;        // (100 MHz, one clock for the whole GPU: when the block started and ended)
     __shared__ __align__(16) uint8_t s_wbuf[S::WBUF5 + 16 + (X6 ? 16 : 0)];    // (X6: 16 bytes in front -- a source frame starts up to 3 bytes below the window)
     __shared__ __align__(16) typename S::Ring8 s_ring;
     __shared__ __align__(16) uint8_t s_cbuf[S::CBUF8 + 16];
@@ -1232,6 +1249,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_decode_v8(rcx_kargs a, int only_
     // two waves take a pair), so slot >> 1 is the executor's age rank among the four of its SIMD
     const uint32_t hwid = (PROF8 || RCX_AGE_PRIO) ? (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) : 0u;
     s.agey = RCX_AGE_PRIO ? ((hwid >> 1) & 7u) >= (uint32_t)RCX_AGE_SPLIT : true;
+    s.agerank = (hwid >> 1) & 3u;
     RCX_SETPRIO_EXEC(s.agey);
     if (X6) { s.lane = rcx_lane(); s.mtab_init(); }
     s.run_executor8(&st, &olen);
@@ -1239,6 +1257,8 @@ __global__ __launch_bounds__(128, 8) void k_lz4_decode_v8(rcx_kargs a, int only_
         uint64_t* q = (uint64_t*)a.scratch + (size_t)b * 32;
         q[11] = (uint64_t)__builtin_readcyclecounter() - tk0;
         q[12] = hwid;
+        q[13] = rt0; q[14] = (uint64_t)__builtin_amdgcn_s_memrealtime();
+        q[15] = (uint64_t)(uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) | ((uint64_t)(uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) << 32);   // HW_ID, XCC_ID
         for (int i = 0; i < 12; i++) q[16 + i] = s.pw[i];
     }
     if ((threadIdx.x & 63u) == 0) {
