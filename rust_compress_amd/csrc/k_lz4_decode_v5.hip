@@ -52,10 +52,11 @@
 #ifndef RCX_AGE_SPLIT
 #define RCX_AGE_SPLIT 2                  /* age ranks below this are "old" */
 #endif
-#define RCX_SETPRIO_EXEC(young) do { if ((RCX_AGE_PRIO & 1) && (young)) __builtin_amdgcn_s_setprio(RCX_EXEC_PRIO + 1); else if ((RCX_AGE_PRIO & 32) && !(young)) __builtin_amdgcn_s_setprio(RCX_EXEC_PRIO - 1); else __builtin_amdgcn_s_setprio(RCX_EXEC_PRIO); } while (0)
-#define RCX_SETPRIO_ROUND(young) do { if ((RCX_AGE_PRIO & 2) && !(young)) __builtin_amdgcn_s_setprio(RCX_ROUND_PRIO - 1); else __builtin_amdgcn_s_setprio(RCX_ROUND_PRIO); } while (0)
+// (young: bit 0 = this batch at the young half's levels; bit 1 = RCX_AGE_LOW: this batch's plain stretches one level down)
+#define RCX_SETPRIO_EXEC(young) do { if ((int)(young) & 2) __builtin_amdgcn_s_setprio(RCX_EXEC_PRIO - 1); else if ((RCX_AGE_PRIO & 1) && ((int)(young) & 1)) __builtin_amdgcn_s_setprio(RCX_EXEC_PRIO + 1); else if ((RCX_AGE_PRIO & 32) && !((int)(young) & 1)) __builtin_amdgcn_s_setprio(RCX_EXEC_PRIO - 1); else __builtin_amdgcn_s_setprio(RCX_EXEC_PRIO); } while (0)
+#define RCX_SETPRIO_ROUND(young) do { if ((RCX_AGE_PRIO & 2) && !((int)(young) & 1)) __builtin_amdgcn_s_setprio(RCX_ROUND_PRIO - 1); else __builtin_amdgcn_s_setprio(RCX_ROUND_PRIO); } while (0)
 // bit 3: the older half drains one level down
-#define RCX_SETPRIO_FLUSH(young) do { if ((RCX_AGE_PRIO & 8) && !(young)) __builtin_amdgcn_s_setprio(RCX_FLUSH_PRIO - 1); else __builtin_amdgcn_s_setprio(RCX_FLUSH_PRIO); } while (0)
+#define RCX_SETPRIO_FLUSH(young) do { if ((RCX_AGE_PRIO & 8) && !((int)(young) & 1)) __builtin_amdgcn_s_setprio(RCX_FLUSH_PRIO - 1); else __builtin_amdgcn_s_setprio(RCX_FLUSH_PRIO); } while (0)
 #include <type_traits>
 #ifdef RCX_MARKS
 #define RCX_MARK(name) asm volatile("; MARK " name)
@@ -310,7 +311,7 @@ struct Lz4V5 : Lz4V4<CB, false, TC, HH, ADLER, MIRROR> {
     // FS (round 6): the derived executor that has Lz4X6's frame store (k_lz4_emit6.hip), or void -- with it (and no staging slots, SB = 0) a
     // gathered match goes to its place as one or two masked frames loaded from `source - a` instead of two exec-narrowing byte stores
     template <bool LITLDS = false, bool NORED = false, int CUT = 0, int FARCAP = 64, class FS = void>
-    __device__ int emit5(int ns, int& lo, uint32_t w0, uint32_t w1, const uint8_t* litbuf = nullptr, bool young = true)   // young: RCX_AGE_PRIO (true: the plain levels)
+    __device__ int emit5(int ns, int& lo, uint32_t w0, uint32_t w1, const uint8_t* litbuf = nullptr, int young = 1)   // young: RCX_AGE_PRIO (true: the plain levels)
     {
         const unsigned lane = this->lane;
         const uint8_t* in = this->in; uint8_t* out = this->out; uint8_t* wb_ = this->wb_;

@@ -89,6 +89,9 @@
 #ifndef RCX_AGE_DYN
 #define RCX_AGE_DYN 0
 #endif
+#ifndef RCX_AGE_LOW
+#define RCX_AGE_LOW 0                    /* a nibble per age rank like RCX_AGE_DUTY: of every four batches, how many run their plain stretches (header, scan, loads) one level down */
+#endif
 #ifndef RCX_AGE_DUTY
 #define RCX_AGE_DUTY 0x4200              /* 0: off (RCX_AGE_SPLIT alone).  Else a nibble per age rank (rank 0 = the oldest pair of waves on the SIMD, in bits 3:0): of every
                                             four batches, how many the executor handles at the YOUNG half's priority levels -- 0x4400 is what RCX_AGE_SPLIT 2 does.
@@ -889,12 +892,13 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
                 dyn_mine = mine;
             }
             if (RCX_AGE_DUTY) agey = (tail & 3u) < ((uint32_t)(RCX_AGE_DUTY >> (4u * agerank)) & 15u);
+            const int agev = (agey ? 1 : 0) | ((RCX_AGE_LOW && (tail & 3u) < ((uint32_t)(RCX_AGE_LOW >> (4u * agerank)) & 15u)) ? 2 : 0);
             tail++;
             if (lane == 0) ring->tail = tail;             // the slot is in registers: hand it back
             // where each entry's literals lie: behind its token, and the tokens follow one another (the second half of a split
             // match, flagged 0x80, is no token)
             if (X6 && plain6) { RCX_V8_STAT(10, lane == 0 && bt.why == B::SOLO_); RCX_V8_STAT(11, lane == 0 && bt.why == B::WIDE_); RCX_V8_STAT(12, lane == 0 ? (uint32_t)bt.ns : 0u); RCX_V8_STAT(13, lane == 0); }
-            if (X6 && plain6 && this->emit6(bt.ns, w1, p0, agey)) {
+            if (X6 && plain6 && this->emit6(bt.ns, w1, p0, agev)) {
                 if (this->after_batch(bt, st)) break;
                 continue;
             }
@@ -949,7 +953,7 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
 #endif
             // CUT 8 (A/B): the executor only drains the ring -- what is left is the parser wave's instructions; 32: nor its own scan
             if (CUT & 8) { if (!(CUT & 32)) this->oend += RCX_U(__builtin_amdgcn_readlane(w0, 63)) & 1u; lo = bt.ns; if (bt.why == B::END_ || bt.why == B::ERR_) break; continue; }   // (nor the long sequence behind the batch: with no output its checks would end the block at once -- round 5's "parser share" measured a few batches per block)
-            while (lo < bt.ns && !e) e = this->template emit5<false, PRED, CUT, (SPLIT ? SPLIT : 64), typename std::conditional<X6, Lz4V8, void>::type>(bt.ns, lo, w0, w1, nullptr, agey);
+            while (lo < bt.ns && !e) e = this->template emit5<false, PRED, CUT, (SPLIT ? SPLIT : 64), typename std::conditional<X6, Lz4V8, void>::type>(bt.ns, lo, w0, w1, nullptr, agev);
             RCX_MARK("x8_post_emit");
             if (e) { st = e; break; }
             if (PROF8) te1 = (uint64_t)__builtin_readcyclecounter();

@@ -162,7 +162,7 @@ struct Lz4X6 : Base {
 
     // One plain batch (ns entries, lane i holds entry i's word; p0: where the batch's first token starts).  Returns false -- nothing
     // touched but the window's position (make_room) -- when the batch has to go through emit5 after all.
-    __device__ __forceinline__ bool emit6(int ns, uint32_t w1raw, uint32_t p0, bool young)
+    __device__ __forceinline__ bool emit6(int ns, uint32_t w1raw, uint32_t p0, int young)
     {
         const unsigned lane = this->lane;
         const uint8_t* in = this->in; uint8_t* out = this->out; uint8_t* wb_ = this->wb_;
