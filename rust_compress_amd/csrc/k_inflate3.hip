@@ -227,6 +227,112 @@ __device__ __forceinline__ uint64_t rcx_inf_hops(uint32_t& q, uint32_t e, uint32
 }
 #endif
 
+// The same loop for the link's repairs (round 6): the lanes in `act` walk from q as above, but every step first looks the position up in
+// the lane's OLD map (o0..o3) -- a marked bit means the walk has met the one the lane made from its guessed start, and the lane leaves
+// through `merged` -- and the marks go to a NEW map (t0..t3).  The serial link calls it with one lane in `act`; it took the portable hop4
+// (~140 instructions) for every step of a repair: 256 steps a member, a sixth of its time (benchmarks/r6_inflate_tile.sh).
+#ifndef RCX_NO_INF_WALK_ASM
+__device__ __forceinline__ uint64_t rcx_inf_rewalk(uint32_t& q, uint32_t e, uint32_t s, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3,
+                                                   uint32_t& t0, uint32_t& t1, uint32_t& t2, uint32_t& t3, uint64_t act, uint64_t& merged, uint32_t cb, uint32_t ll, uint32_t ld)
+{
+    uint32_t a, w0, w1, w2, lo, hi, eL, nb, eD, t, u, bit, ow;
+    uint64_t stall, tmp;
+    asm volatile(
+        "s_mov_b64 %[stall], 0\n\t"
+        "L_top_%=:\n\t"
+        "v_cmp_lt_u32_e32 vcc, %[q], %[e]\n\t"
+        "s_and_b64 vcc, vcc, %[act]\n\t"
+        "s_cbranch_vccz L_out_%=\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "v_lshrrev_b32_e32 %[a], 5, %[q]\n\t"
+        "v_lshl_add_u32 %[a], %[a], 2, %[cb]\n\t"                 // the dword that holds bit q
+        "ds_read_b32 %[w0], %[a]\n\t"
+        "ds_read_b32 %[w1], %[a] offset:4\n\t"
+        "ds_read_b32 %[w2], %[a] offset:8\n\t"
+        "v_sub_u32_e32 %[bit], %[q], %[s]\n\t"                    // (the look-up in the old map, while the bits are on their way)
+        "v_lshrrev_b32_e32 %[a], 5, %[bit]\n\t"                   // map word 0..3
+        "v_lshlrev_b32_e64 %[bit], %[bit], 1\n\t"
+        "v_cmp_eq_u32_e32 vcc, 1, %[a]\n\t"
+        "v_cndmask_b32_e32 %[ow], %[o0], %[o1], vcc\n\t"
+        "v_cmp_eq_u32_e32 vcc, 2, %[a]\n\t"
+        "v_cndmask_b32_e32 %[ow], %[ow], %[o2], vcc\n\t"
+        "v_cmp_eq_u32_e32 vcc, 3, %[a]\n\t"
+        "v_cndmask_b32_e32 %[ow], %[ow], %[o3], vcc\n\t"
+        "v_and_b32_e32 %[ow], %[ow], %[bit]\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %[ow]\n\t"                      // met the old walk
+        "s_or_b64 %[merged], %[merged], vcc\n\t"
+        "s_andn2_b64 %[act], %[act], vcc\n\t"
+        "s_andn2_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz L_wait_%=\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t"
+        "v_alignbit_b32 %[lo], %[w1], %[w0], %[q]\n\t"            // 32 bits from bit q (the shift is q's low five bits)
+        "v_and_b32_e32 %[t], 0x1ff, %[lo]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 1, %[ll]\n\t"
+        "ds_read_u16 %[eL], %[t]\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t"
+        "v_alignbit_b32 %[hi], %[w2], %[w1], %[q]\n\t"            // and the 32 behind them
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_and_b32_e32 %[nb], 15, %[eL]\n\t"                      // a literal's code bits / a length's code + extra bits
+        "v_alignbit_b32 %[t], %[hi], %[lo], %[nb]\n\t"            // the bits behind a length: its distance code
+        "v_and_b32_e32 %[t], 0xff, %[t]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 1, %[ld]\n\t"
+        "ds_read_u16 %[eD], %[t]\n\t"
+        "v_cmp_gt_u32_e32 vcc, 0x1000, %[eL]\n\t"                 // a literal
+        "v_cndmask_b32_e64 %[u], -1, 0, vcc\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_and_b32_e32 %[t], 15, %[eD]\n\t"                       // distance code bits (0: not in the table)
+        "v_bfe_u32 %[eD], %[eD], 4, 5\n\t"                        // distance symbol
+        "v_add_u32_e32 %[w0], -1, %[t]\n\t"
+        "v_sub_u32_e32 %[w1], 29, %[eD]\n\t"
+        "v_or_b32_e32 %[w0], %[w0], %[w1]\n\t"                    // negative: no code, or symbol 30 / 31
+        "v_add_u32_e32 %[eD], -2, %[eD]\n\t"
+        "v_ashrrev_i32_e32 %[eD], 1, %[eD]\n\t"
+        "v_max_i32_e32 %[eD], 0, %[eD]\n\t"                       // its extra bits
+        "v_add3_u32 %[t], %[nb], %[t], %[eD]\n\t"
+        "v_cmp_lt_u32_e32 vcc, 0x7fff, %[eL]\n\t"                 // a length
+        "v_cndmask_b32_e32 %[u], %[u], %[w0], vcc\n\t"
+        "v_cndmask_b32_e32 %[nb], %[nb], %[t], vcc\n\t"
+        "v_cmp_le_i32_e32 vcc, 0, %[u]\n\t"                       // the lanes this path takes
+        "s_andn2_b64 %[tmp], exec, vcc\n\t"
+        "s_or_b64 %[stall], %[stall], %[tmp]\n\t"
+        "s_andn2_b64 %[act], %[act], %[tmp]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, %[a]\n\t"
+        "v_cndmask_b32_e32 %[t], 0, %[bit], vcc\n\t"
+        "v_or_b32_e32 %[t0], %[t0], %[t]\n\t"
+        "v_cmp_eq_u32_e32 vcc, 1, %[a]\n\t"
+        "v_cndmask_b32_e32 %[t], 0, %[bit], vcc\n\t"
+        "v_or_b32_e32 %[t1], %[t1], %[t]\n\t"
+        "v_cmp_eq_u32_e32 vcc, 2, %[a]\n\t"
+        "v_cndmask_b32_e32 %[t], 0, %[bit], vcc\n\t"
+        "v_or_b32_e32 %[t2], %[t2], %[t]\n\t"
+        "v_cmp_eq_u32_e32 vcc, 3, %[a]\n\t"
+        "v_cndmask_b32_e32 %[t], 0, %[bit], vcc\n\t"
+        "v_or_b32_e32 %[t3], %[t3], %[t]\n\t"
+        "v_add_u32_e32 %[q], %[q], %[nb]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch L_top_%=\n\t"
+        "L_wait_%=:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"                                // (the three reads of a step that met the old walk at once)
+        "s_mov_b64 exec, -1\n\t"
+        "s_branch L_top_%=\n\t"
+        "L_out_%=:\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        : [q] "+v"(q), [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2), [t3] "+v"(t3), [act] "+s"(act), [merged] "+s"(merged), [stall] "=&s"(stall), [tmp] "=&s"(tmp),
+          [a] "=&v"(a), [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [lo] "=&v"(lo), [hi] "=&v"(hi), [eL] "=&v"(eL), [nb] "=&v"(nb),
+          [eD] "=&v"(eD), [t] "=&v"(t), [u] "=&v"(u), [bit] "=&v"(bit), [ow] "=&v"(ow)
+        : [e] "v"(e), [s] "v"(s), [o0] "v"(o0), [o1] "v"(o1), [o2] "v"(o2), [o3] "v"(o3), [cb] "s"(cb), [ll] "s"(ll), [ld] "s"(ld)
+        : "vcc", "scc", "memory");
+    return stall;
+}
+#endif
+
+#ifndef INF3_LINK_ISA
+#define INF3_LINK_ISA 0                    /* 1: the link's repairs through rcx_inf_rewalk.  Measured (benchmarks/r6_inflate_modes.sh, one box): the link's cycles a member
+                                              275 K -> 224 K, no step left to the portable hop4 -- and config 3 9.61 -> 9.68 ms: the kernel sits at its 80-VGPR cap with
+                                              20-40 bytes of scratch a lane, and the loop's eighteen registers beside the tile's state cost more in spills than the
+                                              steps save.  Off. */
+#endif
 #ifndef INF3_TCAP
 #define INF3_TCAP 1024
 #endif
@@ -743,6 +849,39 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER, MIRROR> {
             else {
                 const Map mk = lanemap(map, k);
                 if (mtest(mk, cin - sk)) { if ((int)lane == k) { lowv = cin - sk; clr = false; } X = exk; }
+#if !defined(RCX_NO_INF_WALK_ASM) && INF3_LINK_ISA
+                else {                                               // follow the true walk until it meets k's map, leaves k or stops: lane k, hand-written loop
+                    Map tm = {0, 0};                                 // (the marks of the steps the portable code takes: every lane holds them)
+                    uint32_t q2 = cin, stop = 0, qv = cin, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+                    bool merged = false;
+                    for (;;) {
+                        uint64_t mg = 0;
+                        const uint64_t st = rcx_inf_rewalk(qv, e, s, (uint32_t)map.lo, (uint32_t)(map.lo >> 32), (uint32_t)map.hi, (uint32_t)(map.hi >> 32), t0, t1, t2, t3,
+                                                           1ull << k, mg, RCX_U((uint32_t)(uintptr_t)this->cbuf), RCX_U((uint32_t)(uintptr_t)lutL), RCX_U((uint32_t)(uintptr_t)lutD));
+                        q2 = RCX_U(__builtin_amdgcn_readlane(qv, k));
+                        if (mg) { merged = true; break; }
+                        if (!st) break;                              // left the segment
+                        uint32_t kind, nb;                           // a symbol the loop leaves to hop4 (end of block, a long code ...)
+#ifdef INF3_PROF_LINK
+                        pf[2] += 1;
+#endif
+                        hop4(bits64(q2), kind, nb);
+                        kind = RCX_U(kind); nb = RCX_U(nb);
+                        mset(tm, q2 - sk);
+                        if (kind == 1u) { stop = XEOB; break; }
+                        if (kind == 4u) { stop = XGEN; break; }
+                        q2 += nb; qv = q2;
+                        if (q2 >= ek) break;
+                    }
+                    if ((int)lane == k) {
+                        Map nm = map;
+                        if (merged) mbelow(nm, q2 - sk); else { nm.lo = 0; nm.hi = 0; }
+                        nm.lo |= tm.lo | (uint64_t)t0 | ((uint64_t)t1 << 32); nm.hi |= tm.hi | (uint64_t)t2 | ((uint64_t)t3 << 32);
+                        map = nm; lowv = 0; clr = false;
+                    }
+                    X = stop ? stop : merged ? exk : q2;
+                }
+#else
                 else {                                               // follow the true walk until it meets k's map, leaves k or stops
                     Map tm = {0, 0};
                     uint32_t q2 = cin, stop = 0;
@@ -765,6 +904,7 @@ struct Inf3 : Lz4V5<CB, INF3_TCAP, INF3_H, false, INF3_SB, ADLER, MIRROR> {
                     if ((int)lane == k) { map = nm; lowv = 0; clr = false; }
                     X = stop ? stop : merged ? exk : q2;
                 }
+#endif
             }
             forced = X != exk && k + 1 < (int)nseg;
             if (forced) { k++; cin = X; }
