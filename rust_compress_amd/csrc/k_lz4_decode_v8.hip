@@ -1069,6 +1069,9 @@ struct Lz4V8 : Lz4X6<Lz4V5<1024, TC, HH, PROF8, SB, false, MIRROR>, PROF8> {
                 if (chk && eprev < e) { lowv = eprev - (uint32_t)s; ok = (map >> lowv) & 1ull; }
                 if (!ok) lowv = 0;
                 unsigned long long bad = __ballot(chk && !ok);
+#ifdef RCX_LINK_NOREPAIR                  /* (instruction attribution of the parser-only build: results wrong on purpose) */
+                bad = 0;
+#endif
                 c = RCX_U(__builtin_amdgcn_readlane(ex, nseg - 1));
                 int k = 0; uint32_t cin = 0; bool forced = false;
                 for (;;) {
