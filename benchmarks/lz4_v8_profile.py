@@ -30,6 +30,12 @@ if allp[:, 13].min() > 0:      # when each block started and ended (s_memrealtim
     cend = np.array([en[cu == i].max() for i in ids]); cfirst = np.array([en[cu == i].min() for i in ids])
     print("a CU's LAST block ends, us:", q(cend)); print("a CU's FIRST block ends, us:", q(cfirst))
     rank = (hw & 0xf) >> 1
+    ilen = dec.in_len.cpu().numpy()[:nb].astype(np.float64); life = en - st; nbat = allp[:, 9]
+    print("compressed bytes a block: min %d mean %d max %d; batches a block: min %d mean %.1f max %d" % (ilen.min(), ilen.mean(), ilen.max(), nbat.min(), nbat.mean(), nbat.max()))
+    print("corr(block life, compressed bytes) %.3f  corr(block life, batches) %.3f  corr(executor cycles, batches) %.3f" % (np.corrcoef(life, ilen)[0, 1], np.corrcoef(life, nbat)[0, 1], np.corrcoef(allp[:, 11], nbat)[0, 1]))
+    cb = np.array([nbat[cu == i].sum() for i in ids]); print("batches a CU: min %d mean %.0f max %d; corr(CU's last end, its batches) %.3f" % (cb.min(), cb.mean(), cb.max(), np.corrcoef(cend, cb)[0, 1]))
+    wg = np.arange(nb); print("blocks of CU", ids[0], ":", wg[cu == ids[0]][:16], " of CU", ids[1], ":", wg[cu == ids[1]][:16])
+    np.save(os.path.join(ROOT, "gpurun_out", "lz4_block_cu.npy"), cu)
     print("block end by the executor's age rank on its SIMD (wave slot >> 1), us: " + "  ".join("%d: %.1f (n %d)" % (r, en[rank == r].mean(), (rank == r).sum()) for r in np.unique(rank)))
     xe = (allp[:, 11]); print("executor cycles per block: min %.0fK mean %.0fK max %.0fK" % (xe.min() / 1e3, xe.mean() / 1e3, xe.max() / 1e3))
 names = ["walk", "link", "list", "fields", "post(wait)", "-", "tiles", "walk steps", "repairs", "batches"]
