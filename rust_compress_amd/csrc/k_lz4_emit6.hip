@@ -12,6 +12,10 @@
 #include "rcx_dev.h"
 // (Lz4V5 / Lz4V4 -- k_lz4_decode_v5.hip, k_lz4_decode_v4.hip -- come first in the translation unit: tu_lz4.hip)
 
+#ifndef RCX_X6_RR
+#define RCX_X6_RR 3                         /* emit6's redirection rounds (pointer doubling) before the copy rounds: 0 / 1 / 2 / 3 / 4 / 5 / 6: 0.587 / 0.485 / 0.4516 / 0.4468 /
+                                               0.4516 / 0.4585 / 0.4668 ms (emit5 keeps B::RR = 2; tests/wavesim: 2.95 copy rounds a batch at 2) */
+#endif
 #ifndef RCX_X6_MODE
 #define RCX_X6_MODE 1                    /* A/B: 0 = no emit6 at all (round 5's kernel), 2 = its LDS layout and the parser's flag, but every batch through emit5 */
 #endif
@@ -243,9 +247,11 @@ struct Lz4X6 : Base {
         {
             const uint32_t pmd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ka << 2), (int)((isfar || off < M) ? 0xffffffffu : mdst));
             const uint32_t prod = (inb && ka == kb && slo >= pmd && off >= M) ? ka : 64u;
+            RCX_V8_STAT(28, inb && ka != kb); RCX_V8_STAT(29, inb && ka == kb && slo < pmd); RCX_V8_STAT(30, inb && ka == kb && slo >= pmd && off < M);   // (simulator: why a source is not redirected: spans entries / starts in literals / overlaps itself)
+            RCX_V8_STAT(31, inb && ka == kb && shi <= pmd && pmd != 0xffffffffu);
             uint32_t st = prod | (ka << 7) | (kb << 13) | ((uint32_t)inb << 19);
 #pragma unroll
-            for (int rr = 0; rr < B::RR; rr++) {
+            for (int rr = 0; rr < RCX_X6_RR; rr++) {
                 const bool has = (st & 64u) == 0u;
                 const uint32_t j = has ? (st & 63u) : lane;
                 const uint32_t Sj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(j << 2), (int)S);
@@ -323,7 +329,10 @@ struct Lz4X6 : Base {
 #endif
             {
             uint32_t prog = 0;
+            RCX_V8_STAT(16, Mc != 0u); RCX_V8_STAT(17, Mc != 0u && dep != 0ull); RCX_V8_STAT(18, Mc > 16u);       // (simulator: window matches, those that wait, the long ones)
+            uint32_t nr_ = 0;
             while (pm) {
+                nr_++; RCX_V8_STAT(14, lane == 0);
                 const bool ready = ((pm >> lane) & 1ull) && (pm & dep) == 0ull;
                 const bool fill = ready && ovl;
                 const uint32_t left = Mc - prog;
@@ -342,6 +351,7 @@ struct Lz4X6 : Base {
                 prog += fill ? Mc : nv;
                 pm = __ballot(prog < Mc);
             }
+            RCX_V8_STAT(20 + (nr_ < 7u ? nr_ : 7u), lane == 0);
             }
         }
         X6P_ADD(7);

@@ -3,7 +3,7 @@
 #include <sys/mman.h>
 
 namespace ws {
-unsigned long long g_stat[16];
+unsigned long long g_stat[32];
 
 Lane* cur = nullptr;
 Block* blk = nullptr;

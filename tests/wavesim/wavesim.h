@@ -239,7 +239,7 @@ static inline unsigned long long ws_memrealtime_() { static unsigned long long t
 #define __builtin_amdgcn_mbcnt_hi(m, b) (__builtin_popcount((uint32_t)(m) & ((ws::cur->tid & 63) < 32 ? 0u : (1u << (ws::cur->tid & 31)) - 1u)) + (b))
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
-namespace ws { extern unsigned long long g_stat[16]; }
+namespace ws { extern unsigned long long g_stat[32]; }
 #define RCX_V7_STAT(slot, v) (ws::g_stat[slot] += (unsigned long long)(v))
 #define RCX_V8_STAT(slot, v) (ws::g_stat[slot] += (unsigned long long)(v))
 // portable version of rcx_dev.h's hand-scheduled LZ4 token walk (the product uses inline gfx950 asm)
