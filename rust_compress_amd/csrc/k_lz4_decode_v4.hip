@@ -58,6 +58,9 @@ __device__ __forceinline__ void rcx_adler_chunk(const rcx_u32x4 v, uint32_t rel,
 // MIRROR (the host-memory entry point of the LZ4 decoder, rcx_api.hip): every byte that leaves for global memory is stored a second
 // time at the same offset of `out2` -- the caller's page-locked host buffer, written over PCIe while the block is still being
 // decoded -- so that no device-to-host copy follows the launch.  The copy in HBM stays: old matches are gathered from it.
+#ifndef RCX_V4_RR
+#define RCX_V4_RR 2
+#endif
 template <int CB, bool PROF = false, int TC = 2560, int HH = 2048, bool ADLER = false, bool MIRROR = false>
 struct Lz4V4 {
     uint64_t prof[16];
@@ -95,7 +98,7 @@ struct Lz4V4 {
     static constexpr int STAGE = LIN + 64;         // 64 bytes of read slack, then 64 lanes x MCAP bytes of old-match staging
     static constexpr int WBUF = STAGE + 64 * MCAP;
     static constexpr int RH = 128;
-    static constexpr int RR = 2;                   // redirection rounds (pointer doubling) before the copy rounds
+    static constexpr int RR = RCX_V4_RR;           // redirection rounds (pointer doubling) before the copy rounds
     static constexpr int MARGIN = LCAP + 16;
     static constexpr uint32_t FLAG = 0x80000000u;
     static_assert(SOLO <= TCAP && (CB % 1024) == 0 && RH >= 2 * MCAP && (STAGE % 16) == 0, "geometry");
