@@ -646,7 +646,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=25)     # (after the parity check's idle gaps the first ~20 launches run ~2-5 % slower: benchmarks/r5_clock_ramp.py)
     ap.add_argument("--kind", default="text", help="synthetic distribution: text|runs|rand|mix")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant (A/B)")
     ap.add_argument("--nblocks", type=int, default=NBLOCKS)
