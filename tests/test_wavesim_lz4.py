@@ -175,3 +175,20 @@ def test_plain_batches_take_the_straight_line_executor(oracle):
         assert es == s_, (i, es, s_)
         if es == 0:
             assert eo == out
+
+
+def test_plain_batches_need_few_copy_rounds(oracle):
+    """emit6 shortens match chains by pointer doubling before it copies (RCX_X6_RR redirection rounds): on a text a plain batch must
+    get by with fewer than 2.75 copy rounds on average (2.95 with two redirections, 2.57 with three: DESIGN.md 3.1) -- the
+    executor's chain is made of these rounds (k_lz4_emit6.hip; statistics slots 8 / 14 of the simulator)."""
+    import ctypes as C
+    import simrun
+    lib = simrun.lib()
+    lib.sim_stats.restype = C.POINTER(C.c_ulonglong)
+    st = lib.sim_stats()
+    raws = [synth.gen("text", 65536, 21 + i).tobytes() for i in range(2)]
+    blobs = [oracle.lz4_encode_block(r) for r in raws]
+    st[8] = 0; st[14] = 0
+    outs, _, in_used, status, _ = simrun.run(LZ4_DECODE, 0, blobs, [len(r) for r in raws])
+    assert not status.any() and outs == raws
+    assert st[8] > 100 and st[14] < 2.75 * st[8], (st[8], st[14])
