@@ -1175,7 +1175,7 @@ __global__ __launch_bounds__(128, 8) void k_lz4_decode_v8(rcx_kargs a, int only_
 {
     constexpr bool X6 = RCX_X6_MODE != 0 && (X6_ < 0 ? (CUT == 0 && !PRED && SPLIT_ != 0 && !MIRROR) : X6_ != 0);      // (MIRROR: the launch is bound by the PCIe link, and with emit6 inlined as well the kernel spills)
     typedef Lz4V8<TC, HH, X6 ? 0 : 16, PROF8, PRE_, SPLIT_, PRED, PRR, CUT, MIRROR, X6> S;
-    __shared__ __align__(16) uint32_t s_mtab[X6 ? 160 : 4];
+    __shared__ __align__(16) uint32_t s_mtab[X6 ? 20 * RCX_X6_MROW : 4];
     const uint64_t tk0 = PROF8 ? (uint64_t)__builtin_readcyclecounter() : 0;
     const uint64_t rt0 = PROF8 ? (uint64_t)__builtin_amdgcn_s_memrealtime() : 0;        // (100 MHz, one clock for the whole GPU: when the block started and ended)
     __shared__ __align__(16) uint8_t s_wbuf[S::WBUF5 + 16 + (X6 ? 16 : 0)];    // (X6: 16 bytes in front -- a source frame starts up to 3 bytes below the window)

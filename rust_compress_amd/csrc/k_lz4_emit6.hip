@@ -12,6 +12,9 @@
 #include "rcx_dev.h"
 // (Lz4V5 / Lz4V4 -- k_lz4_decode_v5.hip, k_lz4_decode_v4.hip -- come first in the translation unit: tu_lz4.hip)
 
+#ifndef RCX_X6_MROW
+#define RCX_X6_MROW 9                        /* dwords a row of the mask table (8: rows 32 bytes apart, read as b128 + b32 -- the k-th dwords of rows e, e + 4, e + 8 ... share a bank) */
+#endif
 #ifndef RCX_X6_RR
 #define RCX_X6_RR 3                         /* emit6's redirection rounds (pointer doubling) before the copy rounds: 0 / 1 / 2 / 3 / 4 / 5 / 6: 0.587 / 0.485 / 0.4516 / 0.4468 /
                                                0.4516 / 0.4585 / 0.4668 ms (emit5 keeps B::RR = 2; tests/wavesim: 2.95 copy rounds a batch at 2) */
@@ -58,7 +61,7 @@ __device__ __forceinline__ uint64_t rcx_lz4_rounds6(uint32_t s0, uint32_t d4, ui
         "ds_read_b32 %[r4], %[t0] offset:16\n\t"
         "ds_read_b32 %[r5], %[t0] offset:20\n\t"
         "v_min_u32_e32 %[nv], 16, %[nv]\n\t"
-        "v_lshl_add_u32 %[t1], %[nv], 5, %[tb]\n\t"
+        "v_mad_u32_u24 %[t1], %[nv], %[mrow], %[tb]\n\t"
         "ds_read_b32 %[m0], %[t1]\n\t"
         "ds_read_b32 %[m1], %[t1] offset:4\n\t"
         "ds_read_b32 %[m2], %[t1] offset:8\n\t"
@@ -103,7 +106,7 @@ __device__ __forceinline__ uint64_t rcx_lz4_rounds6(uint32_t s0, uint32_t d4, ui
         : [pend] "+s"(pend), [prog] "+v"(prog), [t0] "=&v"(t0), [t1] "=&v"(t1), [nv] "=&v"(nv), [sa] "=&v"(sa), [sh] "=&v"(sh), [da] "=&v"(da),
           [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [r4] "=&v"(r4), [r5] "=&v"(r5),
           [m0] "=&v"(m0), [m1] "=&v"(m1), [m2] "=&v"(m2), [m3] "=&v"(m3), [m4] "=&v"(m4), [sT] "=&s"(sT), [sF] "=&s"(sF)
-        : [s0] "v"(s0), [d4] "v"(d4), [mc] "v"(mc), [dlo] "v"(dep_lo), [dhi] "v"(dep_hi), [tb] "v"(tb), [fix] "v"(fix)
+        : [s0] "v"(s0), [d4] "v"(d4), [mc] "v"(mc), [dlo] "v"(dep_lo), [dhi] "v"(dep_hi), [tb] "v"(tb), [fix] "v"(fix), [mrow] "s"(4u * (uint32_t)RCX_X6_MROW)
         : "vcc", "scc", "memory");
     return pend;
 }
@@ -134,8 +137,8 @@ struct Lz4X6 : Base {
 
     __device__ __forceinline__ void mtab_init()
     {
-        for (uint32_t i = this->lane; i < 160u; i += 64u) {
-            const int32_t e = (int32_t)(i >> 3), k = (int32_t)(i & 7u);
+        for (uint32_t i = this->lane; i < 20u * (uint32_t)RCX_X6_MROW; i += 64u) {
+            const int32_t e = (int32_t)(i / (uint32_t)RCX_X6_MROW), k = (int32_t)(i % (uint32_t)RCX_X6_MROW);
             int32_t t = e - 4 * k; t = t < 0 ? 0 : t > 4 ? 4 : t;
             mtab[i] = (k < 5 && t) ? (0xffffffffu >> (8 * (4 - t))) : 0u;
         }
@@ -149,8 +152,12 @@ struct Lz4X6 : Base {
         const uint32_t w[5] = {w0, w1, w2, w3, w4};
         for (uint32_t j = a; j < a + n; j++) fp[j] = (uint8_t)(w[j >> 2] >> (8u * (j & 3u)));
 #else
-        const RCX_LDS_AS uint32_t* te = mtab + 8u * (a + n);
+        const RCX_LDS_AS uint32_t* te = mtab + (uint32_t)RCX_X6_MROW * (a + n);
+#if RCX_X6_MROW == 8
         const rcx_u32x4 mv = *(const RCX_LDS_AS rcx_u32x4*)te;
+#else
+        rcx_u32x4 mv; mv[0] = te[0]; mv[1] = te[1]; mv[2] = te[2]; mv[3] = te[3];       // (rows of nine dwords: no two rows' k-th dwords in one bank)
+#endif
         const uint32_t m0 = mv[0] & (0xffffffffu << (8u * a));
         const uint32_t fa = (uint32_t)(uintptr_t)fp;                 // (low half of a generic LDS pointer = the LDS byte address)
         if (NW >= 5) {
@@ -318,7 +325,7 @@ struct Lz4X6 : Base {
                 const unsigned long long depx = dep | (ovl ? 1ull << lane : 0ull);
                 for (;;) {
                     pm = rcx_lz4_rounds6(wa + (uint32_t)sfr, wa + (uint32_t)dfr, Mc, (uint32_t)depx, (uint32_t)(depx >> 32), pm,
-                                         (uint32_t)(uintptr_t)mtab + (a2 << 5), 0xffffffffu << (8u * a2));
+                                         (uint32_t)(uintptr_t)mtab + a2 * (4u * (uint32_t)RCX_X6_MROW), 0xffffffffu << (8u * a2));
                     if (!pm) break;
                     const bool fill = ovl && ((pm >> lane) & 1ull) && (pm & dep) == 0ull;
                     if (fill) fill_run();
